@@ -1,0 +1,115 @@
+"""ctypes binding of libctd_hip.so (C ABI in include/ctd_hip.h).
+
+The product path has NO CPU fallback: if the HIP library is missing, or cannot
+be loaded, importing a symbol from here raises.  `build()` compiles it in-tree.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libctd_hip.so")
+SELFTEST_PATH = os.path.join(_HERE, "ctd_selftest")
+
+# ---- constants mirrored from include/ctd_hip.h -------------------------------
+ABI_VERSION = 1
+OK = 0
+PREC_F32, PREC_F16 = 0, 1
+ACT = {"none": 0, "silu": 1, "leaky": 2, "relu": 3, "sigmoid": 4}
+IN_NCHW_F32, IN_NHWC_U8 = 0, 1
+(OP_INPUT, OP_CONV, OP_CONVT, OP_MAXPOOL, OP_AVGPOOL2, OP_DETECT, OP_EXPORT, OP_STEM, OP_SEG_FINAL,
+ OP_DB_UP) = range(1, 11)
+OUT_MASK, OUT_LINES = 0, 1
+
+
+class CtdTensor(C.Structure):
+    _fields_ = [("channels", C.c_int32), ("log2_down", C.c_int32), ("dtype", C.c_int32)]
+
+
+class CtdOp(C.Structure):
+    _fields_ = [
+        ("kind", C.c_int32),
+        ("src0", C.c_int32), ("src0_coff", C.c_int32), ("src0_c", C.c_int32), ("src0_up", C.c_int32),
+        ("src1", C.c_int32), ("src1_coff", C.c_int32), ("src1_c", C.c_int32), ("src1_up", C.c_int32),
+        ("res", C.c_int32), ("res_coff", C.c_int32),
+        ("dst", C.c_int32), ("dst_coff", C.c_int32),
+        ("cout", C.c_int32),
+        ("k", C.c_int32), ("stride", C.c_int32), ("pad", C.c_int32),
+        ("act", C.c_int32),
+        ("w_off", C.c_int64), ("b_off", C.c_int64),
+        ("aux", C.c_int32 * 8),
+        ("faux", C.c_float * 8),
+    ]
+
+
+# every symbol include/ctd_hip.h declares: (restype, argtypes)
+_vp, _i32, _i64, _f = C.c_void_p, C.c_int32, C.c_int64, C.c_float
+SYMBOLS = {
+    "ctd_engine_create": (_i32, [C.POINTER(_vp), C.POINTER(CtdTensor), _i32, C.POINTER(CtdOp), _i32,
+                                 C.POINTER(C.c_float), _i64, _i32, _i32]),
+    "ctd_engine_destroy": (None, [_vp]),
+    "ctd_engine_blks_shape": (_i32, [_vp, _i32, _i32, C.POINTER(_i32), C.POINTER(_i32)]),
+    "ctd_engine_forward": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "ctd_engine_n_ops": (_i32, [_vp]),
+    "ctd_engine_op_work": (_i32, [_vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(_i32)]),
+    "ctd_engine_profile": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp,
+                                  C.POINTER(C.c_float)]),
+    "ctd_engine_read_tensor": (_i32, [_vp, _i32, C.POINTER(C.c_float), _i64]),
+    "ctd_engine_workspace_bytes": (_i64, [_vp]),
+    "ctd_nms_workspace_bytes": (C.c_size_t, [_i32, _i32]),
+    "ctd_nms": (_i32, [_vp, _i32, _i32, _i32, _f, _f, _i32, _i32, _f, _vp, _vp, _vp, C.c_size_t, _vp]),
+    "ctd_ccl_workspace_bytes": (C.c_size_t, [_i32, _i32, _i32]),
+    "ctd_ccl": (_i32, [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _i32, _vp, C.c_size_t, _vp]),
+    "ctd_last_error": (C.c_char_p, []),
+    "ctd_abi_version": (_i32, []),
+    "ctd_device_info": (_i32, [_i32, C.c_char_p, C.POINTER(_i32), C.POINTER(_i64)]),
+}
+
+
+class CtdError(RuntimeError):
+    pass
+
+
+def build(verbose: bool = False) -> None:
+    """Compile the HIP library for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
+    src = os.path.join(_HERE, "csrc")
+    r = subprocess.run(["make", "-C", src, "-j8"], capture_output=True, text=True)
+    if r.returncode != 0:
+        raise CtdError("building libctd_hip.so failed:\n" + r.stdout[-4000:] + r.stderr[-4000:])
+    if verbose:
+        print(r.stdout[-2000:])
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    """Loads libctd_hip.so (loudly failing if absent) and types every entry point."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.isfile(LIB_PATH):
+        raise CtdError(f"{LIB_PATH} is missing: the HIP extension was not built "
+                       "(run `python -c 'import __graft_entry__ as g; g.build()'`). "
+                       "There is no CPU fallback for the product path.")
+    # torch ships its own libamdhip64.so (same SONAME as /opt/rocm's).  Import it
+    # first so the process has ONE HIP runtime: streams and device pointers made by
+    # torch are then valid in this library.
+    import torch  # noqa: F401
+    L = C.CDLL(LIB_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(L, name)       # AttributeError if the library lacks a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    if L.ctd_abi_version() != ABI_VERSION:
+        raise CtdError("libctd_hip.so ABI version mismatch; rebuild")
+    _lib = L
+    return L
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != OK:
+        msg = lib().ctd_last_error().decode("utf8", "replace")
+        raise CtdError(f"{what} failed (rc={rc}): {msg}")

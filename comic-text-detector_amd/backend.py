@@ -1,0 +1,193 @@
+"""`HipTextDetBackend`: the third backend behind the reference's seam
+
+        blks, mask, lines_map = self.net(img_in)            (reference inference.py:146)
+
+next to `TextDetBase` (torch, reference basemodel.py:222-244) and
+`TextDetBaseDNN` (OpenCV-DNN, reference basemodel.py:246-256).  Same call
+contract: `img_in` f32 (B,3,H,W) in [0,1] on the device -> `blks` (B,N,5+nc),
+`mask` (B,1,H,W), `lines_map` (B,2,H,W), all f32 on the device.
+
+PyTorch is used for device memory and streams only; every FLOP runs in
+libctd_hip.so.  There is no CPU path: constructing the backend without a GPU
+or without the built library raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Tuple, Union
+
+import numpy as np
+import torch
+
+from . import _lib as L
+from . import graph
+
+
+def _load_ckpt(model: Union[str, dict]) -> dict:
+    if isinstance(model, dict):
+        return model
+    # the reference's own loader does a plain torch.load of the dict (basemodel.py:212)
+    return torch.load(model, map_location="cpu", weights_only=False)
+
+
+class HipTextDetBackend:
+    def __init__(self, model: Union[str, dict], device: Union[str, int, torch.device] = "cuda",
+                 precision: str = "fp16", act: str = "leaky", bitmap_thresh: float = 0.3):
+        if not torch.cuda.is_available():
+            raise L.CtdError("HipTextDetBackend needs a ROCm GPU (MI355X); there is no CPU fallback")
+        dev = torch.device(device)
+        if dev.type != "cuda":
+            raise L.CtdError(f"device must be a cuda/hip device, got {device!r}")
+        self.device = torch.device("cuda", dev.index if dev.index is not None else torch.cuda.current_device())
+        self.prec = {"fp16": L.PREC_F16, "fp32": L.PREC_F32}[precision]
+        self.precision = precision
+        self._lib = L.lib()
+        ckpt = _load_ckpt(model)
+        self.program = graph.lower(ckpt, self.prec, act=act, bitmap_thresh=bitmap_thresh)
+        T, O, blob = graph.to_ctypes(self.program)
+        self._blob = blob
+        h = C.c_void_p()
+        L.check(self._lib.ctd_engine_create(C.byref(h), T, len(T), O, len(O),
+                                            blob.ctypes.data_as(C.POINTER(C.c_float)), blob.size, self.prec,
+                                            self.device.index), "ctd_engine_create")
+        self._h = h
+        self.no = self.program.meta["no"]
+        self.mask_u8: Optional[torch.Tensor] = None      # fused (uint8)(mask*255), reference inference.py:96-99
+        self.bitmap: Optional[torch.Tensor] = None       # fused lines_map[:,0] > 0.3, reference db_utils.py:71-72
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            try:
+                self._lib.ctd_engine_destroy(h)
+            except Exception:
+                pass
+            self._h = None
+
+    # -- shapes -----------------------------------------------------------------
+    def blks_rows(self, H: int, W: int) -> int:
+        rows, no = C.c_int32(), C.c_int32()
+        L.check(self._lib.ctd_engine_blks_shape(self._h, H, W, C.byref(rows), C.byref(no)), "blks_shape")
+        return rows.value
+
+    def _outputs(self, B: int, H: int, W: int):
+        dev = self.device
+        blks = torch.empty((B, self.blks_rows(H, W), self.no), dtype=torch.float32, device=dev)
+        mask = torch.empty((B, 1, H, W), dtype=torch.float32, device=dev)
+        lines = torch.empty((B, 2, H, W), dtype=torch.float32, device=dev)
+        mask_u8 = torch.empty((B, H, W), dtype=torch.uint8, device=dev)
+        bitmap = torch.empty((B, H, W), dtype=torch.uint8, device=dev)
+        return blks, mask, lines, mask_u8, bitmap
+
+    def _run(self, inp: torch.Tensor, fmt: int, B: int, H: int, W: int, profile: bool = False):
+        if H % 64 or W % 64:
+            raise ValueError("H and W must be multiples of 64 (stride-32 backbone + AvgPool2d(2))")
+        self._last_bhw = (B, H, W)
+        outs = self._outputs(B, H, W)
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        args = [self._h, inp.data_ptr(), fmt, B, H, W] + [t.data_ptr() for t in outs] + [stream]
+        if profile:
+            n = self._lib.ctd_engine_n_ops(self._h)
+            ms = (C.c_float * n)()
+            L.check(self._lib.ctd_engine_profile(*args, ms), "ctd_engine_profile")
+            self.last_op_ms = np.array(ms[:], dtype=np.float64)
+        else:
+            L.check(self._lib.ctd_engine_forward(*args), "ctd_engine_forward")
+        self.mask_u8, self.bitmap = outs[3], outs[4]
+        return outs[0], outs[1], outs[2]
+
+    # -- the seam ---------------------------------------------------------------
+    def __call__(self, img_in: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+        if img_in.dim() != 4 or img_in.shape[1] != 3:
+            raise ValueError("img_in must be (B,3,H,W)")
+        x = img_in.to(device=self.device, dtype=torch.float32).contiguous()
+        B, _, H, W = x.shape
+        return self._run(x, L.IN_NCHW_F32, B, H, W)
+
+    forward = __call__
+
+    def forward_u8(self, pages: torch.Tensor):
+        """pages: (B,H,W,3) uint8 letterboxed, channel order as the net consumes it
+        (SURVEY App. C-1).  Saves the f32 NCHW round trip (12.6 MB -> 3 MB per page)."""
+        if pages.dim() != 4 or pages.shape[3] != 3 or pages.dtype != torch.uint8:
+            raise ValueError("pages must be (B,H,W,3) uint8")
+        x = pages.to(self.device).contiguous()
+        B, H, W, _ = x.shape
+        return self._run(x, L.IN_NHWC_U8, B, H, W)
+
+    # -- measurement helpers ------------------------------------------------------
+    def profile(self, img_in: torch.Tensor):
+        """One forward with a hipEvent pair around every op; returns dict(ms, flops, bytes, cls, names)."""
+        x = img_in.contiguous()
+        if x.dtype == torch.uint8:
+            B, H, W, _ = x.shape
+            self._run(x, L.IN_NHWC_U8, B, H, W, profile=True)
+        else:
+            B, _, H, W = x.shape
+            self._run(x.float(), L.IN_NCHW_F32, B, H, W, profile=True)
+        n = self._lib.ctd_engine_n_ops(self._h)
+        fl, by, cl = (C.c_double * n)(), (C.c_double * n)(), (C.c_int32 * n)()
+        L.check(self._lib.ctd_engine_op_work(self._h, fl, by, cl), "op_work")
+        return dict(ms=self.last_op_ms, flops=np.array(fl[:]), bytes=np.array(by[:]), cls=np.array(cl[:]),
+                    names=[o["name"] for o in self.program.ops])
+
+    def read_tensor(self, name_or_id) -> np.ndarray:
+        """Debug: activation tensor of the last forward as f32 (B,H,W,C).  Only
+        meaningful with CTD_NO_REUSE=1 (otherwise the arena slot may have been reused)."""
+        tid = self.program.taps[name_or_id] if isinstance(name_or_id, str) else int(name_or_id)
+        c, down, _ = self.program.tensors[tid]
+        B, H, W = self._last_bhw
+        shape = (B, H >> down, W >> down, c)
+        out = np.empty(shape, np.float32)
+        L.check(self._lib.ctd_engine_read_tensor(self._h, tid, out.ctypes.data_as(C.POINTER(C.c_float)), out.size),
+                "read_tensor")
+        return out
+
+    def workspace_bytes(self) -> int:
+        return int(self._lib.ctd_engine_workspace_bytes(self._h))
+
+
+# ---------------------------------------------------------------------------
+# post-processing kernels
+# ---------------------------------------------------------------------------
+
+def nms(blks: torch.Tensor, conf_thres: float = 0.4, iou_thres: float = 0.35, max_det: int = 300,
+        max_nms: int = 30000, max_wh: float = 4096.0):
+    """HIP replacement of `non_max_suppression` (reference utils/yolov5_utils.py:124-218).
+    blks (B,rows,no) f32 cuda -> (dets (B,max_det,6) [xyxy,conf,cls], counts (B,) i32)."""
+    lib = L.lib()
+    if not blks.is_cuda:
+        raise L.CtdError("nms: blks must live on the GPU")
+    blks = blks.contiguous().float()
+    B, rows, no = blks.shape
+    dets = torch.empty((B, max_det, 6), dtype=torch.float32, device=blks.device)
+    counts = torch.empty((B,), dtype=torch.int32, device=blks.device)
+    nbytes = lib.ctd_nms_workspace_bytes(B, rows)
+    ws = torch.empty((nbytes,), dtype=torch.uint8, device=blks.device)
+    stream = torch.cuda.current_stream(blks.device).cuda_stream
+    L.check(lib.ctd_nms(blks.data_ptr(), B, rows, no, conf_thres, iou_thres, max_det, max_nms, max_wh,
+                        dets.data_ptr(), counts.data_ptr(), ws.data_ptr(), nbytes, stream), "ctd_nms")
+    return dets, counts
+
+
+def connected_components(img: torch.Tensor, thresh: int = 0, connectivity: int = 8, max_labels: int = 4096):
+    """HIP replacement of `cv2.connectedComponentsWithStats` (reference utils/textmask.py:93,113,138).
+    img (B,H,W) or (H,W) u8 cuda; foreground = img > thresh.
+    Returns labels (B,H,W) i32 (0 = background, 1..n raster order of first pixel),
+    n (B,) i32, stats (B,max_labels,5) i32 [x,y,w,h,area] for labels 1..n."""
+    lib = L.lib()
+    if not img.is_cuda or img.dtype != torch.uint8:
+        raise L.CtdError("connected_components: img must be a uint8 GPU tensor")
+    if img.dim() == 2:
+        img = img[None]
+    img = img.contiguous()
+    B, H, W = img.shape
+    labels = torch.empty((B, H, W), dtype=torch.int32, device=img.device)
+    n = torch.empty((B,), dtype=torch.int32, device=img.device)
+    stats = torch.empty((B, max_labels, 5), dtype=torch.int32, device=img.device)
+    nbytes = lib.ctd_ccl_workspace_bytes(B, H, W)
+    ws = torch.empty((nbytes,), dtype=torch.uint8, device=img.device)
+    stream = torch.cuda.current_stream(img.device).cuda_stream
+    L.check(lib.ctd_ccl(img.data_ptr(), B, H, W, thresh, connectivity, labels.data_ptr(), n.data_ptr(),
+                        stats.data_ptr(), max_labels, ws.data_ptr(), nbytes, stream), "ctd_ccl")
+    return labels, n, stats

@@ -1,0 +1,71 @@
+// Shared device/host declarations for the gfx950 comic-text-detector engine.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/ctd_hip.h"
+
+typedef _Float16 half_t;
+typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
+typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
+typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
+typedef float float4_t __attribute__((ext_vector_type(4)));
+typedef float float16_t __attribute__((ext_vector_type(16)));
+
+// One concatenated-source view: NHWC tensor slice.
+struct SrcView {
+  const void* ptr;  // already offset by the channel offset
+  int pitch;        // elements per pixel of the underlying tensor
+  int c;            // channels used
+  int up;           // 1: tensor is at half the logical resolution (nearest x2)
+  int H, W;         // physical spatial size of the tensor
+};
+
+// Arguments shared by every conv-like kernel (direct and implicit-GEMM).
+struct ConvArgs {
+  SrcView s0, s1;          // s1.c == 0 when unused
+  int B;
+  int Hin, Win;            // logical input size (after upsample)
+  int Mh, Mw;              // output grid enumerated by M (conv: Hout,Wout; convT phase: Hin,Win)
+  int KH, KW;              // taps walked by the K loop
+  int stride;              // input step per output grid step
+  int dy0, dx0;            // input y = oy*stride + dy0 + ty
+  const void* w;           // packed weights (layout depends on kernel)
+  const float* bias;       // padded to the N tile, never null for igemm
+  void* dst;               // offset by channel offset
+  int pitchD;
+  int oH, oW;              // physical output size
+  int osy, osx, ooy, oox;  // output pixel = (y*osy+ooy, x*osx+oox)
+  const void* res;         // residual (same geometry as dst), may be null
+  int pitchR;
+  int act;
+  int N;                   // true output channels
+  int Npad;                // weight rows (multiple of the N tile)
+  int K;                   // KH*KW*(s0.c+s1.c)
+  int M;                   // B*Mh*Mw
+  long long w_phase_stride;  // elements between phases (convT), else 0
+  int nphase;              // 1, or 4 for convT 4x4 s2 (blockIdx.z)
+};
+
+__device__ __forceinline__ float ctd_act(float v, int act) {
+  switch (act) {
+    case CTD_ACT_SILU: return v / (1.0f + __expf(-v));
+    case CTD_ACT_LEAKY: return v > 0.f ? v : 0.1f * v;
+    case CTD_ACT_RELU: return v > 0.f ? v : 0.f;
+    case CTD_ACT_SIGMOID: return 1.0f / (1.0f + __expf(-v));
+    default: return v;
+  }
+}
+// exact-ish variants for the fp32 parity mode (expf instead of the fast exp)
+__device__ __forceinline__ float ctd_act_precise(float v, int act) {
+  switch (act) {
+    case CTD_ACT_SILU: return v / (1.0f + expf(-v));
+    case CTD_ACT_LEAKY: return v > 0.f ? v : 0.1f * v;
+    case CTD_ACT_RELU: return v > 0.f ? v : 0.f;
+    case CTD_ACT_SIGMOID: return 1.0f / (1.0f + expf(-v));
+    default: return v;
+  }
+}
+
+template <typename T> __device__ __forceinline__ float to_f(T v) { return (float)v; }
+template <typename T> __device__ __forceinline__ T from_f(float v) { return (T)v; }

@@ -1,0 +1,738 @@
+// Engine: executes the lowered op program (built by the python host, graph.py)
+// on one MI355X.  Responsibilities:
+//   * validate the program, choose a kernel per op (MFMA implicit GEMM / fused /
+//     direct), repack the f32 parameter blob into the layouts those kernels read;
+//   * plan the activation arena for a given (B,H,W) with liveness-based reuse;
+//   * launch the ops in order on the caller's stream (no host syncs, so the whole
+//     forward can be captured in a hipGraph by the caller);
+//   * per-op hipEvent profiling for bench.py's roofline numbers.
+// It mirrors `TextDetBase.forward` (reference basemodel.py:240-244) only through
+// the program it is given; it has no knowledge of the network itself.
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "kernels.h"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string& msg) {
+  g_err = msg;
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                              \
+  do {                                                                                             \
+    hipError_t _e = (expr);                                                                        \
+    if (_e != hipSuccess)                                                                          \
+      return fail(CTD_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e));                 \
+  } while (0)
+
+enum Impl { IMPL_POINT = 0, IMPL_IGEMM = 1, IMPL_IGEMM_T = 2, IMPL_DIRECT = 3, IMPL_FUSED = 4 };
+
+struct OpState {
+  ctd_op op;
+  int impl = IMPL_POINT;
+  void* w_dev = nullptr;      // packed weights
+  float* b_dev = nullptr;     // bias (padded)
+  float* aux_dev = nullptr;   // anchors etc.
+  int npad = 0;
+  // filled by plan()
+  ConvArgs args{};
+  double flops = 0, bytes = 0;
+};
+
+struct TensorState {
+  ctd_tensor t;
+  int esize = 2;
+  size_t offset = 0;   // arena offset (bytes)
+  size_t bytes = 0;
+  int H = 0, W = 0;
+  int first_def = -1, last_use = -1;
+};
+
+}  // namespace
+
+struct ctd_engine {
+  int device = 0;
+  int prec = CTD_PREC_F16;
+  std::vector<TensorState> tensors;
+  std::vector<OpState> ops;
+  std::vector<void*> owned;  // device allocations to free
+  char* arena = nullptr;
+  size_t arena_bytes = 0;
+  int pB = 0, pH = 0, pW = 0;  // current plan
+  bool no_reuse = false;
+  int det_rows_per_unit = 0;
+  int det_no = 0;
+};
+
+namespace {
+
+template <typename T>
+int upload(ctd_engine* e, const std::vector<T>& host, void** out) {
+  void* d = nullptr;
+  HIP_TRY(hipMalloc(&d, std::max<size_t>(host.size() * sizeof(T), 16)));
+  HIP_TRY(hipMemcpy(d, host.data(), host.size() * sizeof(T), hipMemcpyHostToDevice));
+  e->owned.push_back(d);
+  *out = d;
+  return CTD_OK;
+}
+
+bool tensor_ok(const ctd_engine* e, int id) { return id >= 0 && id < (int)e->tensors.size(); }
+
+// ---- weight packing --------------------------------------------------------
+int pack_op(ctd_engine* e, OpState& s, const float* P, int64_t nP) {
+  const ctd_op& o = s.op;
+  const bool f16 = e->prec == CTD_PREC_F16;
+  auto need = [&](int64_t off, int64_t n) { return off >= 0 && off + n <= nP; };
+  const int cin = o.src0_c + (o.src1 >= 0 ? o.src1_c : 0);
+  const int N = o.cout, k = o.k;
+
+  auto pack_bias = [&](int npad) -> int {
+    std::vector<float> b(npad, 0.f);
+    if (o.b_off >= 0) {
+      if (!need(o.b_off, N)) return fail(CTD_ERR_INVALID, "bias out of range");
+      std::memcpy(b.data(), P + o.b_off, sizeof(float) * N);
+    }
+    return upload(e, b, (void**)&s.b_dev);
+  };
+
+  switch (o.kind) {
+    case CTD_OP_CONV: {
+      if (!need(o.w_off, (int64_t)N * cin * k * k)) return fail(CTD_ERR_INVALID, "conv weights out of range");
+      const float* W = P + o.w_off;  // (N, cin, k, k)
+      // can the MFMA kernel take it?  (channel counts multiple of 32, aligned pitches)
+      bool ig = f16 && (o.src0_c % 32 == 0) && (o.src1 < 0 || o.src1_c % 32 == 0);
+      if (ig) {
+        const ctd_tensor& t0 = e->tensors[o.src0].t;
+        const ctd_tensor& td = e->tensors[o.dst].t;
+        if (t0.channels % 8 || o.src0_coff % 8) ig = false;
+        if (o.src1 >= 0 && (e->tensors[o.src1].t.channels % 8 || o.src1_coff % 8)) ig = false;
+        if (td.channels % 4 || o.dst_coff % 4) ig = false;
+        if (o.res >= 0 && (e->tensors[o.res].t.channels % 4 || o.res_coff % 4)) ig = false;
+        if (t0.dtype != 0 || (o.src1 >= 0 && e->tensors[o.src1].t.dtype != 0)) ig = false;
+        if (o.res >= 0 && e->tensors[o.res].t.dtype != 0) ig = false;
+      }
+      if (ig) {
+        s.impl = IMPL_IGEMM;
+        const int bn = igemm_ntile(N);
+        s.npad = (N + bn - 1) / bn * bn;
+        const int K = k * k * cin;
+        std::vector<half_t> wp((size_t)s.npad * K, (half_t)0.f);
+        for (int n = 0; n < N; ++n)
+          for (int c = 0; c < cin; ++c)
+            for (int ky = 0; ky < k; ++ky)
+              for (int kx = 0; kx < k; ++kx)
+                wp[(size_t)n * K + (size_t)(ky * k + kx) * cin + c] =
+                    (half_t)W[(((size_t)n * cin + c) * k + ky) * k + kx];
+        if (int rc = upload(e, wp, &s.w_dev)) return rc;
+        return pack_bias(s.npad);
+      }
+      if (e->tensors[o.dst].t.dtype != 0 && f16)
+        return fail(CTD_ERR_UNSUPPORTED, "f32 destination needs the MFMA path");
+      s.impl = IMPL_DIRECT;
+      s.npad = N;
+      std::vector<float> wp((size_t)k * k * cin * N);
+      for (int n = 0; n < N; ++n)
+        for (int c = 0; c < cin; ++c)
+          for (int ky = 0; ky < k; ++ky)
+            for (int kx = 0; kx < k; ++kx)
+              wp[((size_t)(ky * k + kx) * cin + c) * N + n] = W[(((size_t)n * cin + c) * k + ky) * k + kx];
+      if (int rc = upload(e, wp, &s.w_dev)) return rc;
+      return pack_bias(N);
+    }
+    case CTD_OP_CONVT: {
+      if (o.src1 >= 0) return fail(CTD_ERR_UNSUPPORTED, "convT takes one source");
+      if (!need(o.w_off, (int64_t)N * cin * k * k)) return fail(CTD_ERR_INVALID, "convT weights out of range");
+      const float* W = P + o.w_off;  // (cin, N, k, k)
+      const ctd_tensor& t0 = e->tensors[o.src0].t;
+      const ctd_tensor& td = e->tensors[o.dst].t;
+      const bool ig = f16 && k == 4 && o.stride == 2 && o.pad == 1 && cin % 32 == 0 && t0.channels % 8 == 0 &&
+                      o.src0_coff % 8 == 0 && td.channels % 4 == 0 && o.dst_coff % 4 == 0 && t0.dtype == 0 &&
+                      td.dtype == 0 && N >= 32;
+      if (ig) {
+        s.impl = IMPL_IGEMM_T;
+        const int bn = igemm_ntile(N);
+        s.npad = (N + bn - 1) / bn * bn;
+        const int K = 4 * cin;
+        std::vector<half_t> wp((size_t)4 * s.npad * K, (half_t)0.f);
+        for (int ph = 0; ph < 4; ++ph) {
+          const int py = ph >> 1, px = ph & 1;
+          for (int ty = 0; ty < 2; ++ty)
+            for (int tx = 0; tx < 2; ++tx) {
+              const int dy = (py ? 0 : -1) + ty, dx = (px ? 0 : -1) + tx;
+              const int ky = py + 1 - 2 * dy, kx = px + 1 - 2 * dx;
+              for (int n = 0; n < N; ++n)
+                for (int c = 0; c < cin; ++c)
+                  wp[((size_t)ph * s.npad + n) * K + (size_t)(ty * 2 + tx) * cin + c] =
+                      (half_t)W[(((size_t)c * N + n) * 4 + ky) * 4 + kx];
+            }
+        }
+        if (int rc = upload(e, wp, &s.w_dev)) return rc;
+        return pack_bias(s.npad);
+      }
+      s.impl = IMPL_DIRECT;
+      s.npad = N;
+      std::vector<float> wp((size_t)k * k * cin * N);
+      for (int c = 0; c < cin; ++c)
+        for (int n = 0; n < N; ++n)
+          for (int ky = 0; ky < k; ++ky)
+            for (int kx = 0; kx < k; ++kx)
+              wp[((size_t)(ky * k + kx) * cin + c) * N + n] = W[(((size_t)c * N + n) * k + ky) * k + kx];
+      if (int rc = upload(e, wp, &s.w_dev)) return rc;
+      return pack_bias(N);
+    }
+    case CTD_OP_STEM: {
+      if (!f16) return fail(CTD_ERR_UNSUPPORTED, "STEM op is fp16-path only; emit INPUT + CONV for fp32");
+      if (N != 32 || k != 6 || o.stride != 2 || o.pad != 2)
+        return fail(CTD_ERR_UNSUPPORTED, "fused stem is 6x6/s2/p2, 3->32 only");
+      if (!need(o.w_off, (int64_t)N * 3 * 36)) return fail(CTD_ERR_INVALID, "stem weights out of range");
+      const float* W = P + o.w_off;
+      std::vector<float> wp((size_t)108 * N);
+      for (int n = 0; n < N; ++n)
+        for (int c = 0; c < 3; ++c)
+          for (int ky = 0; ky < 6; ++ky)
+            for (int kx = 0; kx < 6; ++kx)
+              wp[((size_t)(ky * 6 + kx) * 3 + c) * N + n] = W[(((size_t)n * 3 + c) * 6 + ky) * 6 + kx];
+      s.impl = IMPL_FUSED;
+      if (int rc = upload(e, wp, &s.w_dev)) return rc;
+      return pack_bias(N);
+    }
+    case CTD_OP_SEG_FINAL: {
+      if (!f16) return fail(CTD_ERR_UNSUPPORTED, "SEG_FINAL op is fp16-path only");
+      if (cin != 64 || N != 1) return fail(CTD_ERR_UNSUPPORTED, "fused seg-final is 64->1 only");
+      if (!need(o.w_off, (int64_t)cin * 16)) return fail(CTD_ERR_INVALID, "seg-final weights out of range");
+      const float* W = P + o.w_off;  // (cin, 1, 4, 4)
+      std::vector<float> wp((size_t)16 * cin);
+      for (int c = 0; c < cin; ++c)
+        for (int kk = 0; kk < 16; ++kk) wp[(size_t)kk * cin + c] = W[(size_t)c * 16 + kk];
+      s.impl = IMPL_FUSED;
+      if (int rc = upload(e, wp, &s.w_dev)) return rc;
+      return pack_bias(1);
+    }
+    case CTD_OP_DB_UP: {
+      if (!f16) return fail(CTD_ERR_UNSUPPORTED, "DB_UP op is fp16-path only");
+      const int q = o.aux[1];
+      if (q != 16) return fail(CTD_ERR_UNSUPPORTED, "fused db tail is q=16 only");
+      const int PB = q * q * 4 + q + q * 4 + 1;
+      if (!need(o.w_off, 2 * PB)) return fail(CTD_ERR_INVALID, "db-up params out of range");
+      std::vector<float> wp(P + o.w_off, P + o.w_off + 2 * PB);
+      s.impl = IMPL_FUSED;
+      return upload(e, wp, &s.w_dev);
+    }
+    case CTD_OP_DETECT: {
+      const int na = o.aux[2];
+      if (na < 1 || na > 4) return fail(CTD_ERR_INVALID, "detect: na must be 1..4");
+      std::vector<float> a(o.faux, o.faux + 2 * na);
+      return upload(e, a, (void**)&s.aux_dev);
+    }
+    default:
+      return CTD_OK;
+  }
+}
+
+int validate(ctd_engine* e) {
+  const int nT = (int)e->tensors.size();
+  for (auto& t : e->tensors) {
+    if (t.t.channels < 1 || t.t.log2_down < 0 || t.t.log2_down > 6)
+      return fail(CTD_ERR_INVALID, "tensor: bad channels/log2_down");
+  }
+  for (size_t i = 0; i < e->ops.size(); ++i) {
+    const ctd_op& o = e->ops[i].op;
+    auto bad = [&](const char* m) { return fail(CTD_ERR_INVALID, "op " + std::to_string(i) + ": " + m); };
+    auto slice_ok = [&](int id, int coff, int c) {
+      return tensor_ok(e, id) && coff >= 0 && c >= 1 && coff + c <= e->tensors[id].t.channels;
+    };
+    switch (o.kind) {
+      case CTD_OP_INPUT:
+        if (!slice_ok(o.dst, 0, 3)) return bad("input dst");
+        break;
+      case CTD_OP_STEM:
+        if (!slice_ok(o.dst, o.dst_coff, o.cout)) return bad("stem dst");
+        break;
+      case CTD_OP_CONV:
+      case CTD_OP_CONVT:
+        if (!slice_ok(o.src0, o.src0_coff, o.src0_c)) return bad("src0");
+        if (o.src1 >= 0 && !slice_ok(o.src1, o.src1_coff, o.src1_c)) return bad("src1");
+        if (o.res >= 0 && !slice_ok(o.res, o.res_coff, o.cout)) return bad("res");
+        if (!slice_ok(o.dst, o.dst_coff, o.cout)) return bad("dst");
+        if (o.k < 1 || o.k > 7 || o.stride < 1 || o.stride > 2) return bad("k/stride");
+        break;
+      case CTD_OP_MAXPOOL:
+      case CTD_OP_AVGPOOL2:
+        if (!slice_ok(o.src0, o.src0_coff, o.src0_c) || !slice_ok(o.dst, o.dst_coff, o.src0_c)) return bad("pool");
+        break;
+      case CTD_OP_DETECT:
+        if (!slice_ok(o.src0, o.src0_coff, o.aux[2] * o.aux[3])) return bad("detect src");
+        break;
+      case CTD_OP_EXPORT:
+        if (!slice_ok(o.src0, o.src0_coff, 1)) return bad("export src");
+        break;
+      case CTD_OP_SEG_FINAL:
+      case CTD_OP_DB_UP:
+        if (!slice_ok(o.src0, o.src0_coff, o.src0_c)) return bad("fused src");
+        break;
+      default:
+        return bad("unknown op kind");
+    }
+  }
+  (void)nT;
+  return CTD_OK;
+}
+
+size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// ---- arena planning -----------------------------------------------------------
+int plan(ctd_engine* e, int B, int H, int W) {
+  if (B < 1 || H < 64 || W < 64 || H % 64 || W % 64)
+    return fail(CTD_ERR_INVALID, "H and W must be positive multiples of 64 and B >= 1");
+  const int nT = (int)e->tensors.size(), nO = (int)e->ops.size();
+  for (auto& t : e->tensors) {
+    t.esize = (e->prec == CTD_PREC_F32 || t.t.dtype == 1) ? 4 : 2;
+    t.H = H >> t.t.log2_down;
+    t.W = W >> t.t.log2_down;
+    t.bytes = align_up((size_t)B * t.H * t.W * t.t.channels * t.esize, 256);
+    t.first_def = -1;
+    t.last_use = -1;
+  }
+  auto use = [&](int id, int i) {
+    if (id >= 0) e->tensors[id].last_use = std::max(e->tensors[id].last_use, i);
+  };
+  auto def = [&](int id, int i) {
+    if (id >= 0) {
+      if (e->tensors[id].first_def < 0) e->tensors[id].first_def = i;
+      e->tensors[id].last_use = std::max(e->tensors[id].last_use, i);
+    }
+  };
+  for (int i = 0; i < nO; ++i) {
+    const ctd_op& o = e->ops[i].op;
+    switch (o.kind) {
+      case CTD_OP_INPUT:
+      case CTD_OP_STEM: def(o.dst, i); break;
+      case CTD_OP_CONV:
+      case CTD_OP_CONVT:
+        use(o.src0, i); if (o.src1 >= 0) use(o.src1, i); if (o.res >= 0) use(o.res, i); def(o.dst, i); break;
+      case CTD_OP_MAXPOOL:
+      case CTD_OP_AVGPOOL2: use(o.src0, i); def(o.dst, i); break;
+      default: use(o.src0, i); break;
+    }
+  }
+  for (int t = 0; t < nT; ++t)
+    if (e->tensors[t].last_use >= 0 && e->tensors[t].first_def < 0)
+      return fail(CTD_ERR_INVALID, "tensor " + std::to_string(t) + " is read but never written");
+
+  // first-fit allocation over a free list, in op order
+  struct Blk { size_t off, size; };
+  std::vector<Blk> freel;
+  size_t top = 0;
+  auto alloc = [&](size_t sz) {
+    if (!e->no_reuse) {
+      for (size_t i = 0; i < freel.size(); ++i)
+        if (freel[i].size >= sz) {
+          const size_t off = freel[i].off;
+          freel[i].off += sz;
+          freel[i].size -= sz;
+          if (!freel[i].size) freel.erase(freel.begin() + i);
+          return off;
+        }
+    }
+    const size_t off = top;
+    top += sz;
+    return off;
+  };
+  auto release = [&](size_t off, size_t sz) {
+    freel.push_back({off, sz});
+    std::sort(freel.begin(), freel.end(), [](const Blk& a, const Blk& b) { return a.off < b.off; });
+    for (size_t i = 0; i + 1 < freel.size();) {
+      if (freel[i].off + freel[i].size == freel[i + 1].off) {
+        freel[i].size += freel[i + 1].size;
+        freel.erase(freel.begin() + i + 1);
+      } else ++i;
+    }
+  };
+  for (int i = 0; i < nO; ++i) {
+    for (int t = 0; t < nT; ++t)
+      if (e->tensors[t].first_def == i) e->tensors[t].offset = alloc(e->tensors[t].bytes);
+    for (int t = 0; t < nT; ++t)
+      if (e->tensors[t].first_def >= 0 && e->tensors[t].last_use == i) release(e->tensors[t].offset, e->tensors[t].bytes);
+  }
+  if (top > e->arena_bytes) {
+    HIP_TRY(hipDeviceSynchronize());
+    if (e->arena) HIP_TRY(hipFree(e->arena));
+    e->arena = nullptr;
+    e->arena_bytes = 0;
+    hipError_t me = hipMalloc((void**)&e->arena, top);
+    if (me != hipSuccess) return fail(CTD_ERR_NOMEM, "arena hipMalloc of " + std::to_string(top) + " bytes failed");
+    e->arena_bytes = top;
+  }
+
+  // per-op launch arguments
+  const bool f16 = e->prec == CTD_PREC_F16;
+  for (int i = 0; i < nO; ++i) {
+    OpState& s = e->ops[i];
+    const ctd_op& o = s.op;
+    ConvArgs a{};
+    auto view = [&](int id, int coff, int c, int up) {
+      SrcView v{};
+      const TensorState& t = e->tensors[id];
+      v.ptr = e->arena + t.offset + (size_t)coff * t.esize;
+      v.pitch = t.t.channels;
+      v.c = c;
+      v.up = up;
+      v.H = t.H;
+      v.W = t.W;
+      return v;
+    };
+    s.flops = 0;
+    s.bytes = 0;
+    if (o.kind == CTD_OP_CONV || o.kind == CTD_OP_CONVT) {
+      const TensorState& td = e->tensors[o.dst];
+      a.s0 = view(o.src0, o.src0_coff, o.src0_c, o.src0_up);
+      if (o.src1 >= 0) a.s1 = view(o.src1, o.src1_coff, o.src1_c, o.src1_up);
+      a.B = B;
+      a.Hin = a.s0.H << (o.src0_up ? 1 : 0);
+      a.Win = a.s0.W << (o.src0_up ? 1 : 0);
+      if (o.src1 >= 0) {
+        const int h1 = a.s1.H << (o.src1_up ? 1 : 0), w1 = a.s1.W << (o.src1_up ? 1 : 0);
+        if (h1 != a.Hin || w1 != a.Win) return fail(CTD_ERR_INVALID, "op " + std::to_string(i) + ": source sizes differ");
+      }
+      a.dst = e->arena + td.offset + (size_t)o.dst_coff * td.esize;
+      a.pitchD = td.t.channels;
+      a.oH = td.H;
+      a.oW = td.W;
+      if (o.res >= 0) {
+        const TensorState& tr = e->tensors[o.res];
+        a.res = e->arena + tr.offset + (size_t)o.res_coff * tr.esize;
+        a.pitchR = tr.t.channels;
+        if (tr.H != td.H || tr.W != td.W) return fail(CTD_ERR_INVALID, "residual size mismatch");
+      }
+      a.act = o.act;
+      a.N = o.cout;
+      a.Npad = s.npad;
+      a.w = s.w_dev;
+      a.bias = s.b_dev;
+      const int cin = o.src0_c + (o.src1 >= 0 ? o.src1_c : 0);
+      a.nphase = 1;
+      a.osy = a.osx = 1;
+      if (o.kind == CTD_OP_CONV) {
+        const int Ho = (a.Hin + 2 * o.pad - o.k) / o.stride + 1, Wo = (a.Win + 2 * o.pad - o.k) / o.stride + 1;
+        if (Ho != td.H || Wo != td.W)
+          return fail(CTD_ERR_INVALID, "op " + std::to_string(i) + ": conv output size does not match dst tensor");
+        a.Mh = Ho; a.Mw = Wo;
+        a.KH = a.KW = o.k;
+        a.stride = o.stride;
+        a.dy0 = a.dx0 = -o.pad;
+        a.K = o.k * o.k * cin;
+        a.M = B * Ho * Wo;
+        s.flops = 2.0 * a.M * a.N * a.K;
+      } else {
+        const int Ho = (a.Hin - 1) * o.stride - 2 * o.pad + o.k, Wo = (a.Win - 1) * o.stride - 2 * o.pad + o.k;
+        if (Ho != td.H || Wo != td.W)
+          return fail(CTD_ERR_INVALID, "op " + std::to_string(i) + ": convT output size does not match dst tensor");
+        if (s.impl == IMPL_IGEMM_T) {
+          a.Mh = a.Hin; a.Mw = a.Win;
+          a.KH = a.KW = 2;
+          a.stride = 1;
+          a.K = 4 * cin;
+          a.M = B * a.Hin * a.Win;
+          a.nphase = 4;
+          a.osy = a.osx = 2;
+          a.w_phase_stride = (long long)s.npad * a.K;
+        } else {
+          a.KH = a.KW = o.k;
+          a.stride = o.stride;
+          a.dy0 = a.dx0 = o.pad;
+          a.M = B * Ho * Wo;
+          a.K = o.k * o.k * cin;
+        }
+        // every input pixel meets k*k taps
+        s.flops = 2.0 * (double)B * a.Hin * a.Win * o.k * o.k * cin * a.N;
+      }
+      if ((s.impl == IMPL_IGEMM || s.impl == IMPL_IGEMM_T) && !igemm_supported(a))
+        return fail(CTD_ERR_UNSUPPORTED, "op " + std::to_string(i) + ": shape rejected by the MFMA kernel");
+      const double es = f16 ? 2 : 4;
+      s.bytes = ((double)B * a.s0.H * a.s0.W * a.s0.c + (o.src1 >= 0 ? (double)B * a.s1.H * a.s1.W * a.s1.c : 0)) * es +
+                (double)B * td.H * td.W * a.N * td.esize + (o.res >= 0 ? (double)B * td.H * td.W * a.N * es : 0) +
+                (double)a.N * o.k * o.k * cin * es;
+    }
+    s.args = a;
+  }
+  e->pB = B; e->pH = H; e->pW = W;
+  return CTD_OK;
+}
+
+struct Outs {
+  const void* input; int in_fmt;
+  float* blks; float* mask; float* lines; uint8_t* mask_u8; uint8_t* bitmap;
+  int blk_rows;
+};
+
+int launch_op(ctd_engine* e, int i, const Outs& x, hipStream_t st) {
+  OpState& s = e->ops[i];
+  const ctd_op& o = s.op;
+  const bool f16 = e->prec == CTD_PREC_F16;
+  const int B = e->pB, H = e->pH, W = e->pW;
+  auto tptr = [&](int id, int coff) {
+    const TensorState& t = e->tensors[id];
+    return (void*)(e->arena + t.offset + (size_t)coff * t.esize);
+  };
+  switch (o.kind) {
+    case CTD_OP_INPUT: {
+      void* d = tptr(o.dst, 0);
+      if (x.in_fmt == CTD_IN_NCHW_F32) launch_input_nchw((const float*)x.input, d, B, H, W, f16, st);
+      else launch_input_u8((const uint8_t*)x.input, d, B, H, W, f16, st);
+      break;
+    }
+    case CTD_OP_STEM: {
+      const TensorState& td = e->tensors[o.dst];
+      launch_stem(x.input, x.in_fmt, (half_t*)tptr(o.dst, o.dst_coff), td.t.channels, B, H, W, o.cout,
+                  (const float*)s.w_dev, s.b_dev, o.act, st);
+      break;
+    }
+    case CTD_OP_CONV:
+      if (s.impl == IMPL_IGEMM) launch_conv_igemm(s.args, e->tensors[o.dst].esize == 4, st);
+      else launch_conv_direct(s.args, f16, st);
+      break;
+    case CTD_OP_CONVT:
+      if (s.impl == IMPL_IGEMM_T) launch_conv_igemm(s.args, false, st);
+      else launch_convt_direct(s.args, f16, st);
+      break;
+    case CTD_OP_MAXPOOL: {
+      const TensorState& ts = e->tensors[o.src0];
+      const TensorState& td = e->tensors[o.dst];
+      launch_maxpool(tptr(o.src0, o.src0_coff), ts.t.channels, tptr(o.dst, o.dst_coff), td.t.channels, o.src0_c, B,
+                     ts.H, ts.W, o.k, f16, st);
+      break;
+    }
+    case CTD_OP_AVGPOOL2: {
+      const TensorState& ts = e->tensors[o.src0];
+      const TensorState& td = e->tensors[o.dst];
+      launch_avgpool2(tptr(o.src0, o.src0_coff), ts.t.channels, tptr(o.dst, o.dst_coff), td.t.channels, o.src0_c, B,
+                      td.H, td.W, f16, st);
+      break;
+    }
+    case CTD_OP_DETECT: {
+      const TensorState& ts = e->tensors[o.src0];
+      if (!x.blks) break;
+      // aux[1] is the row offset for a 64x64 unit input scaled by (H/64)*(W/64)
+      const int unit = (H / 64) * (W / 64);
+      launch_detect_decode(tptr(o.src0, o.src0_coff), ts.t.channels, ts.esize == 2, x.blks, x.blk_rows,
+                           o.aux[1] * unit, B, ts.H, ts.W, o.aux[2], o.aux[3], (float)o.aux[0], s.aux_dev, st);
+      break;
+    }
+    case CTD_OP_EXPORT: {
+      const TensorState& ts = e->tensors[o.src0];
+      float* out = o.aux[0] == CTD_OUT_MASK ? x.mask : x.lines;
+      if (!out) break;
+      const int nplanes = o.aux[0] == CTD_OUT_MASK ? 1 : 2;
+      uint8_t* u8 = nullptr;
+      int mode = 0;
+      if (o.aux[0] == CTD_OUT_MASK) { u8 = x.mask_u8; mode = 1; }
+      else if (o.aux[1] == 0) { u8 = x.bitmap; mode = 2; }
+      launch_export_plane(tptr(o.src0, o.src0_coff), ts.t.channels, ts.esize == 2, out, nplanes, o.aux[1], u8, mode,
+                          o.faux[0], B, ts.H, ts.W, st);
+      break;
+    }
+    case CTD_OP_SEG_FINAL: {
+      const TensorState& ts = e->tensors[o.src0];
+      if (!x.mask) break;
+      launch_seg_final((const half_t*)tptr(o.src0, o.src0_coff), ts.t.channels, o.src0_c, B, ts.H, ts.W,
+                       (const float*)s.w_dev, 0.f, x.mask, x.mask_u8, st);
+      break;
+    }
+    case CTD_OP_DB_UP: {
+      const TensorState& ts = e->tensors[o.src0];
+      if (!x.lines) break;
+      launch_db_up((const half_t*)tptr(o.src0, o.src0_coff), ts.t.channels, o.aux[1], B, ts.H, ts.W,
+                   (const float*)s.w_dev, x.lines, x.bitmap, o.faux[0], st);
+      break;
+    }
+  }
+  return CTD_OK;
+}
+
+int prepare(ctd_engine* e, int B, int H, int W) {
+  HIP_TRY(hipSetDevice(e->device));
+  if (B != e->pB || H != e->pH || W != e->pW) return plan(e, B, H, W);
+  return CTD_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* ctd_last_error(void) { return g_err.c_str(); }
+int32_t ctd_abi_version(void) { return CTD_ABI_VERSION; }
+
+int ctd_device_info(int32_t device, char* name, int32_t* cu_count, int64_t* hbm_bytes) {
+  hipDeviceProp_t p;
+  HIP_TRY(hipGetDeviceProperties(&p, device));
+  if (name) { std::strncpy(name, p.name, 255); name[255] = 0; }
+  if (cu_count) *cu_count = p.multiProcessorCount;
+  if (hbm_bytes) *hbm_bytes = (int64_t)p.totalGlobalMem;
+  int arch = 0;
+  const char* g = std::strstr(p.gcnArchName, "gfx");
+  if (g) arch = std::atoi(g + 3);
+  return arch;
+}
+
+int ctd_engine_create(ctd_engine** out, const ctd_tensor* tensors, int32_t n_tensors, const ctd_op* ops,
+                      int32_t n_ops, const float* params, int64_t n_params, int32_t precision, int32_t device) {
+  if (!out || !tensors || !ops || !params || n_tensors < 1 || n_ops < 1)
+    return fail(CTD_ERR_INVALID, "null/empty program");
+  if (precision != CTD_PREC_F32 && precision != CTD_PREC_F16) return fail(CTD_ERR_INVALID, "bad precision");
+  HIP_TRY(hipSetDevice(device));
+  ctd_engine* e = new ctd_engine();
+  e->device = device;
+  e->prec = precision;
+  e->no_reuse = std::getenv("CTD_NO_REUSE") != nullptr;
+  e->tensors.resize(n_tensors);
+  for (int i = 0; i < n_tensors; ++i) e->tensors[i].t = tensors[i];
+  e->ops.resize(n_ops);
+  for (int i = 0; i < n_ops; ++i) e->ops[i].op = ops[i];
+  int rc = validate(e);
+  for (int i = 0; rc == CTD_OK && i < n_ops; ++i) rc = pack_op(e, e->ops[i], params, n_params);
+  if (rc == CTD_OK) {
+    int rows = 0, no = 0;
+    for (auto& s : e->ops)
+      if (s.op.kind == CTD_OP_DETECT) {
+        const int st = s.op.aux[0];
+        if (st < 1 || 64 % st) { rc = fail(CTD_ERR_INVALID, "detect stride must divide 64"); break; }
+        rows += s.op.aux[2] * (64 / st) * (64 / st);
+        no = s.op.aux[3];
+      }
+    e->det_rows_per_unit = rows;
+    e->det_no = no;
+  }
+  if (rc != CTD_OK) {
+    ctd_engine_destroy(e);
+    return rc;
+  }
+  *out = e;
+  return CTD_OK;
+}
+
+void ctd_engine_destroy(ctd_engine* e) {
+  if (!e) return;
+  (void)hipSetDevice(e->device);
+  (void)hipDeviceSynchronize();
+  for (void* p : e->owned) (void)hipFree(p);
+  if (e->arena) (void)hipFree(e->arena);
+  delete e;
+}
+
+int ctd_engine_blks_shape(const ctd_engine* e, int32_t H, int32_t W, int32_t* rows, int32_t* no) {
+  if (!e || H % 64 || W % 64) return fail(CTD_ERR_INVALID, "H, W must be multiples of 64");
+  if (rows) *rows = e->det_rows_per_unit * (H / 64) * (W / 64);
+  if (no) *no = e->det_no;
+  return CTD_OK;
+}
+
+int ctd_engine_forward(ctd_engine* e, const void* input_dev, int32_t input_fmt, int32_t B, int32_t H, int32_t W,
+                       float* blks_dev, float* mask_dev, float* lines_dev, uint8_t* mask_u8_dev, uint8_t* bitmap_dev,
+                       void* stream) {
+  if (!e || !input_dev) return fail(CTD_ERR_INVALID, "null engine/input");
+  if (input_fmt != CTD_IN_NCHW_F32 && input_fmt != CTD_IN_NHWC_U8) return fail(CTD_ERR_INVALID, "bad input format");
+  if (int rc = prepare(e, B, H, W)) return rc;
+  Outs x{input_dev, input_fmt, blks_dev, mask_dev, lines_dev, mask_u8_dev, bitmap_dev,
+         e->det_rows_per_unit * (H / 64) * (W / 64)};
+  for (int i = 0; i < (int)e->ops.size(); ++i)
+    if (int rc = launch_op(e, i, x, (hipStream_t)stream)) return rc;
+  HIP_TRY(hipGetLastError());
+  return CTD_OK;
+}
+
+int32_t ctd_engine_n_ops(const ctd_engine* e) { return e ? (int32_t)e->ops.size() : 0; }
+
+int ctd_engine_op_work(const ctd_engine* e, double* flops, double* bytes, int32_t* kernel_class) {
+  if (!e) return fail(CTD_ERR_INVALID, "null engine");
+  for (size_t i = 0; i < e->ops.size(); ++i) {
+    if (flops) flops[i] = e->ops[i].flops;
+    if (bytes) bytes[i] = e->ops[i].bytes;
+    if (kernel_class) kernel_class[i] = e->ops[i].impl;
+  }
+  return CTD_OK;
+}
+
+int ctd_engine_profile(ctd_engine* e, const void* input_dev, int32_t input_fmt, int32_t B, int32_t H, int32_t W,
+                       float* blks_dev, float* mask_dev, float* lines_dev, uint8_t* mask_u8_dev, uint8_t* bitmap_dev,
+                       void* stream, float* op_ms) {
+  if (!e || !input_dev || !op_ms) return fail(CTD_ERR_INVALID, "null argument");
+  if (int rc = prepare(e, B, H, W)) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  const int n = (int)e->ops.size();
+  std::vector<hipEvent_t> ev(n + 1);
+  for (auto& v : ev) HIP_TRY(hipEventCreate(&v));
+  Outs x{input_dev, input_fmt, blks_dev, mask_dev, lines_dev, mask_u8_dev, bitmap_dev,
+         e->det_rows_per_unit * (H / 64) * (W / 64)};
+  HIP_TRY(hipEventRecord(ev[0], st));
+  for (int i = 0; i < n; ++i) {
+    if (int rc = launch_op(e, i, x, st)) return rc;
+    HIP_TRY(hipEventRecord(ev[i + 1], st));
+  }
+  HIP_TRY(hipStreamSynchronize(st));
+  for (int i = 0; i < n; ++i) HIP_TRY(hipEventElapsedTime(&op_ms[i], ev[i], ev[i + 1]));
+  for (auto& v : ev) (void)hipEventDestroy(v);
+  return CTD_OK;
+}
+
+int ctd_engine_read_tensor(ctd_engine* e, int32_t tensor_id, float* host_out, int64_t n_floats) {
+  if (!e || !tensor_ok(e, tensor_id) || !host_out) return fail(CTD_ERR_INVALID, "bad tensor id");
+  if (!e->arena) return fail(CTD_ERR_INVALID, "no forward has run");
+  const TensorState& t = e->tensors[tensor_id];
+  const int64_t n = (int64_t)e->pB * t.H * t.W * t.t.channels;
+  if (n_floats != n) return fail(CTD_ERR_INVALID, "size mismatch: tensor has " + std::to_string(n) + " elements");
+  HIP_TRY(hipDeviceSynchronize());
+  if (t.esize == 4) {
+    HIP_TRY(hipMemcpy(host_out, e->arena + t.offset, n * 4, hipMemcpyDeviceToHost));
+  } else {
+    std::vector<half_t> tmp(n);
+    HIP_TRY(hipMemcpy(tmp.data(), e->arena + t.offset, n * 2, hipMemcpyDeviceToHost));
+    for (int64_t i = 0; i < n; ++i) host_out[i] = (float)tmp[i];
+  }
+  return CTD_OK;
+}
+
+int64_t ctd_engine_workspace_bytes(const ctd_engine* e) { return e ? (int64_t)e->arena_bytes : 0; }
+
+// ---- post-processing entry points (kernels_post.hip) ------------------------------
+size_t ctd_nms_workspace_bytes(int32_t B, int32_t rows) { return nms_workspace_bytes(B, rows); }
+
+int ctd_nms(const float* blks_dev, int32_t B, int32_t rows, int32_t no, float conf_thres, float iou_thres,
+            int32_t max_det, int32_t max_nms, float max_wh, float* dets_dev, int32_t* counts_dev, void* ws_dev,
+            size_t ws_bytes, void* stream) {
+  if (!blks_dev || !dets_dev || !counts_dev || !ws_dev) return fail(CTD_ERR_INVALID, "null pointer");
+  if (B < 1 || rows < 1 || no < 6 || max_det < 1) return fail(CTD_ERR_INVALID, "bad sizes");
+  // reference utils/yolov5_utils.py:139-140 asserts
+  if (!(conf_thres >= 0.f && conf_thres <= 1.f)) return fail(CTD_ERR_INVALID, "Invalid Confidence threshold");
+  if (!(iou_thres >= 0.f && iou_thres <= 1.f)) return fail(CTD_ERR_INVALID, "Invalid IoU");
+  if (ws_bytes < nms_workspace_bytes(B, rows)) return fail(CTD_ERR_INVALID, "workspace too small");
+  launch_nms(blks_dev, B, rows, no, conf_thres, iou_thres, max_det, max_nms, max_wh, dets_dev, counts_dev, ws_dev,
+             (hipStream_t)stream);
+  HIP_TRY(hipGetLastError());
+  return CTD_OK;
+}
+
+size_t ctd_ccl_workspace_bytes(int32_t B, int32_t H, int32_t W) { return ccl_workspace_bytes(B, H, W); }
+
+int ctd_ccl(const uint8_t* img_dev, int32_t B, int32_t H, int32_t W, int32_t thresh, int32_t connectivity,
+            int32_t* labels_dev, int32_t* n_dev, int32_t* stats_dev, int32_t max_labels, void* ws_dev, size_t ws_bytes,
+            void* stream) {
+  if (!img_dev || !labels_dev || !n_dev || !ws_dev) return fail(CTD_ERR_INVALID, "null pointer");
+  if (connectivity != 4 && connectivity != 8) return fail(CTD_ERR_INVALID, "connectivity must be 4 or 8");
+  if (B < 1 || H < 1 || W < 1 || (long long)H * W >= (1LL << 30)) return fail(CTD_ERR_INVALID, "bad sizes");
+  if (ws_bytes < ccl_workspace_bytes(B, H, W)) return fail(CTD_ERR_INVALID, "workspace too small");
+  launch_ccl(img_dev, B, H, W, thresh, connectivity, labels_dev, n_dev, stats_dev, max_labels, ws_dev,
+             (hipStream_t)stream);
+  HIP_TRY(hipGetLastError());
+  return CTD_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,53 @@
+// Host-side launchers of every device kernel (definitions in the .hip files).
+#pragma once
+#include "ctd_common.h"
+
+// ---- kernels_basic.hip : direct (VALU) kernels, T = float | half_t -------
+// weights for the direct conv: f32 [KH*KW][cin_total][N]
+void launch_conv_direct(const ConvArgs& a, bool f16, hipStream_t st);
+// generic transposed conv; weights f32 [k*k][cin][N]; a.stride = s, a.dy0 = pad, a.KH = k
+void launch_convt_direct(const ConvArgs& a, bool f16, hipStream_t st);
+void launch_input_nchw(const float* in, void* dst, int B, int H, int W, bool f16, hipStream_t st);
+void launch_input_u8(const uint8_t* in, void* dst, int B, int H, int W, bool f16, hipStream_t st);
+void launch_maxpool(const void* src, int pitchS, void* dst, int pitchD, int C, int B, int H, int W, int k,
+                    bool f16, hipStream_t st);
+void launch_avgpool2(const void* src, int pitchS, void* dst, int pitchD, int C, int B, int Ho, int Wo,
+                     bool f16, hipStream_t st);
+// raw: (B,ny,nx,pitch) with na*no used channels -> blks rows [row_off, row_off+na*ny*nx)
+void launch_detect_decode(const void* raw, int pitch, bool raw_f16, float* blks, int rows_total, int row_off,
+                          int B, int ny, int nx, int na, int no, float stride, const float* anchors_px,
+                          hipStream_t st);
+// 1-channel activation -> plane `plane` of an (B,nplanes,H,W) f32 tensor (+ optional u8)
+// u8_mode: 0 none, 1 = (uint8)(v*255) (truncate), 2 = v > thresh
+void launch_export_plane(const void* src, int pitch, bool f16, float* out, int nplanes, int plane, uint8_t* u8,
+                         int u8_mode, float thresh, int B, int H, int W, hipStream_t st);
+
+// ---- kernels_igemm.hip : MFMA implicit-GEMM conv (fp16 in, fp32 acc) ------
+// weights: half [nphase][Npad][K], K index = (ty*KW+tx)*(c0+c1) + c
+bool igemm_supported(const ConvArgs& a);
+int igemm_ntile(int N);  // N tile the dispatcher will use (weights must be padded to it)
+void launch_conv_igemm(const ConvArgs& a, bool dst_f32, hipStream_t st);
+
+// ---- kernels_fused.hip ----------------------------------------------------
+// stem: 6x6 s2 p2, 3 -> N (N <= 32... multiple of 8), reads the network input directly.
+// weights f32 [108][N] (k index = (ky*6+kx)*3 + c), bias f32 [N]
+void launch_stem(const void* in, int in_fmt, half_t* dst, int pitchD, int B, int H, int W, int N,
+                 const float* w, const float* bias, int act, hipStream_t st);
+// seg final: ConvT 4x4 s2 p1 (C -> 1) + sigmoid; src (B,H,W,C) half; weights f32 [16][C] (ky*4+kx)
+void launch_seg_final(const half_t* src, int pitch, int C, int B, int H, int W, const float* w, float bias,
+                      float* mask, uint8_t* mask_u8, hipStream_t st);
+// db tail: src (B,H,W, 2q) half [binarize q | thresh q] (already conv3x3+BN+ReLU)
+// params f32 per branch: W1[q][q][2][2] (cin,cout,ky,kx) b1[q] W2[q][1][2][2] b2[1]
+void launch_db_up(const half_t* src, int pitch, int q, int B, int H, int W, const float* params, float* lines,
+                  uint8_t* bitmap, float thresh, hipStream_t st);
+
+// ---- kernels_post.hip -------------------------------------------------------
+size_t nms_workspace_bytes(int B, int rows);
+void launch_nms(const float* blks, int B, int rows, int no, float conf, float iou, int max_det, int max_nms,
+                float max_wh, float* dets, int* counts, void* ws, hipStream_t st);
+size_t ccl_workspace_bytes(int B, int H, int W);
+void launch_ccl(const uint8_t* img, int B, int H, int W, int thresh, int conn, int* labels, int* n_out,
+                int* stats, int max_labels, void* ws, hipStream_t st);
+
+// ---- mfma layout probe (selftest) -------------------------------------------
+void launch_mfma_probe(const half_t* a, const half_t* b, float* out, hipStream_t st);

@@ -1,0 +1,279 @@
+// Direct (VALU) kernels: the exact-fp32 reference mode of the engine and the
+// universal fallback for shapes the MFMA kernels do not cover.  NHWC layout,
+// channel index fastest across lanes so weight reads and stores coalesce.
+#include "kernels.h"
+
+namespace {
+
+template <typename T>
+__device__ __forceinline__ const T* src_pixel(const SrcView& s, int b, int iy, int ix) {
+  int sy = s.up ? (iy >> 1) : iy;
+  int sx = s.up ? (ix >> 1) : ix;
+  return (const T*)s.ptr + ((size_t)((size_t)b * s.H + sy) * s.W + sx) * s.pitch;
+}
+
+// out[m][n] = act(bias[n] + sum_{ty,tx,c} in[b, oy*s+dy0+ty, ox*s+dx0+tx, c] * w[(ty*KW+tx)*Ct + c][n]) (+res)
+// (reference: nn.Conv2d as used by common.py:30-49 Conv, basemodel.py:91,96,135)
+template <typename T, bool PRECISE>
+__global__ __launch_bounds__(256) void conv_direct_kernel(ConvArgs a) {
+  const long long total = (long long)a.M * a.N;
+  const int Ct = a.s0.c + a.s1.c;
+  const float* __restrict__ w = (const float*)a.w;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (long long)gridDim.x * blockDim.x) {
+    const int n = (int)(idx % a.N);
+    const int m = (int)(idx / a.N);
+    const int ox = m % a.Mw;
+    const int oy = (m / a.Mw) % a.Mh;
+    const int b = m / (a.Mw * a.Mh);
+    float acc = 0.f;
+    for (int ty = 0; ty < a.KH; ++ty) {
+      const int iy = oy * a.stride + a.dy0 + ty;
+      if (iy < 0 || iy >= a.Hin) continue;
+      for (int tx = 0; tx < a.KW; ++tx) {
+        const int ix = ox * a.stride + a.dx0 + tx;
+        if (ix < 0 || ix >= a.Win) continue;
+        const float* wp = w + (size_t)((ty * a.KW + tx) * Ct) * a.N + n;
+        const T* p0 = src_pixel<T>(a.s0, b, iy, ix);
+        for (int c = 0; c < a.s0.c; ++c) acc = fmaf(to_f(p0[c]), wp[(size_t)c * a.N], acc);
+        if (a.s1.c) {
+          const T* p1 = src_pixel<T>(a.s1, b, iy, ix);
+          const float* wq = wp + (size_t)a.s0.c * a.N;
+          for (int c = 0; c < a.s1.c; ++c) acc = fmaf(to_f(p1[c]), wq[(size_t)c * a.N], acc);
+        }
+      }
+    }
+    if (a.bias) acc += a.bias[n];
+    acc = PRECISE ? ctd_act_precise(acc, a.act) : ctd_act(acc, a.act);
+    const size_t opix = ((size_t)b * a.oH + (oy * a.osy + a.ooy)) * a.oW + (ox * a.osx + a.oox);
+    if (a.res) acc += to_f(((const T*)a.res)[opix * a.pitchR + n]);
+    ((T*)a.dst)[opix * a.pitchD + n] = from_f<T>(acc);
+  }
+}
+
+// Generic ConvTranspose2d (reference basemodel.py:26,58,99,102): a.KH = k, a.stride = s, a.dy0 = pad.
+// out[b,oy,ox,n] = bias[n] + sum_{ky,kx,c : oy+p-ky = s*iy} in[b,iy,ix,c] * w[(ky*k+kx)*C + c][n]
+template <typename T, bool PRECISE>
+__global__ __launch_bounds__(256) void convt_direct_kernel(ConvArgs a) {
+  const long long total = (long long)a.B * a.oH * a.oW * a.N;
+  const int C = a.s0.c;
+  const int k = a.KH, s = a.stride, p = a.dy0;
+  const float* __restrict__ w = (const float*)a.w;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (long long)gridDim.x * blockDim.x) {
+    const int n = (int)(idx % a.N);
+    const long long pix = idx / a.N;
+    const int ox = (int)(pix % a.oW);
+    const int oy = (int)((pix / a.oW) % a.oH);
+    const int b = (int)(pix / ((long long)a.oW * a.oH));
+    float acc = 0.f;
+    for (int ky = 0; ky < k; ++ky) {
+      const int ty = oy + p - ky;
+      if (ty < 0 || (ty % s) != 0) continue;
+      const int iy = ty / s;
+      if (iy >= a.Hin) continue;
+      for (int kx = 0; kx < k; ++kx) {
+        const int tx = ox + p - kx;
+        if (tx < 0 || (tx % s) != 0) continue;
+        const int ix = tx / s;
+        if (ix >= a.Win) continue;
+        const T* p0 = src_pixel<T>(a.s0, b, iy, ix);
+        const float* wp = w + (size_t)((ky * k + kx) * C) * a.N + n;
+        for (int c = 0; c < C; ++c) acc = fmaf(to_f(p0[c]), wp[(size_t)c * a.N], acc);
+      }
+    }
+    if (a.bias) acc += a.bias[n];
+    acc = PRECISE ? ctd_act_precise(acc, a.act) : ctd_act(acc, a.act);
+    ((T*)a.dst)[(size_t)pix * a.pitchD + n] = from_f<T>(acc);
+  }
+}
+
+// reference inference.py:77-82: the net sees (B,3,H,W) f32 in [0,1]
+template <typename T>
+__global__ void input_nchw_kernel(const float* __restrict__ in, T* __restrict__ dst, int B, int H, int W) {
+  const long long hw = (long long)H * W;
+  const long long total = (long long)B * hw;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const long long b = i / hw, p = i % hw;
+    const float* src = in + b * 3 * hw + p;
+    T* d = dst + i * 3;
+    d[0] = from_f<T>(src[0]);
+    d[1] = from_f<T>(src[hw]);
+    d[2] = from_f<T>(src[2 * hw]);
+  }
+}
+
+// u8 page in the channel order the net consumes; x/255 as float32 like
+// `astype(np.float32) / 255` (reference inference.py:78)
+template <typename T>
+__global__ void input_u8_kernel(const uint8_t* __restrict__ in, T* __restrict__ dst, long long total3) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total3;
+       i += (long long)gridDim.x * blockDim.x)
+    dst[i] = from_f<T>((float)in[i] / 255.0f);
+}
+
+// nn.MaxPool2d(k, stride 1, pad k/2) (reference common.py:188); padding is -inf
+template <typename T>
+__global__ void maxpool_kernel(const T* __restrict__ src, int pitchS, T* __restrict__ dst, int pitchD, int C,
+                               int B, int H, int W, int k) {
+  const long long total = (long long)B * H * W * C;
+  const int r = k / 2;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    const long long pix = i / C;
+    const int x = (int)(pix % W), y = (int)((pix / W) % H);
+    const long long b = pix / ((long long)W * H);
+    float m = -INFINITY;
+    for (int dy = -r; dy <= r; ++dy) {
+      const int yy = y + dy;
+      if (yy < 0 || yy >= H) continue;
+      for (int dx = -r; dx <= r; ++dx) {
+        const int xx = x + dx;
+        if (xx < 0 || xx >= W) continue;
+        m = fmaxf(m, to_f(src[((b * H + yy) * W + xx) * pitchS + c]));
+      }
+    }
+    dst[pix * pitchD + c] = from_f<T>(m);
+  }
+}
+
+// nn.AvgPool2d(2, stride=2) (reference basemodel.py:38)
+template <typename T>
+__global__ void avgpool2_kernel(const T* __restrict__ src, int pitchS, T* __restrict__ dst, int pitchD, int C,
+                                int B, int Ho, int Wo) {
+  const long long total = (long long)B * Ho * Wo * C;
+  const int Wi = Wo * 2, Hi = Ho * 2;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    const long long pix = i / C;
+    const int x = (int)(pix % Wo), y = (int)((pix / Wo) % Ho);
+    const long long b = pix / ((long long)Wo * Ho);
+    const T* p = src + ((b * Hi + 2 * y) * Wi + 2 * x) * pitchS + c;
+    const float s = (to_f(p[0]) + to_f(p[pitchS])) + (to_f(p[(size_t)Wi * pitchS]) + to_f(p[(size_t)(Wi + 1) * pitchS]));
+    dst[pix * pitchD + c] = from_f<T>(s * 0.25f);
+  }
+}
+
+// reference yolo.py:26-42: view(bs,na,no,ny,nx).permute(0,1,3,4,2); sigmoid;
+// xy = (2s - 0.5 + grid) * stride; wh = (2s)^2 * anchor_grid; rows = (a, y, x)
+template <typename T>
+__global__ void detect_decode_kernel(const T* __restrict__ raw, int pitch, float* __restrict__ blks, int rows_total,
+                                     int row_off, int B, int ny, int nx, int na, int no, float stride,
+                                     const float* __restrict__ anchors) {
+  const long long total = (long long)B * na * ny * nx;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int x = (int)(i % nx), y = (int)((i / nx) % ny);
+    const int an = (int)((i / ((long long)nx * ny)) % na);
+    const long long b = i / ((long long)nx * ny * na);
+    const T* p = raw + ((b * ny + y) * nx + x) * pitch + an * no;
+    float* o = blks + (b * rows_total + row_off + ((long long)an * ny + y) * nx + x) * no;
+    for (int j = 0; j < no; ++j) {
+      const float s = 1.0f / (1.0f + expf(-to_f(p[j])));
+      float v = s;
+      if (j == 0) v = (s * 2.f - 0.5f + (float)x) * stride;
+      else if (j == 1) v = (s * 2.f - 0.5f + (float)y) * stride;
+      else if (j == 2) { const float t = s * 2.f; v = t * t * anchors[an * 2 + 0]; }
+      else if (j == 3) { const float t = s * 2.f; v = t * t * anchors[an * 2 + 1]; }
+      o[j] = v;
+    }
+  }
+}
+
+template <typename T>
+__global__ void export_plane_kernel(const T* __restrict__ src, int pitch, float* __restrict__ out, int nplanes,
+                                    int plane, uint8_t* __restrict__ u8, int u8_mode, float thresh, int B, int H,
+                                    int W) {
+  const long long hw = (long long)H * W;
+  const long long total = (long long)B * hw;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const long long b = i / hw, p = i % hw;
+    const float v = to_f(src[i * pitch]);
+    out[(b * nplanes + plane) * hw + p] = v;
+    if (u8_mode == 1) u8[i] = (uint8_t)(v * 255.0f);       // reference inference.py:96-99 (truncation)
+    else if (u8_mode == 2) u8[i] = v > thresh ? 1 : 0;      // reference db_utils.py:71-72
+  }
+}
+
+inline int grid_for(long long total, int block = 256) {
+  long long g = (total + block - 1) / block;
+  if (g > 256LL * 32) g = 256LL * 32;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+}  // namespace
+
+void launch_conv_direct(const ConvArgs& a, bool f16, hipStream_t st) {
+  const int g = grid_for((long long)a.M * a.N);
+  if (f16) hipLaunchKernelGGL((conv_direct_kernel<half_t, false>), dim3(g), dim3(256), 0, st, a);
+  else hipLaunchKernelGGL((conv_direct_kernel<float, true>), dim3(g), dim3(256), 0, st, a);
+}
+
+void launch_convt_direct(const ConvArgs& a, bool f16, hipStream_t st) {
+  const int g = grid_for((long long)a.B * a.oH * a.oW * a.N);
+  if (f16) hipLaunchKernelGGL((convt_direct_kernel<half_t, false>), dim3(g), dim3(256), 0, st, a);
+  else hipLaunchKernelGGL((convt_direct_kernel<float, true>), dim3(g), dim3(256), 0, st, a);
+}
+
+void launch_input_nchw(const float* in, void* dst, int B, int H, int W, bool f16, hipStream_t st) {
+  const int g = grid_for((long long)B * H * W);
+  if (f16) hipLaunchKernelGGL((input_nchw_kernel<half_t>), dim3(g), dim3(256), 0, st, in, (half_t*)dst, B, H, W);
+  else hipLaunchKernelGGL((input_nchw_kernel<float>), dim3(g), dim3(256), 0, st, in, (float*)dst, B, H, W);
+}
+
+void launch_input_u8(const uint8_t* in, void* dst, int B, int H, int W, bool f16, hipStream_t st) {
+  const long long t = (long long)B * H * W * 3;
+  const int g = grid_for(t);
+  if (f16) hipLaunchKernelGGL((input_u8_kernel<half_t>), dim3(g), dim3(256), 0, st, in, (half_t*)dst, t);
+  else hipLaunchKernelGGL((input_u8_kernel<float>), dim3(g), dim3(256), 0, st, in, (float*)dst, t);
+}
+
+void launch_maxpool(const void* src, int pitchS, void* dst, int pitchD, int C, int B, int H, int W, int k,
+                    bool f16, hipStream_t st) {
+  const int g = grid_for((long long)B * H * W * C);
+  if (f16)
+    hipLaunchKernelGGL((maxpool_kernel<half_t>), dim3(g), dim3(256), 0, st, (const half_t*)src, pitchS,
+                       (half_t*)dst, pitchD, C, B, H, W, k);
+  else
+    hipLaunchKernelGGL((maxpool_kernel<float>), dim3(g), dim3(256), 0, st, (const float*)src, pitchS, (float*)dst,
+                       pitchD, C, B, H, W, k);
+}
+
+void launch_avgpool2(const void* src, int pitchS, void* dst, int pitchD, int C, int B, int Ho, int Wo, bool f16,
+                     hipStream_t st) {
+  const int g = grid_for((long long)B * Ho * Wo * C);
+  if (f16)
+    hipLaunchKernelGGL((avgpool2_kernel<half_t>), dim3(g), dim3(256), 0, st, (const half_t*)src, pitchS,
+                       (half_t*)dst, pitchD, C, B, Ho, Wo);
+  else
+    hipLaunchKernelGGL((avgpool2_kernel<float>), dim3(g), dim3(256), 0, st, (const float*)src, pitchS, (float*)dst,
+                       pitchD, C, B, Ho, Wo);
+}
+
+void launch_detect_decode(const void* raw, int pitch, bool raw_f16, float* blks, int rows_total, int row_off, int B,
+                          int ny, int nx, int na, int no, float stride, const float* anchors_px, hipStream_t st) {
+  const int g = grid_for((long long)B * na * ny * nx);
+  if (raw_f16)
+    hipLaunchKernelGGL((detect_decode_kernel<half_t>), dim3(g), dim3(256), 0, st, (const half_t*)raw, pitch, blks,
+                       rows_total, row_off, B, ny, nx, na, no, stride, anchors_px);
+  else
+    hipLaunchKernelGGL((detect_decode_kernel<float>), dim3(g), dim3(256), 0, st, (const float*)raw, pitch, blks,
+                       rows_total, row_off, B, ny, nx, na, no, stride, anchors_px);
+}
+
+void launch_export_plane(const void* src, int pitch, bool f16, float* out, int nplanes, int plane, uint8_t* u8,
+                         int u8_mode, float thresh, int B, int H, int W, hipStream_t st) {
+  const int g = grid_for((long long)B * H * W);
+  if (!u8) u8_mode = 0;
+  if (f16)
+    hipLaunchKernelGGL((export_plane_kernel<half_t>), dim3(g), dim3(256), 0, st, (const half_t*)src, pitch, out,
+                       nplanes, plane, u8, u8_mode, thresh, B, H, W);
+  else
+    hipLaunchKernelGGL((export_plane_kernel<float>), dim3(g), dim3(256), 0, st, (const float*)src, pitch, out,
+                       nplanes, plane, u8, u8_mode, thresh, B, H, W);
+}

@@ -1,0 +1,377 @@
+// Post-processing kernels: class-aware greedy NMS and connected-component
+// labelling with statistics.  Integer / comparison work, HBM- and latency-bound.
+#include "kernels.h"
+
+namespace {
+
+// ===========================================================================
+// NMS  (reference utils/yolov5_utils.py:124-218 `non_max_suppression`,
+//       multi_label=False, agnostic=False; torchvision.ops.nms at :202)
+// ===========================================================================
+struct Cand {
+  float x1, y1, x2, y2;  // un-offset xyxy
+  float score;
+  int cls;
+  int idx;               // original row (tie-break: lower row first)
+  int alive;
+};
+
+// stage 1: obj > conf (:136,155), conf = obj*cls (:171), best class (:181),
+// conf > conf_thres (:182), xywh -> xyxy (:174, :220-227); compact per page.
+__global__ void nms_filter_kernel(const float* __restrict__ blks, int B, int rows, int no, float conf_thres,
+                                  Cand* __restrict__ cands, int* __restrict__ counts) {
+  const long long total = (long long)B * rows;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int b = (int)(i / rows), r = (int)(i % rows);
+    const float* x = blks + i * no;
+    const float obj = x[4];
+    if (!(obj > conf_thres)) continue;
+    float best = x[5] * obj;
+    int bj = 0;
+    for (int j = 1; j < no - 5; ++j) {
+      const float c = x[5 + j] * obj;
+      if (c > best) { best = c; bj = j; }
+    }
+    if (!(best > conf_thres)) continue;
+    const int pos = atomicAdd(&counts[b], 1);
+    Cand c;
+    c.x1 = x[0] - x[2] / 2;
+    c.y1 = x[1] - x[3] / 2;
+    c.x2 = x[0] + x[2] / 2;
+    c.y2 = x[1] + x[3] / 2;
+    c.score = best;
+    c.cls = bj;
+    c.idx = r;
+    c.alive = 1;
+    cands[(size_t)b * rows + pos] = c;
+  }
+}
+
+struct Best { float s; int idx; int pos; };
+
+__device__ __forceinline__ bool better(const Best& a, const Best& b) {
+  return a.s > b.s || (a.s == b.s && a.idx < b.idx);
+}
+
+__device__ __forceinline__ Best block_argmax(Best v, Best* sh) {
+  for (int off = 32; off > 0; off >>= 1) {
+    Best o;
+    o.s = __shfl_down(v.s, off);
+    o.idx = __shfl_down(v.idx, off);
+    o.pos = __shfl_down(v.pos, off);
+    if (better(o, v)) v = o;
+  }
+  const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+  __syncthreads();
+  if (l == 0) sh[w] = v;
+  __syncthreads();
+  Best r = sh[0];
+  for (int i = 1; i < (int)(blockDim.x >> 6); ++i)
+    if (better(sh[i], r)) r = sh[i];
+  return r;
+}
+
+// stage 2: one block per page.  Greedy: repeatedly take the best alive candidate
+// (score desc, row asc), suppress every alive candidate of IoU > thr computed on
+// the class-offset boxes in fp32 exactly as torchvision's nms kernel does
+// (ovr = inter / (iarea + area_j - inter), strict >), stop at max_det (:203-204).
+__global__ __launch_bounds__(1024) void nms_greedy_kernel(Cand* __restrict__ cands_all, const int* __restrict__ counts,
+                                                          int rows, float iou_thres, int max_det, int max_nms,
+                                                          float max_wh, float* __restrict__ dets,
+                                                          int* __restrict__ out_counts) {
+  __shared__ Best sh[16];
+  __shared__ unsigned cnt_sh;
+  const int b = blockIdx.x;
+  Cand* c = cands_all + (size_t)b * rows;
+  const int n = counts[b];
+  float* out = dets + (size_t)b * max_det * 6;
+
+  // max_nms cap (:196-197): keep the max_nms highest scores (ties at the cut are all kept;
+  // the reference's argsort leaves their order unspecified)
+  if (n > max_nms) {
+    unsigned prefix = 0;
+    for (int bit = 31; bit >= 0; --bit) {
+      const unsigned trial = prefix | (1u << bit);
+      if (threadIdx.x == 0) cnt_sh = 0;
+      __syncthreads();
+      unsigned local = 0;
+      for (int j = threadIdx.x; j < n; j += blockDim.x) local += __float_as_uint(c[j].score) >= trial;
+      atomicAdd(&cnt_sh, local);
+      __syncthreads();
+      if (cnt_sh >= (unsigned)max_nms) prefix = trial;
+      __syncthreads();
+    }
+    for (int j = threadIdx.x; j < n; j += blockDim.x)
+      if (__float_as_uint(c[j].score) < prefix) c[j].alive = 0;
+    __syncthreads();
+  }
+
+  Best mine{-1.f, 0x7fffffff, -1};
+  for (int j = threadIdx.x; j < n; j += blockDim.x)
+    if (c[j].alive) {
+      Best t{c[j].score, c[j].idx, j};
+      if (better(t, mine)) mine = t;
+    }
+  int kept = 0;
+  while (kept < max_det) {
+    const Best top = block_argmax(mine, sh);
+    if (top.pos < 0) break;
+    const Cand k = c[top.pos];
+    const float off = (float)k.cls * max_wh;
+    const float ix1 = k.x1 + off, iy1 = k.y1 + off, ix2 = k.x2 + off, iy2 = k.y2 + off;
+    const float iarea = (ix2 - ix1) * (iy2 - iy1);
+    if (threadIdx.x == 0) {
+      float* o = out + (size_t)kept * 6;
+      o[0] = k.x1; o[1] = k.y1; o[2] = k.x2; o[3] = k.y2; o[4] = k.score; o[5] = (float)k.cls;
+    }
+    ++kept;
+    __syncthreads();
+    mine = Best{-1.f, 0x7fffffff, -1};
+    for (int j = threadIdx.x; j < n; j += blockDim.x) {
+      if (!c[j].alive) continue;
+      if (j == top.pos) { c[j].alive = 0; continue; }
+      const float o2 = (float)c[j].cls * max_wh;
+      const float jx1 = c[j].x1 + o2, jy1 = c[j].y1 + o2, jx2 = c[j].x2 + o2, jy2 = c[j].y2 + o2;
+      const float xx1 = fmaxf(ix1, jx1), yy1 = fmaxf(iy1, jy1);
+      const float xx2 = fminf(ix2, jx2), yy2 = fminf(iy2, jy2);
+      const float w = fmaxf(0.f, xx2 - xx1), h = fmaxf(0.f, yy2 - yy1);
+      const float inter = w * h;
+      const float ovr = inter / (iarea + (jx2 - jx1) * (jy2 - jy1) - inter);
+      if (ovr > iou_thres) { c[j].alive = 0; continue; }
+      Best t{c[j].score, c[j].idx, j};
+      if (better(t, mine)) mine = t;
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out_counts[b] = kept;
+}
+
+// ===========================================================================
+// CCL with stats (replaces cv2.connectedComponentsWithStats, reference
+// utils/textmask.py:93,113,138).  Union-find over pixel indices with atomicMin
+// links (root = smallest linear index of the component = its first pixel in
+// raster order), then roots are ranked in raster order so label ids follow the
+// first-pixel order (OpenCV SAUF numbering for 4-connectivity).
+// ===========================================================================
+__device__ __forceinline__ int uf_find(int* parent, int x) {
+  int p = __atomic_load_n(parent + x, __ATOMIC_RELAXED);
+  while (p != x) {
+    x = p;
+    p = __atomic_load_n(parent + x, __ATOMIC_RELAXED);
+  }
+  return x;
+}
+
+__device__ __forceinline__ void uf_union(int* parent, int a, int b) {
+  while (true) {
+    a = uf_find(parent, a);
+    b = uf_find(parent, b);
+    if (a == b) return;
+    if (a > b) { const int t = a; a = b; b = t; }
+    const int old = atomicMin(parent + b, a);
+    if (old == b) return;
+    b = old;
+  }
+}
+
+__global__ void ccl_init_kernel(const uint8_t* __restrict__ img, int* __restrict__ parent, long long total, int hw,
+                                int thresh) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x)
+    parent[i] = ((int)img[i] > thresh) ? (int)(i % hw) : -1;
+}
+
+__global__ void ccl_merge_kernel(int* __restrict__ parent_all, int B, int H, int W, int conn) {
+  const int hw = H * W;
+  const long long total = (long long)B * hw;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int b = (int)(i / hw), p = (int)(i % hw);
+    int* parent = parent_all + (size_t)b * hw;
+    if (parent[p] < 0) continue;
+    const int x = p % W, y = p / W;
+    if (x > 0 && parent[p - 1] >= 0) uf_union(parent, p, p - 1);
+    if (y > 0) {
+      if (parent[p - W] >= 0) uf_union(parent, p, p - W);
+      if (conn == 8) {
+        if (x > 0 && parent[p - W - 1] >= 0) uf_union(parent, p, p - W - 1);
+        if (x + 1 < W && parent[p - W + 1] >= 0) uf_union(parent, p, p - W + 1);
+      }
+    }
+  }
+}
+
+__global__ void ccl_flatten_kernel(int* __restrict__ parent_all, long long total, int hw) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    int* parent = parent_all + (i / hw) * hw;
+    const int p = (int)(i % hw);
+    if (parent[p] >= 0) parent[p] = uf_find(parent, p);
+  }
+}
+
+constexpr int RK_CHUNK = 4096;  // pixels ranked per block
+constexpr int RK_PER_T = RK_CHUNK / 256;
+
+__device__ __forceinline__ int block_exclusive_scan(int v, int* sh, int* total) {
+  // 256 threads
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  int incl = v;
+  for (int off = 1; off < 64; off <<= 1) {
+    const int t = __shfl_up(incl, off);
+    if (lane >= off) incl += t;
+  }
+  if (lane == 63) sh[w] = incl;
+  __syncthreads();
+  int base = 0;
+  for (int i = 0; i < w; ++i) base += sh[i];
+  *total = sh[0] + sh[1] + sh[2] + sh[3];
+  __syncthreads();
+  return base + incl - v;
+}
+
+// pass 1 (mode 0): count roots per chunk.  pass 3 (mode 1): assign raster-order ids to roots.
+__global__ __launch_bounds__(256) void ccl_rank_kernel(const int* __restrict__ parent_all, int hw, int nchunks,
+                                                       int* __restrict__ chunk_cnt, int* __restrict__ ids_all,
+                                                       int mode) {
+  __shared__ int sh[4];
+  const int b = blockIdx.x / nchunks, ch = blockIdx.x % nchunks;
+  const int* parent = parent_all + (size_t)b * hw;
+  const int p0 = ch * RK_CHUNK + threadIdx.x * RK_PER_T;
+  int local = 0;
+  for (int j = 0; j < RK_PER_T; ++j) {
+    const int p = p0 + j;
+    if (p < hw && parent[p] == p) ++local;
+  }
+  int total;
+  const int excl = block_exclusive_scan(local, sh, &total);
+  if (mode == 0) {
+    if (threadIdx.x == 0) chunk_cnt[blockIdx.x] = total;
+  } else {
+    int id = chunk_cnt[blockIdx.x] + excl;  // chunk_cnt now holds exclusive offsets
+    int* ids = ids_all + (size_t)b * hw;
+    for (int j = 0; j < RK_PER_T; ++j) {
+      const int p = p0 + j;
+      if (p < hw && parent[p] == p) ids[p] = ++id;
+    }
+  }
+}
+
+// pass 2: per image exclusive scan of the chunk counts (one block per image)
+__global__ __launch_bounds__(256) void ccl_scan_chunks_kernel(int* __restrict__ chunk_cnt, int nchunks,
+                                                              int* __restrict__ n_out) {
+  __shared__ int sh[4];
+  int* c = chunk_cnt + (size_t)blockIdx.x * nchunks;
+  int carry = 0;
+  for (int base = 0; base < nchunks; base += 256) {
+    const int i = base + threadIdx.x;
+    const int v = i < nchunks ? c[i] : 0;
+    int total;
+    const int excl = block_exclusive_scan(v, sh, &total);
+    if (i < nchunks) c[i] = carry + excl;
+    carry += total;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) n_out[blockIdx.x] = carry;
+}
+
+__global__ void ccl_stats_init_kernel(int* __restrict__ stats, long long total, int H, int W) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    int* s = stats + i * 5;
+    s[0] = W; s[1] = H; s[2] = -1; s[3] = -1; s[4] = 0;
+  }
+}
+
+__global__ void ccl_label_kernel(int* __restrict__ labels_all, const int* __restrict__ ids_all, int B, int H, int W,
+                                 int* __restrict__ stats, int max_labels) {
+  const int hw = H * W;
+  const long long total = (long long)B * hw;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int b = (int)(i / hw), p = (int)(i % hw);
+    const int root = labels_all[i];
+    int id = 0;
+    if (root >= 0) {
+      id = ids_all[(size_t)b * hw + root];
+      if (stats && id <= max_labels) {
+        int* s = stats + ((size_t)b * max_labels + (id - 1)) * 5;
+        const int x = p % W, y = p / W;
+        atomicMin(s + 0, x);
+        atomicMin(s + 1, y);
+        atomicMax(s + 2, x);
+        atomicMax(s + 3, y);
+        atomicAdd(s + 4, 1);
+      }
+    }
+    labels_all[i] = id;
+  }
+}
+
+__global__ void ccl_stats_final_kernel(int* __restrict__ stats, const int* __restrict__ n_out, int B, int max_labels) {
+  const long long total = (long long)B * max_labels;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int b = (int)(i / max_labels), l = (int)(i % max_labels);
+    int* s = stats + i * 5;
+    if (l < n_out[b]) {
+      s[2] = s[2] - s[0] + 1;
+      s[3] = s[3] - s[1] + 1;
+    } else {
+      s[0] = s[1] = s[2] = s[3] = s[4] = 0;
+    }
+  }
+}
+
+inline int grid_for(long long total, int block = 256) {
+  long long g = (total + block - 1) / block;
+  if (g > 256LL * 32) g = 256LL * 32;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+}  // namespace
+
+size_t nms_workspace_bytes(int B, int rows) { return (size_t)B * rows * sizeof(Cand) + (size_t)B * sizeof(int) + 256; }
+
+void launch_nms(const float* blks, int B, int rows, int no, float conf, float iou, int max_det, int max_nms,
+                float max_wh, float* dets, int* counts, void* ws, hipStream_t st) {
+  int* cnt = (int*)ws;
+  Cand* cands = (Cand*)((char*)ws + ((size_t)B * sizeof(int) + 255) / 256 * 256);
+  hipMemsetAsync(cnt, 0, (size_t)B * sizeof(int), st);
+  hipMemsetAsync(dets, 0, (size_t)B * max_det * 6 * sizeof(float), st);
+  hipLaunchKernelGGL(nms_filter_kernel, dim3(grid_for((long long)B * rows)), dim3(256), 0, st, blks, B, rows, no, conf,
+                     cands, cnt);
+  hipLaunchKernelGGL(nms_greedy_kernel, dim3(B), dim3(1024), 0, st, cands, cnt, rows, iou, max_det, max_nms, max_wh,
+                     dets, counts);
+}
+
+size_t ccl_workspace_bytes(int B, int H, int W) {
+  const size_t hw = (size_t)H * W;
+  const size_t nchunks = (hw + RK_CHUNK - 1) / RK_CHUNK;
+  return (size_t)B * hw * sizeof(int) + (size_t)B * nchunks * sizeof(int) + 512;
+}
+
+void launch_ccl(const uint8_t* img, int B, int H, int W, int thresh, int conn, int* labels, int* n_out, int* stats,
+                int max_labels, void* ws, hipStream_t st) {
+  const int hw = H * W;
+  const long long total = (long long)B * hw;
+  const int nchunks = (hw + RK_CHUNK - 1) / RK_CHUNK;
+  int* ids = (int*)ws;
+  int* chunk_cnt = (int*)((char*)ws + ((size_t)total * sizeof(int) + 255) / 256 * 256);
+  const int g = grid_for(total);
+  hipLaunchKernelGGL(ccl_init_kernel, dim3(g), dim3(256), 0, st, img, labels, total, hw, thresh);
+  hipLaunchKernelGGL(ccl_merge_kernel, dim3(g), dim3(256), 0, st, labels, B, H, W, conn);
+  hipLaunchKernelGGL(ccl_flatten_kernel, dim3(g), dim3(256), 0, st, labels, total, hw);
+  hipLaunchKernelGGL(ccl_rank_kernel, dim3(B * nchunks), dim3(256), 0, st, labels, hw, nchunks, chunk_cnt, ids, 0);
+  hipLaunchKernelGGL(ccl_scan_chunks_kernel, dim3(B), dim3(256), 0, st, chunk_cnt, nchunks, n_out);
+  hipLaunchKernelGGL(ccl_rank_kernel, dim3(B * nchunks), dim3(256), 0, st, labels, hw, nchunks, chunk_cnt, ids, 1);
+  if (stats)
+    hipLaunchKernelGGL(ccl_stats_init_kernel, dim3(grid_for((long long)B * max_labels)), dim3(256), 0, st, stats,
+                       (long long)B * max_labels, H, W);
+  hipLaunchKernelGGL(ccl_label_kernel, dim3(g), dim3(256), 0, st, labels, ids, B, H, W, stats, max_labels);
+  if (stats)
+    hipLaunchKernelGGL(ccl_stats_final_kernel, dim3(grid_for((long long)B * max_labels)), dim3(256), 0, st, stats,
+                       n_out, B, max_labels);
+}

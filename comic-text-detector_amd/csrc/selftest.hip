@@ -1,0 +1,240 @@
+// Standalone GPU self-test + micro-benchmark of the kernels (no python, no torch):
+//   1. MFMA fragment-layout probe (the convention kernels_igemm.hip assumes)
+//   2. MFMA implicit-GEMM conv vs the direct fp32-accumulate kernel on the layer
+//      shapes of the network, incl. concat/upsample/residual/convT
+//   3. timing of each shape (TFLOP/s)
+// Usage: ctd_selftest [batch] [quick]
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "kernels.h"
+
+#define CK(x)                                                                              \
+  do {                                                                                     \
+    hipError_t e_ = (x);                                                                   \
+    if (e_ != hipSuccess) {                                                                \
+      std::printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__);   \
+      std::exit(2);                                                                        \
+    }                                                                                      \
+  } while (0)
+
+static unsigned g_seed = 12345;
+static float frand() {
+  g_seed = g_seed * 1664525u + 1013904223u;
+  return ((g_seed >> 8) & 0xFFFF) / 65536.0f - 0.5f;
+}
+
+template <typename T>
+static T* dev_alloc(size_t n) {
+  T* p;
+  CK(hipMalloc((void**)&p, n * sizeof(T) + 64));
+  return p;
+}
+
+static int g_fail = 0;
+
+static void probe() {
+  std::vector<half_t> A(32 * 16), B(16 * 32);
+  for (auto& v : A) v = (half_t)frand();
+  for (auto& v : B) v = (half_t)frand();
+  half_t *dA = dev_alloc<half_t>(A.size()), *dB = dev_alloc<half_t>(B.size());
+  float* dD = dev_alloc<float>(32 * 32);
+  CK(hipMemcpy(dA, A.data(), A.size() * 2, hipMemcpyHostToDevice));
+  CK(hipMemcpy(dB, B.data(), B.size() * 2, hipMemcpyHostToDevice));
+  launch_mfma_probe(dA, dB, dD, 0);
+  std::vector<float> D(32 * 32);
+  CK(hipMemcpy(D.data(), dD, D.size() * 4, hipMemcpyDeviceToHost));
+  double maxerr = 0;
+  for (int i = 0; i < 32; ++i)
+    for (int j = 0; j < 32; ++j) {
+      double s = 0;
+      for (int k = 0; k < 16; ++k) s += (double)A[i * 16 + k] * (double)B[k * 32 + j];
+      maxerr = std::fmax(maxerr, std::fabs(s - D[i * 32 + j]));
+    }
+  std::printf("[probe] mfma_f32_32x32x16_f16 fragment layout: max|err| = %.3g  %s\n", maxerr,
+              maxerr < 1e-3 ? "OK" : "MISMATCH");
+  if (!(maxerr < 1e-3)) ++g_fail;
+}
+
+struct Case {
+  const char* name;
+  int kind;  // 0 conv, 1 convT4
+  int c0, c1, up0, N, k, s, H;  // H = logical input size (square)
+  int res;
+};
+
+static void run_case(const Case& cs, int B, bool timing) {
+  const int Hin = cs.H, Win = cs.H;
+  const int cin = cs.c0 + cs.c1;
+  const int k = cs.k, s = cs.s, pad = cs.kind ? 1 : k / 2;
+  const int Ho = cs.kind ? 2 * Hin : (Hin + 2 * pad - k) / s + 1;
+  const int Wo = Ho;
+  // sources
+  const int H0 = cs.up0 ? Hin / 2 : Hin;
+  const size_t n0 = (size_t)B * H0 * H0 * cs.c0, n1 = (size_t)B * Hin * Win * cs.c1;
+  std::vector<half_t> h0(n0), h1(n1 ? n1 : 1);
+  for (auto& v : h0) v = (half_t)frand();
+  for (auto& v : h1) v = (half_t)frand();
+  half_t* d0 = dev_alloc<half_t>(n0);
+  half_t* d1 = dev_alloc<half_t>(n1 ? n1 : 1);
+  CK(hipMemcpy(d0, h0.data(), n0 * 2, hipMemcpyHostToDevice));
+  if (n1) CK(hipMemcpy(d1, h1.data(), n1 * 2, hipMemcpyHostToDevice));
+  const size_t nout = (size_t)B * Ho * Wo * cs.N;
+  half_t *dOut = dev_alloc<half_t>(nout), *dRef = dev_alloc<half_t>(nout), *dRes = nullptr;
+  if (cs.res) {
+    std::vector<half_t> hr(nout);
+    for (auto& v : hr) v = (half_t)frand();
+    dRes = dev_alloc<half_t>(nout);
+    CK(hipMemcpy(dRes, hr.data(), nout * 2, hipMemcpyHostToDevice));
+  }
+  // weights in torch layout, values rounded to fp16 so both paths see identical numbers
+  const int bn = igemm_ntile(cs.N);
+  const int Npad = (cs.N + bn - 1) / bn * bn;
+  const float wscale = 1.0f / std::sqrt((float)(cin * (cs.kind ? 4 : k * k)));
+  std::vector<float> W((size_t)cs.N * cin * k * k), bias(Npad, 0.f);
+  for (auto& v : W) v = (float)(half_t)(frand() * 2.f * wscale);
+  for (int n = 0; n < cs.N; ++n) bias[n] = frand();
+  float* dBias = dev_alloc<float>(Npad);
+  CK(hipMemcpy(dBias, bias.data(), Npad * 4, hipMemcpyHostToDevice));
+
+  ConvArgs a{};
+  a.s0 = SrcView{d0, cs.c0, cs.c0, cs.up0, H0, H0};
+  if (cs.c1) a.s1 = SrcView{d1, cs.c1, cs.c1, 0, Hin, Win};
+  a.B = B; a.Hin = Hin; a.Win = Win;
+  a.bias = dBias; a.pitchD = cs.N; a.oH = Ho; a.oW = Wo;
+  a.res = dRes; a.pitchR = cs.N; a.act = CTD_ACT_SILU; a.N = cs.N; a.nphase = 1; a.osy = a.osx = 1;
+
+  ConvArgs ig = a, dr = a;
+  std::vector<half_t> wig;
+  std::vector<float> wdr((size_t)k * k * cin * cs.N);
+  if (cs.kind == 0) {
+    const int K = k * k * cin;
+    wig.assign((size_t)Npad * K, (half_t)0.f);
+    for (int n = 0; n < cs.N; ++n)
+      for (int c = 0; c < cin; ++c)
+        for (int ky = 0; ky < k; ++ky)
+          for (int kx = 0; kx < k; ++kx) {
+            const float w = W[(((size_t)n * cin + c) * k + ky) * k + kx];
+            wig[(size_t)n * K + (size_t)(ky * k + kx) * cin + c] = (half_t)w;
+            wdr[((size_t)(ky * k + kx) * cin + c) * cs.N + n] = w;
+          }
+    ig.Mh = dr.Mh = Ho; ig.Mw = dr.Mw = Wo; ig.KH = ig.KW = dr.KH = dr.KW = k;
+    ig.stride = dr.stride = s; ig.dy0 = ig.dx0 = dr.dy0 = dr.dx0 = -pad;
+    ig.K = dr.K = K; ig.M = dr.M = B * Ho * Wo;
+  } else {
+    // W is (cin, N, 4, 4) here
+    const int K = 4 * cin;
+    wig.assign((size_t)4 * Npad * K, (half_t)0.f);
+    for (int ph = 0; ph < 4; ++ph) {
+      const int py = ph >> 1, px = ph & 1;
+      for (int ty = 0; ty < 2; ++ty)
+        for (int tx = 0; tx < 2; ++tx) {
+          const int dy = (py ? 0 : -1) + ty, dx = (px ? 0 : -1) + tx;
+          const int ky = py + 1 - 2 * dy, kx = px + 1 - 2 * dx;
+          for (int n = 0; n < cs.N; ++n)
+            for (int c = 0; c < cin; ++c)
+              wig[((size_t)ph * Npad + n) * K + (size_t)(ty * 2 + tx) * cin + c] =
+                  (half_t)W[(((size_t)c * cs.N + n) * 4 + ky) * 4 + kx];
+        }
+    }
+    for (int c = 0; c < cin; ++c)
+      for (int n = 0; n < cs.N; ++n)
+        for (int kk = 0; kk < 16; ++kk) wdr[((size_t)kk * cin + c) * cs.N + n] = W[((size_t)c * cs.N + n) * 16 + kk];
+    ig.Mh = Hin; ig.Mw = Win; ig.KH = ig.KW = 2; ig.stride = 1; ig.K = K; ig.M = B * Hin * Win;
+    ig.nphase = 4; ig.osy = ig.osx = 2; ig.w_phase_stride = (long long)Npad * K;
+    dr.KH = dr.KW = 4; dr.stride = 2; dr.dy0 = dr.dx0 = 1; dr.M = B * Ho * Wo; dr.K = 16 * cin;
+  }
+  half_t* dWig = dev_alloc<half_t>(wig.size());
+  float* dWdr = dev_alloc<float>(wdr.size());
+  CK(hipMemcpy(dWig, wig.data(), wig.size() * 2, hipMemcpyHostToDevice));
+  CK(hipMemcpy(dWdr, wdr.data(), wdr.size() * 4, hipMemcpyHostToDevice));
+  ig.w = dWig; ig.Npad = Npad; ig.dst = dOut;
+  dr.w = dWdr; dr.Npad = cs.N; dr.dst = dRef;
+
+  if (!igemm_supported(ig)) {
+    std::printf("[case] %-34s igemm_supported = false  FAIL\n", cs.name);
+    ++g_fail;
+    return;
+  }
+  launch_conv_igemm(ig, false, 0);
+  if (cs.kind == 0) launch_conv_direct(dr, true, 0);
+  else launch_convt_direct(dr, true, 0);
+  CK(hipDeviceSynchronize());
+  std::vector<half_t> o(nout), r(nout);
+  CK(hipMemcpy(o.data(), dOut, nout * 2, hipMemcpyDeviceToHost));
+  CK(hipMemcpy(r.data(), dRef, nout * 2, hipMemcpyDeviceToHost));
+  double maxerr = 0, maxref = 0;
+  size_t bad = 0;
+  for (size_t i = 0; i < nout; ++i) {
+    const double e = std::fabs((double)o[i] - (double)r[i]);
+    maxerr = std::fmax(maxerr, e);
+    maxref = std::fmax(maxref, std::fabs((double)r[i]));
+    if (e > 4e-3 * (1.0 + std::fabs((double)r[i]))) ++bad;
+  }
+  const bool ok = bad == 0;
+  if (!ok) ++g_fail;
+  double tf = 0, ms = 0;
+  if (timing) {
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    for (int i = 0; i < 3; ++i) launch_conv_igemm(ig, false, 0);
+    CK(hipEventRecord(e0, 0));
+    const int it = 20;
+    for (int i = 0; i < it; ++i) launch_conv_igemm(ig, false, 0);
+    CK(hipEventRecord(e1, 0));
+    CK(hipEventSynchronize(e1));
+    float t;
+    CK(hipEventElapsedTime(&t, e0, e1));
+    ms = t / it;
+    const double flops = cs.kind ? 2.0 * B * Hin * Win * 16.0 * cin * cs.N : 2.0 * (double)ig.M * cs.N * ig.K;
+    tf = flops / (ms * 1e-3) / 1e12;
+  }
+  std::printf("[case] %-34s B=%d out %dx%dx%d  max|err| %.3g (max|ref| %.3g) bad %zu  %s   %.3f ms  %.1f TFLOP/s\n",
+              cs.name, B, Ho, Wo, cs.N, maxerr, maxref, bad, ok ? "OK" : "FAIL", ms, tf);
+  hipFree(d0); hipFree(d1); hipFree(dOut); hipFree(dRef); if (dRes) hipFree(dRes);
+  hipFree(dBias); hipFree(dWig); hipFree(dWdr);
+}
+
+int main(int argc, char** argv) {
+  const int B = argc > 1 ? std::atoi(argv[1]) : 4;
+  const bool quick = argc > 2;
+  char name[256];
+  int cus = 0;
+  int64_t hbm = 0;
+  const int arch = ctd_device_info(0, name, &cus, &hbm);
+  std::printf("device: %s gfx%d CUs=%d HBM=%.1f GB\n", name, arch, cus, hbm / 1e9);
+  probe();
+  const Case cases[] = {
+      // name, kind, c0, c1, up0, N, k, s, H, res           (SURVEY App. B shapes)
+      {"1x1 64->64 @256 (N64)", 0, 64, 0, 0, 64, 1, 1, 256, 0},
+      {"1x1 32->32 @256 (N32)", 0, 32, 0, 0, 32, 1, 1, 256, 0},
+      {"1x1 128->21 @128 detect (N21)", 0, 128, 0, 0, 21, 1, 1, 128, 0},
+      {"1x1 256->256 @128", 0, 256, 0, 0, 256, 1, 1, 128, 0},
+      {"1x1 512->512 @64", 0, 512, 0, 0, 512, 1, 1, 64, 0},
+      {"1x1 cat(256up,256)->256 @64", 0, 256, 256, 1, 256, 1, 1, 64, 0},
+      {"1x1 cat(512,256)->512 @32", 0, 512, 256, 0, 512, 1, 1, 32, 0},
+      {"1x1 cat(128,256)->256 @128", 0, 128, 256, 0, 256, 1, 1, 128, 0},
+      {"3x3 32->32 @256 +res", 0, 32, 0, 0, 32, 3, 1, 256, 1},
+      {"3x3 64->64 @128 +res", 0, 64, 0, 0, 64, 3, 1, 128, 1},
+      {"3x3 128->128 @128 +res", 0, 128, 0, 0, 128, 3, 1, 128, 1},
+      {"3x3 256->256 @64 +res", 0, 256, 0, 0, 256, 3, 1, 64, 1},
+      {"3x3 64->32 @256 (db tail)", 0, 64, 0, 0, 32, 3, 1, 256, 0},
+      {"3x3s2 32->64 @512", 0, 32, 0, 0, 64, 3, 2, 512, 0},
+      {"3x3s2 64->128 @256", 0, 64, 0, 0, 128, 3, 2, 256, 0},
+      {"3x3s2 256->512 @64", 0, 256, 0, 0, 512, 3, 2, 64, 0},
+      {"convT4 512->256 @64", 1, 512, 0, 0, 256, 4, 2, 64, 0},
+      {"convT4 256->128 @128", 1, 256, 0, 0, 128, 4, 2, 128, 0},
+      {"convT4 128->64 @256", 1, 128, 0, 0, 64, 4, 2, 256, 0},
+      {"convT4 512->256 @16", 1, 512, 0, 0, 256, 4, 2, 16, 0},
+  };
+  const int ncase = sizeof(cases) / sizeof(cases[0]);
+  for (int i = 0; i < ncase; ++i) {
+    if (quick && i % 3) continue;
+    run_case(cases[i], B, true);
+  }
+  std::printf("selftest: %s (%d failures)\n", g_fail ? "FAILED" : "PASSED", g_fail);
+  return g_fail ? 1 : 0;
+}

@@ -1,0 +1,129 @@
+"""Seeded synthetic checkpoints and pages (there is no network here, so the
+release weights `comictextdetector.pt` cannot be fetched).
+
+`make_checkpoint(seed)` returns a dict in exactly the reference's weight-file
+format (`utils/export.py:23-28`, consumed by `basemodel.py:211-217`):
+
+    {'blk_det': {'cfg': <yolov5 cfg dict>, 'weights': <Model state_dict>},
+     'text_seg': <UnetHead state_dict>, 'text_det': <DBHead state_dict>}
+
+so the same object can be `torch.save`d and loaded by the reference's
+`TextDetBase`, by the oracle and by this backend.  BatchNorm statistics and
+affine terms are randomised so the BN fold is exercised; conv weights are
+variance-preserving so activations stay O(1) in fp16.
+"""
+from __future__ import annotations
+
+import copy
+import math
+from typing import Dict
+
+import numpy as np
+import torch
+
+from . import arch
+
+
+def _bn(sd: Dict[str, torch.Tensor], prefix: str, c: int, g: torch.Generator) -> None:
+    sd[prefix + ".weight"] = torch.empty(c).uniform_(0.6, 1.4, generator=g)
+    sd[prefix + ".bias"] = torch.empty(c).normal_(0.0, 0.15, generator=g)
+    sd[prefix + ".running_mean"] = torch.empty(c).normal_(0.0, 0.15, generator=g)
+    sd[prefix + ".running_var"] = torch.empty(c).uniform_(0.6, 1.4, generator=g)
+    sd[prefix + ".num_batches_tracked"] = torch.tensor(1000, dtype=torch.long)
+
+
+def _conv(sd: Dict[str, torch.Tensor], cs: arch.ConvSpec, g: torch.Generator, gain: float) -> None:
+    if cs.transposed:
+        shape = (cs.c1, cs.c2, cs.k, cs.k)
+        # each output pixel of a stride-s transposed conv sees (k/s)^2 taps
+        fan_in = cs.c1 * (cs.k // cs.s) ** 2
+    else:
+        shape = (cs.c2, cs.c1, cs.k, cs.k)
+        fan_in = cs.c1 * cs.k * cs.k
+    std = gain / math.sqrt(fan_in)
+    sd[cs.prefix + ".weight"] = torch.empty(shape).normal_(0.0, std, generator=g)
+    if cs.bias:
+        sd[cs.prefix + ".bias"] = torch.empty(cs.c2).normal_(0.0, 0.1, generator=g)
+    if cs.bn_prefix is not None:
+        _bn(sd, cs.bn_prefix, cs.c2, g)
+
+
+# Tuned (oracle, seed 0) so every hidden activation has std ~0.2 (no fp16
+# overflow / no decay through the 115 layers), the two sigmoid heads give
+# logits with std ~1.2 (masks spread over (0,1)), and ~1.5 % of the Detect
+# rows pass the 0.4 objectness gate so NMS has work to do.
+_GAIN = {"silu": 1.25, "leaky": 1.0, "relu": 1.0, "sigmoid": 5.0, "none": 20.0}
+
+
+def make_checkpoint(seed: int = 0, cfg: dict | None = None, act: str = "leaky") -> dict:
+    cfg = copy.deepcopy(cfg if cfg is not None else arch.YOLOV5S_CFG)
+    g = torch.Generator().manual_seed(seed)
+    layers, meta = arch.parse_yolo_cfg(cfg)
+
+    blk: Dict[str, torch.Tensor] = {}
+    for cs in arch.iter_convs(layers):
+        _conv(blk, cs, g, _GAIN[cs.act])
+    det = layers[-1]
+    assert det.kind == "Detect"
+    strides = arch.detect_strides(layers)
+    anchors = torch.tensor(meta["anchors"], dtype=torch.float32).view(len(strides), -1, 2)
+    # `Detect.anchors` is stored already divided by the stride (`yolo.py:88`)
+    blk[f"model.{det.i}.anchors"] = anchors / torch.tensor(strides, dtype=torch.float32).view(-1, 1, 1)
+    # Detect biases as `Model._initialize_biases` would leave them (`yolo.py:169-176`)
+    na, no = meta["na"], meta["no"]
+    for j, s in enumerate(strides):
+        b = blk[f"model.{det.i}.m.{j}.bias"].view(na, no)
+        b[:, 4] += math.log(8 / (640 / s) ** 2)
+        b[:, 5:] += math.log(0.6 / (meta["nc"] - 0.999999))
+
+    seg: Dict[str, torch.Tensor] = {}
+    for cs in arch.iter_convs(arch.unet_spec(act)):
+        _conv(seg, cs, g, _GAIN[cs.act])
+    db: Dict[str, torch.Tensor] = {}
+    for cs in arch.iter_convs(arch.db_spec(64, act)):
+        _conv(db, cs, g, _GAIN[cs.act])
+    return {"blk_det": {"cfg": cfg, "weights": blk}, "text_seg": seg, "text_det": db}
+
+
+def throughput_pages(batch: int, size: int = 1024, seed: int = 0) -> torch.Tensor:
+    """Uniform-random u8 pages (B, H, W, 3) BGR.  Network time is data independent."""
+    g = torch.Generator().manual_seed(seed)
+    return torch.randint(0, 256, (batch, size, size, 3), dtype=torch.uint8, generator=g)
+
+
+def text_like_page(size_hw=(1024, 1024), seed: int = 0, n_blocks: int = 18) -> np.ndarray:
+    """A synthetic page for post-processing tests: light background, grey-tone
+    panels, and clusters of dark stroke-like rectangles laid out as horizontal
+    and vertical 'text lines' (about 5 % ink, like the reference's example
+    mask `data/doc/AisazuNihaIrarenai-003-mask.png`).  Returns BGR uint8 HxWx3."""
+    rng = np.random.RandomState(seed)
+    h, w = size_hw
+    img = np.full((h, w, 3), 245, np.uint8)
+    for _ in range(6):   # screentone panels
+        x0, y0 = rng.randint(0, w - 64), rng.randint(0, h - 64)
+        x1, y1 = min(w, x0 + rng.randint(64, w // 2)), min(h, y0 + rng.randint(64, h // 2))
+        img[y0:y1, x0:x1] = rng.randint(150, 235)
+    for _ in range(n_blocks):
+        vertical = rng.rand() < 0.5
+        fs = int(rng.randint(12, 34))
+        nl = int(rng.randint(1, 6))
+        ln = int(rng.randint(3, 12))
+        bw = (nl * int(fs * 1.5)) if vertical else (ln * fs)
+        bh = (ln * fs) if vertical else (nl * int(fs * 1.5))
+        if bw + 8 >= w or bh + 8 >= h:
+            continue
+        x0, y0 = rng.randint(4, w - bw - 4), rng.randint(4, h - bh - 4)
+        img[max(0, y0 - 6):y0 + bh + 6, max(0, x0 - 6):x0 + bw + 6] = 255   # balloon
+        for li in range(nl):
+            for ci in range(ln):
+                if vertical:
+                    cx, cy = x0 + bw - (li + 1) * int(fs * 1.5) + fs // 4, y0 + ci * fs
+                else:
+                    cx, cy = x0 + ci * fs, y0 + li * int(fs * 1.5) + fs // 4
+                for _s in range(4):    # a few strokes per glyph
+                    sx, sy = cx + rng.randint(0, max(1, fs - 4)), cy + rng.randint(0, max(1, fs - 4))
+                    if rng.rand() < 0.5:
+                        img[sy:sy + max(2, fs // 8), sx:min(sx + fs // 2, cx + fs - 2)] = rng.randint(0, 40)
+                    else:
+                        img[sy:min(sy + fs // 2, cy + fs - 2), sx:sx + max(2, fs // 8)] = rng.randint(0, 40)
+    return img

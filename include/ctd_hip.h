@@ -1,0 +1,200 @@
+/*
+ * ctd_hip.h -- C ABI of the MI355X (gfx950) comic-text-detector hot path.
+ *
+ * This library is the third backend behind the reference's backend seam:
+ *
+ *     blks, mask, lines_map = self.net(img_in)          (reference inference.py:146)
+ *
+ * next to `TextDetBase.forward` (reference basemodel.py:240-244, torch) and
+ * `TextDetBaseDNN.__call__` (reference basemodel.py:252-256, OpenCV-DNN/ONNX,
+ * tensor names `images` -> `blk, seg, det`, reference utils/export.py:43-44).
+ *
+ * Plain pointers and sizes only; no torch types.  All pointers named *_dev are
+ * device (HBM) pointers on the engine's device; everything else is host memory.
+ * Every entry point returns CTD_OK (0) or a negative error code, never throws;
+ * `ctd_last_error()` returns a thread-local human readable message.
+ * Calls are asynchronous on the `stream` argument (a hipStream_t passed as
+ * void*; NULL = the null stream) unless stated otherwise.
+ */
+#ifndef CTD_HIP_H
+#define CTD_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CTD_ABI_VERSION 1
+
+/* ---- error codes ------------------------------------------------------ */
+#define CTD_OK 0
+#define CTD_ERR_INVALID (-1)     /* bad argument / malformed program            */
+#define CTD_ERR_HIP (-2)         /* a HIP runtime call failed                   */
+#define CTD_ERR_UNSUPPORTED (-3) /* op/shape outside what the engine implements */
+#define CTD_ERR_NOMEM (-4)
+
+/* ---- arithmetic modes -------------------------------------------------- */
+#define CTD_PREC_F32 0 /* fp32 activations, exact fmaf chains (parity / config 2)   */
+#define CTD_PREC_F16 1 /* fp16 activations+weights, fp32 accumulate on MFMA (config 3) */
+
+/* ---- activations (reference models/yolov5/common.py:36-44, basemodel.py) -- */
+#define CTD_ACT_NONE 0
+#define CTD_ACT_SILU 1
+#define CTD_ACT_LEAKY 2 /* LeakyReLU(0.1) */
+#define CTD_ACT_RELU 3
+#define CTD_ACT_SIGMOID 4
+
+/* ---- network input formats -------------------------------------------- */
+#define CTD_IN_NCHW_F32 0 /* (B,3,H,W) float in [0,1]: what preprocess_img hands the net
+                             (reference inference.py:72-83)                           */
+#define CTD_IN_NHWC_U8 1  /* (B,H,W,3) uint8 letterboxed page, channel order as the net
+                             sees it (BGR, reference SURVEY App.C-1); /255 is fused    */
+
+/* ---- op kinds of the lowered program ----------------------------------- */
+#define CTD_OP_INPUT 1     /* network input -> 3-channel NHWC activation tensor          */
+#define CTD_OP_CONV 2      /* conv2d k x k / stride / pad, <=2 concatenated sources with
+                              optional nearest x2 upsample each, bias, act, residual     */
+#define CTD_OP_CONVT 3     /* ConvTranspose2d k x k / stride / pad, bias, act            */
+#define CTD_OP_MAXPOOL 4   /* k x k, stride 1, pad k/2 (SPPF, reference common.py:188)   */
+#define CTD_OP_AVGPOOL2 5  /* 2x2 stride 2 (reference basemodel.py:38)                   */
+#define CTD_OP_DETECT 6    /* YOLO Detect decode of one level (reference yolo.py:23-44)  */
+#define CTD_OP_EXPORT 7    /* 1-channel activation -> plane of an f32 NCHW output,
+                              optional u8 side output                                    */
+#define CTD_OP_STEM 8      /* fused CTD_OP_INPUT + 6x6/s2/p2 conv (3 -> cout)            */
+#define CTD_OP_SEG_FINAL 9 /* fused ConvT 4x4/s2/p1 (cin -> 1) + sigmoid + exports       */
+#define CTD_OP_DB_UP 10    /* fused DB tail: per branch ConvT2x2(q->q)+ReLU, ConvT2x2(q->1),
+                              sigmoid, exports (reference basemodel.py:99-102,138-142)   */
+
+/* ---- external outputs (selected by ctd_op.aux[0] of EXPORT-like ops) ---- */
+#define CTD_OUT_MASK 0    /* mask      (B,1,H,W) f32 + mask_u8 (B,H,W) = (uint8)(p*255)
+                             (reference inference.py:85-99 postprocess_mask)             */
+#define CTD_OUT_LINES 1   /* lines_map (B,2,H,W) f32 + bitmap (B,H,W) = plane0 > thresh
+                             (reference utils/db_utils.py:71-72 binarize)                */
+
+/* A tensor of the program: NHWC activation with `channels` channels at
+ * spatial size (H >> log2_down, W >> log2_down). */
+typedef struct ctd_tensor {
+  int32_t channels;
+  int32_t log2_down;
+  int32_t dtype; /* 0 = the engine's activation type (f32 / f16), 1 = always f32
+                    (used for the raw Detect logits so the box decode stays fp32) */
+} ctd_tensor;
+
+/* One op.  Sources are (tensor id, channel offset, channel count, upsample
+ * flag); the op reads the channel-concatenation [src0 | src1]. */
+typedef struct ctd_op {
+  int32_t kind;
+  int32_t src0, src0_coff, src0_c, src0_up;
+  int32_t src1, src1_coff, src1_c, src1_up; /* src1 = -1: unused */
+  int32_t res, res_coff;                    /* residual added AFTER act (reference common.py:104); -1: none */
+  int32_t dst, dst_coff;
+  int32_t cout;
+  int32_t k, stride, pad;
+  int32_t act;
+  int64_t w_off; /* element offset of the weights in the f32 parameter blob:
+                    CONV : (cout, cin, k, k)   [torch Conv2d layout, BN folded]
+                    CONVT: (cin, cout, k, k)   [torch ConvTranspose2d layout, BN folded] */
+  int64_t b_off; /* element offset of the bias (cout floats), or -1 */
+  int32_t aux[8];
+  /* DETECT   : aux[0]=level stride, aux[1]=row offset into blks PER 64x64 INPUT UNIT
+                (scaled by (H/64)*(W/64) at run time), aux[2]=na, aux[3]=no
+     EXPORT   : aux[0]=CTD_OUT_*, aux[1]=plane index
+     SEG_FINAL: aux[0]=CTD_OUT_MASK
+     DB_UP    : aux[0]=CTD_OUT_LINES, aux[1]=q (branch channels); parameter
+                layout at w_off: for branch in (binarize, thresh):
+                  W1 (q,q,2,2), b1 (q), W2 (q,1,2,2), b2 (1)                          */
+  float faux[8];
+  /* DETECT   : faux[0..2*na) = anchors in pixels (anchor * stride)
+     EXPORT / DB_UP : faux[0] = binarisation threshold for the u8 bitmap               */
+} ctd_op;
+
+typedef struct ctd_engine ctd_engine;
+
+/* ---- engine ------------------------------------------------------------ */
+
+/* Builds an engine from a lowered program.  `params` is a host blob of
+ * `n_params` floats holding every (BN-folded) weight and bias; the engine
+ * repacks (and for CTD_PREC_F16 converts) them into its own device layouts, so
+ * the caller may free the blob afterwards.  Synchronous. */
+int ctd_engine_create(ctd_engine** out, const ctd_tensor* tensors, int32_t n_tensors,
+                      const ctd_op* ops, int32_t n_ops, const float* params, int64_t n_params,
+                      int32_t precision, int32_t device);
+
+void ctd_engine_destroy(ctd_engine* e);
+
+/* Row count of `blks` for an H x W input (sum over Detect levels of na*ny*nx),
+ * and the per-row width `no` (5 + nc). */
+int ctd_engine_blks_shape(const ctd_engine* e, int32_t H, int32_t W, int32_t* rows, int32_t* no);
+
+/* The fused forward: replaces `TextDetBase.forward` (reference basemodel.py:240-244).
+ *   input_dev : B pages in `input_fmt`
+ *   blks_dev  : (B, rows, no) f32           (`blk`, reference yolo.py:44)
+ *   mask_dev  : (B, 1, H, W) f32            (`seg`, reference basemodel.py:74)
+ *   lines_dev : (B, 2, H, W) f32            (`det`, reference basemodel.py:125)
+ *   mask_u8_dev / bitmap_dev : (B, H, W) u8 fused post-processing side outputs
+ *               (reference inference.py:96-99 / utils/db_utils.py:71-72); may be NULL.
+ * H and W must be multiples of 64 (reference SURVEY section 5).  Workspace is
+ * (re)planned internally when (B,H,W) changes (synchronous in that case). */
+int ctd_engine_forward(ctd_engine* e, const void* input_dev, int32_t input_fmt, int32_t B, int32_t H,
+                       int32_t W, float* blks_dev, float* mask_dev, float* lines_dev,
+                       uint8_t* mask_u8_dev, uint8_t* bitmap_dev, void* stream);
+
+/* Introspection for tests / bench: per-op algorithmic work for the last
+ * planned (B,H,W).  Arrays have ctd_engine_n_ops() entries. */
+int32_t ctd_engine_n_ops(const ctd_engine* e);
+int ctd_engine_op_work(const ctd_engine* e, double* flops, double* bytes, int32_t* kernel_class);
+/* kernel_class: 0 = pointwise/pool/export, 1 = MFMA implicit-GEMM conv, 2 = MFMA convT,
+ *               3 = direct (VALU) conv, 4 = fused stem / seg-final / db-up */
+
+/* Runs one forward with a hipEvent pair around every op on `stream` and
+ * returns the per-op milliseconds (synchronous). */
+int ctd_engine_profile(ctd_engine* e, const void* input_dev, int32_t input_fmt, int32_t B, int32_t H,
+                       int32_t W, float* blks_dev, float* mask_dev, float* lines_dev,
+                       uint8_t* mask_u8_dev, uint8_t* bitmap_dev, void* stream, float* op_ms);
+
+/* Copies activation tensor `tensor_id` of the last forward to host as f32
+ * NHWC (debug / per-layer parity tests).  Synchronous. */
+int ctd_engine_read_tensor(ctd_engine* e, int32_t tensor_id, float* host_out, int64_t n_floats);
+
+/* Bytes of HBM held by the activation arena for the current plan. */
+int64_t ctd_engine_workspace_bytes(const ctd_engine* e);
+
+/* ---- post-processing kernels ------------------------------------------- */
+
+/* Class-aware greedy NMS on the decoded Detect rows; replaces
+ * `non_max_suppression` (reference utils/yolov5_utils.py:124-218, incl. the
+ * torchvision.ops.nms call at :202) for multi_label=False, agnostic=False.
+ *   blks_dev   : (B, rows, no) f32 [cx,cy,w,h,obj,cls...]
+ *   dets_dev   : (B, max_det, 6) f32 [x1,y1,x2,y2,conf,cls], score-descending
+ *   counts_dev : (B) i32 number of valid rows in dets
+ * `ws_dev` scratch of at least ctd_nms_workspace_bytes(B, rows) bytes. */
+size_t ctd_nms_workspace_bytes(int32_t B, int32_t rows);
+int ctd_nms(const float* blks_dev, int32_t B, int32_t rows, int32_t no, float conf_thres,
+            float iou_thres, int32_t max_det, int32_t max_nms, float max_wh, float* dets_dev,
+            int32_t* counts_dev, void* ws_dev, size_t ws_bytes, void* stream);
+
+/* Connected-component labelling with statistics of (img > thresh) on a batch
+ * of u8 images; replaces `cv2.connectedComponentsWithStats` (reference
+ * utils/textmask.py:93,113,138).  connectivity 4 or 8.
+ *   labels_dev : (B, H, W) i32; 0 = background, components numbered 1..n in
+ *                raster order of their first pixel
+ *   n_dev      : (B) i32 number of components (excluding background)
+ *   stats_dev  : (B, max_labels, 5) i32 [x, y, w, h, area] for labels 1..n at
+ *                row label-1 (rows beyond max_labels are dropped, n still counts them) */
+size_t ctd_ccl_workspace_bytes(int32_t B, int32_t H, int32_t W);
+int ctd_ccl(const uint8_t* img_dev, int32_t B, int32_t H, int32_t W, int32_t thresh,
+            int32_t connectivity, int32_t* labels_dev, int32_t* n_dev, int32_t* stats_dev,
+            int32_t max_labels, void* ws_dev, size_t ws_bytes, void* stream);
+
+/* ---- misc -------------------------------------------------------------- */
+const char* ctd_last_error(void);
+int32_t ctd_abi_version(void);
+/* Fills name (<=255 chars) and returns the gfx arch number (950 on MI355X), or <0. */
+int ctd_device_info(int32_t device, char* name, int32_t* cu_count, int64_t* hbm_bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CTD_HIP_H */

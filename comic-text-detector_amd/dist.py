@@ -1,0 +1,87 @@
+"""Multi-GPU: pages are independent units, so the batch is sharded
+contiguously across ranks (one process per GPU) and the ONLY collective on the
+data path is one all-gather of the fixed-capacity per-page result records
+(SURVEY 8(e)).  `backend="nccl"` is RCCL over xGMI on ROCm; the same code runs
+on `gloo` for the CPU tests.
+
+The reference has no distributed code at all; this module is new.
+"""
+from __future__ import annotations
+
+import os
+from typing import Optional, Tuple
+
+import torch
+import torch.distributed as dist
+
+MAX_DET = 300      # reference utils/yolov5_utils.py:125 max_det
+MAX_LINES = 1000   # reference utils/db_utils.py:33 max_candidates
+
+
+def env_world() -> Tuple[int, int, int]:
+    """(rank, local_rank, world_size) from the torchrun environment."""
+    return (int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")),
+            int(os.environ.get("WORLD_SIZE", "1")))
+
+
+def init(backend: Optional[str] = None) -> Tuple[int, int, int]:
+    rank, local_rank, world = env_world()
+    if world > 1 and not dist.is_initialized():
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        kw = {}
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+            kw["device_id"] = torch.device("cuda", local_rank)
+        dist.init_process_group(backend, rank=rank, world_size=world, **kw)
+    return rank, local_rank, world
+
+
+def shard_range(n_items: int, rank: int, world: int) -> Tuple[int, int]:
+    """Contiguous split: rank r owns pages [lo, hi).  Remainder pages go to the
+    lowest ranks so sizes differ by at most one."""
+    q, r = divmod(n_items, world)
+    lo = rank * q + min(rank, r)
+    return lo, lo + q + (1 if rank < r else 0)
+
+
+def pack_records(dets: torch.Tensor, counts: torch.Tensor, lines: Optional[torch.Tensor] = None,
+                 line_counts: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """One fixed-size f32 record per page:
+       [n_blk, n_line, blocks MAX_DET x 6 (xyxy, conf, cls), lines MAX_LINES x 9 (4 pts + score)]."""
+    B = dets.shape[0]
+    rec = torch.zeros((B, 2 + MAX_DET * 6 + MAX_LINES * 9), dtype=torch.float32, device=dets.device)
+    rec[:, 0] = counts.to(torch.float32)
+    rec[:, 2:2 + MAX_DET * 6] = dets.reshape(B, -1)
+    if lines is not None:
+        rec[:, 1] = line_counts.to(torch.float32)
+        rec[:, 2 + MAX_DET * 6:] = lines.reshape(B, -1)
+    return rec
+
+
+def unpack_records(rec: torch.Tensor):
+    B = rec.shape[0]
+    counts = rec[:, 0].to(torch.int32)
+    line_counts = rec[:, 1].to(torch.int32)
+    dets = rec[:, 2:2 + MAX_DET * 6].reshape(B, MAX_DET, 6)
+    lines = rec[:, 2 + MAX_DET * 6:].reshape(B, MAX_LINES, 9)
+    return dets, counts, lines, line_counts
+
+
+def gather_records(rec: torch.Tensor, n_total: int, rank: int, world: int) -> torch.Tensor:
+    """All-gather the per-page records; returns (n_total, R) in global page order on
+    every rank.  Shards may differ by one page, so each rank pads to the largest shard."""
+    if world == 1:
+        return rec
+    per = -(-n_total // world)
+    pad = torch.zeros((per, rec.shape[1]), dtype=rec.dtype, device=rec.device)
+    pad[: rec.shape[0]] = rec
+    out = torch.empty((world * per, rec.shape[1]), dtype=rec.dtype, device=rec.device)
+    dist.all_gather_into_tensor(out, pad)
+    parts = []
+    for r in range(world):
+        lo, hi = shard_range(n_total, r, world)
+        parts.append(out[r * per: r * per + (hi - lo)])
+    return torch.cat(parts, 0)

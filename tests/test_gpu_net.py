@@ -1,0 +1,142 @@
+"""-m gpu: parity of the HIP forward (through the C ABI) with the oracle and
+with the golden vectors produced by the reference's own modules.
+
+Tolerances (fp is not bit-exact across different summation orders):
+  fp32 engine: sigmoid outputs within 2e-5 abs of the reference, Detect rows
+               within 1e-4 relative; u8 mask may differ by one level on <0.1 % px.
+  fp16 engine: fp16 operands/activations with fp32 accumulation vs an fp32
+               reference: sigmoid outputs within 2e-2 abs, mean abs < 2e-3;
+               thresholded (binary) maps IoU >= 0.99 on the synthetic-weight net
+               whose outputs sit near 0.5 (worst case for a threshold).
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import checkpoint, load_golden, pkg
+from oracle import gen_golden
+from oracle.net_ref import OracleNet
+
+pytestmark = pytest.mark.gpu
+
+_BACKENDS = {}
+
+
+def backend(prec: str, seed: int = 0):
+    key = (prec, seed)
+    if key not in _BACKENDS:
+        _BACKENDS[key] = pkg().backend.HipTextDetBackend(checkpoint(seed), device="cuda", precision=prec)
+    return _BACKENDS[key]
+
+
+def iou(a, b):
+    a, b = a.astype(bool), b.astype(bool)
+    u = (a | b).sum()
+    return 1.0 if u == 0 else (a & b).sum() / u
+
+
+@pytest.mark.parametrize("name", sorted(gen_golden.SMALL_CASES))
+def test_fp32_engine_matches_reference_golden(name):
+    g = load_golden(name)
+    be = backend("fp32", int(g["wseed"]))
+    x = gen_golden.make_input(int(g["iseed"]), tuple(int(v) for v in g["shape"]))
+    blks, mask, lines = be(x.cuda())
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(mask.cpu().numpy(), g["mask"], rtol=0, atol=2e-5)
+    np.testing.assert_allclose(lines.cpu().numpy(), g["lines"], rtol=0, atol=2e-5)
+    np.testing.assert_allclose(blks.cpu().numpy(), g["blks"], rtol=1e-4, atol=2e-3)
+    ref_u8 = (g["mask"][:, 0] * 255).astype(np.uint8)
+    got_u8 = be.mask_u8.cpu().numpy()
+    diff = np.abs(ref_u8.astype(int) - got_u8.astype(int))
+    assert diff.max() <= 1 and (diff > 0).mean() < 1e-3
+    assert ((g["lines"][:, 0] > 0.3) != be.bitmap.cpu().numpy().astype(bool)).mean() < 1e-3
+
+
+@pytest.mark.parametrize("name", sorted(gen_golden.SMALL_CASES))
+def test_fp16_engine_close_to_reference_golden(name):
+    g = load_golden(name)
+    be = backend("fp16", int(g["wseed"]))
+    x = gen_golden.make_input(int(g["iseed"]), tuple(int(v) for v in g["shape"]))
+    blks, mask, lines = be(x.cuda())
+    torch.cuda.synchronize()
+    for got, ref in ((mask, g["mask"]), (lines, g["lines"])):
+        d = np.abs(got.cpu().numpy() - ref)
+        assert d.max() < 2e-2 and d.mean() < 2e-3, (d.max(), d.mean())
+    # objectness / class scores are probabilities: same absolute tolerance
+    b = blks.cpu().numpy()
+    assert np.abs(b[..., 4:] - g["blks"][..., 4:]).max() < 2e-2
+    # boxes of confident rows: relative 1 % (fp16 logits -> exp)
+    conf = g["blks"][..., 4] > 0.25
+    if conf.any():
+        rel = np.abs(b[conf][:, :4] - g["blks"][conf][:, :4]) / (np.abs(g["blks"][conf][:, :4]) + 8.0)
+        assert rel.max() < 2e-2, rel.max()
+    assert iou(mask.cpu().numpy() > 0.5, g["mask"] > 0.5) > 0.98
+    assert iou(be.bitmap.cpu().numpy(), g["lines"][:, 0] > 0.3) > 0.98
+
+
+@pytest.mark.parametrize("prec", ["fp32", "fp16"])
+def test_full_size_page_vs_reference_summary(prec):
+    """1024x1024 text-like page: tile means / top Detect rows of the reference."""
+    g = load_golden("net_full_summary")
+    p = pkg()
+    page = p.synth.text_like_page((int(g["size"]),) * 2, int(g["pseed"]))
+    x = gen_golden.page_to_input(page)
+    assert float(x.double().sum()) == pytest.approx(float(g["input_sum"]), abs=1e-6)
+    be = backend(prec, int(g["wseed"]))
+    blks, mask, lines = be(x.cuda())
+    torch.cuda.synchronize()
+    tol = 1e-5 if prec == "fp32" else 3e-3
+    np.testing.assert_allclose(gen_golden.tile_means(mask.cpu()), g["mask_tiles"], rtol=0, atol=tol)
+    np.testing.assert_allclose(gen_golden.tile_means(lines.cpu()), g["lines_tiles"], rtol=0, atol=tol)
+    top = blks[0].cpu().numpy()[g["top_rows"]]
+    if prec == "fp32":
+        np.testing.assert_allclose(top, g["top_blks"], rtol=2e-4, atol=5e-3)
+    else:
+        assert np.abs(top[:, 4:] - g["top_blks"][:, 4:]).max() < 3e-2
+    # u8 histogram of the mask: the fused quantiser saw (almost) the same values
+    hist = np.bincount(be.mask_u8[0].cpu().numpy().ravel(), minlength=256)
+    moved = np.abs(hist - g["mask_u8_hist"]).sum() / hist.sum()
+    assert moved < (2e-3 if prec == "fp32" else 0.2)
+    # the same page through the u8 entry point (fused /255) gives the same result
+    pages = torch.from_numpy(page)[None].cuda()
+    blks2, mask2, lines2 = be.forward_u8(pages)
+    torch.cuda.synchronize()
+    assert torch.allclose(mask2, mask, atol=1e-6 if prec == "fp32" else 2e-3)
+
+
+@pytest.mark.parametrize("prec", ["fp32", "fp16"])
+def test_determinism_and_batch_independence(prec):
+    be = backend(prec)
+    x = gen_golden.make_input(11, (3, 128, 192)).cuda()
+    a = [t.clone() for t in be(x)]
+    b = [t.clone() for t in be(x)]
+    torch.cuda.synchronize()
+    for u, v in zip(a, b):
+        assert torch.equal(u, v), "two runs on the same input differ"
+    c = be(x[1:2].contiguous())
+    torch.cuda.synchronize()
+    for u, v in zip(a, c):
+        assert torch.equal(u[1:2], v), "page result depends on its batch neighbours"
+
+
+def test_fp16_vs_oracle_mid_size_statistics():
+    """512x512, B=2: error statistics of the MFMA path against the fp32 oracle."""
+    ck = checkpoint(0)
+    x = gen_golden.make_input(21, (2, 512, 512))
+    ob, om, ol = OracleNet(ck)(x)
+    be = backend("fp16")
+    blks, mask, lines = be(x.cuda())
+    torch.cuda.synchronize()
+    dm = (mask.cpu() - om).abs()
+    dl = (lines.cpu() - ol).abs()
+    print(f"fp16 vs fp32-oracle @512: mask max {dm.max():.3e} mean {dm.mean():.3e}; "
+          f"lines max {dl.max():.3e} mean {dl.mean():.3e}")
+    assert dm.max() < 3e-2 and dm.mean() < 2e-3 and dl.max() < 3e-2 and dl.mean() < 2e-3
+
+
+def test_bad_shapes_raise():
+    be = backend("fp16")
+    with pytest.raises(ValueError):
+        be(torch.zeros(1, 3, 100, 128, device="cuda"))
+    with pytest.raises(ValueError):
+        be(torch.zeros(1, 4, 128, 128, device="cuda"))

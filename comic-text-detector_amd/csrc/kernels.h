@@ -24,6 +24,7 @@ void launch_export_plane(const void* src, int pitch, bool f16, float* out, int n
 
 // ---- kernels_igemm.hip : MFMA implicit-GEMM conv (fp16 in, fp32 acc) ------
 // weights: half [nphase][Npad][K], K index = (ty*KW+tx)*(c0+c1) + c
+extern int g_igemm_force_bk;  // tuning knob: 0 = heuristic, 32 / 64 = forced K step
 bool igemm_supported(const ConvArgs& a);
 int igemm_ntile(int N);  // N tile the dispatcher will use (weights must be padded to it)
 void launch_conv_igemm(const ConvArgs& a, bool dst_f32, hipStream_t st);

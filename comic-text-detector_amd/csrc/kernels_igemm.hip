@@ -26,15 +26,18 @@
 
 namespace {
 
-constexpr int BK = 32;
-constexpr int LP = 40;  // LDS row pitch in halves
-
-template <int BN, int BM, int WGN, int WGM, bool DST_F32>
+// K step BK = 32 or 64 halves per LDS row, padded by 8 halves (16 B): row pitch 80 B / 144 B.
+// Both pitches map 16 consecutive rows (and the non-contiguous 16-lane groups of
+// ds_read_b128) onto 16 distinct 16-B slots of the 256-B bank row -> conflict free.
+template <int BN, int BM, int WGN, int WGM, int BK, bool DST_F32>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
+  constexpr int LP = BK + 8;                        // LDS row pitch in halves
+  constexpr int SEGS = BK / 8;                      // 16-B chunks per row
+  constexpr int RPP = 256 / SEGS;                   // rows staged per pass of the 256 threads
   constexpr int TN = BN / (32 * WGN);
   constexpr int TM = BM / (32 * WGM);
-  constexpr int AROWS = BM / 64;                    // pixel rows each thread stages
-  constexpr int WCHUNKS = BN * 4;                   // 16-B chunks of the weight tile
+  constexpr int AROWS = BM / RPP;                   // pixel rows each thread stages
+  constexpr int WCHUNKS = BN * SEGS;                // 16-B chunks of the weight tile
   constexpr int WROWS = (WCHUNKS + 255) / 256;
   static_assert(WGN * WGM == 4, "4 waves");
 
@@ -78,13 +81,13 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
   }
 
   // ---- per-thread staging coordinates ----------------------------------------
-  const int seg = t & 3;
-  const int lrow = t >> 2;  // 0..63
+  const int seg = t % SEGS;
+  const int lrow = t / SEGS;  // 0..RPP-1
   int pb[AROWS], piy[AROWS], pix[AROWS];
   bool pvalid[AROWS];
 #pragma unroll
   for (int i = 0; i < AROWS; ++i) {
-    const int m = m0 + lrow + 64 * i;
+    const int m = m0 + lrow + RPP * i;
     pvalid[i] = m < a.M;
     const int mm = pvalid[i] ? m : 0;
     const int ox = mm % a.Mw;
@@ -124,7 +127,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
     for (int i = 0; i < WROWS; ++i) {
       const int chunk = t + 256 * i;
       if (WCHUNKS >= 256 || chunk < WCHUNKS) {
-        const int row = chunk >> 2;
+        const int row = chunk / SEGS;
         rw[i] = *(const half8_t*)(wbase + (size_t)(n0 + row) * a.K + (size_t)ks * BK + seg * 8);
       }
     }
@@ -139,12 +142,12 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
   auto store_tile = [&](int buf) {
 #pragma unroll
     for (int i = 0; i < AROWS; ++i)
-      *(half8_t*)(As + ((size_t)buf * BM + lrow + 64 * i) * LP + seg * 8) = ra[i];
+      *(half8_t*)(As + ((size_t)buf * BM + lrow + RPP * i) * LP + seg * 8) = ra[i];
 #pragma unroll
     for (int i = 0; i < WROWS; ++i) {
       const int chunk = t + 256 * i;
       if (WCHUNKS >= 256 || chunk < WCHUNKS)
-        *(half8_t*)(Ws + ((size_t)buf * BN + (chunk >> 2)) * LP + seg * 8) = rw[i];
+        *(half8_t*)(Ws + ((size_t)buf * BN + (chunk / SEGS)) * LP + seg * 8) = rw[i];
     }
   };
 
@@ -167,7 +170,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
     const half_t* Ab = As + (size_t)buf * BM * LP + (size_t)(wm * TM * 32 + l31) * LP + kg;
     const half_t* Wb = Ws + (size_t)buf * BN * LP + (size_t)(wn * TN * 32 + l31) * LP + kg;
 #pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
+    for (int kk = 0; kk < BK / 16; ++kk) {
       half8_t fw[TN], fx[TM];
 #pragma unroll
       for (int i = 0; i < TN; ++i) fw[i] = *(const half8_t*)(Wb + i * 32 * LP + kk * 16);
@@ -228,15 +231,15 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
   }
 }
 
-template <int BN, int BM, int WGN, int WGM>
+template <int BN, int BM, int WGN, int WGM, int BK>
 void launch_cfg(const ConvArgs& a, bool dst_f32, hipStream_t st) {
   const int ntn = a.Npad / BN;
   const int ntm = (a.M + BM - 1) / BM;
   dim3 grid(ntn * ntm, 1, a.nphase);
   if (dst_f32)
-    hipLaunchKernelGGL((conv_igemm_kernel<BN, BM, WGN, WGM, true>), grid, dim3(256), 0, st, a);
+    hipLaunchKernelGGL((conv_igemm_kernel<BN, BM, WGN, WGM, BK, true>), grid, dim3(256), 0, st, a);
   else
-    hipLaunchKernelGGL((conv_igemm_kernel<BN, BM, WGN, WGM, false>), grid, dim3(256), 0, st, a);
+    hipLaunchKernelGGL((conv_igemm_kernel<BN, BM, WGN, WGM, BK, false>), grid, dim3(256), 0, st, a);
 }
 
 // probe: one wave, D = A(32x16) * B(16x32) with the fragment convention used above
@@ -265,7 +268,17 @@ int igemm_ntile(int N) {
   return 32;
 }
 
+int g_igemm_force_bk = 0;  // selftest / tuning: 0 = heuristic, 32 or 64 = forced
+
+static int pick_bk(const ConvArgs& a) {
+  const bool can64 = (a.s0.c % 64 == 0) && (a.s1.c % 64 == 0);
+  if (g_igemm_force_bk == 32 || !can64) return 32;
+  if (g_igemm_force_bk == 64) return 64;
+  return 64;
+}
+
 bool igemm_supported(const ConvArgs& a) {
+  constexpr int BK = 32;
   if (a.s0.c % BK || a.s1.c % BK) return false;
   if (a.s0.pitch % 8 || (a.s1.c && a.s1.pitch % 8)) return false;
   if (a.pitchD % 4 || (a.res && a.pitchR % 4)) return false;
@@ -275,9 +288,15 @@ bool igemm_supported(const ConvArgs& a) {
 
 void launch_conv_igemm(const ConvArgs& a, bool dst_f32, hipStream_t st) {
   const int bn = igemm_ntile(a.N);
-  if (bn == 128) launch_cfg<128, 128, 2, 2>(a, dst_f32, st);
-  else if (bn == 64) launch_cfg<64, 128, 2, 2>(a, dst_f32, st);
-  else launch_cfg<32, 128, 1, 4>(a, dst_f32, st);
+  if (pick_bk(a) == 64) {
+    if (bn == 128) launch_cfg<128, 128, 2, 2, 64>(a, dst_f32, st);
+    else if (bn == 64) launch_cfg<64, 128, 2, 2, 64>(a, dst_f32, st);
+    else launch_cfg<32, 128, 1, 4, 64>(a, dst_f32, st);
+  } else {
+    if (bn == 128) launch_cfg<128, 128, 2, 2, 32>(a, dst_f32, st);
+    else if (bn == 64) launch_cfg<64, 128, 2, 2, 32>(a, dst_f32, st);
+    else launch_cfg<32, 128, 1, 4, 32>(a, dst_f32, st);
+  }
 }
 
 void launch_mfma_probe(const half_t* a, const half_t* b, float* out, hipStream_t st) {

@@ -45,6 +45,9 @@ struct ConvArgs {
   int M;                   // B*Mh*Mw
   long long w_phase_stride;  // elements between phases (convT), else 0
   int nphase;              // 1, or 4 for convT 4x4 s2 (blockIdx.z)
+  int bk;                  // igemm K step the weights were packed for (32 / 64)
+  int w_tiled;             // igemm weights are tile-major [phase][n_tile][k_step][BN][bk]
+  int k_rot;               // igemm: rotate the K-step order per pixel tile (L2 channel spreading)
 };
 
 __device__ __forceinline__ float ctd_act(float v, int act) {

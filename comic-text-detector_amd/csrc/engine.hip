@@ -43,6 +43,7 @@ struct OpState {
   float* b_dev = nullptr;     // bias (padded)
   float* aux_dev = nullptr;   // anchors etc.
   int npad = 0;
+  int bk = 0;
   // filled by plan()
   ConvArgs args{};
   double flops = 0, bytes = 0;
@@ -69,6 +70,8 @@ struct ctd_engine {
   size_t arena_bytes = 0;
   int pB = 0, pH = 0, pW = 0;  // current plan
   bool no_reuse = false;
+  bool w_tiled = true;   // tile-major MFMA weight packing (CTD_W_TILED=0 disables)
+  bool k_rot = false;    // rotated K order per pixel tile (CTD_K_ROT=1 enables)
   int det_rows_per_unit = 0;
   int det_no = 0;
 };
@@ -125,13 +128,15 @@ int pack_op(ctd_engine* e, OpState& s, const float* P, int64_t nP) {
         const int bn = igemm_ntile(N);
         s.npad = (N + bn - 1) / bn * bn;
         const int K = k * k * cin;
-        std::vector<half_t> wp((size_t)s.npad * K, (half_t)0.f);
+        s.bk = igemm_pick_bk(o.src0_c, o.src1 >= 0 ? o.src1_c : 0, K, N);
+        std::vector<float> lg((size_t)N * K);
         for (int n = 0; n < N; ++n)
           for (int c = 0; c < cin; ++c)
             for (int ky = 0; ky < k; ++ky)
               for (int kx = 0; kx < k; ++kx)
-                wp[(size_t)n * K + (size_t)(ky * k + kx) * cin + c] =
-                    (half_t)W[(((size_t)n * cin + c) * k + ky) * k + kx];
+                lg[(size_t)n * K + (size_t)(ky * k + kx) * cin + c] = W[(((size_t)n * cin + c) * k + ky) * k + kx];
+        std::vector<half_t> wp;
+        igemm_pack_weights(lg.data(), 1, N, K, bn, s.bk, e->w_tiled, wp);
         if (int rc = upload(e, wp, &s.w_dev)) return rc;
         return pack_bias(s.npad);
       }
@@ -162,7 +167,8 @@ int pack_op(ctd_engine* e, OpState& s, const float* P, int64_t nP) {
         const int bn = igemm_ntile(N);
         s.npad = (N + bn - 1) / bn * bn;
         const int K = 4 * cin;
-        std::vector<half_t> wp((size_t)4 * s.npad * K, (half_t)0.f);
+        s.bk = igemm_pick_bk(cin, 0, K, N);
+        std::vector<float> lg((size_t)4 * N * K);
         for (int ph = 0; ph < 4; ++ph) {
           const int py = ph >> 1, px = ph & 1;
           for (int ty = 0; ty < 2; ++ty)
@@ -171,10 +177,12 @@ int pack_op(ctd_engine* e, OpState& s, const float* P, int64_t nP) {
               const int ky = py + 1 - 2 * dy, kx = px + 1 - 2 * dx;
               for (int n = 0; n < N; ++n)
                 for (int c = 0; c < cin; ++c)
-                  wp[((size_t)ph * s.npad + n) * K + (size_t)(ty * 2 + tx) * cin + c] =
-                      (half_t)W[(((size_t)c * N + n) * 4 + ky) * 4 + kx];
+                  lg[((size_t)ph * N + n) * K + (size_t)(ty * 2 + tx) * cin + c] =
+                      W[(((size_t)c * N + n) * 4 + ky) * 4 + kx];
             }
         }
+        std::vector<half_t> wp;
+        igemm_pack_weights(lg.data(), 4, N, K, bn, s.bk, e->w_tiled, wp);
         if (int rc = upload(e, wp, &s.w_dev)) return rc;
         return pack_bias(s.npad);
       }
@@ -418,6 +426,9 @@ int plan(ctd_engine* e, int B, int H, int W) {
       a.Npad = s.npad;
       a.w = s.w_dev;
       a.bias = s.b_dev;
+      a.bk = s.bk;
+      a.w_tiled = e->w_tiled;
+      a.k_rot = e->k_rot;
       const int cin = o.src0_c + (o.src1 >= 0 ? o.src1_c : 0);
       a.nphase = 1;
       a.osy = a.osx = 1;
@@ -593,6 +604,8 @@ int ctd_engine_create(ctd_engine** out, const ctd_tensor* tensors, int32_t n_ten
   e->device = device;
   e->prec = precision;
   e->no_reuse = std::getenv("CTD_NO_REUSE") != nullptr;
+
+
   e->tensors.resize(n_tensors);
   for (int i = 0; i < n_tensors; ++i) e->tensors[i].t = tensors[i];
   e->ops.resize(n_ops);

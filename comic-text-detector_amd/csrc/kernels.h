@@ -1,5 +1,7 @@
 // Host-side launchers of every device kernel (definitions in the .hip files).
 #pragma once
+#include <vector>
+
 #include "ctd_common.h"
 
 // ---- kernels_basic.hip : direct (VALU) kernels, T = float | half_t -------
@@ -25,6 +27,9 @@ void launch_export_plane(const void* src, int pitch, bool f16, float* out, int n
 // ---- kernels_igemm.hip : MFMA implicit-GEMM conv (fp16 in, fp32 acc) ------
 // weights: half [nphase][Npad][K], K index = (ty*KW+tx)*(c0+c1) + c
 extern int g_igemm_force_bk;  // tuning knob: 0 = heuristic, 32 / 64 = forced K step
+int igemm_pick_bk(int c0, int c1, int K, int N);
+void igemm_pack_weights(const float* logical, int nphase, int N, int K, int bn, int bk, bool tiled,
+                        std::vector<half_t>& out);
 bool igemm_supported(const ConvArgs& a);
 int igemm_ntile(int N);  // N tile the dispatcher will use (weights must be padded to it)
 void launch_conv_igemm(const ConvArgs& a, bool dst_f32, hipStream_t st);

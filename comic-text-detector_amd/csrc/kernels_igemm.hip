@@ -22,16 +22,16 @@
 // groups and the 16-lane ds_read_b128 groups hit distinct 16-B bank slots.
 // v_mfma_f32_32x32x16_f16: A/B fragment = 8 consecutive k of row/col (lane & 31),
 // k group = lane >> 5; C/D: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5).
+#include <vector>
+
 #include "kernels.h"
 
 namespace {
 
-// K step BK = 32 or 64 halves per LDS row, padded by 8 halves (16 B): row pitch 80 B / 144 B.
-// Both pitches map 16 consecutive rows (and the non-contiguous 16-lane groups of
-// ds_read_b128) onto 16 distinct 16-B slots of the 256-B bank row -> conflict free.
+// K step BK = 32 or 64 halves per LDS row (64 / 128 B), XOR-swizzled 16-B chunks.
 template <int BN, int BM, int WGN, int WGM, int BK, bool DST_F32>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
-  constexpr int LP = BK + 8;                        // LDS row pitch in halves
+  constexpr int LP = BK;                            // LDS row pitch in halves (XOR swizzled, no pad)
   constexpr int SEGS = BK / 8;                      // 16-B chunks per row
   constexpr int RPP = 256 / SEGS;                   // rows staged per pass of the 256 threads
   constexpr int TN = BN / (32 * WGN);
@@ -80,58 +80,89 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
     wbase += (size_t)phase * a.w_phase_stride;
   }
 
-  // ---- per-thread staging coordinates ----------------------------------------
+  // ---- per-thread staging state ----------------------------------------------
+  // The K loop is instruction-issue bound if addresses are rebuilt per load (PMC:
+  // SQ_ACTIVE_INST_ANY ~4x the MFMA cycles).  So everything per-thread is hoisted:
+  //   aoffN[i] : signed byte offset of this thread's 16-B chunk of row i at tap (0,0)
+  //   vmask[i] : bit t set <=> tap t of row i lies inside the image (zero padding otherwise)
+  // and each K step only adds a wave-uniform (scalar) tap/channel offset.
   const int seg = t % SEGS;
   const int lrow = t / SEGS;  // 0..RPP-1
+  const int Ct = a.s0.c + a.s1.c;
+  const int nk = a.K / BK;
+  int aoff0[AROWS], aoff1[AROWS];
   int pb[AROWS], piy[AROWS], pix[AROWS];
-  bool pvalid[AROWS];
+  unsigned vmask[AROWS];
 #pragma unroll
   for (int i = 0; i < AROWS; ++i) {
     const int m = m0 + lrow + RPP * i;
-    pvalid[i] = m < a.M;
-    const int mm = pvalid[i] ? m : 0;
+    const bool pv = m < a.M;
+    const int mm = pv ? m : 0;
     const int ox = mm % a.Mw;
     const int tq = mm / a.Mw;
     const int oy = tq % a.Mh;
-    pb[i] = tq / a.Mh;
-    piy[i] = oy * a.stride + dy0;
-    pix[i] = ox * a.stride + dx0;
+    const int b = tq / a.Mh;
+    const int iy0 = oy * a.stride + dy0, ix0 = ox * a.stride + dx0;
+    pb[i] = b; piy[i] = iy0; pix[i] = ix0;
+    aoff0[i] = (int)(((((long long)b * a.s0.H + iy0) * a.s0.W + ix0) * a.s0.pitch + seg * 8) * 2);
+    aoff1[i] = (int)(((((long long)b * a.s1.H + iy0) * a.s1.W + ix0) * a.s1.pitch + seg * 8) * 2);
+    unsigned vm = 0;
+    for (int ty = 0; ty < a.KH; ++ty)
+      for (int tx = 0; tx < a.KW; ++tx) {
+        const int iy = iy0 + ty, ix = ix0 + tx;
+        if (pv && iy >= 0 && iy < a.Hin && ix >= 0 && ix < a.Win) vm |= 1u << (ty * a.KW + tx);
+      }
+    vmask[i] = vm;
   }
-  const int Ct = a.s0.c + a.s1.c;
-  const int nk = a.K / BK;
+  // weights: tile-major [n_tile][k_step][BN][BK]; per-thread constant part of the address
+  int woff[WROWS];
+#pragma unroll
+  for (int i = 0; i < WROWS; ++i) woff[i] = (((t + 256 * i) / SEGS) * BK + seg * 8) * 2;
+  const char* wtile = (const char*)(wbase + (size_t)tile_n * nk * BN * BK);
 
   half8_t ra[AROWS];
   half8_t rw[WROWS];
 
-  int cc = 0, ty = 0, tx = 0;  // K-step cursor of the NEXT tile to load
+  int cc = 0, ty = 0, tx = 0, kp = 0;  // K-step cursor of the NEXT tile to load (wave uniform)
+  unsigned rok = 0;                     // bit i: staged row i is inside the image (else zero padding)
 
-  auto load_tile = [&](int ks) {
+  auto load_tile = [&]() {
     // activations
     const bool first = cc < a.s0.c;
     const SrcView& s = first ? a.s0 : a.s1;
-    const int ch = (first ? cc : cc - a.s0.c) + seg * 8;
+    const int ch = first ? cc : cc - a.s0.c;
+    const int tap = ty * a.KW + tx;
+    rok = 0;
+    if (!s.up) {
+      const long long tapoff = (((long long)ty * s.W + tx) * s.pitch + ch) * 2;   // uniform
+      const char* sb = (const char*)s.ptr + tapoff;
+      const int back = (int)-tapoff;                                            // -> s.ptr (always valid)
 #pragma unroll
-    for (int i = 0; i < AROWS; ++i) {
-      const int iy = piy[i] + ty, ix = pix[i] + tx;
-      const bool ok = pvalid[i] && iy >= 0 && iy < a.Hin && ix >= 0 && ix < a.Win;
-      half8_t v = {0, 0, 0, 0, 0, 0, 0, 0};
-      if (ok) {
-        const int sy = s.up ? (iy >> 1) : iy, sx = s.up ? (ix >> 1) : ix;
-        const half_t* p = (const half_t*)s.ptr + ((size_t)((size_t)pb[i] * s.H + sy) * s.W + sx) * s.pitch + ch;
-        v = *(const half8_t*)p;
+      for (int i = 0; i < AROWS; ++i) {
+        const bool ok = (vmask[i] >> tap) & 1u;
+        const int off = ok ? (first ? aoff0[i] : aoff1[i]) : back;
+        ra[i] = *(const half8_t*)(sb + off);      // padding rows read s.ptr; zeroed at store time
+        rok |= (unsigned)ok << i;
       }
-      ra[i] = v;
+    } else {
+      // nearest x2 upsampled producer (yolo neck): source pixel = (iy >> 1, ix >> 1)
+#pragma unroll
+      for (int i = 0; i < AROWS; ++i) {
+        const bool ok = (vmask[i] >> tap) & 1u;
+        const int sy = ok ? ((piy[i] + ty) >> 1) : 0, sx = ok ? ((pix[i] + tx) >> 1) : 0;
+        const half_t* p = (const half_t*)s.ptr +
+                          ((size_t)((size_t)(ok ? pb[i] : 0) * s.H + sy) * s.W + sx) * s.pitch + ch + seg * 8;
+        ra[i] = *(const half8_t*)p;
+        rok |= (unsigned)ok << i;
+      }
     }
     // weights
+    const char* wk = wtile + (size_t)kp * (BN * BK * 2);
 #pragma unroll
-    for (int i = 0; i < WROWS; ++i) {
-      const int chunk = t + 256 * i;
-      if (WCHUNKS >= 256 || chunk < WCHUNKS) {
-        const int row = chunk / SEGS;
-        rw[i] = *(const half8_t*)(wbase + (size_t)(n0 + row) * a.K + (size_t)ks * BK + seg * 8);
-      }
-    }
+    for (int i = 0; i < WROWS; ++i)
+      if (WCHUNKS >= 256 || t + 256 * i < WCHUNKS) rw[i] = *(const half8_t*)(wk + woff[i]);
     // advance cursor
+    ++kp;
     cc += BK;
     if (cc == Ct) {
       cc = 0;
@@ -139,16 +170,33 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
     }
   };
 
+  // LDS image: rows of BK halves, NO padding; the 16-B chunk c of row r lives at chunk
+  // position c ^ f(r), f(r) = (r / rows-per-256B) % chunks-per-row.  With it both the 8-lane
+  // ds_write_b128 groups and the 16-lane ds_read_b128 groups hit distinct 16-B bank slots
+  // (PMC on the padded layout: ds_write 2-way conflicts = 33 % of LDS cycles).
+  constexpr int RPW = 256 / (BK * 2);
+  auto swz = [&](int row) { return (row / RPW) % SEGS; };
+  int sa_off[AROWS], sw_off[WROWS];
+#pragma unroll
+  for (int i = 0; i < AROWS; ++i) {
+    const int r = lrow + RPP * i;
+    sa_off[i] = r * BK + ((seg ^ swz(r)) * 8);
+  }
+#pragma unroll
+  for (int i = 0; i < WROWS; ++i) {
+    const int r = (t + 256 * i) / SEGS;
+    sw_off[i] = r * BK + ((seg ^ swz(r)) * 8);
+  }
   auto store_tile = [&](int buf) {
 #pragma unroll
-    for (int i = 0; i < AROWS; ++i)
-      *(half8_t*)(As + ((size_t)buf * BM + lrow + RPP * i) * LP + seg * 8) = ra[i];
-#pragma unroll
-    for (int i = 0; i < WROWS; ++i) {
-      const int chunk = t + 256 * i;
-      if (WCHUNKS >= 256 || chunk < WCHUNKS)
-        *(half8_t*)(Ws + ((size_t)buf * BN + (chunk / SEGS)) * LP + seg * 8) = rw[i];
+    for (int i = 0; i < AROWS; ++i) {
+      // the zero-fill select sits here, after the MFMAs, so the loads stay in flight during compute
+      const half8_t z = {0, 0, 0, 0, 0, 0, 0, 0};
+      *(half8_t*)(As + (size_t)buf * BM * LP + sa_off[i]) = ((rok >> i) & 1u) ? ra[i] : z;
     }
+#pragma unroll
+    for (int i = 0; i < WROWS; ++i)
+      if (WCHUNKS >= 256 || t + 256 * i < WCHUNKS) *(half8_t*)(Ws + (size_t)buf * BN * LP + sw_off[i]) = rw[i];
   };
 
   float16_t acc[TN][TM];
@@ -159,23 +207,25 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  load_tile(0);
+  load_tile();
   store_tile(0);
   __syncthreads();
 
-  const int l31 = lane & 31, kg = (lane >> 5) * 8;
+  const int l31 = lane & 31, khalf = lane >> 5;
+  const int fl = swz(l31);   // rows of one fragment differ by multiples of 32 -> same swizzle
   for (int ks = 0; ks < nk; ++ks) {
     const int buf = ks & 1;
-    if (ks + 1 < nk) load_tile(ks + 1);
-    const half_t* Ab = As + (size_t)buf * BM * LP + (size_t)(wm * TM * 32 + l31) * LP + kg;
-    const half_t* Wb = Ws + (size_t)buf * BN * LP + (size_t)(wn * TN * 32 + l31) * LP + kg;
+    if (ks + 1 < nk) load_tile();
+    const half_t* Ab = As + (size_t)buf * BM * LP + (size_t)(wm * TM * 32 + l31) * LP;
+    const half_t* Wb = Ws + (size_t)buf * BN * LP + (size_t)(wn * TN * 32 + l31) * LP;
 #pragma unroll
     for (int kk = 0; kk < BK / 16; ++kk) {
+      const int co = ((kk * 2 + khalf) ^ fl) * 8;
       half8_t fw[TN], fx[TM];
 #pragma unroll
-      for (int i = 0; i < TN; ++i) fw[i] = *(const half8_t*)(Wb + i * 32 * LP + kk * 16);
+      for (int i = 0; i < TN; ++i) fw[i] = *(const half8_t*)(Wb + i * 32 * LP + co);
 #pragma unroll
-      for (int j = 0; j < TM; ++j) fx[j] = *(const half8_t*)(Ab + j * 32 * LP + kk * 16);
+      for (int j = 0; j < TM; ++j) fx[j] = *(const half8_t*)(Ab + j * 32 * LP + co);
 #pragma unroll
       for (int i = 0; i < TN; ++i)
 #pragma unroll
@@ -270,11 +320,36 @@ int igemm_ntile(int N) {
 
 int g_igemm_force_bk = 0;  // selftest / tuning: 0 = heuristic, 32 or 64 = forced
 
-static int pick_bk(const ConvArgs& a) {
-  const bool can64 = (a.s0.c % 64 == 0) && (a.s1.c % 64 == 0);
+int igemm_pick_bk(int c0, int c1, int K, int N) {
+  const bool can64 = (c0 % 64 == 0) && (c1 % 64 == 0);
   if (g_igemm_force_bk == 32 || !can64) return 32;
   if (g_igemm_force_bk == 64) return 64;
-  return 64;
+  // measured (selftest, B=8): BK=64 only pays for deep reductions with wide outputs
+  return (K >= 1024 && N >= 128 && c0 + c1 >= 128) ? 64 : 32;
+}
+
+static int pick_bk(const ConvArgs& a) { return a.bk ? a.bk : igemm_pick_bk(a.s0.c, a.s1.c, a.K, a.N); }
+
+// logical weights: float [nphase][N][K] (K index = tap * Ctot + c)  ->  packed halves.
+//   tiled = false : [nphase][Npad][K]
+//   tiled = true  : [nphase][Npad/bn][K/bk][bn][bk]   (one K step of one N tile is contiguous)
+void igemm_pack_weights(const float* logical, int nphase, int N, int K, int bn, int bk, bool tiled,
+                        std::vector<half_t>& out) {
+  const int Npad = (N + bn - 1) / bn * bn;
+  const int nk = K / bk;
+  out.assign((size_t)nphase * Npad * K, (half_t)0.f);
+  for (int ph = 0; ph < nphase; ++ph)
+    for (int n = 0; n < N; ++n) {
+      const float* src = logical + ((size_t)ph * N + n) * K;
+      for (int k = 0; k < K; ++k) {
+        size_t dst;
+        if (tiled)
+          dst = (size_t)ph * Npad * K + ((((size_t)(n / bn) * nk + k / bk) * bn + n % bn) * bk + k % bk);
+        else
+          dst = ((size_t)ph * Npad + n) * K + k;
+        out[dst] = (half_t)src[k];
+      }
+    }
 }
 
 bool igemm_supported(const ConvArgs& a) {

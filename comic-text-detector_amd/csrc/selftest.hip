@@ -109,17 +109,19 @@ static void run_case(const Case& cs, int B, bool timing) {
   a.res = dRes; a.pitchR = pitchD; a.act = CTD_ACT_SILU; a.N = cs.N; a.nphase = 1; a.osy = a.osx = 1;
 
   ConvArgs ig = a, dr = a;
-  std::vector<half_t> wig;
+  std::vector<float> lg;       // logical igemm weights [nphase][N][K]
   std::vector<float> wdr((size_t)k * k * cin * cs.N);
+  int nphase = 1, Kig = 0;
   if (cs.kind == 0) {
     const int K = k * k * cin;
-    wig.assign((size_t)Npad * K, (half_t)0.f);
+    Kig = K;
+    lg.assign((size_t)cs.N * K, 0.f);
     for (int n = 0; n < cs.N; ++n)
       for (int c = 0; c < cin; ++c)
         for (int ky = 0; ky < k; ++ky)
           for (int kx = 0; kx < k; ++kx) {
             const float w = W[(((size_t)n * cin + c) * k + ky) * k + kx];
-            wig[(size_t)n * K + (size_t)(ky * k + kx) * cin + c] = (half_t)w;
+            lg[(size_t)n * K + (size_t)(ky * k + kx) * cin + c] = w;
             wdr[((size_t)(ky * k + kx) * cin + c) * cs.N + n] = w;
           }
     ig.Mh = dr.Mh = Ho; ig.Mw = dr.Mw = Wo; ig.KH = ig.KW = dr.KH = dr.KW = k;
@@ -128,7 +130,9 @@ static void run_case(const Case& cs, int B, bool timing) {
   } else {
     // W is (cin, N, 4, 4) here
     const int K = 4 * cin;
-    wig.assign((size_t)4 * Npad * K, (half_t)0.f);
+    Kig = K;
+    nphase = 4;
+    lg.assign((size_t)4 * cs.N * K, 0.f);
     for (int ph = 0; ph < 4; ++ph) {
       const int py = ph >> 1, px = ph & 1;
       for (int ty = 0; ty < 2; ++ty)
@@ -137,8 +141,8 @@ static void run_case(const Case& cs, int B, bool timing) {
           const int ky = py + 1 - 2 * dy, kx = px + 1 - 2 * dx;
           for (int n = 0; n < cs.N; ++n)
             for (int c = 0; c < cin; ++c)
-              wig[((size_t)ph * Npad + n) * K + (size_t)(ty * 2 + tx) * cin + c] =
-                  (half_t)W[(((size_t)c * cs.N + n) * 4 + ky) * 4 + kx];
+              lg[((size_t)ph * cs.N + n) * K + (size_t)(ty * 2 + tx) * cin + c] =
+                  W[(((size_t)c * cs.N + n) * 4 + ky) * 4 + kx];
         }
     }
     for (int c = 0; c < cin; ++c)
@@ -148,9 +152,8 @@ static void run_case(const Case& cs, int B, bool timing) {
     ig.nphase = 4; ig.osy = ig.osx = 2; ig.w_phase_stride = (long long)Npad * K;
     dr.KH = dr.KW = 4; dr.stride = 2; dr.dy0 = dr.dx0 = 1; dr.M = B * Ho * Wo; dr.K = 16 * cin;
   }
-  half_t* dWig = dev_alloc<half_t>(wig.size());
+  half_t* dWig = dev_alloc<half_t>((size_t)nphase * Npad * Kig);
   float* dWdr = dev_alloc<float>(wdr.size());
-  CK(hipMemcpy(dWig, wig.data(), wig.size() * 2, hipMemcpyHostToDevice));
   CK(hipMemcpy(dWdr, wdr.data(), wdr.size() * 4, hipMemcpyHostToDevice));
   ig.w = dWig; ig.Npad = Npad; ig.dst = dOut;
   dr.w = dWdr; dr.Npad = cs.N; dr.dst = dRef;
@@ -168,9 +171,21 @@ static void run_case(const Case& cs, int B, bool timing) {
   const double flops = cs.kind ? 2.0 * B * Hin * Win * 16.0 * cin * cs.N : 2.0 * (double)ig.M * cs.N * ig.K;
   const double bytes = 2.0 * ((double)n0 + n1 + (double)B * Ho * Wo * cs.N * (cs.res ? 2 : 1) + (double)cs.N * cin * k * k);
   std::printf("[case] %-32s B=%d out %dx%dx%d |", cs.name, B, Ho, Wo, cs.N);
-  for (int bk = 32; bk <= 64; bk += 32) {
-    if (bk == 64 && (cs.c0 % 64 || cs.c1 % 64)) { std::printf("  bk64: n/a"); continue; }
+  struct Var { const char* name; int bk, tiled, rot; };
+  const Var vars[] = {{"bk32", 32, 1, 0}, {"bk64", 64, 1, 0}};
+
+  const char* vsel = std::getenv("ST_VAR");   // ST_VAR=1: only variant index 1
+  for (const Var& v : vars) {
+    if (vsel && std::atoi(vsel) != (int)(&v - vars)) continue;
+    const int bk = v.bk;
+    if (bk == 64 && (cs.c0 % 64 || cs.c1 % 64)) continue;
     g_igemm_force_bk = bk;
+    ig.bk = bk; ig.w_tiled = v.tiled; ig.k_rot = v.rot;
+    {
+      std::vector<half_t> wig;
+      igemm_pack_weights(lg.data(), nphase, cs.N, Kig, bn, bk, v.tiled, wig);
+      CK(hipMemcpy(dWig, wig.data(), wig.size() * 2, hipMemcpyHostToDevice));
+    }
     CK(hipMemset(dOut, 0xff, nout * 2));
     launch_conv_igemm(ig, false, 0);
     CK(hipDeviceSynchronize());
@@ -198,8 +213,9 @@ static void run_case(const Case& cs, int B, bool timing) {
       CK(hipEventElapsedTime(&t, e0, e1));
       ms = t / it;
     }
-    std::printf("  bk%d: err %.2g %s %.3f ms %.0f TF/s %.0f GB/s |", bk, maxerr, bad ? "FAIL" : "ok", ms,
+    std::printf("  %s: %s %.3f ms %.0f TF %.0f GB/s |", v.name, bad ? "FAIL" : "ok", ms,
                 flops / (ms * 1e-3) / 1e12, bytes / (ms * 1e-3) / 1e9);
+    (void)maxerr;
   }
   std::printf("\n");
   g_igemm_force_bk = 0;
@@ -240,8 +256,19 @@ int main(int argc, char** argv) {
       {"convT4 512->256 @16", 1, 512, 0, 0, 256, 4, 2, 16, 0},
   };
   const int ncase = sizeof(cases) / sizeof(cases[0]);
+  // ST_CASES="16,3": run only these case indices (PMC runs want few dispatches)
+  const char* sel = std::getenv("ST_CASES");
   for (int i = 0; i < ncase; ++i) {
     if (quick && i % 3) continue;
+    if (sel) {
+      bool on = false;
+      for (const char* p = sel; *p;) {
+        if (std::atoi(p) == i) on = true;
+        while (*p && *p != ',') ++p;
+        if (*p == ',') ++p;
+      }
+      if (!on) continue;
+    }
     run_case(cases[i], B, true);
   }
   std::printf("selftest: %s (%d failures)\n", g_fail ? "FAILED" : "PASSED", g_fail);

@@ -15,5 +15,5 @@ echo "== bench"; timeout 900 python bench.py --steps ${BENCH_STEPS:-5} --warmup 
 sort -t$'\t' -k3 -g -r gpurun_out/ops.tsv | head -25
 fi
 if [ -n "$DO_ROCPROF" ]; then
-echo "== rocprofv3"; cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/gpurun_out/prof -o r01 -- python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $GRAFT_REPO_ROOT/gpurun_out/rocprof.log 2>&1; echo "rc=$?"; cd $GRAFT_REPO_ROOT; tail -3 gpurun_out/rocprof.log; find gpurun_out/prof -name "*stats*" | head
+echo "== rocprofv3"; cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof -o r01 -- python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $GRAFT_REPO_ROOT/gpurun_out/rocprof.log 2>&1; echo "rc=$?"; cd $GRAFT_REPO_ROOT; tail -3 gpurun_out/rocprof.log; find gpurun_out/prof -name "*stats*" | head
 fi

@@ -128,7 +128,7 @@ int pack_op(ctd_engine* e, OpState& s, const float* P, int64_t nP) {
         const int bn = igemm_ntile(N);
         s.npad = (N + bn - 1) / bn * bn;
         const int K = k * k * cin;
-        s.bk = igemm_pick_bk(o.src0_c, o.src1 >= 0 ? o.src1_c : 0, K, N);
+        s.bk = igemm_pick_bk(o.src0_c, o.src1 >= 0 ? o.src1_c : 0, K, N, e->tensors[o.dst].t.log2_down);
         std::vector<float> lg((size_t)N * K);
         for (int n = 0; n < N; ++n)
           for (int c = 0; c < cin; ++c)
@@ -167,7 +167,7 @@ int pack_op(ctd_engine* e, OpState& s, const float* P, int64_t nP) {
         const int bn = igemm_ntile(N);
         s.npad = (N + bn - 1) / bn * bn;
         const int K = 4 * cin;
-        s.bk = igemm_pick_bk(cin, 0, K, N);
+        s.bk = igemm_pick_bk(cin, 0, K, N, e->tensors[o.src0].t.log2_down);
         std::vector<float> lg((size_t)4 * N * K);
         for (int ph = 0; ph < 4; ++ph) {
           const int py = ph >> 1, px = ph & 1;

@@ -26,8 +26,9 @@ void launch_export_plane(const void* src, int pitch, bool f16, float* out, int n
 
 // ---- kernels_igemm.hip : MFMA implicit-GEMM conv (fp16 in, fp32 acc) ------
 // weights: half [nphase][Npad][K], K index = (ty*KW+tx)*(c0+c1) + c
+extern int g_igemm_occ_lo;
 extern int g_igemm_force_bk;  // tuning knob: 0 = heuristic, 32 / 64 = forced K step
-int igemm_pick_bk(int c0, int c1, int K, int N);
+int igemm_pick_bk(int c0, int c1, int K, int N, int log2_down);
 void igemm_pack_weights(const float* logical, int nphase, int N, int K, int bn, int bk, bool tiled,
                         std::vector<half_t>& out);
 bool igemm_supported(const ConvArgs& a);

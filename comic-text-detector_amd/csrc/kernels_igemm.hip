@@ -26,11 +26,13 @@
 
 #include "kernels.h"
 
+int g_igemm_occ_lo = 0;  // tuning: 1 = do not force the high-occupancy register budget
+
 namespace {
 
 // K step BK = 32 or 64 halves per LDS row (64 / 128 B), XOR-swizzled 16-B chunks.
-template <int BN, int BM, int WGN, int WGM, int BK, bool DST_F32>
-__global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
+template <int BN, int BM, int WGN, int WGM, int BK, bool DST_F32, int MINW, int PF>
+__global__ __launch_bounds__(256, MINW) void conv_igemm_kernel(ConvArgs a) {
   constexpr int LP = BK;                            // LDS row pitch in halves (XOR swizzled, no pad)
   constexpr int SEGS = BK / 8;                      // 16-B chunks per row
   constexpr int RPP = 256 / SEGS;                   // rows staged per pass of the 256 threads
@@ -41,7 +43,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
   constexpr int WROWS = (WCHUNKS + 255) / 256;
   static_assert(WGN * WGM == 4, "4 waves");
 
-  __shared__ __attribute__((aligned(16))) half_t lds[2 * (BM + BN) * LP];
+  constexpr int LDS_STAGE = 2 * (BM + BN) * LP, LDS_OUT = BM * (BN + 8);
+  __shared__ __attribute__((aligned(16))) half_t lds[LDS_STAGE > LDS_OUT ? LDS_STAGE : LDS_OUT];
   half_t* As = lds;                 // [2][BM][LP]  pixels
   half_t* Ws = lds + 2 * BM * LP;   // [2][BN][LP]  weights
 
@@ -120,13 +123,19 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
   for (int i = 0; i < WROWS; ++i) woff[i] = (((t + 256 * i) / SEGS) * BK + seg * 8) * 2;
   const char* wtile = (const char*)(wbase + (size_t)tile_n * nk * BN * BK);
 
-  half8_t ra[AROWS];
-  half8_t rw[WROWS];
+  // One staged K step held in registers between its global loads and its LDS store.
+  struct Stage {
+    half8_t ra[AROWS];
+    half8_t rw[WROWS];
+    unsigned rok;   // bit i: staged row i is inside the image (else zero padding)
+  };
 
   int cc = 0, ty = 0, tx = 0, kp = 0;  // K-step cursor of the NEXT tile to load (wave uniform)
-  unsigned rok = 0;                     // bit i: staged row i is inside the image (else zero padding)
 
-  auto load_tile = [&]() {
+  auto load_tile = [&](Stage& sg) {
+    half8_t (&ra)[AROWS] = sg.ra;
+    half8_t (&rw)[WROWS] = sg.rw;
+    unsigned& rok = sg.rok;
     // activations
     const bool first = cc < a.s0.c;
     const SrcView& s = first ? a.s0 : a.s1;
@@ -187,7 +196,10 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
     const int r = (t + 256 * i) / SEGS;
     sw_off[i] = r * BK + ((seg ^ swz(r)) * 8);
   }
-  auto store_tile = [&](int buf) {
+  auto store_tile = [&](const Stage& sg, int buf) {
+    const half8_t (&ra)[AROWS] = sg.ra;
+    const half8_t (&rw)[WROWS] = sg.rw;
+    const unsigned rok = sg.rok;
 #pragma unroll
     for (int i = 0; i < AROWS; ++i) {
       // the zero-fill select sits here, after the MFMAs, so the loads stay in flight during compute
@@ -207,15 +219,15 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  load_tile();
-  store_tile(0);
+  Stage sA, sB;
+  load_tile(sA);
+  if (PF == 2 && nk > 1) load_tile(sB);
+  store_tile(sA, 0);
   __syncthreads();
 
   const int l31 = lane & 31, khalf = lane >> 5;
   const int fl = swz(l31);   // rows of one fragment differ by multiples of 32 -> same swizzle
-  for (int ks = 0; ks < nk; ++ks) {
-    const int buf = ks & 1;
-    if (ks + 1 < nk) load_tile();
+  auto compute = [&](int buf) {
     const half_t* Ab = As + (size_t)buf * BM * LP + (size_t)(wm * TM * 32 + l31) * LP;
     const half_t* Wb = Ws + (size_t)buf * BN * LP + (size_t)(wn * TN * 32 + l31) * LP;
 #pragma unroll
@@ -232,64 +244,128 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
         for (int j = 0; j < TM; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fw[i], fx[j], acc[i][j], 0, 0, 0);
     }
-    if (ks + 1 < nk) store_tile(buf ^ 1);
-    __syncthreads();
+  };
+  if (PF == 1) {
+    // one K step in flight: loads of step k+1 issued before the MFMAs of step k
+    for (int ks = 0; ks < nk; ++ks) {
+      const int buf = ks & 1;
+      if (ks + 1 < nk) load_tile(sA);
+      compute(buf);
+      if (ks + 1 < nk) store_tile(sA, buf ^ 1);
+      __syncthreads();
+    }
+  } else {
+    // two K steps in flight (register sets sA / sB alternate, statically named so they stay
+    // in VGPRs): needed by the short-K, HBM-bound layers whose whole K loop is 2-6 steps.
+    for (int ks = 0; ks < nk; ks += 2) {
+      if (ks + 2 < nk) load_tile(sA);     // LDS[0] = step ks, sB = step ks+1, sA free
+      compute(0);
+      if (ks + 1 < nk) store_tile(sB, 1);
+      __syncthreads();
+      if (ks + 1 >= nk) break;
+      if (ks + 3 < nk) load_tile(sB);     // LDS[1] = step ks+1, sA = step ks+2, sB free
+      compute(1);
+      if (ks + 2 < nk) store_tile(sA, 0);
+      __syncthreads();
+    }
   }
 
   // ---- epilogue: bias + activation (+ residual) -> NHWC store -----------------
   const int hi = lane >> 5;
+  constexpr int OP = BN + 8;   // LDS pitch (halves) of the staged output tile, +16 B against conflicts
+  half_t* Os = lds;            // [BM][OP], reuses the (now idle) staging buffers
+  const bool staged = !DST_F32 && (a.pitchD % 8 == 0) && (a.N % 8 == 0);
 #pragma unroll
   for (int j = 0; j < TM; ++j) {
-    const int m = m0 + (wm * TM + j) * 32 + l31;
-    if (m >= a.M) continue;
-    const int ox = m % a.Mw;
-    const int tq = m / a.Mw;
+    const int pl = (wm * TM + j) * 32 + l31;   // pixel inside the tile
+    const int m = m0 + pl;
+    const bool mv = m < a.M;
+    const int mm = mv ? m : 0;
+    const int ox = mm % a.Mw;
+    const int tq = mm / a.Mw;
     const int oy = tq % a.Mh;
     const int b = tq / a.Mh;
     const size_t opix = ((size_t)b * a.oH + (oy * a.osy + ooy)) * a.oW + (ox * a.osx + oox);
 #pragma unroll
     for (int i = 0; i < TN; ++i) {
-      const int nb = n0 + (wn * TN + i) * 32 + 4 * hi;
+      const int nl = (wn * TN + i) * 32 + 4 * hi;   // channel inside the tile
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        const int n = nb + 8 * g;
-        if (n >= a.N) continue;
+        const int n = n0 + nl + 8 * g;
         float v[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = ctd_act(acc[i][j][4 * g + e] + a.bias[n + e], a.act);
-        if (a.res) {
+        if (a.res && mv && n < a.N) {
           const half4_t rv = *(const half4_t*)((const half_t*)a.res + opix * a.pitchR + n);
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] += (float)rv[e];
         }
-        if (n + 3 < a.N) {
-          if (DST_F32) {
-            float4_t o = {v[0], v[1], v[2], v[3]};
-            *(float4_t*)((float*)a.dst + opix * a.pitchD + n) = o;
+        if (staged) {
+          half4_t o = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+          *(half4_t*)(Os + (size_t)pl * OP + nl + 8 * g) = o;
+        } else if (mv && n < a.N) {
+          if (n + 3 < a.N) {
+            if (DST_F32) {
+              float4_t o = {v[0], v[1], v[2], v[3]};
+              *(float4_t*)((float*)a.dst + opix * a.pitchD + n) = o;
+            } else {
+              half4_t o = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+              *(half4_t*)((half_t*)a.dst + opix * a.pitchD + n) = o;
+            }
           } else {
-            half4_t o = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
-            *(half4_t*)((half_t*)a.dst + opix * a.pitchD + n) = o;
-          }
-        } else {
-          for (int e = 0; e < 4 && n + e < a.N; ++e) {
-            if (DST_F32) ((float*)a.dst)[opix * a.pitchD + n + e] = v[e];
-            else ((half_t*)a.dst)[opix * a.pitchD + n + e] = (half_t)v[e];
+            for (int e = 0; e < 4 && n + e < a.N; ++e) {
+              if (DST_F32) ((float*)a.dst)[opix * a.pitchD + n + e] = v[e];
+              else ((half_t*)a.dst)[opix * a.pitchD + n + e] = (half_t)v[e];
+            }
           }
         }
       }
     }
   }
+  if (staged) {
+    // The MFMA C layout gives each lane 4 channels of one pixel: storing that directly makes
+    // 16-B write requests scattered over 32 cache lines per instruction (PMC: TCP_TCC_WRITE_REQ
+    // = bytes / 16).  Transposing through LDS lets 8-16 consecutive lanes write one pixel's
+    // whole channel row with 16 B each.
+    __syncthreads();
+    constexpr int CPP = BN / 8;          // 16-B chunks per pixel row of the tile
+    constexpr int PPI = 256 / CPP;       // pixels covered by one pass of the block
+    const int c = t % CPP;
+    const int n = n0 + c * 8;
+#pragma unroll
+    for (int it = 0; it < BM / PPI; ++it) {
+      const int pl = it * PPI + t / CPP;
+      const int m = m0 + pl;
+      if (m < a.M && n < a.N) {
+        const int ox = m % a.Mw;
+        const int tq = m / a.Mw;
+        const int oy = tq % a.Mh;
+        const int b = tq / a.Mh;
+        const size_t opix = ((size_t)b * a.oH + (oy * a.osy + ooy)) * a.oW + (ox * a.osx + oox);
+        *(half8_t*)((half_t*)a.dst + opix * a.pitchD + n) = *(const half8_t*)(Os + (size_t)pl * OP + c * 8);
+      }
+    }
+  }
 }
 
+// MINW = minimum waves per SIMD the register allocator must allow (launch bound).  The
+// 128x128 / BK 32 tile needs 149 registers by default (3 waves/SIMD) and fits 127 under
+// MINW = 4 without scratch; BK 64 tiles are LDS-limited to 2 blocks per CU anyway.
 template <int BN, int BM, int WGN, int WGM, int BK>
 void launch_cfg(const ConvArgs& a, bool dst_f32, hipStream_t st) {
   const int ntn = a.Npad / BN;
   const int ntm = (a.M + BM - 1) / BM;
   dim3 grid(ntn * ntm, 1, a.nphase);
-  if (dst_f32)
-    hipLaunchKernelGGL((conv_igemm_kernel<BN, BM, WGN, WGM, BK, true>), grid, dim3(256), 0, st, a);
-  else
-    hipLaunchKernelGGL((conv_igemm_kernel<BN, BM, WGN, WGM, BK, false>), grid, dim3(256), 0, st, a);
+  constexpr int HI = BK == 32 ? 4 : 2;
+  constexpr int LO = BK == 32 ? 3 : 2;
+  (void)LO;
+  if (dst_f32) {
+    hipLaunchKernelGGL((conv_igemm_kernel<BN, BM, WGN, WGM, BK, true, HI, 1>), grid, dim3(256), 0, st, a);
+  } else if (g_igemm_occ_lo) {   // tuning variant: prefetch depth 2
+    hipLaunchKernelGGL((conv_igemm_kernel<BN, BM, WGN, WGM, BK, false, HI, 2>), grid, dim3(256), 0, st, a);
+  } else {
+    hipLaunchKernelGGL((conv_igemm_kernel<BN, BM, WGN, WGM, BK, false, HI, 1>), grid, dim3(256), 0, st, a);
+  }
 }
 
 // probe: one wave, D = A(32x16) * B(16x32) with the fragment convention used above
@@ -320,15 +396,17 @@ int igemm_ntile(int N) {
 
 int g_igemm_force_bk = 0;  // selftest / tuning: 0 = heuristic, 32 or 64 = forced
 
-int igemm_pick_bk(int c0, int c1, int K, int N) {
+int igemm_pick_bk(int c0, int c1, int K, int N, int log2_down) {
   const bool can64 = (c0 % 64 == 0) && (c1 % 64 == 0);
   if (g_igemm_force_bk == 32 || !can64) return 32;
   if (g_igemm_force_bk == 64) return 64;
-  // measured (selftest, B=8): BK=64 only pays for deep reductions with wide outputs
-  return (K >= 1024 && N >= 128 && c0 + c1 >= 128) ? 64 : 32;
+  // measured (selftest, B=8): BK=32 at 4 waves/SIMD wins wherever the grid fills the chip;
+  // BK=64 (half the barriers) only pays on the low-resolution maps (<= 1/32 scale) whose
+  // grids are a few hundred blocks, and only for deep reductions with wide outputs
+  return (log2_down >= 5 && K >= 512 && N >= 128) ? 64 : 32;
 }
 
-static int pick_bk(const ConvArgs& a) { return a.bk ? a.bk : igemm_pick_bk(a.s0.c, a.s1.c, a.K, a.N); }
+static int pick_bk(const ConvArgs& a) { return a.bk ? a.bk : igemm_pick_bk(a.s0.c, a.s1.c, a.K, a.N, 0); }
 
 // logical weights: float [nphase][N][K] (K index = tap * Ctot + c)  ->  packed halves.
 //   tiled = false : [nphase][Npad][K]

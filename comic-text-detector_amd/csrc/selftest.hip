@@ -180,7 +180,8 @@ static void run_case(const Case& cs, int B, bool timing) {
     const int bk = v.bk;
     if (bk == 64 && (cs.c0 % 64 || cs.c1 % 64)) continue;
     g_igemm_force_bk = bk;
-    ig.bk = bk; ig.w_tiled = v.tiled; ig.k_rot = v.rot;
+    ig.bk = bk; ig.w_tiled = v.tiled; ig.k_rot = 0;
+    g_igemm_occ_lo = v.rot;   // third field reused: 1 = default register budget
     {
       std::vector<half_t> wig;
       igemm_pack_weights(lg.data(), nphase, cs.N, Kig, bn, bk, v.tiled, wig);

@@ -157,3 +157,90 @@ def connected_components_with_stats(img: np.ndarray, connectivity: int = 8) -> T
         for l, sl in enumerate(objs, start=1):
             stats[l] = [sl[1].start, sl[0].start, sl[1].stop - sl[1].start, sl[0].stop - sl[0].start, areas[l]]
     return n + 1, lab.astype(np.int32), stats
+
+
+# --------------------------------------------------------------------------
+# P4-P7: SegDetectorRepresenter.boxes_from_bitmap  (reference utils/db_utils.py:32-72,123-211)
+# --------------------------------------------------------------------------
+from . import cv_ref as cv  # noqa: E402
+
+
+def get_mini_boxes(contour: np.ndarray, grow: float = 0.0):
+    """reference utils/db_utils.py:176-195: minAreaRect -> boxPoints -> sort by x -> TL,TR,BR,BL;
+    returns (4 points, short side)."""
+    box, w, h = cv.min_area_box(contour, grow)
+    points = sorted([p for p in box], key=lambda p: p[0])            # :178 (stable on x)
+    if points[1][1] > points[0][1]:
+        i1, i4 = 0, 1
+    else:
+        i1, i4 = 1, 0
+    if points[3][1] > points[2][1]:
+        i2, i3 = 2, 3
+    else:
+        i2, i3 = 3, 2
+    return [points[i1], points[i2], points[i3], points[i4]], min(w, h)
+
+
+def box_score_fast(bitmap: np.ndarray, _box: np.ndarray) -> float:
+    """reference utils/db_utils.py:197-211: mean of the prob map over the filled polygon."""
+    h, w = bitmap.shape[:2]
+    box = _box.copy().astype(np.float64)
+    xmin = int(np.clip(np.floor(box[:, 0].min()), 0, w - 1))
+    xmax = int(np.clip(np.ceil(box[:, 0].max()), 0, w - 1))
+    ymin = int(np.clip(np.floor(box[:, 1].min()), 0, h - 1))
+    ymax = int(np.clip(np.ceil(box[:, 1].max()), 0, h - 1))
+    box[:, 0] -= xmin
+    box[:, 1] -= ymin
+    mask = cv.fill_poly((ymax - ymin + 1, xmax - xmin + 1), box.astype(np.int32))
+    return cv.masked_mean(bitmap[ymin:ymax + 1, xmin:xmax + 1].astype(np.float32), mask)
+
+
+def unclip_box(points: np.ndarray, unclip_ratio: float = 1.5):
+    """reference utils/db_utils.py:168-174 followed by get_mini_boxes (:154).
+    distance = area * ratio / perimeter (shapely, float64); pyclipper truncates the float
+    corners to integers before offsetting (C cast in _to_clipper_path); the min-area rectangle
+    of the JT_ROUND offset polygon is the calipers rectangle of the truncated quad grown by
+    `distance` on every side.  UNPINNED: Clipper's integer arc approximation (arc tolerance
+    0.25) can move a side by <1 px before the final np.round."""
+    pts = np.asarray(points, np.float32)
+    distance = cv.polygon_area(pts) * unclip_ratio / cv.polygon_length(pts)
+    ipts = np.trunc(pts.astype(np.float64)).astype(np.int64)
+    return get_mini_boxes(ipts, grow=distance)
+
+
+def boxes_from_bitmap(pred: np.ndarray, bitmap: np.ndarray, dest_width: int, dest_height: int,
+                      max_candidates: int = 1000, unclip_ratio: float = 1.5):
+    """reference utils/db_utils.py:123-166."""
+    assert bitmap.ndim == 2                                              # :129
+    height, width = bitmap.shape
+    contours = cv.find_contours((bitmap * 255).astype(np.uint8))         # :136
+    num_contours = min(len(contours), max_candidates)                    # :137
+    boxes = np.zeros((num_contours, 4, 2), dtype=np.int16)               # :138
+    scores = np.zeros((num_contours,), dtype=np.float32)
+    for index in range(num_contours):
+        contour = contours[index]
+        points, sside = get_mini_boxes(contour)                          # :143
+        if sside < 2:                                                    # :146-147
+            continue
+        points = np.array(points)
+        score = box_score_fast(pred, contour)                            # :149 (the CONTOUR polygon)
+        box, sside = unclip_box(points, unclip_ratio)                    # :153-154
+        box = np.array(box)
+        box[:, 0] = np.clip(np.round(box[:, 0] / width * dest_width), 0, dest_width)      # :162
+        box[:, 1] = np.clip(np.round(box[:, 1] / height * dest_height), 0, dest_height)   # :163
+        boxes[index, :, :] = box.astype(np.int16)                        # :164
+        scores[index] = score
+    return boxes, scores
+
+
+def seg_rep(input_size, pred: np.ndarray, thresh: float = 0.3):
+    """SegDetectorRepresenter.__call__ (reference utils/db_utils.py:40-69): pred (B,2,H,W)."""
+    p0 = pred[:, 0]
+    seg = binarize(p0, thresh)
+    boxes_batch, scores_batch = [], []
+    for b in range(p0.shape[0]):
+        h, w = p0.shape[1:]
+        boxes, scores = boxes_from_bitmap(p0[b], seg[b], w, h)
+        boxes_batch.append(boxes)
+        scores_batch.append(scores)
+    return boxes_batch, scores_batch

@@ -1,0 +1,84 @@
+"""-m gpu: the whole `TextDetector.__call__` mirror (network outputs -> NMS -> DB boxes ->
+block grouping -> mask refinement) against the oracle's restatement of reference
+inference.py:148-178, (a) on rendered text-like network outputs at 1024x1024 and
+(b) driven by the real HIP forward with seeded random weights at 256x256."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import checkpoint, pkg
+from oracle import postproc_ref as R
+from test_post_host import blocks_equal, fake_outputs
+
+pytestmark = pytest.mark.gpu
+
+_DET = {}
+
+
+def detector(size):
+    if size not in _DET:
+        _DET[size] = pkg().detector.TextDetector(checkpoint(0), input_size=size, device="cuda", half=True)
+    return _DET[size]
+
+
+def blks_tensor(blks, rows=4096):
+    """(blines, cls, confs) -> a fake Detect tensor (1,rows,7) whose NMS gives those blocks back."""
+    blines, cls, confs = blks
+    t = np.zeros((1, rows, 7), np.float32)
+    for i, (bb, c, s) in enumerate(zip(blines, cls, confs)):
+        x1, y1, x2, y2 = bb
+        t[0, i] = [(x1 + x2) / 2, (y1 + y2) / 2, x2 - x1, y2 - y1, 0.99, 0.0, 0.0]
+        t[0, i, 5 + c] = s / 0.99
+    return t
+
+
+@pytest.mark.parametrize("seed,keep", [(0, False), (1, True), (2, True)])
+def test_tail_on_text_like_outputs_matches_oracle(seed, keep):
+    size = 1024
+    page, mask_u8, prob, blks = fake_outputs(seed, size)
+    det = detector(size)
+    bt = blks_tensor(blks)
+    bitmap = (prob > 0.3).astype(np.uint8)
+    got = det.tail_batch([page], torch.from_numpy(bt).cuda(), torch.from_numpy(mask_u8)[None].cuda(),
+                         torch.from_numpy(prob)[None].cuda(), torch.from_numpy(bitmap)[None].cuda(),
+                         refine_mode=1 if keep else 0, keep_undetected_mask=keep)[0]
+    mask_f = (mask_u8.astype(np.float32) + 0.5) / 255            # postprocess_mask truncates back to mask_u8
+    lines_map = np.stack([prob, np.zeros_like(prob)])[None]
+    ref = R.detector_tail(page, bt, mask_f[None, None], lines_map, input_size=(size, size),
+                          refine_mode=1 if keep else 0, keep_undetected_mask=keep)
+    np.testing.assert_array_equal(got[0], ref[0])                # mask (after the in-place edit when keep=True)
+    blocks_equal(got[2], ref[2])
+    np.testing.assert_array_equal(got[1], ref[1])                # refined mask, bit exact
+    assert len(got[2]) > 3 and (got[1] > 0).mean() > 0.005
+
+
+def test_full_detector_on_network_outputs_matches_oracle():
+    """The real forward (random weights -> noisy maps: many tiny contours, the worst case for
+    the contour/box code) feeding the tail; the oracle tail runs on the same network outputs."""
+    size = 256
+    p = pkg()
+    page = p.synth.text_like_page((size, size), 5, n_blocks=4)
+    det = detector(size)
+    m, refined, blk_list = det(page, refine_mode=0, keep_undetected_mask=True)
+    blks, mask, lines_map = det.net.forward_u8(torch.from_numpy(page)[None].cuda())
+    torch.cuda.synchronize()
+    ref = R.detector_tail(page, blks.cpu().numpy(), mask.cpu().numpy(), lines_map.cpu().numpy(),
+                          input_size=(size, size), refine_mode=0, keep_undetected_mask=True)
+    np.testing.assert_array_equal(m, ref[0])
+    blocks_equal(blk_list, ref[2])
+    np.testing.assert_array_equal(refined, ref[1])
+
+
+def test_detect_batch_equals_single_calls():
+    size = 256
+    p = pkg()
+    pages = [p.synth.text_like_page((size, size), s, n_blocks=4) for s in (7, 8, 9)]
+    det = detector(size)
+    batch = det.detect_batch(pages)
+    for pg, (m, r, bl) in zip(pages, batch):
+        m1, r1, bl1 = det(pg)
+        np.testing.assert_array_equal(m, m1)
+        np.testing.assert_array_equal(r, r1)
+        blocks_equal(bl, bl1)
+    with pytest.raises(NotImplementedError):
+        det(np.zeros((100, 100, 3), np.uint8))

@@ -1,0 +1,141 @@
+"""Host logic of the post-processing mirror (textblock / textmask / geom / SegRepresenter)
+against the oracle restatement, on CPU.  GPU labelling is replaced by a scipy labeller
+(test infrastructure) so only the host arithmetic is under test here; the GPU kernels
+themselves are checked in tests/test_gpu_post.py and end-to-end in tests/test_gpu_e2e.py."""
+import copy
+
+import numpy as np
+import pytest
+
+from conftest import pkg
+from oracle import cv_ref as cv
+from oracle import postproc_ref as R
+
+
+def scipy_labeler(masks, connectivity):
+    out = []
+    for m in masks:
+        n, lab, stats = R.connected_components_with_stats(m, connectivity)
+        out.append((lab.astype(np.int32), stats[1:].astype(np.int32)))
+    return out
+
+
+def fake_outputs(seed=0, size=512):
+    """Plausible network outputs rendered from a synthetic page's ink (no network needed)."""
+    p = pkg()
+    page = p.synth.text_like_page((size, size), seed, n_blocks=10)
+    ink = (page.min(axis=2) < 60)
+    mask = cv.dilate((ink * 255).astype(np.uint8), cv.RECT3, 1)
+    mask_u8 = (mask.astype(np.float32) / 255 * 0.9 * 255).astype(np.uint8)
+    blob = cv.dilate((ink * 255).astype(np.uint8), cv.RECT3, 4)
+    prob = (blob / 255.0 * 0.85 + 0.05).astype(np.float32)
+    big = cv.dilate((ink * 255).astype(np.uint8), cv.RECT3, 10)
+    n, lab, stats = R.connected_components_with_stats(big, 8)
+    rng = np.random.RandomState(seed)
+    blines = np.array([[x, y, x + w, y + h] for x, y, w, h, a in stats[1:]], np.int32).reshape(-1, 4)
+    cls = rng.randint(0, 2, len(blines)).astype(np.int32)
+    confs = np.round(rng.uniform(0.5, 1, len(blines)), 3)
+    return page, mask_u8, prob, (blines, cls, confs)
+
+
+def blocks_equal(a, b):
+    assert len(a) == len(b)
+    for x, y in zip(a, b):
+        assert [int(v) for v in x.xyxy] == [int(v) for v in y.xyxy]
+        assert np.array_equal(np.asarray(x.lines), np.asarray(y.lines))
+        assert (x.language, bool(x.vertical), int(x.angle)) == (y.language, bool(y.vertical), int(y.angle))
+        assert float(x.font_size) == pytest.approx(float(y.font_size))
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_db_boxes_group_output_refine_match_oracle(seed):
+    p = pkg()
+    page, mask_u8, prob, blks = fake_outputs(seed)
+    H, W = prob.shape
+    # --- DB boxes: product host geometry on scipy labels vs the contour-walking oracle
+    bitmap = prob > 0.3
+    nf, lab_f, st_f = R.connected_components_with_stats(bitmap.astype(np.uint8), 8)
+    nb, lab_b, st_b = R.connected_components_with_stats((~bitmap).astype(np.uint8), 4)
+    rep = p.postproc.SegRepresenter()
+    boxes, scores = rep._page(prob, lab_f, st_f[1:], lab_b, st_b[1:], W, H)
+    rboxes, rscores = R.boxes_from_bitmap(prob, bitmap, W, H)
+    assert len(boxes) == len(rboxes)
+    np.testing.assert_array_equal(boxes, rboxes)
+    np.testing.assert_allclose(scores, rscores, rtol=0, atol=1e-6)
+    # --- grouping
+    lines = boxes[scores > 0.6].astype(np.int32)
+    got = p.textblock.group_output(copy.deepcopy(blks), lines.copy(), W, H, mask_u8)
+    ref = R.group_output(copy.deepcopy(blks), lines.copy(), W, H, mask_u8)
+    blocks_equal(got, ref)
+    # --- mask refinement (both modes) + undetected-mask pass
+    for mode in (0, 1):
+        a = p.textmask.refine_mask(page, mask_u8, got, mode, labeler=scipy_labeler)
+        b = R.refine_mask(page, mask_u8, ref, mode)
+        np.testing.assert_array_equal(a, b)
+    m1, m2 = mask_u8.copy(), mask_u8.copy()
+    a = p.textmask.refine_undetected_mask(page, m1, p.textmask.refine_mask(page, mask_u8, got, 1, labeler=scipy_labeler),
+                                          got[: len(got) // 2], 1, labeler=scipy_labeler)
+    b = R.refine_undetected_mask(page, m2, R.refine_mask(page, mask_u8, ref, 1), ref[: len(ref) // 2], 1)
+    np.testing.assert_array_equal(a, b)
+    np.testing.assert_array_equal(m1, m2)          # the in-place mutation of mask_pred is mirrored too
+
+
+def test_group_output_hand_built_scenes():
+    p = pkg()
+    W = H = 600
+    mask = np.full((H, W), 255, np.uint8)
+
+    def quad(x, y, w, h):
+        return [[x, y], [x + w, y], [x + w, y + h], [x, y + h]]
+    # vertical JA block with 3 columns + a far column that must split off; horizontal EN block;
+    # two scattered horizontal lines that merge; one scattered line over empty mask that is dropped
+    lines = np.array([quad(300, 50, 20, 200), quad(270, 50, 20, 200), quad(240, 50, 20, 180), quad(120, 60, 20, 150),
+                      quad(50, 400, 200, 24), quad(50, 430, 180, 24),
+                      quad(400, 500, 100, 20), quad(400, 524, 90, 20), quad(10, 10, 30, 8)], np.int32)
+    mask[5:25, 5:50] = 0
+    blks = (np.array([[110, 40, 330, 260], [40, 390, 260, 460]], np.int32), np.array([1, 0], np.int32),
+            np.array([0.9, 0.8]))
+    got = p.textblock.group_output(copy.deepcopy(blks), lines.copy(), W, H, mask)
+    ref = R.group_output(copy.deepcopy(blks), lines.copy(), W, H, mask)
+    blocks_equal(got, ref)
+    assert any(b.vertical for b in got) and any(b.language == "eng" for b in got)
+    assert sum(len(b.lines) for b in got) == 8      # the line over empty mask was dropped
+    # empty inputs are legal (reference inference.py:166-167)
+    assert p.textblock.group_output((np.zeros((0, 4), np.int32), np.zeros(0, np.int32), np.zeros(0)), [], W, H, mask) == []
+
+
+def test_geometry_primitives_match_oracle():
+    p = pkg()
+    rng = np.random.RandomState(3)
+    for _ in range(50):
+        pts = rng.randint(0, 200, (rng.randint(1, 40), 2))
+        a, aw, ah = p.geom.min_area_box(pts, grow=1.5)
+        b, bw, bh = cv.min_area_box(pts, grow=1.5)
+        assert aw * ah == pytest.approx(bw * bh, rel=1e-9, abs=1e-9)
+    for _ in range(200):
+        q1 = rng.randint(0, 50, (4, 2))
+        q2 = rng.randint(0, 50, (4, 2))
+        assert p.geom.quads_intersect(q1, q2) == cv.polygons_intersect(q1, q2)
+    img = rng.randint(0, 256, (40, 60, 3)).astype(np.uint8)
+    np.testing.assert_array_equal(p.textmask.bgr2gray(img), cv.cvt_bgr2gray(img))
+    for _ in range(20):
+        ch = rng.randint(0, 256, (30, 30)).astype(np.uint8) // rng.randint(1, 5)
+        assert p.textmask.otsu_value(ch) == cv.otsu_threshold_value(ch)
+
+
+def test_oracle_contours_and_cc_against_scipy():
+    """Pins what can be pinned of the unpinned half: contour count = 8-connected components +
+    enclosed 4-connected background regions; the filled outer contour = component with holes filled."""
+    from scipy import ndimage
+    rng = np.random.RandomState(1)
+    img = (ndimage.uniform_filter(rng.rand(80, 120), 5) > 0.5).astype(np.uint8)
+    contours = cv.find_contours(img)
+    ncomp = ndimage.label(img, structure=np.ones((3, 3)))[1]
+    bg, nbg = ndimage.label(1 - img)
+    border = set(np.unique(np.r_[bg[0], bg[-1], bg[:, 0], bg[:, -1]])) - {0}
+    assert len(contours) == ncomp + (nbg - len(border))
+    lab, n = ndimage.label(img, structure=np.ones((3, 3)))
+    sizes = sorted(int(ndimage.binary_fill_holes(lab == l).sum()) for l in range(1, n + 1))
+    filled = sorted(int(cv.fill_poly(img.shape, c).sum()) for c in contours)
+    for s in sizes:
+        assert s in filled

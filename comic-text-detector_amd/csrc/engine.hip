@@ -218,9 +218,10 @@ int pack_op(ctd_engine* e, OpState& s, const float* P, int64_t nP) {
       if (cin != 64 || N != 1) return fail(CTD_ERR_UNSUPPORTED, "fused seg-final is 64->1 only");
       if (!need(o.w_off, (int64_t)cin * 16)) return fail(CTD_ERR_INVALID, "seg-final weights out of range");
       const float* W = P + o.w_off;  // (cin, 1, 4, 4)
-      std::vector<float> wp((size_t)16 * cin);
+      // fp16, [cin/8][16 taps][8 channels]: one 8-channel group of all taps = 64 dwords of scalar loads
+      std::vector<half_t> wp((size_t)16 * cin);
       for (int c = 0; c < cin; ++c)
-        for (int kk = 0; kk < 16; ++kk) wp[(size_t)kk * cin + c] = W[(size_t)c * 16 + kk];
+        for (int kk = 0; kk < 16; ++kk) wp[((size_t)(c / 8) * 16 + kk) * 8 + (c % 8)] = (half_t)W[(size_t)c * 16 + kk];
       s.impl = IMPL_FUSED;
       if (int rc = upload(e, wp, &s.w_dev)) return rc;
       return pack_bias(1);
@@ -231,7 +232,21 @@ int pack_op(ctd_engine* e, OpState& s, const float* P, int64_t nP) {
       if (q != 16) return fail(CTD_ERR_UNSUPPORTED, "fused db tail is q=16 only");
       const int PB = q * q * 4 + q + q * 4 + 1;
       if (!need(o.w_off, 2 * PB)) return fail(CTD_ERR_INVALID, "db-up params out of range");
-      std::vector<float> wp(P + o.w_off, P + o.w_off + 2 * PB);
+      // blob per branch: W1 (c,o,py,px), b1 (o), W2 (o,0,qy,qx), b2  ->  device layout of
+      // kernels_fused.hip DbUpLayout: W1p[pp][c][o], b1, W2p[qq][o], b2, padded to x4 floats
+      const int SIZE = (4 * q * q + q + 4 * q + 1 + 3) / 4 * 4;
+      std::vector<float> wp((size_t)2 * SIZE, 0.f);
+      for (int br = 0; br < 2; ++br) {
+        const float* src = P + o.w_off + (size_t)br * PB;
+        float* dst = wp.data() + (size_t)br * SIZE;
+        for (int c = 0; c < q; ++c)
+          for (int oo = 0; oo < q; ++oo)
+            for (int pp = 0; pp < 4; ++pp) dst[(pp * q + c) * q + oo] = src[(c * q + oo) * 4 + pp];
+        for (int oo = 0; oo < q; ++oo) dst[4 * q * q + oo] = src[4 * q * q + oo];
+        for (int oo = 0; oo < q; ++oo)
+          for (int qq = 0; qq < 4; ++qq) dst[4 * q * q + q + qq * q + oo] = src[4 * q * q + q + oo * 4 + qq];
+        dst[4 * q * q + q + 4 * q] = src[4 * q * q + q + 4 * q];
+      }
       s.impl = IMPL_FUSED;
       return upload(e, wp, &s.w_dev);
     }

@@ -139,6 +139,35 @@ __global__ void maxpool_kernel(const T* __restrict__ src, int pitchS, T* __restr
   }
 }
 
+// fp16 fast path of the same pool: one lane = 8 channels (16-B loads / stores)
+__global__ void maxpool_h8_kernel(const half_t* __restrict__ src, int pitchS, half_t* __restrict__ dst, int pitchD,
+                                  int C8, int B, int H, int W, int k) {
+  const long long total = (long long)B * H * W * C8;
+  const int r = k / 2;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C8) * 8;
+    const long long pix = i / C8;
+    const int x = (int)(pix % W), y = (int)((pix / W) % H);
+    const long long b = pix / ((long long)W * H);
+    half8_t m;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) m[e] = (half_t)-65504.f;
+    for (int dy = -r; dy <= r; ++dy) {
+      const int yy = y + dy;
+      if (yy < 0 || yy >= H) continue;
+      for (int dx = -r; dx <= r; ++dx) {
+        const int xx = x + dx;
+        if (xx < 0 || xx >= W) continue;
+        const half8_t v = *(const half8_t*)(src + ((b * H + yy) * W + xx) * pitchS + c);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) m[e] = v[e] > m[e] ? v[e] : m[e];
+      }
+    }
+    *(half8_t*)(dst + pix * pitchD + c) = m;
+  }
+}
+
 // nn.AvgPool2d(2, stride=2) (reference basemodel.py:38)
 template <typename T>
 __global__ void avgpool2_kernel(const T* __restrict__ src, int pitchS, T* __restrict__ dst, int pitchD, int C,
@@ -236,7 +265,10 @@ void launch_input_u8(const uint8_t* in, void* dst, int B, int H, int W, bool f16
 void launch_maxpool(const void* src, int pitchS, void* dst, int pitchD, int C, int B, int H, int W, int k,
                     bool f16, hipStream_t st) {
   const int g = grid_for((long long)B * H * W * C);
-  if (f16)
+  if (f16 && C % 8 == 0 && pitchS % 8 == 0 && pitchD % 8 == 0 && (((uintptr_t)src | (uintptr_t)dst) & 15) == 0)
+    hipLaunchKernelGGL(maxpool_h8_kernel, dim3(grid_for((long long)B * H * W * (C / 8))), dim3(256), 0, st,
+                       (const half_t*)src, pitchS, (half_t*)dst, pitchD, C / 8, B, H, W, k);
+  else if (f16)
     hipLaunchKernelGGL((maxpool_kernel<half_t>), dim3(g), dim3(256), 0, st, (const half_t*)src, pitchS,
                        (half_t*)dst, pitchD, C, B, H, W, k);
   else

@@ -86,30 +86,50 @@ __global__ __launch_bounds__(256) void stem_kernel(const void* __restrict__ in, 
 // (reference basemodel.py:58-61) fused with the f32 `mask` export and the u8
 // quantisation of postprocess_mask (reference inference.py:96-99).
 // out(2y+py, 2x+px) = sum_{dy,dx} in(y+dy, x+dx) . w[ky = py+1-2dy][kx = px+1-2dx]
-// One lane per input pixel -> 2x2 outputs.  w is f32 [16][C] (ky*4+kx).
+// One lane per input pixel -> 2x2 outputs.  w: fp16 pairs packed [C/8][16 taps (ky*4+kx)][8].
 // ---------------------------------------------------------------------------
+// Block = 16x16 input pixels; the 18x18 halo tile (C fp16 channels per pixel, pixel pitch
+// padded by 16 B so the 16-lane ds_read_b128 groups spread over the banks) is staged in LDS
+// once, so every input byte is fetched from HBM/L2 once instead of 9 times.
+constexpr int SF_T = 16;
 template <int C>
 __global__ __launch_bounds__(256) void seg_final_kernel(const half_t* __restrict__ src, int pitch, int B, int H, int W,
                                                         const float* __restrict__ w, float bias,
                                                         float* __restrict__ mask, uint8_t* __restrict__ mask_u8) {
-  const long long total = (long long)B * H * W;
-  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= total) return;
-  const int x = (int)(i % W), y = (int)((i / W) % H);
-  const long long b = i / ((long long)W * H);
+  constexpr int TP = SF_T + 2;          // tile edge with halo
+  constexpr int PP = C + 8;             // LDS pixel pitch in halves
+  __shared__ __attribute__((aligned(16))) half_t tile[TP * TP * PP];
+  const int tiles_x = (W + SF_T - 1) / SF_T, tiles_y = (H + SF_T - 1) / SF_T;
+  int bid = blockIdx.x;
+  const int x0 = (bid % tiles_x) * SF_T;
+  bid /= tiles_x;
+  const int y0 = (bid % tiles_y) * SF_T;
+  const long long b = bid / tiles_y;
+  constexpr int CH = C / 8;             // 16-B chunks per pixel
+  for (int i = threadIdx.x; i < TP * TP * CH; i += 256) {
+    const int c = i % CH, pp = i / CH;
+    const int ty = pp / TP, tx = pp % TP;
+    const int yy = y0 + ty - 1, xx = x0 + tx - 1;
+    half8_t v = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (yy >= 0 && yy < H && xx >= 0 && xx < W) v = *(const half8_t*)(src + ((b * H + yy) * W + xx) * pitch + c * 8);
+    *(half8_t*)(tile + pp * PP + c * 8) = v;
+  }
+  __syncthreads();
+  const int lx = threadIdx.x % SF_T, ly = threadIdx.x / SF_T;
+  const int x = x0 + lx, y = y0 + ly;
   float o[2][2] = {{bias, bias}, {bias, bias}};
+  // Weights: fp16 pairs packed [C/8][16 taps][4 dwords]; wave-uniform -> scalar loads.  The
+  // channel-group loop is NOT unrolled: unrolling it makes the compiler hoist all 1024 scalar
+  // weights and spill SGPRs through v_writelane/v_readlane (first version: 256 VGPRs, 1 wave/SIMD).
+  const unsigned* __restrict__ wq = (const unsigned*)w;
+#pragma unroll 1
+  for (int c8 = 0; c8 < C / 8; ++c8) {
+    const unsigned* wc = wq + c8 * 64;
 #pragma unroll
-  for (int dy = -1; dy <= 1; ++dy) {
-    const int yy = y + dy;
-    if (yy < 0 || yy >= H) continue;
+    for (int dy = -1; dy <= 1; ++dy) {
 #pragma unroll
-    for (int dx = -1; dx <= 1; ++dx) {
-      const int xx = x + dx;
-      if (xx < 0 || xx >= W) continue;
-      const half_t* p = src + ((b * H + yy) * W + xx) * pitch;
-#pragma unroll
-      for (int c8 = 0; c8 < C / 8; ++c8) {
-        const half8_t v = *(const half8_t*)(p + c8 * 8);
+      for (int dx = -1; dx <= 1; ++dx) {
+        const half8_t v = *(const half8_t*)(tile + ((ly + 1 + dy) * TP + (lx + 1 + dx)) * PP + c8 * 8);
 #pragma unroll
         for (int py = 0; py < 2; ++py) {
           const int ky = py + 1 - 2 * dy;
@@ -118,16 +138,21 @@ __global__ __launch_bounds__(256) void seg_final_kernel(const half_t* __restrict
           for (int px = 0; px < 2; ++px) {
             const int kx = px + 1 - 2 * dx;
             if (kx < 0 || kx > 3) continue;
-            const float* wk = w + (ky * 4 + kx) * C + c8 * 8;
             float s = o[py][px];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) s = fmaf((float)v[e], wk[e], s);
+            for (int q = 0; q < 4; ++q) {
+              const unsigned wb = wc[(ky * 4 + kx) * 4 + q];
+              half2_t wv, xv = {v[2 * q], v[2 * q + 1]};
+              __builtin_memcpy(&wv, &wb, 4);
+              s = __builtin_amdgcn_fdot2(xv, wv, s, false);
+            }
             o[py][px] = s;
           }
         }
       }
     }
   }
+  if (x >= W || y >= H) return;
   const int Wo = 2 * W;
   const long long Ho = 2LL * H;
 #pragma unroll
@@ -153,67 +178,94 @@ __global__ __launch_bounds__(256) void seg_final_kernel(const half_t* __restrict
 // `lines_map` export and `binarize` pred > thresh (reference db_utils.py:71-72).
 // params per branch (f32): W1[c][o][py][px] (q*q*4), b1[q], W2[o][0][py][px] (q*4), b2[1]
 // ---------------------------------------------------------------------------
+// Device parameter layout per branch (floats): W1p[pp = py*2+px][c][o] (4*Q*Q), b1[Q],
+// W2p[qq = qy*2+qx][o] (4*Q), b2, padding to a multiple of 4.  The parameters live in LDS and
+// are read with wave-uniform (broadcast) ds_read_b128; as scalar loads the fully unrolled
+// kernel spilled >1000 SGPRs through v_writelane/v_readlane.
+template <int Q>
+struct DbUpLayout {
+  static constexpr int W1 = 0, B1 = 4 * Q * Q, W2 = B1 + Q, B2 = W2 + 4 * Q, SIZE = (B2 + 1 + 3) / 4 * 4;
+};
+
 template <int Q>
 __global__ __launch_bounds__(256) void db_up_kernel(const half_t* __restrict__ src, int pitch, int B, int H, int W,
                                                     const float* __restrict__ params, float* __restrict__ lines,
                                                     uint8_t* __restrict__ bitmap, float thresh) {
+  using Lt = DbUpLayout<Q>;
+  __shared__ __attribute__((aligned(16))) float P[2 * Lt::SIZE];
+  __shared__ float xs[Q * 256];     // this thread's input channels, [c][tid]: lets the c loop stay rolled
+  for (int i = threadIdx.x; i < 2 * Lt::SIZE; i += 256) P[i] = params[i];
+  __syncthreads();
   const long long total = (long long)B * H * W;
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= total) return;
+  const int tid = threadIdx.x;
   const int x = (int)(i % W), y = (int)((i / W) % H);
   const long long b = i / ((long long)W * H);
   const half_t* p = src + i * pitch;
-  constexpr int PB = Q * Q * 4 + Q + Q * 4 + 1;
   const int Wo = 4 * W;
   const long long Ho = 4LL * H;
-#pragma unroll
+  // Loops are deliberately NOT unrolled (except the 16-wide output vector): full unrolling made
+  // the compiler hoist every parameter load (1000+ registers -> scratch, 1 wave/SIMD).
+#pragma unroll 1
   for (int br = 0; br < 2; ++br) {
-    const float* W1 = params + br * PB;
-    const float* b1 = W1 + Q * Q * 4;
-    const float* W2 = b1 + Q;
-    const float b2 = W2[Q * 4];
-    float xin[Q];
+    const float* Pb = P + br * Lt::SIZE;
 #pragma unroll
     for (int c8 = 0; c8 < Q / 8; ++c8) {
       const half8_t v = *(const half8_t*)(p + br * Q + c8 * 8);
 #pragma unroll
-      for (int e = 0; e < 8; ++e) xin[c8 * 8 + e] = (float)v[e];
+      for (int e = 0; e < 8; ++e) xs[(c8 * 8 + e) * 256 + tid] = (float)v[e];
     }
-    float out[4][4];
+#pragma unroll 1
+    for (int pp = 0; pp < 4; ++pp) {
+      float h[Q];
 #pragma unroll
-    for (int py = 0; py < 2; ++py)
+      for (int o4 = 0; o4 < Q / 4; ++o4) {
+        const float4 t = *(const float4*)(Pb + Lt::B1 + o4 * 4);
+        h[o4 * 4 + 0] = t.x; h[o4 * 4 + 1] = t.y; h[o4 * 4 + 2] = t.z; h[o4 * 4 + 3] = t.w;
+      }
+#pragma unroll 1
+      for (int c = 0; c < Q; ++c) {
+        const float xc = xs[c * 256 + tid];
 #pragma unroll
-      for (int px = 0; px < 2; ++px) {
-        float h[Q];
-#pragma unroll
-        for (int o = 0; o < Q; ++o) h[o] = b1[o];
-#pragma unroll
-        for (int c = 0; c < Q; ++c)
-#pragma unroll
-          for (int o = 0; o < Q; ++o) h[o] = fmaf(xin[c], W1[((c * Q + o) * 2 + py) * 2 + px], h[o]);
-#pragma unroll
-        for (int o = 0; o < Q; ++o) h[o] = fmaxf(h[o], 0.f);   // stays fp32: closer to the fp32 reference
-#pragma unroll
-        for (int qy = 0; qy < 2; ++qy)
-#pragma unroll
-          for (int qx = 0; qx < 2; ++qx) {
-            float s = b2;
-#pragma unroll
-            for (int o = 0; o < Q; ++o) s = fmaf(h[o], W2[(o * 2 + qy) * 2 + qx], s);
-            out[2 * py + qy][2 * px + qx] = 1.0f / (1.0f + __expf(-s));
-          }
+        for (int o4 = 0; o4 < Q / 4; ++o4) {
+          const float4 t = *(const float4*)(Pb + Lt::W1 + (pp * Q + c) * Q + o4 * 4);
+          h[o4 * 4 + 0] = fmaf(xc, t.x, h[o4 * 4 + 0]);
+          h[o4 * 4 + 1] = fmaf(xc, t.y, h[o4 * 4 + 1]);
+          h[o4 * 4 + 2] = fmaf(xc, t.z, h[o4 * 4 + 2]);
+          h[o4 * 4 + 3] = fmaf(xc, t.w, h[o4 * 4 + 3]);
+        }
       }
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const long long off = ((b * 2 + br) * Ho + (4 * y + r)) * Wo + 4 * x;
-      *(float4*)(lines + off) = make_float4(out[r][0], out[r][1], out[r][2], out[r][3]);
-      if (br == 0 && bitmap) {
-        uchar4 q;
-        q.x = out[r][0] > thresh;
-        q.y = out[r][1] > thresh;
-        q.z = out[r][2] > thresh;
-        q.w = out[r][3] > thresh;
-        *(uchar4*)(bitmap + (b * Ho + (4 * y + r)) * Wo + 4 * x) = q;
+      for (int o = 0; o < Q; ++o) h[o] = fmaxf(h[o], 0.f);   // stays fp32: closer to the fp32 reference
+      const float b2 = Pb[Lt::B2];
+      float r4[4];
+#pragma unroll
+      for (int qq = 0; qq < 4; ++qq) {
+        float s = b2;
+#pragma unroll
+        for (int o4 = 0; o4 < Q / 4; ++o4) {
+          const float4 t = *(const float4*)(Pb + Lt::W2 + qq * Q + o4 * 4);
+          s = fmaf(h[o4 * 4 + 0], t.x, s);
+          s = fmaf(h[o4 * 4 + 1], t.y, s);
+          s = fmaf(h[o4 * 4 + 2], t.z, s);
+          s = fmaf(h[o4 * 4 + 3], t.w, s);
+        }
+        r4[qq] = 1.0f / (1.0f + __expf(-s));
+      }
+      // sub-pixel (py,px) of the first ConvT owns output rows 4y+2py+{0,1}, columns 4x+2px+{0,1}
+      const int py = pp >> 1, px = pp & 1;
+#pragma unroll
+      for (int qy = 0; qy < 2; ++qy) {
+        const long long row = 4 * y + 2 * py + qy;
+        const long long off = ((b * 2 + br) * Ho + row) * Wo + 4 * x + 2 * px;
+        *(float2*)(lines + off) = make_float2(r4[qy * 2], r4[qy * 2 + 1]);
+        if (br == 0 && bitmap) {
+          uchar2 q;
+          q.x = r4[qy * 2] > thresh;
+          q.y = r4[qy * 2 + 1] > thresh;
+          *(uchar2*)(bitmap + (b * Ho + row) * Wo + 4 * x + 2 * px) = q;
+        }
       }
     }
   }
@@ -232,8 +284,7 @@ void launch_stem(const void* in, int in_fmt, half_t* dst, int pitchD, int B, int
 
 void launch_seg_final(const half_t* src, int pitch, int C, int B, int H, int W, const float* w, float bias,
                       float* mask, uint8_t* mask_u8, hipStream_t st) {
-  const long long total = (long long)B * H * W;
-  const int g = (int)((total + 255) / 256);
+  const int g = ((W + SF_T - 1) / SF_T) * ((H + SF_T - 1) / SF_T) * B;
   hipLaunchKernelGGL((seg_final_kernel<64>), dim3(g), dim3(256), 0, st, src, pitch, B, H, W, w, bias, mask, mask_u8);
   (void)C;
 }

@@ -1,0 +1,14 @@
+#!/bin/bash
+# HBM traffic of the dominant kernel family from PMC counters (FETCH_SIZE / WRITE_SIZE in
+# their own --pmc passes, --kernel-trace only), on the same workload as bench.py.
+export TMPDIR=/tmp
+ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$ROOT/gpurun_out/traffic
+mkdir -p $OUT
+cd /tmp
+for C in FETCH_SIZE WRITE_SIZE; do
+  timeout 600 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/$C -o $C -- \
+     python $ROOT/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-post > $OUT/$C.log 2>&1
+  echo "$C rc=$?"
+done
+python3 $ROOT/scripts/traffic_summary.py $OUT

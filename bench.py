@@ -179,7 +179,20 @@ def main() -> None:
         else:
             roof = {"bound": "mfma", "achieved": round(ach_tf, 1), "peak": peak_tf, "unit": "TFLOP/s",
                     "frac": round(ach_tf / peak_tf, 4)}
-        roof.update({"traffic": None, "kernel": "conv_igemm_kernel (MFMA implicit-GEMM conv/convT family)",
+        # HBM traffic of the same kernel family from PMC counters (FETCH_SIZE x2 on gfx950 +
+        # WRITE_SIZE, separate rocprofv3 --pmc passes: scripts/gpu_traffic.sh); PMC cannot be
+        # collected inside this process, so the committed measurement of this exact workload is
+        # attached when it exists, else null.
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "r01_traffic_pmc.json")
+        if os.path.isfile(tpath) and (B, S, args.precision) == (32, 1024, "fp16"):
+            try:
+                traffic = float(json.load(open(tpath))["hbm_bytes_per_forward_corrected"])
+            except Exception:
+                traffic = None
+        roof.update({"traffic": traffic, "traffic_note": "bytes per step (92 launches), rocprofv3 PMC run of "
+                     "bench.py --steps 1 --warmup 1 --no-post, see profiles/README.md" if traffic else None,
+                     "kernel": "conv_igemm_kernel (MFMA implicit-GEMM conv/convT family)",
                      "launches_per_step": int(fam.sum()), "family_ms_per_step": round(fam_ms, 3),
                      "net_ms_per_step": round(net_ms, 3), "alg_bytes_per_step": fam_bytes,
                      "alg_flops_per_step": fam_flops, "tflops": round(ach_tf, 1),

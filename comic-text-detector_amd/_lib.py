@@ -62,6 +62,7 @@ SYMBOLS = {
     "ctd_nms": (_i32, [_vp, _i32, _i32, _i32, _f, _f, _i32, _i32, _f, _vp, _vp, _vp, C.c_size_t, _vp]),
     "ctd_ccl_workspace_bytes": (C.c_size_t, [_i32, _i32, _i32]),
     "ctd_ccl": (_i32, [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _i32, _vp, C.c_size_t, _vp]),
+    "ctd_resize_linear_u8": (_i32, [_vp, _i32, _i32, _i32, _vp, _i32, _i32, _i32, _i32, _vp]),
     "ctd_last_error": (C.c_char_p, []),
     "ctd_abi_version": (_i32, []),
     "ctd_device_info": (_i32, [_i32, C.c_char_p, C.POINTER(_i32), C.POINTER(_i64)]),

@@ -191,3 +191,22 @@ def connected_components(img: torch.Tensor, thresh: int = 0, connectivity: int =
     L.check(lib.ctd_ccl(img.data_ptr(), B, H, W, thresh, connectivity, labels.data_ptr(), n.data_ptr(),
                         stats.data_ptr(), max_labels, ws.data_ptr(), nbytes, stream), "ctd_ccl")
     return labels, n, stats
+
+
+def resize_linear_u8(src: torch.Tensor, dst_hw, canvas_hw=None) -> torch.Tensor:
+    """HIP replacement of cv2.resize(INTER_LINEAR) for uint8 (H,W) or (H,W,3) GPU tensors
+    (reference utils/imgproc_utils.py:113, inference.py:165); with `canvas_hw` larger than
+    `dst_hw` the result sits in the top-left corner of a zero canvas = the reference's letterbox."""
+    lib = L.lib()
+    if not src.is_cuda or src.dtype != torch.uint8:
+        raise L.CtdError("resize_linear_u8: src must be a uint8 GPU tensor")
+    src = src.contiguous()
+    C = 1 if src.dim() == 2 else src.shape[2]
+    dH, dW = dst_hw
+    cH, cW = canvas_hw if canvas_hw is not None else dst_hw
+    shape = (cH, cW) if src.dim() == 2 else (cH, cW, C)
+    dst = torch.empty(shape, dtype=torch.uint8, device=src.device)
+    stream = torch.cuda.current_stream(src.device).cuda_stream
+    L.check(lib.ctd_resize_linear_u8(src.data_ptr(), src.shape[0], src.shape[1], C, dst.data_ptr(), dH, dW, cH, cW,
+                                     stream), "ctd_resize_linear_u8")
+    return dst

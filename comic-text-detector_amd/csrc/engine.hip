@@ -763,4 +763,14 @@ int ctd_ccl(const uint8_t* img_dev, int32_t B, int32_t H, int32_t W, int32_t thr
   return CTD_OK;
 }
 
+int ctd_resize_linear_u8(const uint8_t* src_dev, int32_t sH, int32_t sW, int32_t C, uint8_t* dst_dev, int32_t dH,
+                         int32_t dW, int32_t canvasH, int32_t canvasW, void* stream) {
+  if (!src_dev || !dst_dev) return fail(CTD_ERR_INVALID, "null pointer");
+  if (C != 1 && C != 3) return fail(CTD_ERR_UNSUPPORTED, "resize: 1 or 3 channels");
+  if (sH < 1 || sW < 1 || dH < 1 || dW < 1 || canvasH < dH || canvasW < dW) return fail(CTD_ERR_INVALID, "bad sizes");
+  launch_resize_linear_u8(src_dev, sH, sW, C, dst_dev, dH, dW, canvasH, canvasW, (hipStream_t)stream);
+  HIP_TRY(hipGetLastError());
+  return CTD_OK;
+}
+
 }  // extern "C"

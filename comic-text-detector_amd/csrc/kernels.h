@@ -56,5 +56,10 @@ size_t ccl_workspace_bytes(int B, int H, int W);
 void launch_ccl(const uint8_t* img, int B, int H, int W, int thresh, int conn, int* labels, int* n_out,
                 int* stats, int max_labels, void* ws, hipStream_t st);
 
+// ---- kernels_pre.hip ----------------------------------------------------------
+// cv2.resize(INTER_LINEAR) u8 (C = 1 or 3) into the top-left (dH,dW) of a zero-padded canvas
+void launch_resize_linear_u8(const uint8_t* src, int sH, int sW, int C, uint8_t* dst, int dH, int dW, int canvasH,
+                             int canvasW, hipStream_t st);
+
 // ---- mfma layout probe (selftest) -------------------------------------------
 void launch_mfma_probe(const half_t* a, const half_t* b, float* out, hipStream_t st);

@@ -42,50 +42,64 @@ class TextDetector:
         self.backend = "hip"
         self.seg_rep = PP.SegRepresenter(thresh=0.3)          # inference.py:139
 
-    # -- preprocessing: host mirror of inference.py:72-83 for pages that already have the
-    #    network size (the letterbox resize of arbitrary pages is SURVEY row f-1, not built yet)
-    def _pack(self, pages: Sequence[np.ndarray]) -> torch.Tensor:
-        H, W = self.input_size[1], self.input_size[0]
+    # -- preprocessing: `preprocess_img` + `letterbox` (inference.py:72-83, imgproc_utils.py:86-117).
+    #    The aspect-keeping bilinear resize and the bottom/right zero padding run on the GPU
+    #    (ctd_resize_linear_u8); the /255 and the layout change are fused into the stem kernel.
+    #    Channel order: BGR2RGB (:74) followed by [::-1] (:77) = the net consumes BGR planes,
+    #    and the per-channel resize commutes with the swaps, so the BGR page is resized as is.
+    def _prepare(self, pages: Sequence[np.ndarray]):
+        Hn, Wn = self.input_size[1], self.input_size[0]
+        canv, metas = [], []
         for p in pages:
-            if p.shape[:2] != (H, W) or p.dtype != np.uint8 or p.shape[2] != 3:
-                raise NotImplementedError(
-                    f"pages must be uint8 BGR of the network size {H}x{W}; letterbox resize of other sizes "
-                    "(reference imgproc_utils.py:86-117) is not built yet")
-        # BGR2RGB then [::-1] on channels (inference.py:74,77): the net consumes BGR planes
-        return torch.from_numpy(np.stack(pages)).to(self.net.device)
+            if p.dtype != np.uint8 or p.ndim != 3 or p.shape[2] != 3:
+                raise ValueError("pages must be uint8 BGR (H,W,3) arrays")
+            im_h, im_w = p.shape[:2]
+            r = min(Hn / im_h, Wn / im_w)
+            nw, nh = int(round(im_w * r)), int(round(im_h * r))
+            dw, dh = int(Wn - nw), int(Hn - nh)
+            src = torch.from_numpy(np.ascontiguousarray(p)).to(self.net.device)
+            canv.append(BK.resize_linear_u8(src, (nh, nw), (Hn, Wn)))
+            metas.append((im_h, im_w, dw, dh))
+        return torch.stack(canv), metas
 
     @torch.no_grad()
     def detect_batch(self, pages: Sequence[np.ndarray], refine_mode=REFINEMASK_INPAINT,
                      keep_undetected_mask=False) -> List[Tuple[np.ndarray, np.ndarray, List[TextBlock]]]:
-        x = self._pack(pages)
+        x, metas = self._prepare(pages)
         blks, mask, lines_map = self.net.forward_u8(x)                      # the seam (inference.py:146)
         return self.tail_batch(pages, blks, self.net.mask_u8, lines_map[:, 0], self.net.bitmap, refine_mode,
-                               keep_undetected_mask)
+                               keep_undetected_mask, metas)
 
     def tail_batch(self, pages: Sequence[np.ndarray], blks: torch.Tensor, mask_u8: torch.Tensor,
                    prob: torch.Tensor, bitmap: torch.Tensor, refine_mode=REFINEMASK_INPAINT,
-                   keep_undetected_mask=False):
+                   keep_undetected_mask=False, metas=None):
         """Everything after the network (inference.py:148-178) for a batch whose network outputs are
         already on the GPU: blks (B,rows,no) f32, mask_u8 (B,H,W) u8, prob = lines_map[:,0] (B,H,W) f32,
-        bitmap (B,H,W) u8."""
+        bitmap (B,H,W) u8.  metas[b] = (im_h, im_w, dw, dh) of the letterbox (default: no resize)."""
         B = len(pages)
-        im_h, im_w = pages[0].shape[:2]
-        ratio = (im_w / self.input_size[0], im_h / self.input_size[1])      # dw = dh = 0 (:148)
-        yolo = PP.postprocess_yolo(blks, self.conf_thresh, self.nms_thresh, [ratio] * B)      # :149
-        mask_np = mask_u8.cpu().numpy()                                     # fused postprocess_mask (:156)
-        boxes, scores = self.seg_rep(prob, bitmap)                          # :158
+        Hn, Wn = self.input_size[1], self.input_size[0]
+        if metas is None:
+            metas = [(p.shape[0], p.shape[1], 0, 0) for p in pages]
+        ratios = [(im_w / (Wn - dw), im_h / (Hn - dh)) for im_h, im_w, dw, dh in metas]       # :148
+        yolo = PP.postprocess_yolo(blks, self.conf_thresh, self.nms_thresh, ratios)             # :149
+        boxes, scores = self.seg_rep(prob, bitmap)                                              # :158
         out = []
         for b in range(B):
+            im_h, im_w, dw, dh = metas[b]
             keep = scores[b] > 0.6                                          # box_thresh (:159-161)
             lines = boxes[b][keep]
             if lines.size == 0:
                 lines = []
             else:
                 lines = lines.astype(np.float64)
-                lines[..., 0] *= ratio[0]
-                lines[..., 1] *= ratio[1]
+                lines[..., 0] *= ratios[b][0]
+                lines[..., 1] *= ratios[b][1]
                 lines = lines.astype(np.int32)
-            m = mask_np[b].copy()
+            # fused postprocess_mask (:156), crop of the padding (:164), resize to the page (:165)
+            m = mask_u8[b, : Hn - dh, : Wn - dw]
+            if (im_h, im_w) != (Hn - dh, Wn - dw):
+                m = BK.resize_linear_u8(m.contiguous(), (im_h, im_w))
+            m = m.cpu().numpy().copy()
             blk_list = group_output(yolo[b], lines, im_w, im_h, m)          # :173
             refined = refine_mask(pages[b], m, blk_list, refine_mode, self.net.device)        # :174
             if keep_undetected_mask:

@@ -188,6 +188,17 @@ int ctd_ccl(const uint8_t* img_dev, int32_t B, int32_t H, int32_t W, int32_t thr
             int32_t connectivity, int32_t* labels_dev, int32_t* n_dev, int32_t* stats_dev,
             int32_t max_labels, void* ws_dev, size_t ws_bytes, void* stream);
 
+/* ---- pre / post resampling ---------------------------------------------- */
+
+/* cv2.resize(src, (dW,dH), INTER_LINEAR) for uint8 images with C = 1 or 3 interleaved
+ * channels, OpenCV's fixed-point arithmetic, written into the top-left corner of a
+ * (canvasH, canvasW, C) buffer whose remaining bottom/right area is zero filled.
+ * With canvas > d this is the reference's `letterbox` (utils/imgproc_utils.py:86-117:
+ * resize :113 + copyMakeBorder :116); with canvas == d it is the mask resize of
+ * inference.py:165. */
+int ctd_resize_linear_u8(const uint8_t* src_dev, int32_t sH, int32_t sW, int32_t C, uint8_t* dst_dev,
+                         int32_t dH, int32_t dW, int32_t canvasH, int32_t canvasW, void* stream);
+
 /* ---- misc -------------------------------------------------------------- */
 const char* ctd_last_error(void);
 int32_t ctd_abi_version(void);

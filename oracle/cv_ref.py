@@ -101,32 +101,63 @@ def in_range(img: np.ndarray, lo: float, hi: float) -> np.ndarray:
     return np.where((v >= lo) & (v <= hi), 255, 0).astype(np.uint8)
 
 
+def _linear_coeffs(dst: int, src: int, zero_frac_at_edges: bool):
+    """OpenCV resize INTER_LINEAR coefficient tables (imgproc/resize.cpp):
+    f = (float)((d + 0.5) * scale - 0.5); s = floor(f); f -= s; the pair (1-f, f) is stored as
+    shorts saturate_cast<short>(c * 2048) (cvRound = round half to even).  For x the fraction is
+    zeroed outside [0, src-1); for y the two rows are clamped instead."""
+    scale = 1.0 / (dst / src)
+    d = np.arange(dst, dtype=np.float64)
+    f = ((d + 0.5) * scale - 0.5).astype(np.float32)
+    s0 = np.floor(f).astype(np.int64)
+    f = (f - s0.astype(np.float32)).astype(np.float32)
+    if zero_frac_at_edges:
+        lo = s0 < 0
+        f = np.where(lo, np.float32(0), f)
+        s0 = np.where(lo, 0, s0)
+        hi = s0 >= src - 1
+        f = np.where(hi, np.float32(0), f)
+        s0 = np.where(hi, src - 1, s0)
+    c0 = np.rint((np.float32(1) - f) * np.float32(2048)).astype(np.int64)
+    c1 = np.rint(f * np.float32(2048)).astype(np.int64)
+    i0 = np.clip(s0, 0, src - 1)
+    i1 = np.clip(s0 + 1, 0, src - 1)
+    return i0, i1, c0, c1
+
+
 def resize_linear_u8(img: np.ndarray, size_wh: Tuple[int, int]) -> np.ndarray:
-    """cv2.resize(mask, (w,h), INTER_LINEAR) for uint8 (reference inference.py:165).  Identity
-    when the size is unchanged (the 1024x1024 synthetic pages); otherwise OpenCV's fixed-point
-    bilinear (11-bit coefficients, half-pixel centres)."""
+    """cv2.resize(img, (w,h), interpolation=INTER_LINEAR) for uint8, 1 or 3 channels
+    (reference utils/imgproc_utils.py:113, inference.py:165): OpenCV's fixed-point path
+    (HResizeLinear -> int = S0*a0 + S1*a1, VResizeLinear ->
+    (((b0*(S0>>4))>>16) + ((b1*(S1>>4))>>16) + 2) >> 2).
+    UNPINNED: opencv-python wheels built with IPP may round differently by +-1."""
     w, h = size_wh
     sh, sw = img.shape[:2]
-    if (sw, sh) == (w, h):
-        return img.copy()
-    def coeffs(dst, src):
-        scale = src / dst
-        f = (np.arange(dst) + 0.5) * scale - 0.5
-        i0 = np.floor(f).astype(np.int64)
-        a = f - i0
-        a = np.where(i0 < 0, 0.0, a)
-        i0c = np.clip(i0, 0, src - 1)
-        i1c = np.clip(i0 + 1, 0, src - 1)
-        a = np.where(i0 + 1 > src - 1, 0.0, a) if False else a
-        a1 = np.rint(a * 2048).astype(np.int64)
-        return i0c, i1c, 2048 - a1, a1
-    y0, y1, wy0, wy1 = coeffs(h, sh)
-    x0, x1, wx0, wx1 = coeffs(w, sw)
+    x0, x1, a0, a1 = _linear_coeffs(w, sw, True)
+    y0, y1, b0, b1 = _linear_coeffs(h, sh, False)
     src = img.astype(np.int64)
-    top = src[y0][:, x0] * wx0 + src[y0][:, x1] * wx1
-    bot = src[y1][:, x0] * wx0 + src[y1][:, x1] * wx1
-    out = (top * wy0[:, None] + bot * wy1[:, None] + (1 << 21)) >> 22
-    return np.clip(out, 0, 255).astype(np.uint8)
+    if src.ndim == 2:
+        src = src[..., None]
+    hor = src[:, x0] * a0[None, :, None] + src[:, x1] * a1[None, :, None]        # (sh, w, C) ints
+    r0, r1 = hor[y0], hor[y1]
+    out = (((b0[:, None, None] * (r0 >> 4)) >> 16) + ((b1[:, None, None] * (r1 >> 4)) >> 16) + 2) >> 2
+    out = np.clip(out, 0, 255).astype(np.uint8)
+    return out[..., 0] if img.ndim == 2 else out
+
+
+def letterbox(im: np.ndarray, new_shape=(1024, 1024)):
+    """reference utils/imgproc_utils.py:86-117 with auto=False, scaleFill=False, scaleup=True:
+    aspect-keeping resize, then pad bottom/right with 0.  Returns (image, (rw, rh), (dw, dh))."""
+    shape = im.shape[:2]
+    r = min(new_shape[0] / shape[0], new_shape[1] / shape[1])
+    new_unpad = int(round(shape[1] * r)), int(round(shape[0] * r))
+    dw, dh = new_shape[1] - new_unpad[0], new_shape[0] - new_unpad[1]
+    dh, dw = int(dh), int(dw)
+    if shape[::-1] != new_unpad:
+        im = resize_linear_u8(im, new_unpad)
+    out = np.zeros((im.shape[0] + dh, im.shape[1] + dw) + im.shape[2:], np.uint8)
+    out[: im.shape[0], : im.shape[1]] = im
+    return out, (r, r), (dw, dh)
 
 
 # --------------------------------------------------------------------------

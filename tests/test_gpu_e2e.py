@@ -80,5 +80,41 @@ def test_detect_batch_equals_single_calls():
         np.testing.assert_array_equal(m, m1)
         np.testing.assert_array_equal(r, r1)
         blocks_equal(bl, bl1)
-    with pytest.raises(NotImplementedError):
-        det(np.zeros((100, 100, 3), np.uint8))
+
+
+def test_resize_kernel_matches_opencv_restatement():
+    """ctd_resize_linear_u8 vs the oracle's restatement of cv2.resize(INTER_LINEAR) (bit exact)."""
+    from oracle import cv_ref as cv
+    p = pkg()
+    rng = np.random.RandomState(0)
+    for (sh, sw), (dh, dw) in [((117, 165), (72, 102)), ((300, 200), (1024, 683)), ((64, 64), (64, 64)),
+                               ((1654, 1170), (1024, 724)), ((50, 70), (333, 97))]:
+        img = rng.randint(0, 256, (sh, sw, 3)).astype(np.uint8)
+        got = p.backend.resize_linear_u8(torch.from_numpy(img).cuda(), (dh, dw)).cpu().numpy()
+        np.testing.assert_array_equal(got, cv.resize_linear_u8(img, (dw, dh)))
+        m = img[..., 0].copy()
+        got = p.backend.resize_linear_u8(torch.from_numpy(m).cuda(), (dh, dw), (dh + 5, dw + 9)).cpu().numpy()
+        ref = np.zeros((dh + 5, dw + 9), np.uint8)
+        ref[:dh, :dw] = cv.resize_linear_u8(m, (dw, dh))
+        np.testing.assert_array_equal(got, ref)
+
+
+def test_detector_on_page_of_another_size_matches_oracle():
+    """A portrait page larger than the network input: letterbox (GPU) -> net -> tail with the
+    inverse mapping (mask crop + resize, box / line rescale), reference inference.py:143-172."""
+    from oracle import cv_ref as cv
+    size = 256
+    p = pkg()
+    page = p.synth.text_like_page((413, 292), 11, n_blocks=5)        # 1654x1170 / 4, like the reference's example
+    det = detector(size)
+    m, refined, blk_list = det(page, refine_mode=1, keep_undetected_mask=True)
+    lb, ratio, (dw, dh) = cv.letterbox(page, (size, size))
+    x = torch.from_numpy(lb)[None].cuda()
+    blks, mask, lines_map = det.net.forward_u8(x)
+    torch.cuda.synchronize()
+    ref = R.detector_tail(page, blks.cpu().numpy(), mask.cpu().numpy(), lines_map.cpu().numpy(),
+                          input_size=(size, size), dw=dw, dh=dh, refine_mode=1, keep_undetected_mask=True)
+    assert m.shape == page.shape[:2]
+    np.testing.assert_array_equal(m, ref[0])
+    blocks_equal(blk_list, ref[2])
+    np.testing.assert_array_equal(refined, ref[1])

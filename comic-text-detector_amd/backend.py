@@ -82,6 +82,20 @@ class HipTextDetBackend:
     def _run(self, inp: torch.Tensor, fmt: int, B: int, H: int, W: int, profile: bool = False):
         if H % 64 or W % 64:
             raise ValueError("H and W must be multiples of 64 (stride-32 backbone + AvgPool2d(2))")
+        # the MFMA kernel uses 32-bit byte offsets inside a tensor: the largest activation
+        # (64 fp16 channels at H/2 x W/2... up to 128 B per input pixel) must stay below 2 GiB,
+        # so larger batches run as consecutive sub-batches (pages are independent)
+        # (largest tensor of this network: 64 channels at half resolution = 32 B per input pixel)
+        max_b = max(1, (2 ** 31 - 1) // (H * W * 40)) if self.prec == L.PREC_F16 else B
+        if B > max_b and not profile:
+            parts, side = [], []
+            for i in range(0, B, max_b):
+                parts.append(self._run(inp[i: i + max_b], fmt, min(max_b, B - i), H, W))
+                side.append((self.mask_u8, self.bitmap))
+            self.mask_u8 = torch.cat([s[0] for s in side])
+            self.bitmap = torch.cat([s[1] for s in side])
+            self._last_bhw = (B, H, W)
+            return tuple(torch.cat([p[k] for p in parts]) for k in range(3))
         self._last_bhw = (B, H, W)
         outs = self._outputs(B, H, W)
         stream = torch.cuda.current_stream(self.device).cuda_stream

@@ -324,6 +324,9 @@ int plan(ctd_engine* e, int B, int H, int W) {
     t.bytes = align_up((size_t)B * t.H * t.W * t.t.channels * t.esize, 256);
     t.first_def = -1;
     t.last_use = -1;
+    // the MFMA kernel addresses a tensor with signed 32-bit byte offsets
+    if (e->prec == CTD_PREC_F16 && t.bytes >= (1ull << 31))
+      return fail(CTD_ERR_UNSUPPORTED, "an activation tensor would exceed 2 GiB; split the batch (B*H*W*64 B < 2^31)");
   }
   auto use = [&](int id, int i) {
     if (id >= 0) e->tensors[id].last_use = std::max(e->tensors[id].last_use, i);

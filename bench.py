@@ -94,6 +94,7 @@ def main() -> None:
                     help="bitmap fed to the CCL stage: rendered text-like line blobs (default; random weights "
                          "give a noise bitmap, SURVEY 8(d)) or the network's own bitmap")
     ap.add_argument("--dump-ops", default="", help="write the per-op profile table to this file")
+    ap.add_argument("--graph", action="store_true", help="replay the forward from a captured hipGraph")
     args = ap.parse_args()
 
     pkg = importlib.import_module("comic-text-detector_amd")
@@ -120,6 +121,10 @@ def main() -> None:
     else:
         inp = pages_u8
         run_net = lambda: be.forward_u8(inp)
+    if args.graph:
+        static_in, replay = be.capture(hi - lo, S, S, "f32" if args.input == "nchw_f32" else "u8")
+        static_in.copy_(inp)
+        run_net = replay
 
     ccl_in = None
     if args.ccl_input == "textlike" and not args.no_post:

@@ -44,6 +44,16 @@ class CtdOp(C.Structure):
     ]
 
 
+class CtdWindow(C.Structure):
+    _fields_ = [("img", C.c_void_p), ("mask", C.c_void_p), ("img_w", C.c_int32), ("mask_w", C.c_int32),
+                ("x1", C.c_int32), ("y1", C.c_int32), ("w", C.c_int32), ("h", C.c_int32)]
+
+
+class CtdRule(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("lo", C.c_float), ("hi", C.c_float), ("invert", C.c_int32),
+                ("aux", C.c_int32)]
+
+
 # every symbol include/ctd_hip.h declares: (restype, argtypes)
 _vp, _i32, _i64, _f = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 SYMBOLS = {
@@ -63,6 +73,9 @@ SYMBOLS = {
     "ctd_ccl_workspace_bytes": (C.c_size_t, [_i32, _i32, _i32]),
     "ctd_ccl": (_i32, [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _i32, _vp, C.c_size_t, _vp]),
     "ctd_resize_linear_u8": (_i32, [_vp, _i32, _i32, _i32, _vp, _i32, _i32, _i32, _i32, _vp]),
+    "ctd_win_hist": (_i32, [C.POINTER(CtdWindow), _i32, _vp, _vp]),
+    "ctd_win_xor": (_i32, [C.POINTER(CtdWindow), _i32, C.POINTER(CtdRule), _i32, _vp, _vp]),
+    "ctd_win_render": (_i32, [C.POINTER(CtdWindow), _i32, C.POINTER(CtdRule), C.POINTER(_i32), _i32, _vp, _i32, _vp]),
     "ctd_last_error": (C.c_char_p, []),
     "ctd_abi_version": (_i32, []),
     "ctd_device_info": (_i32, [_i32, C.c_char_p, C.POINTER(_i32), C.POINTER(_i64)]),

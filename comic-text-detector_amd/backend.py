@@ -129,6 +129,30 @@ class HipTextDetBackend:
         B, H, W, _ = x.shape
         return self._run(x, L.IN_NHWC_U8, B, H, W)
 
+    # -- hipGraph replay ------------------------------------------------------------
+    def capture(self, B: int, H: int, W: int, fmt: str = "u8"):
+        """Captures one forward for a fixed (B,H,W) into a hipGraph (through torch's stream
+        capture: the engine launches on the capturing stream and never synchronises).  Returns
+        (static_input, replay) where replay() re-launches the ~100 kernels with one graph launch
+        and returns (blks, mask, lines_map) views of static output buffers; `mask_u8` / `bitmap`
+        are static too.  Worth it for small batches, where launch overhead rivals kernel time."""
+        shape, dtype, code = ((B, H, W, 3), torch.uint8, L.IN_NHWC_U8) if fmt == "u8" else \
+                             ((B, 3, H, W), torch.float32, L.IN_NCHW_F32)
+        static_in = torch.zeros(shape, dtype=dtype, device=self.device)
+        self._run(static_in, code, B, H, W)              # plans the arena outside the capture
+        torch.cuda.synchronize(self.device)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            outs = self._run(static_in, code, B, H, W)
+        side = (self.mask_u8, self.bitmap)
+
+        def replay():
+            g.replay()
+            self.mask_u8, self.bitmap = side
+            return outs
+
+        return static_in, replay
+
     # -- measurement helpers ------------------------------------------------------
     def profile(self, img_in: torch.Tensor):
         """One forward with a hipEvent pair around every op; returns dict(ms, flops, bytes, cls, names)."""

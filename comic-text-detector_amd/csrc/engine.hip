@@ -776,4 +776,90 @@ int ctd_resize_linear_u8(const uint8_t* src_dev, int32_t sH, int32_t sW, int32_t
   return CTD_OK;
 }
 
+// ---- per-window kernels: small host tables are staged in a growable device scratch --------
+namespace {
+struct Scratch {
+  void* p = nullptr;
+  size_t cap = 0;
+};
+thread_local Scratch g_tab[3];
+
+int stage(int slot, const void* host, size_t bytes, hipStream_t st, void** dev) {
+  Scratch& s = g_tab[slot];
+  // the previous call's kernels may still read the table: drain the stream before reuse
+  HIP_TRY(hipStreamSynchronize(st));
+  if (bytes > s.cap) {
+    if (s.p) HIP_TRY(hipFree(s.p));
+    s.p = nullptr;
+    s.cap = 0;
+    const size_t cap = std::max<size_t>(bytes * 2, 4096);
+    HIP_TRY(hipMalloc(&s.p, cap));
+    s.cap = cap;
+  }
+  HIP_TRY(hipMemcpyAsync(s.p, host, bytes, hipMemcpyHostToDevice, st));
+  *dev = s.p;
+  return CTD_OK;
+}
+
+int max_pixels(const ctd_window* w, int n) {
+  int m = 1;
+  for (int i = 0; i < n; ++i) m = std::max(m, w[i].w * w[i].h);
+  return m;
+}
+
+int check_windows(const ctd_window* w, int n) {
+  if (!w || n < 1) return fail(CTD_ERR_INVALID, "no windows");
+  for (int i = 0; i < n; ++i)
+    if (!w[i].img || !w[i].mask || w[i].w < 1 || w[i].h < 1 || w[i].x1 < 0 || w[i].y1 < 0 ||
+        w[i].x1 + w[i].w > w[i].img_w || w[i].x1 + w[i].w > w[i].mask_w)
+      return fail(CTD_ERR_INVALID, "window " + std::to_string(i) + " is malformed");
+  return CTD_OK;
+}
+}  // namespace
+
+int ctd_win_hist(const ctd_window* wins, int32_t n, uint32_t* hist_dev, void* stream) {
+  if (int rc = check_windows(wins, n)) return rc;
+  if (!hist_dev) return fail(CTD_ERR_INVALID, "null hist");
+  hipStream_t st = (hipStream_t)stream;
+  void* wd;
+  if (int rc = stage(0, wins, sizeof(ctd_window) * n, st, &wd)) return rc;
+  HIP_TRY(hipMemsetAsync(hist_dev, 0, (size_t)n * 1024 * sizeof(uint32_t), st));
+  launch_win_hist((const CtdWin*)wd, n, max_pixels(wins, n), hist_dev, st);
+  HIP_TRY(hipGetLastError());
+  return CTD_OK;
+}
+
+int ctd_win_xor(const ctd_window* wins, int32_t n, const ctd_rule* rules, int32_t nrules, uint64_t* sums_dev,
+                void* stream) {
+  if (int rc = check_windows(wins, n)) return rc;
+  if (!rules || !sums_dev || nrules < 1 || nrules > 6) return fail(CTD_ERR_INVALID, "bad rules");
+  hipStream_t st = (hipStream_t)stream;
+  void *wd, *rd;
+  if (int rc = stage(0, wins, sizeof(ctd_window) * n, st, &wd)) return rc;
+  if (int rc = stage(1, rules, sizeof(ctd_rule) * (size_t)n * nrules, st, &rd)) return rc;
+  HIP_TRY(hipMemsetAsync(sums_dev, 0, (size_t)n * nrules * sizeof(uint64_t), st));
+  launch_win_xor((const CtdWin*)wd, (const CtdRule*)rd, n, nrules, max_pixels(wins, n),
+                 (unsigned long long*)sums_dev, st);
+  HIP_TRY(hipGetLastError());
+  return CTD_OK;
+}
+
+int ctd_win_render(const ctd_window* wins, int32_t n, const ctd_rule* bands, const int32_t* tops, int32_t nbands,
+                   uint8_t* canvas_dev, int32_t canvas_w, void* stream) {
+  if (int rc = check_windows(wins, n)) return rc;
+  if (!bands || !tops || !canvas_dev || nbands < 1) return fail(CTD_ERR_INVALID, "bad bands");
+  for (int i = 0; i < nbands; ++i)
+    if (bands[i].aux < 0 || bands[i].aux >= n || wins[bands[i].aux].w > canvas_w || tops[i] < 0)
+      return fail(CTD_ERR_INVALID, "band " + std::to_string(i) + " is malformed");
+  hipStream_t st = (hipStream_t)stream;
+  void *wd, *rd, *td;
+  if (int rc = stage(0, wins, sizeof(ctd_window) * n, st, &wd)) return rc;
+  if (int rc = stage(1, bands, sizeof(ctd_rule) * (size_t)nbands, st, &rd)) return rc;
+  if (int rc = stage(2, tops, sizeof(int32_t) * (size_t)nbands, st, &td)) return rc;
+  launch_win_render((const CtdWin*)wd, (const CtdRule*)rd, (const int*)td, nbands, max_pixels(wins, n), canvas_dev,
+                    canvas_w, st);
+  HIP_TRY(hipGetLastError());
+  return CTD_OK;
+}
+
 }  // extern "C"

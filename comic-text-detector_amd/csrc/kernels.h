@@ -61,5 +61,12 @@ void launch_ccl(const uint8_t* img, int B, int H, int W, int thresh, int conn, i
 void launch_resize_linear_u8(const uint8_t* src, int sH, int sW, int C, uint8_t* dst, int dH, int dW, int canvasH,
                              int canvasW, hipStream_t st);
 
+// ---- kernels_win.hip : batched per-window kernels of the mask refinement -----------
+void launch_win_hist(const CtdWin* wins_dev, int n, int max_pix, unsigned* hist_dev, hipStream_t st);
+void launch_win_xor(const CtdWin* wins_dev, const CtdRule* rules_dev, int n, int nrules, int max_pix,
+                    unsigned long long* sums_dev, hipStream_t st);
+void launch_win_render(const CtdWin* wins_dev, const CtdRule* rules_dev, const int* tops_dev, int nbands, int max_pix,
+                       uint8_t* canvas_dev, int canvas_w, hipStream_t st);
+
 // ---- mfma layout probe (selftest) -------------------------------------------
 void launch_mfma_probe(const half_t* a, const half_t* b, float* out, hipStream_t st);

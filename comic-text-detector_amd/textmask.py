@@ -1,23 +1,34 @@
 """Mask refinement: mirror of reference utils/textmask.py (`refine_mask` :159-169,
 `refine_undetected_mask` :135-156 and helpers :16-132).
 
-Formulation: for a candidate mask, a connected component is
-OR-ed into the merged mask iff, among its pixels not merged yet, more lie on
-predicted-text pixels than on predicted-background pixels -- equivalent to the
-reference's `xor_merged < xor_origin` test on the component's bounding box, and
-independent of the labelling order.  All connected-component labelling runs on
-the GPU (`ctd_ccl`): the windows of a page are stacked into one canvas so a page
-needs two labelling launches (candidates, then hole filling) instead of ~6 per
-text block.  Candidate generation (Otsu, grey top-k ranges, xor distances) is
-small-window integer work done with numpy on the host in this round.
+GPU / host split (one page = a few launches, independent of the number of text blocks):
+
+  HIP  ctd_win_hist    grey conversion, 3x3 erosion, the four histograms of every window
+  host                 top-k grey colours (np.histogram semantics) and Otsu thresholds from them
+  HIP  ctd_win_xor     xor distance of the <= 6 candidate rules of every window to the raw mask
+  host                 polarity (`minxor_thresh`), best Otsu channel, ordering by distance
+  HIP  ctd_win_render  the chosen candidates as bands of one labelling canvas
+  HIP  ctd_ccl         8-connected components of all candidates of all windows (one launch)
+  host                 accept / reject per component (bincount), 3x3 dilation, hole-fill threshold
+  HIP  ctd_ccl         components of the complements (hole filling, one launch)
+
+Accept rule: a component is OR-ed into the merged mask iff, among its
+pixels not merged yet, more lie on predicted-text pixels than on predicted-background pixels --
+equivalent to the reference's `xor_merged < xor_origin` on the component's bounding box and
+independent of the labelling order inside one candidate.
+
+The pure-numpy candidate path (`candidate_masks`) is kept for the CPU test-suite, which injects
+a labeller and checks the host logic against the oracle without a GPU.
 """
 from __future__ import annotations
 
-from typing import List, Sequence, Tuple
+import ctypes as C
+from typing import List, Optional, Sequence, Tuple
 
 import numpy as np
 import torch
 
+from . import _lib as L
 from . import backend as BK
 from .textblock import TextBlock
 
@@ -27,6 +38,10 @@ REFINEMASK_ANNOTATION = 1
 _RECT = ((-1, -1), (-1, 0), (-1, 1), (0, -1), (0, 0), (0, 1), (1, -1), (1, 0), (1, 1))
 _CROSS = ((-1, 0), (0, -1), (0, 0), (0, 1), (1, 0))
 
+
+# --------------------------------------------------------------------------
+# small host helpers (exact integer / float64 arithmetic of the reference)
+# --------------------------------------------------------------------------
 
 def _morph(img: np.ndarray, offsets, erode: bool) -> np.ndarray:
     """3x3 erode / dilate; neighbours outside the image are ignored (OpenCV's default border)."""
@@ -47,11 +62,11 @@ def bgr2gray(img: np.ndarray) -> np.ndarray:
     return ((c[..., 0] * 1868 + c[..., 1] * 9617 + c[..., 2] * 4899 + 8192) >> 14).astype(np.uint8)
 
 
-def otsu_value(ch: np.ndarray) -> int:
-    """Threshold picked by cv2.threshold(..., THRESH_OTSU) (textmask.py:47), vectorised:
-    between-class variance for every split from cumulative histogram sums, first maximum."""
-    hist = np.bincount(ch.ravel(), minlength=256).astype(np.float64)
-    p = hist / ch.size
+def otsu_from_hist(hist: np.ndarray) -> int:
+    """Threshold picked by cv2.threshold(..., THRESH_OTSU) (textmask.py:47) from a 256-bin
+    histogram: between-class variance for every split from cumulative sums, first maximum."""
+    hist = hist.astype(np.float64)
+    p = hist / hist.sum()
     i = np.arange(256, dtype=np.float64)
     q1 = np.cumsum(p)
     m1 = np.cumsum(p * i)
@@ -67,26 +82,17 @@ def otsu_value(ch: np.ndarray) -> int:
     return best if sigma[best] > 0 else 0
 
 
-def _closer_polarity(cand: np.ndarray, msk: np.ndarray) -> Tuple[np.ndarray, int]:
-    """`minxor_thresh` (textmask.py:29-41): the candidate or its negative, whichever has the
-    smaller L1 distance to the raw 0..255 mask (255^m = 255-m, 0^m = m)."""
-    m = msk.astype(np.int64)
-    on = cand == 255
-    d_pos = int(np.where(on, 255 - m, m).sum())
-    d_neg = int(np.where(on, m, 255 - m).sum())
-    if d_neg < d_pos:
-        return (255 - cand).astype(np.uint8), d_neg
-    return cand, d_pos
+def otsu_value(ch: np.ndarray) -> int:
+    return otsu_from_hist(np.bincount(ch.ravel(), minlength=256))
 
 
-def candidate_masks(im: np.ndarray, msk: np.ndarray) -> List[Tuple[np.ndarray, int]]:
-    """`get_topk_masklist` + `get_otsuthresh_masklist(per_channel=False)` (textmask.py:43-71)."""
-    out: List[Tuple[np.ndarray, int]] = []
-    grey = bgr2gray(im)
-    sel = grey[_morph(msk, _RECT, erode=True) > 127]
-    counts, edges = np.histogram(sel, bins=255)                       # (:61) 255 bins over data min..max
-    order = np.argsort(-counts, kind="stable")                        # (:17)
-    colors, cnt = edges[order], counts[order]                         # edges[:255] pair with counts; edges has 256
+def topk_colors_from_hist(hist_sel: np.ndarray) -> List[float]:
+    """`get_topk_masklist`'s colour pick (textmask.py:61-62, 16-27) from the integer histogram of
+    the selected grey values: np.histogram(px, bins=255) only depends on the multiset of values."""
+    sel = np.repeat(np.arange(256, dtype=np.uint8), hist_sel.astype(np.int64))
+    counts, edges = np.histogram(sel, bins=255)
+    order = np.argsort(-counts, kind="stable")
+    colors, cnt = edges[order], counts[order]
     top = [colors[0]]
     tol = cnt.sum() * 0.001
     for c, n in zip(colors[1:], cnt[1:]):
@@ -94,18 +100,39 @@ def candidate_masks(im: np.ndarray, msk: np.ndarray) -> List[Tuple[np.ndarray, i
             top.append(c)
         if len(top) >= 3 or n < tol:
             break
+    return top
+
+
+def _pick(d_pos: int, npix: int) -> Tuple[int, int]:
+    """`minxor_thresh` (textmask.py:29-41): (invert, distance); the negative wins only if strictly closer."""
+    d_neg = 255 * npix - d_pos
+    return (1, d_neg) if d_neg < d_pos else (0, d_pos)
+
+
+# --------------------------------------------------------------------------
+# numpy candidate path (CPU test-suite / reference for the GPU path)
+# --------------------------------------------------------------------------
+
+def candidate_masks(im: np.ndarray, msk: np.ndarray) -> List[Tuple[np.ndarray, int]]:
+    """`get_topk_masklist` + `get_otsuthresh_masklist(per_channel=False)` (textmask.py:43-71)."""
+    grey = bgr2gray(im)
+    sel = grey[_morph(msk, _RECT, erode=True) > 127]
+    top = topk_colors_from_hist(np.bincount(sel, minlength=256))
+    m = msk.astype(np.int64)
+    out: List[Tuple[np.ndarray, int]] = []
+
+    def add(on: np.ndarray):
+        inv, d = _pick(int(np.where(on, 255 - m, m).sum()), m.size)
+        return np.where(on != bool(inv), 255, 0).astype(np.uint8), d
+
+    g = grey.astype(np.float64)
     for c in top:
         hi = min(c + 30, 255)
-        lo = hi - 60
-        g = grey.astype(np.float64)
-        cand = np.where((g >= lo) & (g <= hi), 255, 0).astype(np.uint8)
-        out.append(_closer_polarity(cand, msk))
+        out.append(add((g >= hi - 60) & (g <= hi)))
     best = None
     for ch in range(3):
-        plane = np.ascontiguousarray(im[..., ch])
-        t = otsu_value(plane)
-        cand = np.where(plane > t, 255, 0).astype(np.uint8)
-        r = _closer_polarity(cand, msk)
+        plane = im[..., ch]
+        r = add(plane > otsu_value(np.ascontiguousarray(plane)))
         if best is None or r[1] < best[1]:
             best = r
     out.append(best)
@@ -113,44 +140,121 @@ def candidate_masks(im: np.ndarray, msk: np.ndarray) -> List[Tuple[np.ndarray, i
 
 
 # --------------------------------------------------------------------------
-# batched GPU labelling of many small masks
+# GPU labelling of many small masks with one launch
 # --------------------------------------------------------------------------
 
-def label_stack(masks: Sequence[np.ndarray], connectivity: int, device) -> List[Tuple[np.ndarray, np.ndarray]]:
-    """Labels every mask (foreground = non-zero) with ONE `ctd_ccl` launch: the masks are
-    stacked vertically in a canvas, separated by an empty row, so components cannot join
-    and the raster-order label ids of each mask form a contiguous range.
-    Returns per mask (labels int32 with local ids 1..n, stats (n,5) [x,y,w,h,area] local)."""
-    if not masks:
-        return []
-    wmax = max(m.shape[1] for m in masks)
-    tot = sum(m.shape[0] + 1 for m in masks)
-    canvas = np.zeros((tot, wmax), np.uint8)
-    tops = []
-    y = 0
-    for m in masks:
-        tops.append(y)
-        canvas[y: y + m.shape[0], : m.shape[1]] = (m != 0)
-        y += m.shape[0] + 1
-    cap = max(1024, int(canvas.sum()) // 1 + 1)
-    cap = min(cap, 1 << 20)
-    labels, n, stats = BK.connected_components(torch.from_numpy(canvas).to(device), 0, connectivity, max_labels=cap)
-    labels = labels[0].cpu().numpy()
-    n = int(n[0])
-    stats = stats[0, : min(n, cap)].cpu().numpy()
+def _split_labels(labels: np.ndarray, stats: np.ndarray, shapes, tops):
+    """Canvas labels -> per band (local labels 1..n, local stats).  Bands are stacked vertically,
+    so the raster-order ids of a band form a contiguous range."""
     out = []
-    for m, top in zip(masks, tops):
-        lab = labels[top: top + m.shape[0], : m.shape[1]]
+    for (h, w), top in zip(shapes, tops):
+        lab = labels[top: top + h, :w]
         nz = lab[lab > 0]
         if nz.size == 0:
-            out.append((np.zeros(m.shape, np.int32), np.zeros((0, 5), np.int32)))
+            out.append((np.zeros((h, w), np.int32), np.zeros((0, 5), np.int32)))
             continue
         lo, hi = int(nz.min()), int(nz.max())
-        local = np.where(lab > 0, lab - (lo - 1), 0).astype(np.int32)
         st = stats[lo - 1: hi].copy()
         st[:, 1] -= top
-        out.append((local, st))
+        out.append((np.where(lab > 0, lab - (lo - 1), 0).astype(np.int32), st))
     return out
+
+
+def _label_canvas(canvas: torch.Tensor, shapes, tops, connectivity: int, fg_upper: int):
+    cap = int(min(max(1024, fg_upper + 1), 1 << 20))
+    labels, n, stats = BK.connected_components(canvas, 0, connectivity, max_labels=cap)
+    labels = labels[0].cpu().numpy()
+    stats = stats[0, : min(int(n[0]), cap)].cpu().numpy()
+    return _split_labels(labels, stats, shapes, tops)
+
+
+def _band_layout(shapes):
+    tops, y = [], 0
+    for h, _ in shapes:
+        tops.append(y)
+        y += h + 1                        # an empty row keeps neighbouring bands apart
+    return tops, y, max(w for _, w in shapes)
+
+
+def label_stack(masks: Sequence[np.ndarray], connectivity: int, device) -> List[Tuple[np.ndarray, np.ndarray]]:
+    """Labels host masks (foreground = non-zero) with ONE `ctd_ccl` launch."""
+    if not masks:
+        return []
+    shapes = [m.shape for m in masks]
+    tops, rows, wmax = _band_layout(shapes)
+    canvas = np.zeros((rows, wmax), np.uint8)
+    for m, top in zip(masks, tops):
+        canvas[top: top + m.shape[0], : m.shape[1]] = (m != 0)
+    return _label_canvas(torch.from_numpy(canvas).to(device), shapes, tops, connectivity, int(canvas.sum()))
+
+
+# --------------------------------------------------------------------------
+# GPU candidate path
+# --------------------------------------------------------------------------
+
+def _gpu_candidates(img_gpu: torch.Tensor, mask_gpu: torch.Tensor, wins: Sequence[Tuple[int, int, int, int]]):
+    """For every window (x1,y1,x2,y2): the ordered candidate masks as labelled components.
+    Returns per window a list of (labels, stats) in the reference's merge order."""
+    lib = L.lib()
+    n = len(wins)
+    stream = torch.cuda.current_stream(img_gpu.device).cuda_stream
+    W = (L.CtdWindow * n)()
+    for i, (x1, y1, x2, y2) in enumerate(wins):
+        W[i].img, W[i].mask = img_gpu.data_ptr(), mask_gpu.data_ptr()
+        W[i].img_w, W[i].mask_w = img_gpu.shape[1], mask_gpu.shape[1]
+        W[i].x1, W[i].y1, W[i].w, W[i].h = x1, y1, x2 - x1, y2 - y1
+    hist = torch.empty((n, 4, 256), dtype=torch.int32, device=img_gpu.device)
+    L.check(lib.ctd_win_hist(W, n, hist.data_ptr(), stream), "ctd_win_hist")
+    hist = hist.cpu().numpy().astype(np.int64)
+    # rules: 0..2 grey ranges (top-k colours), 3..5 Otsu thresholds of B, G, R
+    R = (L.CtdRule * (n * 6))()
+    for i in range(n):
+        top = topk_colors_from_hist(hist[i, 0])
+        for k in range(3):
+            r = R[i * 6 + k]
+            if k < len(top):
+                hi = min(top[k] + 30, 255)
+                r.kind, r.lo, r.hi = 0, float(hi - 60), float(hi)
+            else:
+                r.kind = -1
+        for ch in range(3):
+            r = R[i * 6 + 3 + ch]
+            r.kind, r.lo = 1 + ch, float(otsu_from_hist(hist[i, 1 + ch]))
+    sums = torch.empty((n, 6), dtype=torch.int64, device=img_gpu.device)
+    L.check(lib.ctd_win_xor(W, n, R, 6, sums.data_ptr(), stream), "ctd_win_xor")
+    sums = sums.cpu().numpy()
+    bands, shapes, owner = [], [], []
+    for i, (x1, y1, x2, y2) in enumerate(wins):
+        npix = (x2 - x1) * (y2 - y1)
+        cands = []
+        for k in range(3):
+            if R[i * 6 + k].kind >= 0:
+                inv, d = _pick(int(sums[i, k]), npix)
+                cands.append((d, k, inv))
+        best = None
+        for ch in range(3):
+            inv, d = _pick(int(sums[i, 3 + ch]), npix)
+            if best is None or d < best[0]:
+                best = (d, 3 + ch, inv)
+        cands.append(best)
+        cands.sort(key=lambda c: c[0])                    # stable, like mask_list.sort (textmask.py:74)
+        for d, k, inv in cands:
+            src = R[i * 6 + k]
+            bands.append((src.kind, src.lo, src.hi, inv, i))
+            shapes.append((y2 - y1, x2 - x1))
+            owner.append(i)
+    tops, rows, wmax = _band_layout(shapes)
+    Bd = (L.CtdRule * len(bands))()
+    for j, (kind, lo, hi, inv, i) in enumerate(bands):
+        Bd[j].kind, Bd[j].lo, Bd[j].hi, Bd[j].invert, Bd[j].aux = kind, lo, hi, inv, i
+    T = (C.c_int32 * len(bands))(*tops)
+    canvas = torch.zeros((rows, wmax), dtype=torch.uint8, device=img_gpu.device)
+    L.check(lib.ctd_win_render(W, n, Bd, T, len(bands), canvas.data_ptr(), wmax, stream), "ctd_win_render")
+    labelled = _label_canvas(canvas, shapes, tops, 8, sum(h * w for h, w in shapes))
+    per_win: List[list] = [[] for _ in range(n)]
+    for o, lab in zip(owner, labelled):
+        per_win[o].append(lab)
+    return per_win
 
 
 # --------------------------------------------------------------------------
@@ -167,11 +271,12 @@ def _accept(labels: np.ndarray, pred_bin: np.ndarray, merged: np.ndarray, allowe
 
 
 def refine_mask(img: np.ndarray, pred_mask: np.ndarray, blk_list: Sequence[TextBlock],
-                refine_mode: int = REFINEMASK_INPAINT, device="cuda", labeler=None) -> np.ndarray:
-    """textmask.py:159-169 for all blocks of one page.  `labeler(masks, connectivity)` defaults to
-    the GPU `label_stack`; the CPU test-suite injects its own to exercise the host logic."""
-    if labeler is None:
-        labeler = lambda masks, conn: label_stack(masks, conn, device)   # noqa: E731
+                refine_mode: int = REFINEMASK_INPAINT, device="cuda", labeler=None,
+                gpu: Optional[Tuple[torch.Tensor, torch.Tensor]] = None) -> np.ndarray:
+    """textmask.py:159-169 for all blocks of one page.
+    `gpu` = (page BGR u8, mask u8) already resident on the device (else they are uploaded).
+    `labeler(masks, connectivity)`: the CPU test-suite injects its own labeller, which also
+    selects the numpy candidate path (no GPU needed)."""
     refined = np.zeros_like(pred_mask)
     im_h, im_w = img.shape[:2]
     jobs = []
@@ -181,35 +286,41 @@ def refine_mask(img: np.ndarray, pred_mask: np.ndarray, blk_list: Sequence[TextB
         pad = int(round((max(h, w) * 0.25 + min(h, w) * 0.75) / 16))       # expand_textwindow(expand_r=16)
         x1, y1 = max(0, x1 - pad), max(0, y1 - pad)
         x2, y2 = min(im_w - 1, x2 + pad), min(im_h - 1, y2 + pad)
-        im = img[y1:y2, x1:x2]
-        msk = np.ascontiguousarray(pred_mask[y1:y2, x1:x2])
-        if im.size == 0 or msk.size == 0:
+        if x2 <= x1 or y2 <= y1:
             continue
-        cands = candidate_masks(im, msk)
-        cands.sort(key=lambda c: c[1])                                      # stable (:74)
+        msk = np.ascontiguousarray(pred_mask[y1:y2, x1:x2])
         pred_bin = np.where(_morph(msk, _CROSS, erode=True) > 60, 255, 0).astype(np.uint8)   # (:85-89)
-        jobs.append(dict(win=(x1, y1, x2, y2), cands=[c[0] for c in cands], pred=pred_bin))
+        jobs.append(dict(win=(int(x1), int(y1), int(x2), int(y2)), pred=pred_bin))
     if not jobs:
         return refined
-    # labelling launch 1: every candidate of every window
-    flat = [c for j in jobs for c in j["cands"]]
-    lab1 = labeler(flat, 8)
-    k = 0
-    for j in jobs:
+    if labeler is None:
+        if gpu is None:
+            gpu = (torch.from_numpy(np.ascontiguousarray(img)).to(device),
+                   torch.from_numpy(np.ascontiguousarray(pred_mask)).to(device))
+        cand_labels = _gpu_candidates(gpu[0], gpu[1], [j["win"] for j in jobs])
+        labeler2 = lambda masks, conn: label_stack(masks, conn, device)     # noqa: E731
+    else:
+        cand_labels = []
+        for j in jobs:
+            x1, y1, x2, y2 = j["win"]
+            cands = candidate_masks(img[y1:y2, x1:x2], np.ascontiguousarray(pred_mask[y1:y2, x1:x2]))
+            cands.sort(key=lambda c: c[1])                                  # stable (:74)
+            cand_labels.append(labeler([c[0] for c in cands], 8))
+        labeler2 = labeler
+    for j, labs in zip(jobs, cand_labels):
         merged = np.zeros_like(j["pred"])
-        for _ in j["cands"]:
-            labels, st = lab1[k]
-            k += 1
+        for labels, st in labs:
             if len(st):
                 _accept(labels, j["pred"], merged, (st[:, 2] * st[:, 3]) >= 3)          # (:98-99)
         if refine_mode == REFINEMASK_INPAINT:
             merged = _morph(merged, _RECT, erode=False)                                  # (:110-111)
         j["merged"] = merged
-    # labelling launch 2: hole filling on the complements (:113-131)
-    lab2 = labeler([255 - j["merged"] for j in jobs], 8)
+    # hole filling on the complements (:113-131): second labelling launch
+    lab2 = labeler2([255 - j["merged"] for j in jobs], 8)
     for j, (labels, st) in zip(jobs, lab2):
         merged = j["merged"]
-        areas = np.r_[int((merged == 255).sum()), st[:, 4]] if len(st) else np.array([int((merged == 255).sum())])
+        bg = int((merged == 255).sum())
+        areas = np.r_[bg, st[:, 4]] if len(st) else np.array([bg])
         srt = np.sort(areas)
         thr = srt[-2] if len(srt) > 1 else srt[-1]
         if len(st):

@@ -199,6 +199,42 @@ int ctd_ccl(const uint8_t* img_dev, int32_t B, int32_t H, int32_t W, int32_t thr
 int ctd_resize_linear_u8(const uint8_t* src_dev, int32_t sH, int32_t sW, int32_t C, uint8_t* dst_dev,
                          int32_t dH, int32_t dW, int32_t canvasH, int32_t canvasW, void* stream);
 
+/* ---- per-window kernels of the mask refinement (reference utils/textmask.py:29-71) ---- */
+
+/* One text-block window of a page: both images live on the device. */
+typedef struct ctd_window {
+  const uint8_t* img;  /* page, BGR u8 interleaved, row = img_w * 3 bytes          */
+  const uint8_t* mask; /* predicted mask of the page, u8, row = mask_w bytes        */
+  int32_t img_w, mask_w;
+  int32_t x1, y1, w, h; /* window [x1, x1+w) x [y1, y1+h) (reference textmask.py:162-164) */
+} ctd_window;
+
+/* A candidate-mask rule: kind -1 unused; 0 = cv2.inRange(grey, lo, hi);
+ * 1/2/3 = threshold(channel B/G/R, lo, 255, THRESH_BINARY).  `invert` selects the negative
+ * (255 - mask), `aux` = window index (render only). */
+typedef struct ctd_rule {
+  int32_t kind;
+  float lo, hi;
+  int32_t invert;
+  int32_t aux;
+} ctd_rule;
+
+/* hist_dev (n,4,256) u32: [0] grey (BGR2GRAY) of the pixels whose 3x3-eroded mask > 127
+ * (textmask.py:58-61), [1..3] B, G, R of the whole window (Otsu input, textmask.py:44-47).
+ * `wins` is a HOST array (copied internally). */
+int ctd_win_hist(const ctd_window* wins, int32_t n, uint32_t* hist_dev, void* stream);
+
+/* sums_dev (n,nrules) u64: sum over the window of (rule(pixel) ? 255 - m : m), the xor distance
+ * of `minxor_thresh` (textmask.py:36-37); nrules <= 6; rules is a HOST array (n*nrules). */
+int ctd_win_xor(const ctd_window* wins, int32_t n, const ctd_rule* rules, int32_t nrules, uint64_t* sums_dev,
+                void* stream);
+
+/* Renders nbands candidate masks {0,255} into a (rows, canvas_w) u8 canvas: band k uses window
+ * bands[k].aux with rule bands[k] and starts at row tops[k], left aligned.  The canvas feeds
+ * ctd_ccl (reference textmask.py:93).  bands / tops are HOST arrays. */
+int ctd_win_render(const ctd_window* wins, int32_t n, const ctd_rule* bands, const int32_t* tops, int32_t nbands,
+                   uint8_t* canvas_dev, int32_t canvas_w, void* stream);
+
 /* ---- misc -------------------------------------------------------------- */
 const char* ctd_last_error(void);
 int32_t ctd_abi_version(void);

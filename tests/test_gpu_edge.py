@@ -1,0 +1,99 @@
+"""-m gpu: edge cases of the hot path -- empty / saturated maps, smallest and largest page
+sizes, non-square inputs, batch remainders (reference behaviour: empty results are legal,
+inference.py:166-167; H, W multiples of 64)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import checkpoint, pkg
+from oracle import gen_golden
+from oracle import postproc_ref as R
+from oracle.net_ref import OracleNet
+from test_post_host import blocks_equal
+
+pytestmark = pytest.mark.gpu
+
+
+def _det(size):
+    from test_gpu_e2e import detector
+    return detector(size)
+
+
+def test_no_detections_gives_empty_results():
+    size = 256
+    det = _det(size)
+    page = np.full((size, size, 3), 255, np.uint8)
+    z = lambda *s, dt=torch.float32: torch.zeros(*s, dtype=dt, device="cuda")       # noqa: E731
+    m, refined, blks = det.tail_batch([page], z(1, 1008, 7), z(1, size, size, dt=torch.uint8), z(1, size, size),
+                                      z(1, size, size, dt=torch.uint8), keep_undetected_mask=True)[0]
+    assert blks == [] and refined.sum() == 0 and m.sum() == 0
+    ref = R.detector_tail(page, np.zeros((1, 1008, 7), np.float32), np.zeros((1, 1, size, size), np.float32),
+                          np.zeros((1, 2, size, size), np.float32), input_size=(size, size), keep_undetected_mask=True)
+    assert ref[2] == [] and ref[1].sum() == 0
+
+
+def test_saturated_maps_single_component():
+    """Everything is text: one component touching all borders, no holes; one block covering the page."""
+    size = 256
+    det = _det(size)
+    page = np.random.RandomState(0).randint(0, 256, (size, size, 3)).astype(np.uint8)
+    blks = np.zeros((1, 1008, 7), np.float32)
+    blks[0, 0] = [size / 2, size / 2, size - 20, size - 20, 0.95, 0.1, 0.9]
+    mask_u8 = np.full((size, size), 230, np.uint8)
+    prob = np.full((size, size), 0.9, np.float32)
+    got = det.tail_batch([page], torch.from_numpy(blks).cuda(), torch.from_numpy(mask_u8)[None].cuda(),
+                         torch.from_numpy(prob)[None].cuda(), torch.ones(1, size, size, dtype=torch.uint8, device="cuda"),
+                         keep_undetected_mask=True)[0]
+    ref = R.detector_tail(page, blks, ((mask_u8.astype(np.float32) + 0.5) / 255)[None, None],
+                          np.stack([prob, np.zeros_like(prob)])[None], input_size=(size, size), keep_undetected_mask=True)
+    np.testing.assert_array_equal(got[0], ref[0])
+    blocks_equal(got[2], ref[2])
+    np.testing.assert_array_equal(got[1], ref[1])
+
+
+@pytest.mark.parametrize("shape", [(1, 64, 64), (1, 640, 1024), (3, 128, 64), (1, 1536, 1536)])
+def test_network_sizes_against_oracle(shape):
+    """Smallest legal input, non-square, odd batch, and the largest bucket of BASELINE config 5."""
+    ck = checkpoint(0)
+    x = gen_golden.make_input(31, shape)
+    ob, om, ol = OracleNet(ck)(x)
+    p = pkg()
+    for prec, tol in (("fp32", 3e-5), ("fp16", 3e-2)):
+        if prec == "fp32" and shape[1] * shape[2] > 1024 * 1024:
+            continue                                   # the exact-fp32 direct kernels are slow; fp16 covers it
+        be = p.backend.HipTextDetBackend(ck, device="cuda", precision=prec)
+        blks, mask, lines = be(x.cuda())
+        torch.cuda.synchronize()
+        assert blks.shape == ob.shape
+        assert float((mask.cpu() - om).abs().max()) < tol
+        assert float((lines.cpu() - ol).abs().max()) < tol
+        assert float((blks.cpu()[..., 4:] - ob[..., 4:]).abs().max()) < tol
+        del be
+
+
+def test_replanning_between_sizes_keeps_results():
+    """A mixed-size stream re-plans the arena; going back to an earlier size reproduces its result."""
+    be = pkg().backend.HipTextDetBackend(checkpoint(0), device="cuda", precision="fp16")
+    xa = gen_golden.make_input(41, (2, 256, 256)).cuda()
+    xb = gen_golden.make_input(42, (1, 512, 384)).cuda()
+    a1 = [t.clone() for t in be(xa)]
+    b1 = [t.clone() for t in be(xb)]
+    a2 = be(xa)
+    torch.cuda.synchronize()
+    for u, v in zip(a1, a2):
+        assert torch.equal(u, v)
+    assert b1[1].shape == (1, 1, 512, 384)
+
+
+def test_large_batch_is_split_transparently():
+    """B above the 2 GiB-per-tensor limit of the MFMA kernel's 32-bit offsets runs as sub-batches."""
+    be = pkg().backend.HipTextDetBackend(checkpoint(0), device="cuda", precision="fp16")
+    H = W = 256
+    max_b = (2 ** 31 - 1) // (H * W * 40)
+    B = max_b + 3
+    pages = torch.randint(0, 256, (B, H, W, 3), dtype=torch.uint8, generator=torch.Generator().manual_seed(1)).cuda()
+    blks, mask, lines = be.forward_u8(pages)
+    assert mask.shape[0] == B and be.mask_u8.shape[0] == B
+    one = be.forward_u8(pages[B - 1: B].contiguous())
+    torch.cuda.synchronize()
+    assert torch.equal(one[1][0], mask[B - 1])

@@ -49,6 +49,7 @@ struct ConvArgs {
   int nphase;              // 1, or 4 for convT 4x4 s2 (blockIdx.z)
   int bk;                  // igemm K step the weights were packed for (32 / 64)
   int w_tiled;             // igemm weights are tile-major [phase][n_tile][k_step][BN][bk]
+  const void* zeros;       // >= 16 B of zeros in HBM: source of padding rows for LDS-DMA loads
   int k_rot;               // igemm: rotate the K-step order per pixel tile (L2 channel spreading)
 };
 

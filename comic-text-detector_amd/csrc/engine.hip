@@ -74,6 +74,7 @@ struct ctd_engine {
   bool k_rot = false;    // rotated K order per pixel tile (CTD_K_ROT=1 enables)
   int det_rows_per_unit = 0;
   int det_no = 0;
+  void* zeros = nullptr;  // 256 B of zeros (padding source of the LDS-DMA loads)
 };
 
 namespace {
@@ -445,6 +446,7 @@ int plan(ctd_engine* e, int B, int H, int W) {
       a.w = s.w_dev;
       a.bias = s.b_dev;
       a.bk = s.bk;
+      a.zeros = e->zeros;
       a.w_tiled = e->w_tiled;
       a.k_rot = e->k_rot;
       const int cin = o.src0_c + (o.src1 >= 0 ? o.src1_c : 0);
@@ -628,6 +630,10 @@ int ctd_engine_create(ctd_engine** out, const ctd_tensor* tensors, int32_t n_ten
   for (int i = 0; i < n_tensors; ++i) e->tensors[i].t = tensors[i];
   e->ops.resize(n_ops);
   for (int i = 0; i < n_ops; ++i) e->ops[i].op = ops[i];
+  {
+    std::vector<uint8_t> z(256, 0);
+    if (int zrc = upload(e, z, &e->zeros)) { ctd_engine_destroy(e); return zrc; }
+  }
   int rc = validate(e);
   for (int i = 0; rc == CTD_OK && i < n_ops; ++i) rc = pack_op(e, e->ops[i], params, n_params);
   if (rc == CTD_OK) {

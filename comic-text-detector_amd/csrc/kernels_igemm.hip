@@ -16,17 +16,17 @@
 //   * ConvTranspose2d 4x4/s2/p1 + BN + ReLU as 4 sub-pixel phase GEMMs (blockIdx.z),
 //     each a 2x2-tap conv over the input grid                         (basemodel.py:26-28)
 //
-// Tiling: 256 threads = 4 waves (64 lanes each).  Block tile BN x BM, K step 32.
-// Global -> registers -> LDS staging, double buffered, one barrier per K step.
-// LDS rows are 32 halves padded to 40 (80 B) so that both the 8-lane ds_write_b128
-// groups and the 16-lane ds_read_b128 groups hit distinct 16-B bank slots.
+// Tiling: 256 threads = 4 waves (64 lanes each).  Block tile BN x BM, K step 32 / 64.
+// Global -> LDS by LDS-DMA (global_load_lds, 16 B per lane, swizzle on the source address),
+// double buffered, one barrier per K step; LDS rows are unpadded with XOR-swizzled 16-B
+// chunks so the 16-lane ds_read_b128 groups hit distinct bank slots.
 // v_mfma_f32_32x32x16_f16: A/B fragment = 8 consecutive k of row/col (lane & 31),
 // k group = lane >> 5; C/D: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5).
 #include <vector>
 
 #include "kernels.h"
 
-int g_igemm_occ_lo = 0;  // tuning: 1 = do not force the high-occupancy register budget
+int g_igemm_occ_lo = 0;  // tuning: 1 = register-staged loads instead of LDS-DMA
 
 namespace {
 
@@ -93,11 +93,22 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_kernel(ConvArgs a) {
   const int lrow = t / SEGS;  // 0..RPP-1
   const int Ct = a.s0.c + a.s1.c;
   const int nk = a.K / BK;
+  // LDS image: rows of BK halves, NO padding; the 16-B chunk c of row r lives at chunk
+  // position c ^ f(r), f(r) = (r / rows-per-256B) % chunks-per-row.  With it both the 8-lane
+  // ds_write_b128 groups and the 16-lane ds_read_b128 groups hit distinct 16-B bank slots
+  // (PMC on the padded layout: ds_write 2-way conflicts = 33 % of LDS cycles).
+  // Register-staged mode: this thread loads global chunk `seg` and stores it at seg ^ f(r).
+  // LDS-DMA mode (PF == 2): the DMA writes lane-linear, i.e. at position `seg`, so the thread
+  // fetches global chunk seg ^ f(r) instead (swizzle on the SOURCE address).
+  constexpr int RPW = 256 / (BK * 2);
+  auto swz = [&](int row) { return (row / RPW) % SEGS; };
+  constexpr bool GLDS = PF == 2;
   int aoff0[AROWS], aoff1[AROWS];
-  int pb[AROWS], piy[AROWS], pix[AROWS];
+  int pb[AROWS], piy[AROWS], pix[AROWS], gseg[AROWS];
   unsigned vmask[AROWS];
 #pragma unroll
   for (int i = 0; i < AROWS; ++i) {
+    gseg[i] = GLDS ? (seg ^ swz(lrow + RPP * i)) : seg;
     const int m = m0 + lrow + RPP * i;
     const bool pv = m < a.M;
     const int mm = pv ? m : 0;
@@ -107,8 +118,8 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_kernel(ConvArgs a) {
     const int b = tq / a.Mh;
     const int iy0 = oy * a.stride + dy0, ix0 = ox * a.stride + dx0;
     pb[i] = b; piy[i] = iy0; pix[i] = ix0;
-    aoff0[i] = (int)(((((long long)b * a.s0.H + iy0) * a.s0.W + ix0) * a.s0.pitch + seg * 8) * 2);
-    aoff1[i] = (int)(((((long long)b * a.s1.H + iy0) * a.s1.W + ix0) * a.s1.pitch + seg * 8) * 2);
+    aoff0[i] = (int)(((((long long)b * a.s0.H + iy0) * a.s0.W + ix0) * a.s0.pitch + gseg[i] * 8) * 2);
+    aoff1[i] = (int)(((((long long)b * a.s1.H + iy0) * a.s1.W + ix0) * a.s1.pitch + gseg[i] * 8) * 2);
     unsigned vm = 0;
     for (int ty = 0; ty < a.KH; ++ty)
       for (int tx = 0; tx < a.KW; ++tx) {
@@ -120,7 +131,10 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_kernel(ConvArgs a) {
   // weights: tile-major [n_tile][k_step][BN][BK]; per-thread constant part of the address
   int woff[WROWS];
 #pragma unroll
-  for (int i = 0; i < WROWS; ++i) woff[i] = (((t + 256 * i) / SEGS) * BK + seg * 8) * 2;
+  for (int i = 0; i < WROWS; ++i) {
+    const int r = (t + 256 * i) / SEGS;
+    woff[i] = (r * BK + (GLDS ? (seg ^ swz(r)) : seg) * 8) * 2;
+  }
   const char* wtile = (const char*)(wbase + (size_t)tile_n * nk * BN * BK);
 
   // One staged K step held in registers between its global loads and its LDS store.
@@ -132,10 +146,20 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_kernel(ConvArgs a) {
 
   int cc = 0, ty = 0, tx = 0, kp = 0;  // K-step cursor of the NEXT tile to load (wave uniform)
 
-  auto load_tile = [&](Stage& sg) {
+  using gptr_t = const __attribute__((address_space(1))) void*;
+  using lptr_t = __attribute__((address_space(3))) void*;
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);   // provably wave-uniform for the LDS-DMA base
+  // LDS-DMA: a wave's 64 lanes write 64 consecutive 16-B chunks starting at a wave-uniform base
+  auto dma = [&](const void* g, half_t* tile_base, int i) {
+    __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(tile_base + (i * 256 + wave_u * 64) * 8), 16, 0, 0);
+  };
+
+  auto load_tile = [&](Stage& sg, int dbuf) {
     half8_t (&ra)[AROWS] = sg.ra;
     half8_t (&rw)[WROWS] = sg.rw;
     unsigned& rok = sg.rok;
+    half_t* Ad = As + (size_t)dbuf * BM * LP;
+    half_t* Wd = Ws + (size_t)dbuf * BN * LP;
     // activations
     const bool first = cc < a.s0.c;
     const SrcView& s = first ? a.s0 : a.s1;
@@ -149,9 +173,13 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_kernel(ConvArgs a) {
 #pragma unroll
       for (int i = 0; i < AROWS; ++i) {
         const bool ok = (vmask[i] >> tap) & 1u;
-        const int off = ok ? (first ? aoff0[i] : aoff1[i]) : back;
-        ra[i] = *(const half8_t*)(sb + off);      // padding rows read s.ptr; zeroed at store time
-        rok |= (unsigned)ok << i;
+        if (GLDS) {
+          dma(ok ? (const void*)(sb + (first ? aoff0[i] : aoff1[i])) : a.zeros, Ad, i);   // padding rows DMA zeros
+        } else {
+          const int off = ok ? (first ? aoff0[i] : aoff1[i]) : back;
+          ra[i] = *(const half8_t*)(sb + off);      // padding rows read s.ptr; zeroed at store time
+          rok |= (unsigned)ok << i;
+        }
       }
     } else {
       // nearest x2 upsampled producer (yolo neck): source pixel = (iy >> 1, ix >> 1)
@@ -160,16 +188,23 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_kernel(ConvArgs a) {
         const bool ok = (vmask[i] >> tap) & 1u;
         const int sy = ok ? ((piy[i] + ty) >> 1) : 0, sx = ok ? ((pix[i] + tx) >> 1) : 0;
         const half_t* p = (const half_t*)s.ptr +
-                          ((size_t)((size_t)(ok ? pb[i] : 0) * s.H + sy) * s.W + sx) * s.pitch + ch + seg * 8;
-        ra[i] = *(const half8_t*)p;
-        rok |= (unsigned)ok << i;
+                          ((size_t)((size_t)(ok ? pb[i] : 0) * s.H + sy) * s.W + sx) * s.pitch + ch + gseg[i] * 8;
+        if (GLDS) {
+          dma(ok ? (const void*)p : a.zeros, Ad, i);
+        } else {
+          ra[i] = *(const half8_t*)p;
+          rok |= (unsigned)ok << i;
+        }
       }
     }
     // weights
     const char* wk = wtile + (size_t)kp * (BN * BK * 2);
 #pragma unroll
     for (int i = 0; i < WROWS; ++i)
-      if (WCHUNKS >= 256 || t + 256 * i < WCHUNKS) rw[i] = *(const half8_t*)(wk + woff[i]);
+      if (WCHUNKS >= 256 || t + 256 * i < WCHUNKS) {
+        if (GLDS) dma(wk + woff[i], Wd, i);
+        else rw[i] = *(const half8_t*)(wk + woff[i]);
+      }
     // advance cursor
     ++kp;
     cc += BK;
@@ -179,12 +214,6 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_kernel(ConvArgs a) {
     }
   };
 
-  // LDS image: rows of BK halves, NO padding; the 16-B chunk c of row r lives at chunk
-  // position c ^ f(r), f(r) = (r / rows-per-256B) % chunks-per-row.  With it both the 8-lane
-  // ds_write_b128 groups and the 16-lane ds_read_b128 groups hit distinct 16-B bank slots
-  // (PMC on the padded layout: ds_write 2-way conflicts = 33 % of LDS cycles).
-  constexpr int RPW = 256 / (BK * 2);
-  auto swz = [&](int row) { return (row / RPW) % SEGS; };
   int sa_off[AROWS], sw_off[WROWS];
 #pragma unroll
   for (int i = 0; i < AROWS; ++i) {
@@ -219,11 +248,10 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_kernel(ConvArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  Stage sA, sB;
-  load_tile(sA);
-  if (PF == 2 && nk > 1) load_tile(sB);
-  store_tile(sA, 0);
-  __syncthreads();
+  Stage sA;
+  load_tile(sA, 0);
+  if (!GLDS) store_tile(sA, 0);
+  __syncthreads();     // with LDS-DMA pending the compiler's barrier sequence waits vmcnt(0) first
 
   const int l31 = lane & 31, khalf = lane >> 5;
   const int fl = swz(l31);   // rows of one fragment differ by multiples of 32 -> same swizzle
@@ -245,29 +273,13 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_kernel(ConvArgs a) {
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fw[i], fx[j], acc[i][j], 0, 0, 0);
     }
   };
-  if (PF == 1) {
-    // one K step in flight: loads of step k+1 issued before the MFMAs of step k
-    for (int ks = 0; ks < nk; ++ks) {
-      const int buf = ks & 1;
-      if (ks + 1 < nk) load_tile(sA);
-      compute(buf);
-      if (ks + 1 < nk) store_tile(sA, buf ^ 1);
-      __syncthreads();
-    }
-  } else {
-    // two K steps in flight (register sets sA / sB alternate, statically named so they stay
-    // in VGPRs): needed by the short-K, HBM-bound layers whose whole K loop is 2-6 steps.
-    for (int ks = 0; ks < nk; ks += 2) {
-      if (ks + 2 < nk) load_tile(sA);     // LDS[0] = step ks, sB = step ks+1, sA free
-      compute(0);
-      if (ks + 1 < nk) store_tile(sB, 1);
-      __syncthreads();
-      if (ks + 1 >= nk) break;
-      if (ks + 3 < nk) load_tile(sB);     // LDS[1] = step ks+1, sA = step ks+2, sB free
-      compute(1);
-      if (ks + 2 < nk) store_tile(sA, 0);
-      __syncthreads();
-    }
+  // one K step in flight: the loads (or LDS-DMAs) of step k+1 are issued before the MFMAs of step k
+  for (int ks = 0; ks < nk; ++ks) {
+    const int buf = ks & 1;
+    if (ks + 1 < nk) load_tile(sA, buf ^ 1);
+    compute(buf);
+    if (!GLDS && ks + 1 < nk) store_tile(sA, buf ^ 1);
+    __syncthreads();
   }
 
   // ---- epilogue: bias + activation (+ residual) -> NHWC store -----------------
@@ -361,10 +373,10 @@ void launch_cfg(const ConvArgs& a, bool dst_f32, hipStream_t st) {
   (void)LO;
   if (dst_f32) {
     hipLaunchKernelGGL((conv_igemm_kernel<BN, BM, WGN, WGM, BK, true, HI, 1>), grid, dim3(256), 0, st, a);
-  } else if (g_igemm_occ_lo) {   // tuning variant: prefetch depth 2
-    hipLaunchKernelGGL((conv_igemm_kernel<BN, BM, WGN, WGM, BK, false, HI, 2>), grid, dim3(256), 0, st, a);
-  } else {
+  } else if (g_igemm_occ_lo) {   // tuning variant: register-staged loads (global -> VGPR -> ds_write)
     hipLaunchKernelGGL((conv_igemm_kernel<BN, BM, WGN, WGM, BK, false, HI, 1>), grid, dim3(256), 0, st, a);
+  } else {                       // default: LDS-DMA (global_load_lds, 16 B per lane), +5..10 % measured
+    hipLaunchKernelGGL((conv_igemm_kernel<BN, BM, WGN, WGM, BK, false, HI, 2>), grid, dim3(256), 0, st, a);
   }
 }
 

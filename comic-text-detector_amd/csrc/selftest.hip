@@ -108,6 +108,9 @@ static void run_case(const Case& cs, int B, bool timing) {
   a.bias = dBias; a.pitchD = pitchD; a.oH = Ho; a.oW = Wo;
   a.res = dRes; a.pitchR = pitchD; a.act = CTD_ACT_SILU; a.N = cs.N; a.nphase = 1; a.osy = a.osx = 1;
 
+  static void* zeros = nullptr;
+  if (!zeros) { CK(hipMalloc(&zeros, 256)); CK(hipMemset(zeros, 0, 256)); }
+  a.zeros = zeros;
   ConvArgs ig = a, dr = a;
   std::vector<float> lg;       // logical igemm weights [nphase][N][K]
   std::vector<float> wdr((size_t)k * k * cin * cs.N);
@@ -172,7 +175,7 @@ static void run_case(const Case& cs, int B, bool timing) {
   const double bytes = 2.0 * ((double)n0 + n1 + (double)B * Ho * Wo * cs.N * (cs.res ? 2 : 1) + (double)cs.N * cin * k * k);
   std::printf("[case] %-32s B=%d out %dx%dx%d |", cs.name, B, Ho, Wo, cs.N);
   struct Var { const char* name; int bk, tiled, rot; };
-  const Var vars[] = {{"bk32", 32, 1, 0}, {"bk64", 64, 1, 0}};
+  const Var vars[] = {{"bk32/glds", 32, 1, 0}, {"bk32/reg", 32, 1, 1}, {"bk64/glds", 64, 1, 0}};
 
   const char* vsel = std::getenv("ST_VAR");   // ST_VAR=1: only variant index 1
   for (const Var& v : vars) {

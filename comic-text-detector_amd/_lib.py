@@ -76,6 +76,7 @@ SYMBOLS = {
     "ctd_win_hist": (_i32, [C.POINTER(CtdWindow), _i32, _vp, _vp]),
     "ctd_win_xor": (_i32, [C.POINTER(CtdWindow), _i32, C.POINTER(CtdRule), _i32, _vp, _vp]),
     "ctd_win_render": (_i32, [C.POINTER(CtdWindow), _i32, C.POINTER(CtdRule), C.POINTER(_i32), _i32, _vp, _i32, _vp]),
+    "ctd_db_boxes": (_i32, [_vp, _vp, _vp, _i32, _vp, _vp, _i32, _i32, _i32, _i32, C.c_double, _vp, _vp, C.POINTER(_i32)]),
     "ctd_last_error": (C.c_char_p, []),
     "ctd_abi_version": (_i32, []),
     "ctd_device_info": (_i32, [_i32, C.c_char_p, C.POINTER(_i32), C.POINTER(_i64)]),

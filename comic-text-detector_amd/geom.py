@@ -1,103 +1,14 @@
-"""Host-side geometry used by the post-processing mirror (O(#components) scalar
-work; SURVEY 2.1: "small host code for O(#contours) geometry").  Replaces the
-reference's calls into OpenCV / pyclipper / shapely:
+"""Host-side polygon predicate used by the text-block grouping (O(#lines^2) scalar work on a
+few dozen quads).  Replaces the reference's call into shapely:
 
-  cv2.minAreaRect + boxPoints   utils/db_utils.py:177-178   -> min_area_box
-  pyclipper offset + minAreaRect utils/db_utils.py:171-173,154 -> min_area_box(grow=d)
-  shapely area / length          utils/db_utils.py:169-170   -> quad_area / quad_perimeter
-  shapely intersects             utils/textblock.py:355,400  -> quads_intersect
+  shapely Polygon.intersects   utils/textblock.py:355,400  -> quads_intersect
+
+The contour geometry of the DB stage (hull, calipers rectangle, unclip) lives in the native
+host code behind `ctd_db_boxes` (csrc/host_db.cpp).
 """
 from __future__ import annotations
 
 import numpy as np
-
-
-def hull(points: np.ndarray) -> np.ndarray:
-    """Convex hull (counter-clockwise in x-right/y-down image axes = clockwise on screen),
-    float64, no repeated vertex.  Vectorised pre-filter + monotone chain."""
-    p = np.asarray(points, np.float64).reshape(-1, 2)
-    if len(p) > 64:
-        # keep only per-row extremes: every hull vertex is the min-x or max-x point of its row
-        order = np.lexsort((p[:, 0], p[:, 1]))
-        p = p[order]
-        first = np.r_[True, p[1:, 1] != p[:-1, 1]]
-        last = np.r_[first[1:], True]
-        p = p[first | last]
-    p = np.unique(p, axis=0)
-    if len(p) <= 2:
-        return p
-    p = p[np.lexsort((p[:, 1], p[:, 0]))]
-
-    def half(pts):
-        out = []
-        for q in pts:
-            while len(out) >= 2:
-                a, b = out[-2], out[-1]
-                if (b[0] - a[0]) * (q[1] - a[1]) - (b[1] - a[1]) * (q[0] - a[0]) <= 0:
-                    out.pop()
-                else:
-                    break
-            out.append(q)
-        return out
-
-    lo = half(p)
-    up = half(p[::-1])
-    return np.array(lo[:-1] + up[:-1], np.float64)
-
-
-def min_area_box(points: np.ndarray, grow: float = 0.0):
-    """Corners (4,2) float32 of the minimum-area rectangle enclosing `points`, optionally
-    grown by `grow` on every side, plus its two side lengths.  All hull edges are evaluated
-    at once (rotating-calipers result: the optimum shares a side with the hull)."""
-    h = hull(points)
-    n = len(h)
-    if n == 0:
-        return np.zeros((4, 2), np.float32), 0.0, 0.0
-    if n == 1:
-        c, g = h[0], grow
-        b = np.array([[c[0] - g, c[1] - g], [c[0] + g, c[1] - g], [c[0] + g, c[1] + g], [c[0] - g, c[1] + g]])
-        return b.astype(np.float32), 2 * g, 2 * g
-    e = np.roll(h, -1, axis=0) - h
-    if n == 2:
-        e = e[:1]
-    L = np.hypot(e[:, 0], e[:, 1])
-    keep = L > 0
-    e, L = e[keep], L[keep]
-    u = e / L[:, None]                       # (m,2)
-    v = np.stack([-u[:, 1], u[:, 0]], 1)
-    pu = h @ u.T                             # (n,m)
-    pv = h @ v.T
-    lo_u, hi_u = pu.min(0) - grow, pu.max(0) + grow
-    lo_v, hi_v = pv.min(0) - grow, pv.max(0) + grow
-    area = (hi_u - lo_u) * (hi_v - lo_v)
-    # first minimum in hull-edge order, with the same tie tolerance as a sequential scan
-    k = 0
-    for i in range(1, len(area)):
-        if area[i] < area[k] - 1e-12:
-            k = i
-    uu, vv = u[k], v[k]
-    box = np.array([uu * lo_u[k] + vv * lo_v[k], uu * hi_u[k] + vv * lo_v[k],
-                    uu * hi_u[k] + vv * hi_v[k], uu * lo_u[k] + vv * hi_v[k]])
-    return box.astype(np.float32), float(hi_u[k] - lo_u[k]), float(hi_v[k] - lo_v[k])
-
-
-def order_box(box: np.ndarray):
-    """`get_mini_boxes` ordering (utils/db_utils.py:178-194): sort by x, then TL, TR, BR, BL."""
-    pts = sorted([p for p in box], key=lambda p: p[0])
-    i1, i4 = (0, 1) if pts[1][1] > pts[0][1] else (1, 0)
-    i2, i3 = (2, 3) if pts[3][1] > pts[2][1] else (3, 2)
-    return np.array([pts[i1], pts[i2], pts[i3], pts[i4]])
-
-
-def quad_area(p: np.ndarray) -> float:
-    p = np.asarray(p, np.float64).reshape(-1, 2)
-    return abs(float(np.dot(p[:, 0], np.roll(p[:, 1], -1)) - np.dot(p[:, 1], np.roll(p[:, 0], -1)))) * 0.5
-
-
-def quad_perimeter(p: np.ndarray) -> float:
-    p = np.asarray(p, np.float64).reshape(-1, 2)
-    d = np.roll(p, -1, axis=0) - p
-    return float(np.hypot(d[:, 0], d[:, 1]).sum())
 
 
 def _orient(ax, ay, bx, by, cx, cy):

@@ -3,7 +3,7 @@ second-level seams, driving the HIP kernels for the O(pixels)
 work and doing the O(#boxes) scalar geometry on the host.
 
   postprocess_yolo      reference inference.py:101-114      -> ctd_nms (HIP)
-  SegRepresenter        reference utils/db_utils.py:32-211  -> ctd_ccl (HIP) x2 + host geometry
+  SegRepresenter        reference utils/db_utils.py:32-211  -> ctd_ccl (HIP) x2 + ctd_db_boxes (native host geometry)
   group_output          reference utils/textblock.py:421-508 -> textblock.py (host, tiny N)
   refine_mask           reference utils/textmask.py:159-169  -> textmask.py
 
@@ -13,11 +13,13 @@ from __future__ import annotations
 
 from typing import List, Tuple
 
+import ctypes as C
+
 import numpy as np
 import torch
 
+from . import _lib as L
 from . import backend as BK
-from . import geom
 
 
 # --------------------------------------------------------------------------
@@ -84,59 +86,17 @@ class SegRepresenter:
 
     # one page ---------------------------------------------------------------
     def _page(self, prob, lab_f, st_f, lab_b, st_b, W, H):
-        from scipy import ndimage
-        items = []   # (discovery key, kind, label)
-        for l, (x, y, w, h, a) in enumerate(st_f, start=1):
-            # outer border starts at the component's first pixel in raster order
-            row = lab_f[y, x: x + w]
-            fx = x + int(np.argmax(row == l))
-            items.append((y * W + fx, 0, l))
-        for l, (x, y, w, h, a) in enumerate(st_b, start=1):
-            if x == 0 or y == 0 or x + w == W or y + h == H:
-                continue                      # touches the frame: the outer background, no hole border
-            row = lab_b[y, x: x + w]
-            fx = x + int(np.argmax(row == l))
-            items.append((y * W + fx - 1, 1, l))    # hole border starts at the pixel left of the hole
-        # OpenCV hands RETR_LIST contours back newest first
-        items.sort(key=lambda t: t[0], reverse=True)
-        items = items[: self.max_candidates]
-        n = len(items)
-        boxes = np.zeros((n, 4, 2), np.int16)
-        scores = np.zeros((n,), np.float32)
-        for idx, (_, kind, l) in enumerate(items):
-            if kind == 0:
-                x, y, w, h, _ = st_f[l - 1]
-                comp = lab_f[y: y + h, x: x + w] == l
-                ys, xs = np.nonzero(comp)
-                pts = np.stack([xs + x, ys + y], 1)
-                region = ndimage.binary_fill_holes(comp)
-                x0, y0 = x, y
-            else:
-                x, y, w, h, _ = st_b[l - 1]
-                x0, y0 = x - 1, y - 1
-                hole = np.zeros((h + 2, w + 2), bool)
-                hole[1:-1, 1:-1] = lab_b[y: y + h, x: x + w] == l
-                ring = np.zeros_like(hole)
-                ring[1:, :] |= hole[:-1, :]
-                ring[:-1, :] |= hole[1:, :]
-                ring[:, 1:] |= hole[:, :-1]
-                ring[:, :-1] |= hole[:, 1:]
-                ring &= ~hole
-                ys, xs = np.nonzero(ring)
-                pts = np.stack([xs + x0, ys + y0], 1)
-                region = ndimage.binary_fill_holes(hole | ring)
-            box, bw, bh = geom.min_area_box(pts)
-            if min(bw, bh) < 2:                                   # db_utils.py:146-147
-                continue
-            box = geom.order_box(box)
-            rh, rw = region.shape
-            scores[idx] = prob[y0: y0 + rh, x0: x0 + rw][region].astype(np.float64).mean()
-            # unclip (db_utils.py:168-174) + get_mini_boxes (:154): pyclipper truncates the corners
-            # to integers; the round-join offset's min-area rectangle = calipers rectangle + distance
-            dist = geom.quad_area(box) * self.unclip_ratio / geom.quad_perimeter(box)
-            ub, _, _ = geom.min_area_box(np.trunc(box.astype(np.float64)), grow=dist)
-            ub = geom.order_box(ub)
-            ub[:, 0] = np.clip(np.round(ub[:, 0] / W * W), 0, W)    # dest size == bitmap size (inference.py:158)
-            ub[:, 1] = np.clip(np.round(ub[:, 1] / H * H), 0, H)
-            boxes[idx] = ub.astype(np.int16)
-        return boxes, scores
+        """Contours -> boxes for one page: `ctd_db_boxes` (native host geometry, csrc/host_db.cpp)."""
+        lib = L.lib()
+        cap = int(self.max_candidates)
+        boxes = np.zeros((cap, 4, 2), np.int16)
+        scores = np.zeros((cap,), np.float32)
+        n = C.c_int32(0)
+        prob = np.ascontiguousarray(prob, np.float32)
+        lab_f, lab_b = np.ascontiguousarray(lab_f, np.int32), np.ascontiguousarray(lab_b, np.int32)
+        st_f, st_b = np.ascontiguousarray(st_f, np.int32), np.ascontiguousarray(st_b, np.int32)
+        L.check(lib.ctd_db_boxes(prob.ctypes.data, lab_f.ctypes.data, st_f.ctypes.data, len(st_f),
+                                 lab_b.ctypes.data, st_b.ctypes.data, len(st_b), W, H, cap,
+                                 float(self.unclip_ratio), boxes.ctypes.data, scores.ctypes.data, C.byref(n)),
+                "ctd_db_boxes")
+        return boxes[: n.value], scores[: n.value]

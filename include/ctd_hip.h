@@ -235,6 +235,24 @@ int ctd_win_xor(const ctd_window* wins, int32_t n, const ctd_rule* rules, int32_
 int ctd_win_render(const ctd_window* wins, int32_t n, const ctd_rule* bands, const int32_t* tops, int32_t nbands,
                    uint8_t* canvas_dev, int32_t canvas_w, void* stream);
 
+/* ---- host-side contour geometry of the DB text-line stage -------------- */
+
+/* `SegDetectorRepresenter.boxes_from_bitmap` (reference utils/db_utils.py:134-211) downstream of
+ * the two labelling passes: all pointers are HOST memory, no device work (scalar O(#contours)
+ * double arithmetic).  prob (H,W) f32 = shrink map; lab_f / st_f / n_f = labels,
+ * [x,y,w,h,area] stats and count of `ctd_ccl(bitmap, connectivity 8)`; lab_b / st_b / n_b =
+ * those of `ctd_ccl(1 - bitmap, connectivity 4)`.  The contour set of
+ * cv2.findContours(RETR_LIST) (db_utils.py:142) = one outer border per foreground component + one
+ * hole border per background component that does not touch the frame, newest first.  Per
+ * contour: get_mini_boxes (:177-194), the min-side test (:146-147), box_score_fast (:196-211),
+ * unclip (:168-174), second get_mini_boxes (:154) and the rescale/clip of :158-163 with dest
+ * size == bitmap size.  Outputs: boxes (n,4,2) i16 and scores (n) f32 with n = min(#contours,
+ * max_candidates) in *n_out; rejected contours keep all-zero rows, like the reference's
+ * preallocated arrays (:143-144).  boxes / scores must hold max_candidates entries. */
+int ctd_db_boxes(const float* prob, const int32_t* lab_f, const int32_t* st_f, int32_t n_f, const int32_t* lab_b,
+                 const int32_t* st_b, int32_t n_b, int32_t W, int32_t H, int32_t max_candidates,
+                 double unclip_ratio, int16_t* boxes, float* scores, int32_t* n_out);
+
 /* ---- misc -------------------------------------------------------------- */
 const char* ctd_last_error(void);
 int32_t ctd_abi_version(void);

@@ -50,7 +50,9 @@ struct ConvArgs {
   int bk;                  // igemm K step the weights were packed for (32 / 64)
   int w_tiled;             // igemm weights are tile-major [phase][n_tile][k_step][BN][bk]
   const void* zeros;       // >= 16 B of zeros in HBM: source of padding rows for LDS-DMA loads
-  int k_rot;               // igemm: rotate the K-step order per pixel tile (L2 channel spreading)
+  unsigned mw_mul, mw_sh;  // igemm: n / Mw == (uint64(n) * mw_mul) >> mw_sh for n < 2^31 (filled by the launcher)
+  unsigned mh_mul, mh_sh;  //        same for Mh
+  int k_rot;               // igemm: selftest ablation bits (0 in the product): 1 no K-loop loads, 2 no MFMAs, 4 no stores
 };
 
 __device__ __forceinline__ float ctd_act(float v, int act) {
@@ -61,6 +63,14 @@ __device__ __forceinline__ float ctd_act(float v, int act) {
     case CTD_ACT_SIGMOID: return 1.0f / (1.0f + __expf(-v));
     default: return v;
   }
+}
+// compile-time activation for the MFMA epilogue: hardware rcp / exp2 (1 ulp, well inside fp16 rounding)
+template <int ACT> __device__ __forceinline__ float ctd_act_fast(float v) {
+  if (ACT == CTD_ACT_SILU) return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v));
+  if (ACT == CTD_ACT_LEAKY) return v > 0.f ? v : 0.1f * v;
+  if (ACT == CTD_ACT_RELU) return v > 0.f ? v : 0.f;
+  if (ACT == CTD_ACT_SIGMOID) return __builtin_amdgcn_rcpf(1.0f + __expf(-v));
+  return v;
 }
 // exact-ish variants for the fp32 parity mode (expf instead of the fast exp)
 __device__ __forceinline__ float ctd_act_precise(float v, int act) {

@@ -71,7 +71,6 @@ struct ctd_engine {
   int pB = 0, pH = 0, pW = 0;  // current plan
   bool no_reuse = false;
   bool w_tiled = true;   // tile-major MFMA weight packing (CTD_W_TILED=0 disables)
-  bool k_rot = false;    // rotated K order per pixel tile (CTD_K_ROT=1 enables)
   int det_rows_per_unit = 0;
   int det_no = 0;
   void* zeros = nullptr;  // 256 B of zeros (padding source of the LDS-DMA loads)
@@ -448,7 +447,7 @@ int plan(ctd_engine* e, int B, int H, int W) {
       a.bk = s.bk;
       a.zeros = e->zeros;
       a.w_tiled = e->w_tiled;
-      a.k_rot = e->k_rot;
+      a.k_rot = 0;
       const int cin = o.src0_c + (o.src1 >= 0 ? o.src1_c : 0);
       a.nphase = 1;
       a.osy = a.osx = 1;

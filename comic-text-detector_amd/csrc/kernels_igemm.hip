@@ -22,6 +22,7 @@
 // chunks so the 16-lane ds_read_b128 groups hit distinct bank slots.
 // v_mfma_f32_32x32x16_f16: A/B fragment = 8 consecutive k of row/col (lane & 31),
 // k group = lane >> 5; C/D: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5).
+#include <type_traits>
 #include <vector>
 
 #include "kernels.h"
@@ -103,6 +104,17 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_kernel(ConvArgs a) {
   constexpr int RPW = 256 / (BK * 2);
   auto swz = [&](int row) { return (row / RPW) % SEGS; };
   constexpr bool GLDS = PF == 2;
+  // m -> (batch, grid row, grid column) with the launcher's magic multipliers: an integer
+  // division costs ~40 VALU instructions, and the per-block set-up / epilogue, not the K loop,
+  // is what the shallow (K <= 128) layers spend their issue slots on (PMC: 1200 VALU per wave
+  // for 8 MFMAs on the 1x1 64->64 layer before this).
+  auto split = [&](int m, int& b, int& oy, int& ox) {
+    const unsigned tq = (unsigned)(((unsigned long long)(unsigned)m * a.mw_mul) >> a.mw_sh);
+    ox = m - (int)tq * a.Mw;
+    const unsigned bb = (unsigned)(((unsigned long long)tq * a.mh_mul) >> a.mh_sh);
+    oy = (int)tq - (int)bb * a.Mh;
+    b = (int)bb;
+  };
   int aoff0[AROWS], aoff1[AROWS];
   int pb[AROWS], piy[AROWS], pix[AROWS], gseg[AROWS];
   unsigned vmask[AROWS];
@@ -111,22 +123,19 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_kernel(ConvArgs a) {
     gseg[i] = GLDS ? (seg ^ swz(lrow + RPP * i)) : seg;
     const int m = m0 + lrow + RPP * i;
     const bool pv = m < a.M;
-    const int mm = pv ? m : 0;
-    const int ox = mm % a.Mw;
-    const int tq = mm / a.Mw;
-    const int oy = tq % a.Mh;
-    const int b = tq / a.Mh;
+    int b, oy, ox;
+    split(pv ? m : 0, b, oy, ox);
     const int iy0 = oy * a.stride + dy0, ix0 = ox * a.stride + dx0;
     pb[i] = b; piy[i] = iy0; pix[i] = ix0;
-    aoff0[i] = (int)(((((long long)b * a.s0.H + iy0) * a.s0.W + ix0) * a.s0.pitch + gseg[i] * 8) * 2);
-    aoff1[i] = (int)(((((long long)b * a.s1.H + iy0) * a.s1.W + ix0) * a.s1.pitch + gseg[i] * 8) * 2);
-    unsigned vm = 0;
-    for (int ty = 0; ty < a.KH; ++ty)
-      for (int tx = 0; tx < a.KW; ++tx) {
-        const int iy = iy0 + ty, ix = ix0 + tx;
-        if (pv && iy >= 0 && iy < a.Hin && ix >= 0 && ix < a.Win) vm |= 1u << (ty * a.KW + tx);
-      }
-    vmask[i] = vm;
+    // tensors are < 2 GiB (engine plan guard), so byte offsets fit 32 bits
+    aoff0[i] = (((b * a.s0.H + iy0) * a.s0.W + ix0) * a.s0.pitch + gseg[i] * 8) * 2;
+    aoff1[i] = (((b * a.s1.H + iy0) * a.s1.W + ix0) * a.s1.pitch + gseg[i] * 8) * 2;
+    // tap validity is separable: rows inside x columns inside
+    unsigned ym = 0, xm = 0, vm = 0;
+    for (int ty = 0; ty < a.KH; ++ty) ym |= (unsigned)((unsigned)(iy0 + ty) < (unsigned)a.Hin) << ty;
+    for (int tx = 0; tx < a.KW; ++tx) xm |= (unsigned)((unsigned)(ix0 + tx) < (unsigned)a.Win) << tx;
+    for (int ty = 0; ty < a.KH; ++ty) vm |= ((ym >> ty) & 1u) ? xm << (ty * a.KW) : 0u;
+    vmask[i] = pv ? vm : 0u;
   }
   // weights: tile-major [n_tile][k_step][BN][BK]; per-thread constant part of the address
   int woff[WROWS];
@@ -273,11 +282,14 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_kernel(ConvArgs a) {
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fw[i], fx[j], acc[i][j], 0, 0, 0);
     }
   };
-  // one K step in flight: the loads (or LDS-DMAs) of step k+1 are issued before the MFMAs of step k
+  const int abl = a.k_rot;   // selftest ablation bits: 1 = no loads in the K loop, 2 = no MFMAs, 4 = no stores
+  // One K step in flight: the LDS-DMAs (or loads) of step k+1 are issued before the MFMAs of step k.
+  // (A 3-deep ring with two steps in flight and a counted vmcnt measured 3-6 % SLOWER on every
+  // layer shape: the K loop is not short of bytes in flight, see DESIGN.md.)
   for (int ks = 0; ks < nk; ++ks) {
     const int buf = ks & 1;
-    if (ks + 1 < nk) load_tile(sA, buf ^ 1);
-    compute(buf);
+    if (ks + 1 < nk && !(abl & 1)) load_tile(sA, buf ^ 1);
+    if (!(abl & 2)) compute(buf);
     if (!GLDS && ks + 1 < nk) store_tile(sA, buf ^ 1);
     __syncthreads();
   }
@@ -287,52 +299,63 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_kernel(ConvArgs a) {
   constexpr int OP = BN + 8;   // LDS pitch (halves) of the staged output tile, +16 B against conflicts
   half_t* Os = lds;            // [BM][OP], reuses the (now idle) staging buffers
   const bool staged = !DST_F32 && (a.pitchD % 8 == 0) && (a.N % 8 == 0);
+  auto out_pixel = [&](int m) {
+    int b, oy, ox;
+    split(m, b, oy, ox);
+    return ((size_t)b * a.oH + (oy * a.osy + ooy)) * a.oW + (ox * a.osx + oox);
+  };
+  auto epilogue = [&](auto act_tag) {
+    constexpr int ACT = decltype(act_tag)::value;
 #pragma unroll
-  for (int j = 0; j < TM; ++j) {
-    const int pl = (wm * TM + j) * 32 + l31;   // pixel inside the tile
-    const int m = m0 + pl;
-    const bool mv = m < a.M;
-    const int mm = mv ? m : 0;
-    const int ox = mm % a.Mw;
-    const int tq = mm / a.Mw;
-    const int oy = tq % a.Mh;
-    const int b = tq / a.Mh;
-    const size_t opix = ((size_t)b * a.oH + (oy * a.osy + ooy)) * a.oW + (ox * a.osx + oox);
+    for (int j = 0; j < TM; ++j) {
+      const int pl = (wm * TM + j) * 32 + l31;   // pixel inside the tile
+      const int m = m0 + pl;
+      const bool mv = m < a.M;
+      const size_t opix = out_pixel(mv ? m : 0);
 #pragma unroll
-    for (int i = 0; i < TN; ++i) {
-      const int nl = (wn * TN + i) * 32 + 4 * hi;   // channel inside the tile
+      for (int i = 0; i < TN; ++i) {
+        const int nl = (wn * TN + i) * 32 + 4 * hi;   // channel inside the tile
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int n = n0 + nl + 8 * g;
-        float v[4];
+        for (int g = 0; g < 4; ++g) {
+          const int n = n0 + nl + 8 * g;
+          const float4_t bv = *(const float4_t*)(a.bias + n);   // bias is padded to the N tile
+          float v[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = ctd_act(acc[i][j][4 * g + e] + a.bias[n + e], a.act);
-        if (a.res && mv && n < a.N) {
-          const half4_t rv = *(const half4_t*)((const half_t*)a.res + opix * a.pitchR + n);
+          for (int e = 0; e < 4; ++e) v[e] = ctd_act_fast<ACT>(acc[i][j][4 * g + e] + bv[e]);
+          if (a.res && mv && n < a.N) {
+            const half4_t rv = *(const half4_t*)((const half_t*)a.res + opix * a.pitchR + n);
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] += (float)rv[e];
-        }
-        if (staged) {
-          half4_t o = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
-          *(half4_t*)(Os + (size_t)pl * OP + nl + 8 * g) = o;
-        } else if (mv && n < a.N) {
-          if (n + 3 < a.N) {
-            if (DST_F32) {
-              float4_t o = {v[0], v[1], v[2], v[3]};
-              *(float4_t*)((float*)a.dst + opix * a.pitchD + n) = o;
+            for (int e = 0; e < 4; ++e) v[e] += (float)rv[e];
+          }
+          if (staged) {
+            half4_t o = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+            *(half4_t*)(Os + (size_t)pl * OP + nl + 8 * g) = o;
+          } else if (mv && n < a.N) {
+            if (n + 3 < a.N) {
+              if (DST_F32) {
+                float4_t o = {v[0], v[1], v[2], v[3]};
+                *(float4_t*)((float*)a.dst + opix * a.pitchD + n) = o;
+              } else {
+                half4_t o = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+                *(half4_t*)((half_t*)a.dst + opix * a.pitchD + n) = o;
+              }
             } else {
-              half4_t o = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
-              *(half4_t*)((half_t*)a.dst + opix * a.pitchD + n) = o;
-            }
-          } else {
-            for (int e = 0; e < 4 && n + e < a.N; ++e) {
-              if (DST_F32) ((float*)a.dst)[opix * a.pitchD + n + e] = v[e];
-              else ((half_t*)a.dst)[opix * a.pitchD + n + e] = (half_t)v[e];
+              for (int e = 0; e < 4 && n + e < a.N; ++e) {
+                if (DST_F32) ((float*)a.dst)[opix * a.pitchD + n + e] = v[e];
+                else ((half_t*)a.dst)[opix * a.pitchD + n + e] = (half_t)v[e];
+              }
             }
           }
         }
       }
     }
+  };
+  switch (a.act) {   // block-uniform: one specialised copy of the epilogue arithmetic runs
+    case CTD_ACT_SILU: epilogue(std::integral_constant<int, CTD_ACT_SILU>{}); break;
+    case CTD_ACT_LEAKY: epilogue(std::integral_constant<int, CTD_ACT_LEAKY>{}); break;
+    case CTD_ACT_RELU: epilogue(std::integral_constant<int, CTD_ACT_RELU>{}); break;
+    case CTD_ACT_SIGMOID: epilogue(std::integral_constant<int, CTD_ACT_SIGMOID>{}); break;
+    default: epilogue(std::integral_constant<int, CTD_ACT_NONE>{}); break;
   }
   if (staged) {
     // The MFMA C layout gives each lane 4 channels of one pixel: storing that directly makes
@@ -348,12 +371,8 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_kernel(ConvArgs a) {
     for (int it = 0; it < BM / PPI; ++it) {
       const int pl = it * PPI + t / CPP;
       const int m = m0 + pl;
-      if (m < a.M && n < a.N) {
-        const int ox = m % a.Mw;
-        const int tq = m / a.Mw;
-        const int oy = tq % a.Mh;
-        const int b = tq / a.Mh;
-        const size_t opix = ((size_t)b * a.oH + (oy * a.osy + ooy)) * a.oW + (ox * a.osx + oox);
+      if (m < a.M && n < a.N && !(abl & 4)) {
+        const size_t opix = out_pixel(m);
         *(half8_t*)((half_t*)a.dst + opix * a.pitchD + n) = *(const half8_t*)(Os + (size_t)pl * OP + c * 8);
       }
     }
@@ -373,9 +392,9 @@ void launch_cfg(const ConvArgs& a, bool dst_f32, hipStream_t st) {
   (void)LO;
   if (dst_f32) {
     hipLaunchKernelGGL((conv_igemm_kernel<BN, BM, WGN, WGM, BK, true, HI, 1>), grid, dim3(256), 0, st, a);
-  } else if (g_igemm_occ_lo) {   // tuning variant: register-staged loads (global -> VGPR -> ds_write)
+  } else if (g_igemm_occ_lo == 1) {   // tuning variant: register-staged loads (global -> VGPR -> ds_write)
     hipLaunchKernelGGL((conv_igemm_kernel<BN, BM, WGN, WGM, BK, false, HI, 1>), grid, dim3(256), 0, st, a);
-  } else {                       // default: LDS-DMA (global_load_lds, 16 B per lane), +5..10 % measured
+  } else {                            // default: LDS-DMA (global_load_lds, 16 B per lane), +5..10 % measured
     hipLaunchKernelGGL((conv_igemm_kernel<BN, BM, WGN, WGM, BK, false, HI, 2>), grid, dim3(256), 0, st, a);
   }
 }
@@ -451,7 +470,18 @@ bool igemm_supported(const ConvArgs& a) {
   return true;
 }
 
-void launch_conv_igemm(const ConvArgs& a, bool dst_f32, hipStream_t st) {
+// n / d == (uint64(n) * mul) >> sh for every n < 2^31 (Granlund-Montgomery, 31-bit dividend)
+static void magic_div(int d, unsigned& mul, unsigned& sh) {
+  int L = 0;
+  while ((1ll << L) < d) ++L;
+  sh = 31 + L;
+  mul = (unsigned)(((1ull << sh) / (unsigned)d) + 1);
+}
+
+void launch_conv_igemm(const ConvArgs& a_in, bool dst_f32, hipStream_t st) {
+  ConvArgs a = a_in;
+  magic_div(a.Mw, a.mw_mul, a.mw_sh);
+  magic_div(a.Mh, a.mh_mul, a.mh_sh);
   const int bn = igemm_ntile(a.N);
   if (pick_bk(a) == 64) {
     if (bn == 128) launch_cfg<128, 128, 2, 2, 64>(a, dst_f32, st);

@@ -57,6 +57,32 @@ res = det.tail_batch(pages, bt, mu, pr, bm, keep_undetected_mask=True)
 out["tail_ms_per_page_textlike_1024"] = round((time.perf_counter() - t0) / 4 * 1e3, 1)
 out["tail_blocks_per_page"] = [len(r[2]) for r in res]
 
+# per-stage split of the same tail (host wall clock, device synchronised at the stage ends)
+from importlib import import_module                  # noqa: E402
+PP = pkg.postproc
+stage = {}
+
+
+def clock(name, fn):
+    torch.cuda.synchronize()
+    t = time.perf_counter()
+    r = fn()
+    torch.cuda.synchronize()
+    stage[name] = stage.get(name, 0.0) + (time.perf_counter() - t) * 1e3 / 4
+    return r
+
+
+ratios = [(1.0, 1.0)] * 4
+yolo = clock("nms+unpack", lambda: PP.postprocess_yolo(bt, det.conf_thresh, det.nms_thresh, ratios))
+boxes, scores = clock("db_boxes(ccl x2 + download + ctd_db_boxes)", lambda: det.seg_rep(pr, bm))
+for b in range(4):
+    lines = boxes[b][scores[b] > 0.6].astype(np.int32)
+    m = clock("mask download", lambda: mu[b].cpu().numpy().copy())
+    blk = clock("group_output", lambda: pkg.textblock.group_output(yolo[b], lines, 1024, 1024, m))
+    ref = clock("refine_mask", lambda: pkg.textmask.refine_mask(pages[b], m, blk, 0, "cuda"))
+    clock("refine_undetected_mask", lambda: pkg.textmask.refine_undetected_mask(pages[b], m, ref, blk, 0, "cuda"))
+out["tail_stage_ms_per_page"] = {k: round(v, 2) for k, v in stage.items()}
+
 be32 = pkg.backend.HipTextDetBackend(ck, precision="fp32")
 x = torch.rand(8, 3, 1024, 1024).cuda()
 out["config2_fp32_direct_ms_per_8_pages"] = round(timeit(lambda: be32(x), n=2, warm=1), 1)

@@ -50,6 +50,7 @@ struct ConvArgs {
   int bk;                  // igemm K step the weights were packed for (32 / 64)
   int w_tiled;             // igemm weights are tile-major [phase][n_tile][k_step][BN][bk]
   const void* zeros;       // >= 16 B of zeros in HBM: source of padding rows for LDS-DMA loads
+  long long* dbg;          // selftest only (k_rot & 16): per-block cycle stamps [nblk][8]; null in the product
   unsigned mw_mul, mw_sh;  // igemm: n / Mw == (uint64(n) * mw_mul) >> mw_sh for n < 2^31 (filled by the launcher)
   unsigned mh_mul, mh_sh;  //        same for Mh
   int k_rot;               // igemm: selftest ablation bits (0 in the product): 1 no K-loop loads, 2 no MFMAs, 4 no stores

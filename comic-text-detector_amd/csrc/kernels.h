@@ -33,7 +33,12 @@ void igemm_pack_weights(const float* logical, int nphase, int N, int K, int bn, 
                         std::vector<half_t>& out);
 bool igemm_supported(const ConvArgs& a);
 int igemm_ntile(int N);  // N tile the dispatcher will use (weights must be padded to it)
-void launch_conv_igemm(const ConvArgs& a, bool dst_f32, hipStream_t st);
+void launch_conv_igemm(const ConvArgs& a, bool dst_f32, hipStream_t st);   // dispatches to the halo kernel when it applies
+
+// ---- kernels_halo.hip : halo-tile MFMA conv (stride-1 3x3, ConvTranspose phases) ----
+extern int g_conv_halo;   // 0 disables (selftest A/B)
+bool conv_halo_supported(const ConvArgs& a, bool dst_f32);
+void launch_conv_halo(const ConvArgs& a, hipStream_t st);
 
 // ---- kernels_fused.hip ----------------------------------------------------
 // stem: 6x6 s2 p2, 3 -> N (N <= 32... multiple of 8), reads the network input directly.

@@ -1,0 +1,282 @@
+// Halo-tile MFMA convolution for gfx950: the stride-1 3x3 convolutions and the four 2x2-tap
+// sub-pixel phases of ConvTranspose 4x4/s2/p1 (reference: Conv / C3 bottlenecks of
+// models/yolov5/common.py and the ConvTranspose2d of basemodel.py double_conv_up_c3).
+//
+// Why a second kernel next to kernels_igemm.hip: ablations of the implicit-GEMM kernel (selftest
+// ST_ABL=1) show its K loop is bound by bytes through the vector-memory -> LDS path, not by MFMA
+// issue or by bytes in flight: dropping the (always L1/L2-hit) weight loads alone buys 15-20 %,
+// dropping the activation loads ~30 %.  Per K step that kernel moves a 128-pixel activation tile
+// for EVERY tap plus a 128-row weight tile, 16 KB per 1 MFLOP.  Here
+//   * a block owns a 16x16 pixel patch and stages its haloed (16+KH-1)x(16+KW-1) input patch in
+//     LDS ONCE per 32-channel chunk; all KH*KW taps read it at shifted LDS addresses;
+//   * the patch is 256 pixels (8 waves), so a weight tile is amortised over twice the pixels.
+// 3x3, 128 -> 128 channels: 5 KB per MFLOP through the vector-memory path instead of 15.
+//
+// Layout: NHWC fp16 activations, fp32 accumulation; weights in the implicit-GEMM tile-major
+// packing [phase][N/BN][K/32][BN][32] (K index = tap * Ctot + channel), so both kernels share
+// one packed copy.  K walk here: channel chunk outer, tap inner.
+#include <type_traits>
+
+#include "kernels.h"
+
+int g_conv_halo = 1;   // selftest / tuning: 0 sends everything to the implicit-GEMM kernel
+
+namespace {
+
+constexpr int TWP = 16, THP = 16;     // pixel patch
+constexpr int BMH = TWP * THP;        // 256 pixels per block
+constexpr int BKH = 32;               // channels per K chunk (64-B LDS rows)
+constexpr int AROWS_PAD = 384;        // haloed rows rounded up to 3 DMA passes of 512 threads x 16 B
+constexpr int NTHR = 512;
+
+template <int BN, int WGN, int WGM>
+__global__ __launch_bounds__(NTHR, 4) void conv_halo_kernel(ConvArgs a) {   // 4 waves / SIMD = 2 blocks / CU
+  constexpr int TN = BN / (32 * WGN);
+  constexpr int TM = BMH / (32 * WGM);
+  static_assert(WGN * WGM == 8, "8 waves");
+  constexpr int A_BUF = AROWS_PAD * BKH;          // halves
+  constexpr int W_BUF = BN * BKH;
+  constexpr int LDS_STAGE = 2 * A_BUF + 2 * W_BUF;
+  constexpr int OP = BN + 8;
+  constexpr int LDS_OUT = BMH * OP;
+  __shared__ __attribute__((aligned(16))) half_t lds[LDS_STAGE > LDS_OUT ? LDS_STAGE : LDS_OUT];
+  half_t* As = lds;               // [2][AROWS_PAD][32]
+  half_t* Ws = lds + 2 * A_BUF;   // [2][BN][32]
+
+  const int t = threadIdx.x;
+  const int lane = t & 63;
+  const int wave_u = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wn = wave_u % WGN, wm = wave_u / WGN;
+  const int l31 = lane & 31, khalf = lane >> 5;
+
+  // ---- block -> (batch, patch, phase, N tile); XCD-aware: each XCD gets a contiguous run so
+  // the N tiles / phases / neighbouring patches that share input pixels share an L2
+  const int ntn = a.Npad / BN;
+  const int tilesX = (a.Mw + TWP - 1) / TWP, tilesY = (a.Mh + THP - 1) / THP;
+  const int nblk = ntn * a.nphase * tilesX * tilesY * a.B;
+  int v = blockIdx.x;
+  {
+    const int xcd = v & 7, within = v >> 3;
+    const int q = nblk >> 3, r = nblk & 7;
+    v = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + within;
+  }
+  const int tile_n = v % ntn;
+  v /= ntn;
+  int phase = 0;
+  if (a.nphase == 4) {
+    phase = v & 3;
+    v >>= 2;
+  }
+  const int tpx = v % tilesX;
+  v /= tilesX;
+  const int tpy = v % tilesY;
+  const int b = v / tilesY;
+  const int n0 = tile_n * BN;
+  const int y0 = tpy * THP, x0 = tpx * TWP;
+
+  int dy0 = a.dy0, dx0 = a.dx0, ooy = a.ooy, oox = a.oox;
+  const half_t* __restrict__ wbase = (const half_t*)a.w;
+  if (a.nphase == 4) {
+    const int py = phase >> 1, px = phase & 1;
+    dy0 = py ? 0 : -1;
+    dx0 = px ? 0 : -1;
+    ooy = py;
+    oox = px;
+    wbase += (size_t)phase * a.w_phase_stride;
+  }
+  const int HW = TWP + a.KW - 1, HH = THP + a.KH - 1;   // haloed patch
+  const int taps = a.KH * a.KW;
+  const int Ct = a.s0.c + a.s1.c;
+  const int nchunk = Ct / BKH;
+  const int nkc = Ct / BKH;                            // K steps per tap in the weight packing
+
+  using gptr_t = const __attribute__((address_space(1))) void*;
+  using lptr_t = __attribute__((address_space(3))) void*;
+  // LDS rows are 64 B, 16-B chunk c of row r sits at chunk position c ^ ((r >> 2) & 3).  The DMA
+  // writes lane-linear (chunk position = lane % 4), so the swizzle goes on the SOURCE chunk.
+  auto swz = [](int row) { return (row >> 2) & 3; };
+
+  // ---- this thread's three haloed-patch rows (one 16-B chunk of each) ------------
+  int aoff0[3], aoff1[3];
+  bool aok[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const int q = i * NTHR + t;
+    const int r = q >> 2, pos = q & 3;
+    const int hy = r / HW, hx = r - hy * HW;
+    const int iy = y0 + hy + dy0, ix = x0 + hx + dx0;
+    aok[i] = r < HH * HW && iy >= 0 && iy < a.Hin && ix >= 0 && ix < a.Win;
+    const int gs = (pos ^ swz(r)) * 8;
+    aoff0[i] = aok[i] ? (((b * a.s0.H + iy) * a.s0.W + ix) * a.s0.pitch + gs) * 2 : 0;
+    aoff1[i] = aok[i] ? (((b * a.s1.H + iy) * a.s1.W + ix) * a.s1.pitch + gs) * 2 : 0;
+  }
+  // weights: one 16-B chunk per thread per K step (threads beyond the tile idle)
+  constexpr int WCHUNKS = BN * 4;
+  const int wr = t >> 2;
+  const int woff = (wr * BKH + ((t & 3) ^ swz(wr)) * 8) * 2;
+  const char* wtile = (const char*)(wbase + (size_t)tile_n * (size_t)(a.K / BKH) * BN * BKH);
+
+  auto dma_a = [&](int chunk, int i) {   // pass i (0..2) of the haloed patch of channel chunk `chunk`
+    const int cc = chunk * BKH;
+    const bool first = cc < a.s0.c;
+    const char* base = first ? (const char*)a.s0.ptr + (size_t)cc * 2 : (const char*)a.s1.ptr + (size_t)(cc - a.s0.c) * 2;
+    const int off = first ? aoff0[i] : aoff1[i];
+    const void* g = aok[i] ? (const void*)(base + off) : a.zeros;
+    half_t* dst = As + (size_t)(chunk & 1) * A_BUF + (size_t)(i * NTHR + wave_u * 64) * 8;
+    __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)dst, 16, 0, 0);
+  };
+  auto dma_w = [&](int chunk, int tap, int buf) {
+    if (WCHUNKS >= NTHR || t < WCHUNKS) {
+      const char* wk = wtile + (size_t)(tap * nkc + chunk) * (BN * BKH * 2);
+      half_t* dst = Ws + (size_t)buf * W_BUF + (size_t)(wave_u * 64) * 8;
+      __builtin_amdgcn_global_load_lds((gptr_t)(wk + woff), (lptr_t)dst, 16, 0, 0);
+    }
+  };
+
+  float16_t acc[TN][TM];
+#pragma unroll
+  for (int i = 0; i < TN; ++i)
+#pragma unroll
+    for (int j = 0; j < TM; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // fragment j of this wave = patch rows 2f, 2f+1 (f = wm*TM + j); row of tap (0,0) per lane
+  int row0[TM];
+#pragma unroll
+  for (int j = 0; j < TM; ++j) {
+    const int f = wm * TM + j;
+    row0[j] = (2 * f + (l31 >> 4)) * HW + (l31 & 15);
+  }
+  const int flw = swz(l31);   // weight rows of one fragment differ by multiples of 32
+
+  // prologue: patch of chunk 0 + weights of step 0
+  dma_a(0, 0);
+  dma_a(0, 1);
+  dma_a(0, 2);
+  dma_w(0, 0, 0);
+  __syncthreads();
+
+  int step = 0;
+  for (int c = 0; c < nchunk; ++c) {
+    const half_t* Ac = As + (size_t)(c & 1) * A_BUF;
+    int tap = 0;
+    for (int ty = 0; ty < a.KH; ++ty)
+      for (int tx = 0; tx < a.KW; ++tx, ++tap, ++step) {
+        // next step's weights, and a third of the next chunk's patch during the first three taps
+        const bool last_tap = tap + 1 == taps;
+        if (!(last_tap && c + 1 == nchunk)) dma_w(last_tap ? c + 1 : c, last_tap ? 0 : tap + 1, (step + 1) & 1);
+        if (c + 1 < nchunk) {   // static pass index: the row tables stay in registers
+          if (tap == 0) dma_a(c + 1, 0);
+          else if (tap == 1) dma_a(c + 1, 1);
+          else if (tap == 2) dma_a(c + 1, 2);
+        }
+        const half_t* Wb = Ws + (size_t)(step & 1) * W_BUF + (size_t)(wn * TN * 32 + l31) * BKH;
+        const int tapoff = ty * HW + tx;
+#pragma unroll
+        for (int kk = 0; kk < BKH / 16; ++kk) {
+          half8_t fw[TN], fx[TM];
+#pragma unroll
+          for (int i = 0; i < TN; ++i) fw[i] = *(const half8_t*)(Wb + i * 32 * BKH + (((kk * 2 + khalf) ^ flw) * 8));
+#pragma unroll
+          for (int j = 0; j < TM; ++j) {
+            const int row = row0[j] + tapoff;
+            fx[j] = *(const half8_t*)(Ac + row * BKH + (((kk * 2 + khalf) ^ swz(row)) * 8));
+          }
+#pragma unroll
+          for (int i = 0; i < TN; ++i)
+#pragma unroll
+            for (int j = 0; j < TM; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fw[i], fx[j], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();   // waits the DMAs (vmcnt 0) and fences the LDS buffers for reuse
+      }
+  }
+
+  // ---- epilogue: bias + activation (+ residual), transposed through LDS for 16-B row stores ----
+  const int hi = lane >> 5;
+  half_t* Os = lds;   // [256][OP]
+  auto epilogue = [&](auto act_tag) {
+    constexpr int ACT = decltype(act_tag)::value;
+#pragma unroll
+    for (int j = 0; j < TM; ++j) {
+      const int pl = (wm * TM + j) * 32 + l31;
+      const int oy = y0 + (pl >> 4), ox = x0 + (pl & 15);
+      const bool mv = oy < a.Mh && ox < a.Mw;
+      const size_t opix = mv ? ((size_t)b * a.oH + (oy * a.osy + ooy)) * a.oW + (ox * a.osx + oox) : 0;
+#pragma unroll
+      for (int i = 0; i < TN; ++i) {
+        const int nl = (wn * TN + i) * 32 + 4 * hi;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int n = n0 + nl + 8 * g;
+          const float4_t bv = *(const float4_t*)(a.bias + n);
+          float vv[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) vv[e] = ctd_act_fast<ACT>(acc[i][j][4 * g + e] + bv[e]);
+          if (a.res && mv && n < a.N) {
+            const half4_t rv = *(const half4_t*)((const half_t*)a.res + opix * a.pitchR + n);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) vv[e] += (float)rv[e];
+          }
+          half4_t o = {(half_t)vv[0], (half_t)vv[1], (half_t)vv[2], (half_t)vv[3]};
+          *(half4_t*)(Os + (size_t)pl * OP + nl + 8 * g) = o;
+        }
+      }
+    }
+  };
+  switch (a.act) {
+    case CTD_ACT_SILU: epilogue(std::integral_constant<int, CTD_ACT_SILU>{}); break;
+    case CTD_ACT_LEAKY: epilogue(std::integral_constant<int, CTD_ACT_LEAKY>{}); break;
+    case CTD_ACT_RELU: epilogue(std::integral_constant<int, CTD_ACT_RELU>{}); break;
+    case CTD_ACT_SIGMOID: epilogue(std::integral_constant<int, CTD_ACT_SIGMOID>{}); break;
+    default: epilogue(std::integral_constant<int, CTD_ACT_NONE>{}); break;
+  }
+  __syncthreads();
+  constexpr int CPP = BN / 8;          // 16-B chunks per pixel row of the tile
+  constexpr int PPI = NTHR / CPP;      // pixels covered by one pass of the block
+  const int cch = t % CPP;
+  const int n = n0 + cch * 8;
+#pragma unroll
+  for (int it = 0; it < BMH / PPI; ++it) {
+    const int pl = it * PPI + t / CPP;
+    const int oy = y0 + (pl >> 4), ox = x0 + (pl & 15);
+    if (oy < a.Mh && ox < a.Mw && n < a.N) {
+      const size_t opix = ((size_t)b * a.oH + (oy * a.osy + ooy)) * a.oW + (ox * a.osx + oox);
+      *(half8_t*)((half_t*)a.dst + opix * a.pitchD + n) = *(const half8_t*)(Os + (size_t)pl * OP + cch * 8);
+    }
+  }
+}
+
+template <int BN, int WGN, int WGM>
+void launch_halo_cfg(const ConvArgs& a, hipStream_t st) {
+  const int ntn = a.Npad / BN;
+  const int tilesX = (a.Mw + TWP - 1) / TWP, tilesY = (a.Mh + THP - 1) / THP;
+  dim3 grid((unsigned)(ntn * a.nphase * tilesX * tilesY * a.B), 1, 1);
+  hipLaunchKernelGGL((conv_halo_kernel<BN, WGN, WGM>), grid, dim3(NTHR), 0, st, a);
+}
+
+}  // namespace
+
+// Stride-1 KxK (K = 2 or 3) windows over non-upsampled fp16 sources whose M grid equals the input
+// grid; fp16 destination with 16-B aligned channel rows; weights packed for the 32-channel K step.
+bool conv_halo_supported(const ConvArgs& a, bool dst_f32) {
+  if (!g_conv_halo || dst_f32) return false;
+  if (a.stride != 1 || a.s0.up || (a.s1.c && a.s1.up)) return false;
+  if (!((a.KH == 3 && a.KW == 3) || (a.KH == 2 && a.KW == 2))) return false;
+  if (a.Mh != a.Hin || a.Mw != a.Win) return false;
+  if (a.s0.c % BKH || a.s1.c % BKH || a.bk != BKH || !a.w_tiled) return false;
+  if (a.pitchD % 8 || a.N % 8) return false;
+  if (a.s0.H != a.Hin || a.s0.W != a.Win || (a.s1.c && (a.s1.H != a.Hin || a.s1.W != a.Win))) return false;
+  // small maps: too few 256-pixel patches to fill 256 CUs twice -> the 128-pixel kernel does better
+  const long long patches = (long long)a.B * ((a.Mh + THP - 1) / THP) * ((a.Mw + TWP - 1) / TWP) * a.nphase *
+                            (a.Npad / igemm_ntile(a.N));
+  return patches >= 1024;
+}
+
+void launch_conv_halo(const ConvArgs& a, hipStream_t st) {
+  const int bn = igemm_ntile(a.N);
+  if (bn == 128) launch_halo_cfg<128, 2, 4>(a, st);
+  else if (bn == 64) launch_halo_cfg<64, 2, 4>(a, st);
+  else launch_halo_cfg<32, 1, 8>(a, st);
+}

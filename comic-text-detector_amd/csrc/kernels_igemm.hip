@@ -49,6 +49,7 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_kernel(ConvArgs a) {
   half_t* As = lds;                 // [2][BM][LP]  pixels
   half_t* Ws = lds + 2 * BM * LP;   // [2][BN][LP]  weights
 
+  const long long T0 = (a.k_rot & 16) ? (long long)__builtin_readcyclecounter() : 0ll;
   const int t = threadIdx.x;
   const int lane = t & 63;
   const int wave = t >> 6;
@@ -57,9 +58,11 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_kernel(ConvArgs a) {
   // ---- XCD-aware tile mapping: consecutive block ids land on different XCDs
   // (id % 8); give each XCD a contiguous run of tiles so that the N tiles of one
   // pixel tile (and neighbouring pixel tiles sharing 3x3 halos) share an L2.
+  // The 4 sub-pixel phases of a ConvTranspose read the same input pixels, so they sit next to
+  // each other in that order too (phase-major launch order streamed the input 4x from HBM).
   const int ntn = a.Npad / BN;
   const int ntm = (a.M + BM - 1) / BM;
-  const int nblk = ntn * ntm;
+  const int nblk = ntn * ntm * a.nphase;
   int bid = blockIdx.x;
   {
     const int xcd = bid & 7, within = bid >> 3;
@@ -67,12 +70,17 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_kernel(ConvArgs a) {
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + within;
   }
   const int tile_n = bid % ntn;
-  const int tile_m = bid / ntn;
+  const int bq = bid / ntn;
+  int phase = a.nphase == 4 ? (bq & 3) : 0;
+  int tile_m = a.nphase == 4 ? (bq >> 2) : bq;
+  if ((a.k_rot & 8) && a.nphase == 4) {   // selftest A/B: phase-major order
+    phase = bq / ntm;
+    tile_m = bq % ntm;
+  }
   const int n0 = tile_n * BN;
   const int m0 = tile_m * BM;
 
   // ---- phase (ConvTranspose 4x4 s2 p1 sub-pixel decomposition) --------------
-  const int phase = blockIdx.z;
   int dy0 = a.dy0, dx0 = a.dx0, ooy = a.ooy, oox = a.oox;
   const half_t* __restrict__ wbase = (const half_t*)a.w;
   if (a.nphase == 4) {
@@ -137,6 +145,15 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_kernel(ConvArgs a) {
     for (int ty = 0; ty < a.KH; ++ty) vm |= ((ym >> ty) & 1u) ? xm << (ty * a.KW) : 0u;
     vmask[i] = pv ? vm : 0u;
   }
+  // wave-uniform: all rows staged by this wave have all their taps inside the image
+  bool interior;
+  {
+    const unsigned full = (1u << (a.KH * a.KW)) - 1u;
+    bool ok = true;
+#pragma unroll
+    for (int i = 0; i < AROWS; ++i) ok = ok && vmask[i] == full;
+    interior = __builtin_amdgcn_ballot_w64(ok) == ~0ull && !(a.k_rot & 32);
+  }
   // weights: tile-major [n_tile][k_step][BN][BK]; per-thread constant part of the address
   int woff[WROWS];
 #pragma unroll
@@ -154,6 +171,7 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_kernel(ConvArgs a) {
   };
 
   int cc = 0, ty = 0, tx = 0, kp = 0;  // K-step cursor of the NEXT tile to load (wave uniform)
+  long long tb0 = 0, tb1 = 0;          // byte offset of tap (ty, tx) in source 0 / 1, updated on tap changes only
 
   using gptr_t = const __attribute__((address_space(1))) void*;
   using lptr_t = __attribute__((address_space(3))) void*;
@@ -175,8 +193,17 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_kernel(ConvArgs a) {
     const int ch = first ? cc : cc - a.s0.c;
     const int tap = ty * a.KW + tx;
     rok = 0;
-    if (!s.up) {
-      const long long tapoff = (((long long)ty * s.W + tx) * s.pitch + ch) * 2;   // uniform
+    if ((a.k_rot & 128) && kp > 0) {
+      // selftest ablation: no activation loads after the first K step
+    } else if (GLDS && interior && !s.up) {
+      // interior pixel tile: every tap of every row is inside the image.  One scalar base per
+      // K step + this thread's constant 32-bit row offset -> no per-row VALU work at all
+      // (the K loop spends its issue slots on address arithmetic, not on MFMAs, otherwise).
+      const char* sb = (const char*)s.ptr + ((first ? tb0 : tb1) + ch * 2);
+#pragma unroll
+      for (int i = 0; i < AROWS; ++i) dma(sb + (size_t)(unsigned)(first ? aoff0[i] : aoff1[i]), Ad, i);
+    } else if (!s.up) {
+      const long long tapoff = (first ? tb0 : tb1) + ch * 2;   // uniform
       const char* sb = (const char*)s.ptr + tapoff;
       const int back = (int)-tapoff;                                            // -> s.ptr (always valid)
 #pragma unroll
@@ -210,7 +237,7 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_kernel(ConvArgs a) {
     const char* wk = wtile + (size_t)kp * (BN * BK * 2);
 #pragma unroll
     for (int i = 0; i < WROWS; ++i)
-      if (WCHUNKS >= 256 || t + 256 * i < WCHUNKS) {
+      if ((WCHUNKS >= 256 || t + 256 * i < WCHUNKS) && !((a.k_rot & 64) && kp > 0)) {
         if (GLDS) dma(wk + woff[i], Wd, i);
         else rw[i] = *(const half8_t*)(wk + woff[i]);
       }
@@ -220,6 +247,8 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_kernel(ConvArgs a) {
     if (cc == Ct) {
       cc = 0;
       if (++tx == a.KW) { tx = 0; ++ty; }
+      tb0 = (((long long)ty * a.s0.W + tx) * a.s0.pitch) * 2;
+      tb1 = (((long long)ty * a.s1.W + tx) * a.s1.pitch) * 2;
     }
   };
 
@@ -257,10 +286,16 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_kernel(ConvArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+  // selftest instrumentation (k_rot & 16): cycle stamps of wave 0 -> where a block's time goes
+  const bool prof = (a.k_rot & 16) && a.dbg;
+  auto stamp = [&]() -> long long { return prof ? (long long)__builtin_readcyclecounter() : 0ll; };
+  long long t_issue = 0, t_comp = 0, t_wait = 0;
+  const long long T1 = stamp();
   Stage sA;
   load_tile(sA, 0);
   if (!GLDS) store_tile(sA, 0);
   __syncthreads();     // with LDS-DMA pending the compiler's barrier sequence waits vmcnt(0) first
+  const long long T2 = stamp();
 
   const int l31 = lane & 31, khalf = lane >> 5;
   const int fl = swz(l31);   // rows of one fragment differ by multiples of 32 -> same swizzle
@@ -288,11 +323,17 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_kernel(ConvArgs a) {
   // layer shape: the K loop is not short of bytes in flight, see DESIGN.md.)
   for (int ks = 0; ks < nk; ++ks) {
     const int buf = ks & 1;
+    const long long s0 = stamp();
     if (ks + 1 < nk && !(abl & 1)) load_tile(sA, buf ^ 1);
+    const long long s1 = stamp();
     if (!(abl & 2)) compute(buf);
     if (!GLDS && ks + 1 < nk) store_tile(sA, buf ^ 1);
+    const long long s2 = stamp();
     __syncthreads();
+    const long long s3 = stamp();
+    t_issue += s1 - s0; t_comp += s2 - s1; t_wait += s3 - s2;
   }
+  const long long T3 = stamp();
 
   // ---- epilogue: bias + activation (+ residual) -> NHWC store -----------------
   const int hi = lane >> 5;
@@ -357,6 +398,7 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_kernel(ConvArgs a) {
     case CTD_ACT_SIGMOID: epilogue(std::integral_constant<int, CTD_ACT_SIGMOID>{}); break;
     default: epilogue(std::integral_constant<int, CTD_ACT_NONE>{}); break;
   }
+  const long long T4 = stamp();
   if (staged) {
     // The MFMA C layout gives each lane 4 channels of one pixel: storing that directly makes
     // 16-B write requests scattered over 32 cache lines per instruction (PMC: TCP_TCC_WRITE_REQ
@@ -377,6 +419,13 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_kernel(ConvArgs a) {
       }
     }
   }
+  if (prof) {
+    const long long T5 = stamp();
+    if (t == 0) {
+      long long* d = a.dbg + (size_t)blockIdx.x * 8;
+      d[0] = T1 - T0; d[1] = T2 - T1; d[2] = t_issue; d[3] = t_comp; d[4] = t_wait; d[5] = T4 - T3; d[6] = T5 - T4; d[7] = T5 - T0;
+    }
+  }
 }
 
 // MINW = minimum waves per SIMD the register allocator must allow (launch bound).  The
@@ -386,7 +435,7 @@ template <int BN, int BM, int WGN, int WGM, int BK>
 void launch_cfg(const ConvArgs& a, bool dst_f32, hipStream_t st) {
   const int ntn = a.Npad / BN;
   const int ntm = (a.M + BM - 1) / BM;
-  dim3 grid(ntn * ntm, 1, a.nphase);
+  dim3 grid(ntn * ntm * a.nphase, 1, 1);
   constexpr int HI = BK == 32 ? 4 : 2;
   constexpr int LO = BK == 32 ? 3 : 2;
   (void)LO;
@@ -482,6 +531,11 @@ void launch_conv_igemm(const ConvArgs& a_in, bool dst_f32, hipStream_t st) {
   ConvArgs a = a_in;
   magic_div(a.Mw, a.mw_mul, a.mw_sh);
   magic_div(a.Mh, a.mh_mul, a.mh_sh);
+  a.bk = pick_bk(a);
+  if (conv_halo_supported(a, dst_f32)) {
+    launch_conv_halo(a, st);
+    return;
+  }
   const int bn = igemm_ntile(a.N);
   if (pick_bk(a) == 64) {
     if (bn == 128) launch_cfg<128, 128, 2, 2, 64>(a, dst_f32, st);

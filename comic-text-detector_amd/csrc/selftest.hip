@@ -176,9 +176,10 @@ static void run_case(const Case& cs, int B, bool timing) {
   std::printf("[case] %-32s B=%d out %dx%dx%d |", cs.name, B, Ho, Wo, cs.N);
   struct Var { const char* name; int bk, tiled, rot, abl; };
   // ST_ABL=1 appends ablations of the default kernel (wrong results by construction, timing only)
-  const Var vars[] = {{"bk32/glds", 32, 1, 0, 0}, {"bk32/reg", 32, 1, 1, 0}, {"bk64/glds", 64, 1, 0, 0},
+  // rot: 0 = default dispatch (halo kernel where it applies), 2 = implicit-GEMM kernel only, 1 = register staged
+  const Var vars[] = {{"default", 32, 1, 0, 0}, {"igemm", 32, 1, 2, 0}, {"bk32/reg", 32, 1, 1, 0}, {"bk64/glds", 64, 1, 2, 0},
                       {"noload", 32, 1, 0, 1}, {"nomfma", 32, 1, 0, 2}, {"nostore", 32, 1, 0, 4},
-                      {"loadonly", 32, 1, 0, 6}, {"mfmaonly", 32, 1, 0, 5}};
+                      {"loadonly", 32, 1, 0, 6}, {"mfmaonly", 32, 1, 0, 5}, {"phasemajor", 32, 1, 0, 8}, {"nofastpath", 32, 1, 0, 32}, {"noWloads", 32, 1, 0, 64}, {"noAloads", 32, 1, 0, 128}};
 
   const char* vsel = std::getenv("ST_VAR");   // ST_VAR=1: only variant index 1
   for (const Var& v : vars) {
@@ -188,7 +189,8 @@ static void run_case(const Case& cs, int B, bool timing) {
     if (bk == 64 && (cs.c0 % 64 || cs.c1 % 64)) continue;
     g_igemm_force_bk = bk;
     ig.bk = bk; ig.w_tiled = v.tiled; ig.k_rot = v.abl;
-    g_igemm_occ_lo = v.rot;   // staging mode: 0 = LDS-DMA, 1 = register staged
+    g_igemm_occ_lo = v.rot == 1;   // staging mode: 0 = LDS-DMA, 1 = register staged
+    g_conv_halo = v.rot == 0;
     {
       std::vector<half_t> wig;
       igemm_pack_weights(lg.data(), nphase, cs.N, Kig, bn, bk, v.tiled, wig);
@@ -223,6 +225,25 @@ static void run_case(const Case& cs, int B, bool timing) {
     }
     std::printf("  %s: %s %.3f ms %.0f TF %.0f GB/s |", v.name, v.abl ? "--" : bad ? "FAIL" : "ok", ms,
                 flops / (ms * 1e-3) / 1e12, bytes / (ms * 1e-3) / 1e9);
+    if (std::getenv("ST_PROF") && !v.abl && v.rot == 2 && bk == 32) {
+      // cycle stamps of wave 0 of every block (s_memtime): mean over blocks
+      const int bnp = igemm_ntile(cs.N);
+      const size_t nblk = (size_t)((cs.N + bnp - 1) / bnp) * ((ig.M + 127) / 128) * nphase;
+      long long* dd = nullptr;
+      CK(hipMalloc(&dd, nblk * 8 * sizeof(long long)));
+      CK(hipMemset(dd, 0, nblk * 8 * sizeof(long long)));
+      ig.k_rot = 16; ig.dbg = dd;
+      launch_conv_igemm(ig, false, 0);
+      CK(hipDeviceSynchronize());
+      std::vector<long long> hd(nblk * 8);
+      CK(hipMemcpy(hd.data(), dd, hd.size() * sizeof(long long), hipMemcpyDeviceToHost));
+      double m8[8] = {0};
+      for (size_t b = 0; b < nblk; ++b) for (int q = 0; q < 8; ++q) m8[q] += (double)hd[b * 8 + q] / nblk;
+      std::printf("\n      [prof, cycles/block of wave 0, %zu blocks, %d K steps] setup %.0f  first-tile %.0f  K-loop: issue %.0f compute %.0f wait+barrier %.0f  epilogue math %.0f  staged store %.0f  total %.0f\n      ",
+                  nblk, ig.K / 32, m8[0], m8[1], m8[2], m8[3], m8[4], m8[5], m8[6], m8[7]);
+      ig.k_rot = 0; ig.dbg = nullptr;
+      (void)hipFree(dd);
+    }
     (void)maxerr;
   }
   std::printf("\n");

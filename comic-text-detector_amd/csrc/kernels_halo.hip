@@ -26,10 +26,11 @@ namespace {
 constexpr int TWP = 16, THP = 16;     // pixel patch
 constexpr int BMH = TWP * THP;        // 256 pixels per block
 constexpr int BKH = 32;               // channels per K chunk (64-B LDS rows)
-constexpr int AROWS_PAD = 384;        // haloed rows rounded up to 3 DMA passes of 512 threads x 16 B
+constexpr int AROWS_PAD = 336;        // 18x18 = 324 haloed rows, rounded up to whole waves of the third DMA pass
+                                      // (LDS decides the blocks per CU: 336 rows let the 64-channel variant keep 3)
 constexpr int NTHR = 512;
 
-template <int BN, int WGN, int WGM>
+template <int BN, int WGN, int WGM, bool PROF>
 __global__ __launch_bounds__(NTHR, 4) void conv_halo_kernel(ConvArgs a) {   // 4 waves / SIMD = 2 blocks / CU
   constexpr int TN = BN / (32 * WGN);
   constexpr int TM = BMH / (32 * WGM);
@@ -43,6 +44,10 @@ __global__ __launch_bounds__(NTHR, 4) void conv_halo_kernel(ConvArgs a) {   // 4
   half_t* As = lds;               // [2][AROWS_PAD][32]
   half_t* Ws = lds + 2 * A_BUF;   // [2][BN][32]
 
+  constexpr bool prof = PROF;   // selftest instantiation: cycle stamps of wave 0 (compiled out otherwise)
+  auto stamp = [&]() -> long long { return PROF ? (long long)__builtin_readcyclecounter() : 0ll; };
+  const long long T0 = stamp();
+  long long t_issue = 0, t_comp = 0, t_wait = 0;
   const int t = threadIdx.x;
   const int lane = t & 63;
   const int wave_u = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -123,7 +128,8 @@ __global__ __launch_bounds__(NTHR, 4) void conv_halo_kernel(ConvArgs a) {   // 4
     const int off = first ? aoff0[i] : aoff1[i];
     const void* g = aok[i] ? (const void*)(base + off) : a.zeros;
     half_t* dst = As + (size_t)(chunk & 1) * A_BUF + (size_t)(i * NTHR + wave_u * 64) * 8;
-    __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)dst, 16, 0, 0);
+    if ((i * NTHR + wave_u * 64) / 4 < AROWS_PAD)   // pass 2: waves 0..4 cover rows 256..335
+      __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)dst, 16, 0, 0);
   };
   auto dma_w = [&](int chunk, int tap, int buf) {
     if (WCHUNKS >= NTHR || t < WCHUNKS) {
@@ -151,12 +157,18 @@ __global__ __launch_bounds__(NTHR, 4) void conv_halo_kernel(ConvArgs a) {   // 4
   const int flw = swz(l31);   // weight rows of one fragment differ by multiples of 32
 
   // prologue: patch of chunk 0 + weights of step 0
+  const long long T1 = stamp();
   dma_a(0, 0);
   dma_a(0, 1);
   dma_a(0, 2);
   dma_w(0, 0, 0);
   __syncthreads();
+  const long long T2 = stamp();
 
+  // One step of prefetch.  (Weight tiles two steps ahead in a 3-deep ring with a counted
+  // s_waitcnt vmcnt measured slower: the extra 4-8 KB of LDS costs the 32/64-channel variants
+  // their third resident block, and the 128-channel variant gains nothing -- like the
+  // implicit-GEMM kernel, the loop is not short of bytes in flight.)
   int step = 0;
   for (int c = 0; c < nchunk; ++c) {
     const half_t* Ac = As + (size_t)(c & 1) * A_BUF;
@@ -164,6 +176,7 @@ __global__ __launch_bounds__(NTHR, 4) void conv_halo_kernel(ConvArgs a) {   // 4
     for (int ty = 0; ty < a.KH; ++ty)
       for (int tx = 0; tx < a.KW; ++tx, ++tap, ++step) {
         // next step's weights, and a third of the next chunk's patch during the first three taps
+        const long long s0 = stamp();
         const bool last_tap = tap + 1 == taps;
         if (!(last_tap && c + 1 == nchunk)) dma_w(last_tap ? c + 1 : c, last_tap ? 0 : tap + 1, (step + 1) & 1);
         if (c + 1 < nchunk) {   // static pass index: the row tables stay in registers
@@ -171,6 +184,7 @@ __global__ __launch_bounds__(NTHR, 4) void conv_halo_kernel(ConvArgs a) {   // 4
           else if (tap == 1) dma_a(c + 1, 1);
           else if (tap == 2) dma_a(c + 1, 2);
         }
+        const long long s1 = stamp();
         const half_t* Wb = Ws + (size_t)(step & 1) * W_BUF + (size_t)(wn * TN * 32 + l31) * BKH;
         const int tapoff = ty * HW + tx;
 #pragma unroll
@@ -189,9 +203,13 @@ __global__ __launch_bounds__(NTHR, 4) void conv_halo_kernel(ConvArgs a) {   // 4
             for (int j = 0; j < TM; ++j)
               acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fw[i], fx[j], acc[i][j], 0, 0, 0);
         }
+        const long long s2 = stamp();
         __syncthreads();   // waits the DMAs (vmcnt 0) and fences the LDS buffers for reuse
+        const long long s3 = stamp();
+        t_issue += s1 - s0; t_comp += s2 - s1; t_wait += s3 - s2;
       }
   }
+  const long long T3 = stamp();
 
   // ---- epilogue: bias + activation (+ residual), transposed through LDS for 16-B row stores ----
   const int hi = lane >> 5;
@@ -232,6 +250,7 @@ __global__ __launch_bounds__(NTHR, 4) void conv_halo_kernel(ConvArgs a) {   // 4
     case CTD_ACT_SIGMOID: epilogue(std::integral_constant<int, CTD_ACT_SIGMOID>{}); break;
     default: epilogue(std::integral_constant<int, CTD_ACT_NONE>{}); break;
   }
+  const long long T4 = stamp();
   __syncthreads();
   constexpr int CPP = BN / 8;          // 16-B chunks per pixel row of the tile
   constexpr int PPI = NTHR / CPP;      // pixels covered by one pass of the block
@@ -246,6 +265,13 @@ __global__ __launch_bounds__(NTHR, 4) void conv_halo_kernel(ConvArgs a) {   // 4
       *(half8_t*)((half_t*)a.dst + opix * a.pitchD + n) = *(const half8_t*)(Os + (size_t)pl * OP + cch * 8);
     }
   }
+  if (prof) {
+    const long long T5 = stamp();
+    if (t == 0) {
+      long long* d = a.dbg + (size_t)blockIdx.x * 8;
+      d[0] = T1 - T0; d[1] = T2 - T1; d[2] = t_issue; d[3] = t_comp; d[4] = t_wait; d[5] = T4 - T3; d[6] = T5 - T4; d[7] = T5 - T0;
+    }
+  }
 }
 
 template <int BN, int WGN, int WGM>
@@ -253,7 +279,8 @@ void launch_halo_cfg(const ConvArgs& a, hipStream_t st) {
   const int ntn = a.Npad / BN;
   const int tilesX = (a.Mw + TWP - 1) / TWP, tilesY = (a.Mh + THP - 1) / THP;
   dim3 grid((unsigned)(ntn * a.nphase * tilesX * tilesY * a.B), 1, 1);
-  hipLaunchKernelGGL((conv_halo_kernel<BN, WGN, WGM>), grid, dim3(NTHR), 0, st, a);
+  if ((a.k_rot & 16) && a.dbg) hipLaunchKernelGGL((conv_halo_kernel<BN, WGN, WGM, true>), grid, dim3(NTHR), 0, st, a);
+  else hipLaunchKernelGGL((conv_halo_kernel<BN, WGN, WGM, false>), grid, dim3(NTHR), 0, st, a);
 }
 
 }  // namespace

@@ -32,7 +32,7 @@ int g_igemm_occ_lo = 0;  // tuning: 1 = register-staged loads instead of LDS-DMA
 namespace {
 
 // K step BK = 32 or 64 halves per LDS row (64 / 128 B), XOR-swizzled 16-B chunks.
-template <int BN, int BM, int WGN, int WGM, int BK, bool DST_F32, int MINW, int PF>
+template <int BN, int BM, int WGN, int WGM, int BK, bool DST_F32, int MINW, int PF, bool PROF = false>
 __global__ __launch_bounds__(256, MINW) void conv_igemm_kernel(ConvArgs a) {
   constexpr int LP = BK;                            // LDS row pitch in halves (XOR swizzled, no pad)
   constexpr int SEGS = BK / 8;                      // 16-B chunks per row
@@ -49,7 +49,7 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_kernel(ConvArgs a) {
   half_t* As = lds;                 // [2][BM][LP]  pixels
   half_t* Ws = lds + 2 * BM * LP;   // [2][BN][LP]  weights
 
-  const long long T0 = (a.k_rot & 16) ? (long long)__builtin_readcyclecounter() : 0ll;
+  const long long T0 = PROF ? (long long)__builtin_readcyclecounter() : 0ll;
   const int t = threadIdx.x;
   const int lane = t & 63;
   const int wave = t >> 6;
@@ -287,8 +287,8 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_kernel(ConvArgs a) {
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   // selftest instrumentation (k_rot & 16): cycle stamps of wave 0 -> where a block's time goes
-  const bool prof = (a.k_rot & 16) && a.dbg;
-  auto stamp = [&]() -> long long { return prof ? (long long)__builtin_readcyclecounter() : 0ll; };
+  constexpr bool prof = PROF;   // selftest instantiation only; compiled out of the product kernels
+  auto stamp = [&]() -> long long { return PROF ? (long long)__builtin_readcyclecounter() : 0ll; };
   long long t_issue = 0, t_comp = 0, t_wait = 0;
   const long long T1 = stamp();
   Stage sA;
@@ -443,6 +443,8 @@ void launch_cfg(const ConvArgs& a, bool dst_f32, hipStream_t st) {
     hipLaunchKernelGGL((conv_igemm_kernel<BN, BM, WGN, WGM, BK, true, HI, 1>), grid, dim3(256), 0, st, a);
   } else if (g_igemm_occ_lo == 1) {   // tuning variant: register-staged loads (global -> VGPR -> ds_write)
     hipLaunchKernelGGL((conv_igemm_kernel<BN, BM, WGN, WGM, BK, false, HI, 1>), grid, dim3(256), 0, st, a);
+  } else if ((a.k_rot & 16) && a.dbg) {   // selftest: cycle-stamped instantiation
+    hipLaunchKernelGGL((conv_igemm_kernel<BN, BM, WGN, WGM, BK, false, HI, 2, true>), grid, dim3(256), 0, st, a);
   } else {                            // default: LDS-DMA (global_load_lds, 16 B per lane), +5..10 % measured
     hipLaunchKernelGGL((conv_igemm_kernel<BN, BM, WGN, WGM, BK, false, HI, 2>), grid, dim3(256), 0, st, a);
   }

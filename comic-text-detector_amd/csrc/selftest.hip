@@ -225,10 +225,10 @@ static void run_case(const Case& cs, int B, bool timing) {
     }
     std::printf("  %s: %s %.3f ms %.0f TF %.0f GB/s |", v.name, v.abl ? "--" : bad ? "FAIL" : "ok", ms,
                 flops / (ms * 1e-3) / 1e12, bytes / (ms * 1e-3) / 1e9);
-    if (std::getenv("ST_PROF") && !v.abl && v.rot == 2 && bk == 32) {
+    if (std::getenv("ST_PROF") && !v.abl && (v.rot == 2 || v.rot == 0) && bk == 32) {
       // cycle stamps of wave 0 of every block (s_memtime): mean over blocks
       const int bnp = igemm_ntile(cs.N);
-      const size_t nblk = (size_t)((cs.N + bnp - 1) / bnp) * ((ig.M + 127) / 128) * nphase;
+      const size_t nblk = (size_t)((cs.N + bnp - 1) / bnp) * ((ig.M + 127) / 128) * nphase;   // >= halo grid too
       long long* dd = nullptr;
       CK(hipMalloc(&dd, nblk * 8 * sizeof(long long)));
       CK(hipMemset(dd, 0, nblk * 8 * sizeof(long long)));

@@ -203,12 +203,8 @@ int pack_op(ctd_engine* e, OpState& s, const float* P, int64_t nP) {
         return fail(CTD_ERR_UNSUPPORTED, "fused stem is 6x6/s2/p2, 3->32 only");
       if (!need(o.w_off, (int64_t)N * 3 * 36)) return fail(CTD_ERR_INVALID, "stem weights out of range");
       const float* W = P + o.w_off;
-      std::vector<float> wp((size_t)108 * N);
-      for (int n = 0; n < N; ++n)
-        for (int c = 0; c < 3; ++c)
-          for (int ky = 0; ky < 6; ++ky)
-            for (int kx = 0; kx < 6; ++kx)
-              wp[((size_t)(ky * 6 + kx) * 3 + c) * N + n] = W[(((size_t)n * 3 + c) * 6 + ky) * 6 + kx];
+      std::vector<half_t> wp;
+      stem_pack_weights(W, wp);
       s.impl = IMPL_FUSED;
       if (int rc = upload(e, wp, &s.w_dev)) return rc;
       return pack_bias(N);
@@ -523,7 +519,7 @@ int launch_op(ctd_engine* e, int i, const Outs& x, hipStream_t st) {
     case CTD_OP_STEM: {
       const TensorState& td = e->tensors[o.dst];
       launch_stem(x.input, x.in_fmt, (half_t*)tptr(o.dst, o.dst_coff), td.t.channels, B, H, W, o.cout,
-                  (const float*)s.w_dev, s.b_dev, o.act, st);
+                  (const half_t*)s.w_dev, s.b_dev, o.act, st);
       break;
     }
     case CTD_OP_CONV:

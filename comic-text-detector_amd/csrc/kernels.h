@@ -42,9 +42,10 @@ void launch_conv_halo(const ConvArgs& a, hipStream_t st);
 
 // ---- kernels_fused.hip ----------------------------------------------------
 // stem: 6x6 s2 p2, 3 -> N (N <= 32... multiple of 8), reads the network input directly.
-// weights f32 [108][N] (k index = (ky*6+kx)*3 + c), bias f32 [N]
+// weights: MFMA A fragments from stem_pack_weights (two variants: float / uint8 input), bias f32 [N]
 void launch_stem(const void* in, int in_fmt, half_t* dst, int pitchD, int B, int H, int W, int N,
-                 const float* w, const float* bias, int act, hipStream_t st);
+                 const half_t* wfrag, const float* bias, int act, hipStream_t st);
+void stem_pack_weights(const float* W /* (32, 3, 6, 6) */, std::vector<half_t>& out);
 // seg final: ConvT 4x4 s2 p1 (C -> 1) + sigmoid; src (B,H,W,C) half; weights f32 [16][C] (ky*4+kx)
 void launch_seg_final(const half_t* src, int pitch, int C, int B, int H, int W, const float* w, float bias,
                       float* mask, uint8_t* mask_u8, hipStream_t st);

@@ -1,6 +1,8 @@
 // Fused head/tail kernels of the fp16 fast path.  These layers have a tiny
 // channel count on one side (3 in, or 1 out), so they are HBM/VALU work, not
 // GEMMs: no MFMA here (north_star: "MFMA only ... where it is a true GEMM").
+#include <vector>
+
 #include "kernels.h"
 
 namespace {
@@ -8,76 +10,109 @@ namespace {
 // ---------------------------------------------------------------------------
 // Stem: network input -> Conv 6x6 / s2 / p2 (3 -> 32) + folded BN + SiLU
 // (reference yolo cfg layer 0; input conversion inference.py:77-82 fused).
-// Block = 16x16 output pixels; the 36x36x3 input patch is staged in LDS as f32;
-// weights are wave-uniform -> scalar loads; each lane owns one pixel x 32 channels.
+//
+// As a direct convolution this layer is VALU bound (3456 FMAs per pixel-lane, 0.78 ms per 32
+// pages against 0.2 ms of HBM time), so it runs on the matrix cores like everything else:
+// K = 6 rows x 24 (8 columns x 3 channels; columns 6, 7 carry zero weights) = 144 = 9 MFMA
+// k-steps.  With the input patch in LDS as fp16 [row][col][channel], the 8 consecutive k of a
+// lane's B fragment are 16 contiguous bytes of one patch row, so a fragment is four
+// ds_read_b32.  The 32 x 144 weight matrix lives in registers as 9 A fragments per lane.
+// Block = 8 x 32 output pixels (4 waves x 2 rows).  uint8 input is staged as the exact
+// integers 0..255 with 128/255 folded into the packed weights (sums x 1/128); float input is rounded to fp16.
 // ---------------------------------------------------------------------------
-constexpr int ST = 16;             // output tile edge
-constexpr int SI = 2 * ST + 4;     // input tile edge (36)
-constexpr int SIP = SI + 2;        // padded row (38 floats, keeps 8-B alignment of float2 reads)
+constexpr int SM_TW = 32, SM_TH = 8;          // output tile
+constexpr int SM_PH = 2 * SM_TH + 4;          // patch rows (20)
+constexpr int SM_PW = 2 * SM_TW + 4;          // patch columns (68)
+constexpr int SM_PITCH = 72 * 3;              // LDS row pitch in halves: 72 columns (4 zero pad) x 3 channels
+constexpr int SM_OP = 40;                     // output staging pitch (32 channels + 8) in halves
 
-template <int N>
-__global__ __launch_bounds__(256) void stem_kernel(const void* __restrict__ in, int in_fmt, half_t* __restrict__ dst,
-                                                   int pitchD, int B, int H, int W, const float* __restrict__ w,
-                                                   const float* __restrict__ bias, int act) {
-  __shared__ __attribute__((aligned(16))) float tile[3][SI][SIP];
+__global__ __launch_bounds__(256) void stem_mfma_kernel(const void* __restrict__ in, int in_fmt, half_t* __restrict__ dst,
+                                                        int pitchD, int B, int H, int W,
+                                                        const half_t* __restrict__ wfrag,
+                                                        const float* __restrict__ bias, int act) {
+  __shared__ __attribute__((aligned(16))) half_t patch[SM_PH * SM_PITCH + 8];
+  __shared__ __attribute__((aligned(16))) half_t ostage[4][32 * SM_OP];
   const int Ho = H / 2, Wo = W / 2;
-  const int tiles_x = (Wo + ST - 1) / ST, tiles_y = (Ho + ST - 1) / ST;
+  const int tiles_x = (Wo + SM_TW - 1) / SM_TW, tiles_y = (Ho + SM_TH - 1) / SM_TH;
   int bid = blockIdx.x;
-  const int tx0 = (bid % tiles_x) * ST;
+  const int tx0 = (bid % tiles_x) * SM_TW;
   bid /= tiles_x;
-  const int ty0 = (bid % tiles_y) * ST;
+  const int ty0 = (bid % tiles_y) * SM_TH;
   const int b = bid / tiles_y;
   const int iy0 = 2 * ty0 - 2, ix0 = 2 * tx0 - 2;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
 
-  for (int i = threadIdx.x; i < 3 * SI * SI; i += 256) {
-    const int c = i / (SI * SI);
-    const int r = (i / SI) % SI;
-    const int q = i % SI;
-    const int iy = iy0 + r, ix = ix0 + q;
-    float v = 0.f;
-    if (iy >= 0 && iy < H && ix >= 0 && ix < W) {
-      if (in_fmt == CTD_IN_NCHW_F32)
-        v = ((const float*)in)[(((size_t)b * 3 + c) * H + iy) * W + ix];
-      else
-        v = (float)((const uint8_t*)in)[(((size_t)b * H + iy) * W + ix) * 3 + c] / 255.0f;
+  // A fragments: 9 k-steps x (32 channels x 16 k), one 16-B load each
+  half8_t wf[9];
+  const half_t* wsel = wfrag + (in_fmt == CTD_IN_NCHW_F32 ? 0 : 9 * 64 * 8);
+#pragma unroll
+  for (int s = 0; s < 9; ++s) wf[s] = *(const half8_t*)(wsel + ((size_t)s * 64 + lane) * 8);
+
+  // ---- stage the input patch as fp16 [row][col][c]
+  if (in_fmt == CTD_IN_NCHW_F32) {
+    for (int i = t; i < 3 * SM_PH * SM_PW; i += 256) {
+      const int c = i / (SM_PH * SM_PW);
+      const int r = (i / SM_PW) % SM_PH;
+      const int q = i % SM_PW;
+      const int iy = iy0 + r, ix = ix0 + q;
+      float v = 0.f;
+      if (iy >= 0 && iy < H && ix >= 0 && ix < W) v = ((const float*)in)[(((size_t)b * 3 + c) * H + iy) * W + ix];
+      patch[r * SM_PITCH + q * 3 + c] = (half_t)v;
     }
-    tile[c][r][q] = v;
+  } else {
+    for (int i = t; i < SM_PH * SM_PW * 3; i += 256) {
+      const int r = i / (SM_PW * 3), j = i % (SM_PW * 3);
+      const int iy = iy0 + r, ix = ix0 + j / 3;
+      float v = 0.f;
+      if (iy >= 0 && iy < H && ix >= 0 && ix < W)
+        v = (float)((const uint8_t*)in)[(((long long)b * H + iy) * W + ix0) * 3 + j];
+      patch[r * SM_PITCH + j] = (half_t)v;
+    }
   }
+  for (int i = t; i < SM_PH * 12; i += 256) patch[(i / 12) * SM_PITCH + SM_PW * 3 + i % 12] = (half_t)0.f;   // pad columns
+  if (t < 8) patch[SM_PH * SM_PITCH + t] = (half_t)0.f;
   __syncthreads();
 
-  const int lx = threadIdx.x % ST, ly = threadIdx.x / ST;
-  const int ox = tx0 + lx, oy = ty0 + ly;
-  float acc[N];
+  const int lx = lane & 31, kg = lane >> 5, hi = lane >> 5;
+  const float oscale = in_fmt == CTD_IN_NCHW_F32 ? 1.0f : 1.0f / 128.0f;
+  half_t* os = ostage[wave];
+#pragma unroll 1
+  for (int g = 0; g < 2; ++g) {
+    const int ly = 2 * wave + g;
+    float16_t acc;
 #pragma unroll
-  for (int n = 0; n < N; ++n) acc[n] = bias[n];
-  for (int ky = 0; ky < 6; ++ky) {
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const half_t* prow = patch + (2 * ly) * SM_PITCH + lx * 6;
 #pragma unroll
-    for (int c = 0; c < 3; ++c) {
-      const float* row = &tile[c][2 * ly + ky][2 * lx];
-      float x[6];
-#pragma unroll
-      for (int h = 0; h < 3; ++h) {
-        const float2 p = *(const float2*)(row + 2 * h);
-        x[2 * h] = p.x;
-        x[2 * h + 1] = p.y;
-      }
-#pragma unroll
-      for (int kx = 0; kx < 6; ++kx) {
-        const float* wk = w + ((ky * 6 + kx) * 3 + c) * N;
-#pragma unroll
-        for (int n = 0; n < N; ++n) acc[n] = fmaf(x[kx], wk[n], acc[n]);
-      }
+    for (int s = 0; s < 9; ++s) {
+      // k group G = 2s + kg: row ky = G / 3, first of 8 consecutive (col, channel) entries j0 = (G % 3) * 8
+      const int offA = ((2 * s) / 3) * SM_PITCH + ((2 * s) % 3) * 8;
+      const int offB = ((2 * s + 1) / 3) * SM_PITCH + ((2 * s + 1) % 3) * 8;
+      const uint32_t* p = (const uint32_t*)(prow + (kg ? offB : offA));   // 4-B aligned
+      union { uint32_t u[4]; half8_t h; } fx;
+      fx.u[0] = p[0]; fx.u[1] = p[1]; fx.u[2] = p[2]; fx.u[3] = p[3];
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[s], fx.h, acc, 0, 0, 0);
     }
-  }
-  if (ox < Wo && oy < Ho) {
-    half_t* o = dst + (((size_t)b * Ho + oy) * Wo + ox) * pitchD;
+    // bias + activation; lane = pixel lx, channels 8*q + 4*hi + e
 #pragma unroll
-    for (int n8 = 0; n8 < N / 8; ++n8) {
-      half8_t v;
+    for (int q = 0; q < 4; ++q) {
+      const float4_t bv = *(const float4_t*)(bias + 8 * q + 4 * hi);
+      half4_t o;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = (half_t)ctd_act(acc[n8 * 8 + e], act);
-      *(half8_t*)(o + n8 * 8) = v;
+      for (int e = 0; e < 4; ++e) o[e] = (half_t)ctd_act(acc[4 * q + e] * oscale + bv[e], act);
+      *(half4_t*)(os + lx * SM_OP + 8 * q + 4 * hi) = o;
     }
+    __builtin_amdgcn_wave_barrier();
+    const int oy = ty0 + ly;
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int qq = it * 64 + lane;
+      const int px = qq >> 2, part = qq & 3;
+      const int ox = tx0 + px;
+      const half8_t v = *(const half8_t*)(os + px * SM_OP + part * 8);
+      if (oy < Ho && ox < Wo) *(half8_t*)(dst + (((size_t)b * Ho + oy) * Wo + ox) * pitchD + part * 8) = v;
+    }
+    __builtin_amdgcn_wave_barrier();
   }
 }
 
@@ -273,13 +308,31 @@ __global__ __launch_bounds__(256) void db_up_kernel(const half_t* __restrict__ s
 
 }  // namespace
 
-void launch_stem(const void* in, int in_fmt, half_t* dst, int pitchD, int B, int H, int W, int N, const float* w,
+void launch_stem(const void* in, int in_fmt, half_t* dst, int pitchD, int B, int H, int W, int N, const half_t* wfrag,
                  const float* bias, int act, hipStream_t st) {
   const int Ho = H / 2, Wo = W / 2;
-  const int tiles = ((Wo + ST - 1) / ST) * ((Ho + ST - 1) / ST) * B;
-  // only N == 32 is instantiated (YOLOv5s); the engine falls back to INPUT + direct conv otherwise
-  hipLaunchKernelGGL((stem_kernel<32>), dim3(tiles), dim3(256), 0, st, in, in_fmt, dst, pitchD, B, H, W, w, bias, act);
+  const int tiles = ((Wo + SM_TW - 1) / SM_TW) * ((Ho + SM_TH - 1) / SM_TH) * B;
+  // N == 32 only (YOLOv5s); the engine falls back to INPUT + direct conv otherwise
+  hipLaunchKernelGGL(stem_mfma_kernel, dim3(tiles), dim3(256), 0, st, in, in_fmt, dst, pitchD, B, H, W, wfrag, bias, act);
   (void)N;
+}
+
+// MFMA A fragments of the stem weights: [variant: float input, uint8 input (x 128/255, the kernel
+// multiplies the sums by 1/128: keeps the scaled weights out of the fp16 subnormals)][9 k-steps][64 lanes][8];
+// lane = (channel n = lane & 31, k group = lane >> 5), k = 16 s + 8 kgroup + e = 24 ky + 3 kx + c (kx < 6).
+void stem_pack_weights(const float* W /* (32, 3, 6, 6) */, std::vector<half_t>& out) {
+  out.assign((size_t)2 * 9 * 64 * 8, (half_t)0.f);
+  for (int var = 0; var < 2; ++var)
+    for (int s = 0; s < 9; ++s)
+      for (int lane = 0; lane < 64; ++lane)
+        for (int e = 0; e < 8; ++e) {
+          const int n = lane & 31, k = 16 * s + 8 * (lane >> 5) + e;
+          const int ky = k / 24, j = k % 24;
+          if (j >= 18) continue;
+          const int kx = j / 3, c = j % 3;
+          const float w = W[(((size_t)n * 3 + c) * 6 + ky) * 6 + kx] * (var ? 128.0f / 255.0f : 1.0f);
+          out[(((size_t)var * 9 + s) * 64 + lane) * 8 + e] = (half_t)w;
+        }
 }
 
 void launch_seg_final(const half_t* src, int pitch, int C, int B, int H, int W, const float* w, float bias,

@@ -48,26 +48,47 @@ __global__ __launch_bounds__(256) void stem_mfma_kernel(const void* __restrict__
 #pragma unroll
   for (int s = 0; s < 9; ++s) wf[s] = *(const half8_t*)(wsel + ((size_t)s * 64 + lane) * 8);
 
-  // ---- stage the input patch as fp16 [row][col][c]
+  // ---- stage the input patch as fp16 [row][col][c].  All 16 loads of a thread are issued before
+  // the first use (clamped addresses instead of branches): a load -> convert -> store loop pays
+  // one memory round trip per iteration, 16 x ~2 us per block.
+  constexpr int NEL = 3 * SM_PH * SM_PW;            // 4080
+  constexpr int NIT = (NEL + 255) / 256;            // 16
   if (in_fmt == CTD_IN_NCHW_F32) {
-    for (int i = t; i < 3 * SM_PH * SM_PW; i += 256) {
+    const float* src = (const float*)in + (size_t)b * 3 * H * W;
+    float v[NIT];
+    int dsti[NIT];
+#pragma unroll
+    for (int k = 0; k < NIT; ++k) {
+      const int i = t + 256 * k;
       const int c = i / (SM_PH * SM_PW);
       const int r = (i / SM_PW) % SM_PH;
       const int q = i % SM_PW;
       const int iy = iy0 + r, ix = ix0 + q;
-      float v = 0.f;
-      if (iy >= 0 && iy < H && ix >= 0 && ix < W) v = ((const float*)in)[(((size_t)b * 3 + c) * H + iy) * W + ix];
-      patch[r * SM_PITCH + q * 3 + c] = (half_t)v;
+      const bool ok = i < NEL && iy >= 0 && iy < H && ix >= 0 && ix < W;
+      v[k] = src[ok ? ((size_t)c * H + iy) * W + ix : 0];
+      if (!ok) v[k] = 0.f;
+      dsti[k] = i < NEL ? r * SM_PITCH + q * 3 + c : -1;
     }
+#pragma unroll
+    for (int k = 0; k < NIT; ++k)
+      if (dsti[k] >= 0) patch[dsti[k]] = (half_t)v[k];
   } else {
-    for (int i = t; i < SM_PH * SM_PW * 3; i += 256) {
+    const uint8_t* src = (const uint8_t*)in + (size_t)b * H * W * 3;
+    uint8_t v[NIT];
+    int dsti[NIT];
+#pragma unroll
+    for (int k = 0; k < NIT; ++k) {
+      const int i = t + 256 * k;
       const int r = i / (SM_PW * 3), j = i % (SM_PW * 3);
       const int iy = iy0 + r, ix = ix0 + j / 3;
-      float v = 0.f;
-      if (iy >= 0 && iy < H && ix >= 0 && ix < W)
-        v = (float)((const uint8_t*)in)[(((long long)b * H + iy) * W + ix0) * 3 + j];
-      patch[r * SM_PITCH + j] = (half_t)v;
+      const bool ok = i < NEL && iy >= 0 && iy < H && ix >= 0 && ix < W;
+      v[k] = src[ok ? ((long long)iy * W + ix0) * 3 + j : 0];
+      if (!ok) v[k] = 0;
+      dsti[k] = i < NEL ? r * SM_PITCH + j : -1;
     }
+#pragma unroll
+    for (int k = 0; k < NIT; ++k)
+      if (dsti[k] >= 0) patch[dsti[k]] = (half_t)(float)v[k];
   }
   for (int i = t; i < SM_PH * 12; i += 256) patch[(i / 12) * SM_PITCH + SM_PW * 3 + i % 12] = (half_t)0.f;   // pad columns
   if (t < 8) patch[SM_PH * SM_PITCH + t] = (half_t)0.f;
@@ -141,13 +162,27 @@ __global__ __launch_bounds__(256) void seg_final_kernel(const half_t* __restrict
   const int y0 = (bid % tiles_y) * SF_T;
   const long long b = bid / tiles_y;
   constexpr int CH = C / 8;             // 16-B chunks per pixel
-  for (int i = threadIdx.x; i < TP * TP * CH; i += 256) {
-    const int c = i % CH, pp = i / CH;
-    const int ty = pp / TP, tx = pp % TP;
-    const int yy = y0 + ty - 1, xx = x0 + tx - 1;
-    half8_t v = {0, 0, 0, 0, 0, 0, 0, 0};
-    if (yy >= 0 && yy < H && xx >= 0 && xx < W) v = *(const half8_t*)(src + ((b * H + yy) * W + xx) * pitch + c * 8);
-    *(half8_t*)(tile + pp * PP + c * 8) = v;
+  // all loads of a thread are issued before the first LDS store (clamped addresses, no
+  // branches): a load -> store loop pays one memory round trip per iteration
+  constexpr int NCH = TP * TP * CH, NIT = (NCH + 255) / 256;
+  {
+    half8_t v[NIT];
+    bool ok[NIT];
+#pragma unroll
+    for (int k = 0; k < NIT; ++k) {
+      const int i = threadIdx.x + 256 * k;
+      const int c = i % CH, pp = i / CH;
+      const int ty = pp / TP, tx = pp % TP;
+      const int yy = y0 + ty - 1, xx = x0 + tx - 1;
+      ok[k] = i < NCH && yy >= 0 && yy < H && xx >= 0 && xx < W;
+      v[k] = *(const half8_t*)(src + (ok[k] ? ((b * H + yy) * W + xx) * pitch + c * 8 : 0));
+    }
+#pragma unroll
+    for (int k = 0; k < NIT; ++k) {
+      const int i = threadIdx.x + 256 * k;
+      const half8_t z = {0, 0, 0, 0, 0, 0, 0, 0};
+      if (i < NCH) *(half8_t*)(tile + (i / CH) * PP + (i % CH) * 8) = ok[k] ? v[k] : z;
+    }
   }
   __syncthreads();
   const int lx = threadIdx.x % SF_T, ly = threadIdx.x / SF_T;

@@ -219,9 +219,6 @@ __global__ __launch_bounds__(NTHR, 4) void conv_halo_kernel(ConvArgs a) {   // 4
 #pragma unroll
     for (int j = 0; j < TM; ++j) {
       const int pl = (wm * TM + j) * 32 + l31;
-      const int oy = y0 + (pl >> 4), ox = x0 + (pl & 15);
-      const bool mv = oy < a.Mh && ox < a.Mw;
-      const size_t opix = mv ? ((size_t)b * a.oH + (oy * a.osy + ooy)) * a.oW + (ox * a.osx + oox) : 0;
 #pragma unroll
       for (int i = 0; i < TN; ++i) {
         const int nl = (wn * TN + i) * 32 + 4 * hi;
@@ -232,11 +229,6 @@ __global__ __launch_bounds__(NTHR, 4) void conv_halo_kernel(ConvArgs a) {   // 4
           float vv[4];
 #pragma unroll
           for (int e = 0; e < 4; ++e) vv[e] = ctd_act_fast<ACT>(acc[i][j][4 * g + e] + bv[e]);
-          if (a.res && mv && n < a.N) {
-            const half4_t rv = *(const half4_t*)((const half_t*)a.res + opix * a.pitchR + n);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) vv[e] += (float)rv[e];
-          }
           half4_t o = {(half_t)vv[0], (half_t)vv[1], (half_t)vv[2], (half_t)vv[3]};
           *(half4_t*)(Os + (size_t)pl * OP + nl + 8 * g) = o;
         }
@@ -256,13 +248,38 @@ __global__ __launch_bounds__(NTHR, 4) void conv_halo_kernel(ConvArgs a) {   // 4
   constexpr int PPI = NTHR / CPP;      // pixels covered by one pass of the block
   const int cch = t % CPP;
   const int n = n0 + cch * 8;
+  // The residual (C3 shortcut) joins here, on whole 16-B channel rows: coalesced loads, all of
+  // them issued before the first use, and the sum is rounded like the reference's half-precision
+  // `x + cv2(cv1(x))` (conv output rounded to fp16, then the add).  In the MFMA register layout
+  // the same loads are 8-B pieces behind branches: one memory round trip each.
+  constexpr int NIT = BMH / PPI;
+  size_t opix[NIT];
+  bool okp[NIT];
 #pragma unroll
-  for (int it = 0; it < BMH / PPI; ++it) {
+  for (int it = 0; it < NIT; ++it) {
     const int pl = it * PPI + t / CPP;
     const int oy = y0 + (pl >> 4), ox = x0 + (pl & 15);
-    if (oy < a.Mh && ox < a.Mw && n < a.N) {
-      const size_t opix = ((size_t)b * a.oH + (oy * a.osy + ooy)) * a.oW + (ox * a.osx + oox);
-      *(half8_t*)((half_t*)a.dst + opix * a.pitchD + n) = *(const half8_t*)(Os + (size_t)pl * OP + cch * 8);
+    okp[it] = oy < a.Mh && ox < a.Mw && n < a.N;
+    opix[it] = okp[it] ? ((size_t)b * a.oH + (oy * a.osy + ooy)) * a.oW + (ox * a.osx + oox) : 0;
+  }
+  if (a.res) {
+    half8_t rv[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) rv[it] = *(const half8_t*)((const half_t*)a.res + opix[it] * a.pitchR + (okp[it] ? n : 0));
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int pl = it * PPI + t / CPP;
+      const half8_t o = *(const half8_t*)(Os + (size_t)pl * OP + cch * 8);
+      half8_t s;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s[e] = (half_t)((float)o[e] + (float)rv[it][e]);
+      if (okp[it]) *(half8_t*)((half_t*)a.dst + opix[it] * a.pitchD + n) = s;
+    }
+  } else {
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int pl = it * PPI + t / CPP;
+      if (okp[it]) *(half8_t*)((half_t*)a.dst + opix[it] * a.pitchD + n) = *(const half8_t*)(Os + (size_t)pl * OP + cch * 8);
     }
   }
   if (prof) {

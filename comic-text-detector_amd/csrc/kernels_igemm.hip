@@ -363,7 +363,7 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_kernel(ConvArgs a) {
           float v[4];
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] = ctd_act_fast<ACT>(acc[i][j][4 * g + e] + bv[e]);
-          if (a.res && mv && n < a.N) {
+          if (!staged && a.res && mv && n < a.N) {   // staged tiles add the residual on whole rows below
             const half4_t rv = *(const half4_t*)((const half_t*)a.res + opix * a.pitchR + n);
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] += (float)rv[e];
@@ -409,14 +409,35 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_kernel(ConvArgs a) {
     constexpr int PPI = 256 / CPP;       // pixels covered by one pass of the block
     const int c = t % CPP;
     const int n = n0 + c * 8;
+    // The residual (C3 shortcut) joins here on whole 16-B channel rows: coalesced loads, all
+    // issued before the first use, rounded like the reference's half-precision x + cv2(cv1(x)).
+    constexpr int NIT = BM / PPI;
+    size_t opx[NIT];
+    bool okp[NIT];
 #pragma unroll
-    for (int it = 0; it < BM / PPI; ++it) {
-      const int pl = it * PPI + t / CPP;
-      const int m = m0 + pl;
-      if (m < a.M && n < a.N && !(abl & 4)) {
-        const size_t opix = out_pixel(m);
-        *(half8_t*)((half_t*)a.dst + opix * a.pitchD + n) = *(const half8_t*)(Os + (size_t)pl * OP + c * 8);
+    for (int it = 0; it < NIT; ++it) {
+      const int m = m0 + it * PPI + t / CPP;
+      okp[it] = m < a.M && n < a.N && !(abl & 4);
+      opx[it] = okp[it] ? out_pixel(m) : 0;
+    }
+    if (a.res) {
+      half8_t rv[NIT];
+#pragma unroll
+      for (int it = 0; it < NIT; ++it)
+        rv[it] = *(const half8_t*)((const half_t*)a.res + opx[it] * a.pitchR + (okp[it] ? n : 0));
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        const half8_t o = *(const half8_t*)(Os + (size_t)(it * PPI + t / CPP) * OP + c * 8);
+        half8_t sum;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) sum[e] = (half_t)((float)o[e] + (float)rv[it][e]);
+        if (okp[it]) *(half8_t*)((half_t*)a.dst + opx[it] * a.pitchD + n) = sum;
       }
+    } else {
+#pragma unroll
+      for (int it = 0; it < NIT; ++it)
+        if (okp[it])
+          *(half8_t*)((half_t*)a.dst + opx[it] * a.pitchD + n) = *(const half8_t*)(Os + (size_t)(it * PPI + t / CPP) * OP + c * 8);
     }
   }
   if (prof) {

@@ -165,7 +165,7 @@ def main() -> None:
         dt = float(t.item())
 
     if rank == 0:
-        # ---- roofline of the dominant kernel family (MFMA implicit-GEMM conv + convT) ----
+        # ---- roofline of the dominant kernel family (MFMA conv + convT: halo-tile and implicit-GEMM kernels) ----
         prof = be.profile(inp)
         ms, fl, by, cls = prof["ms"], prof["flops"], prof["bytes"], prof["cls"]
         fam = (cls == 1) | (cls == 2)
@@ -197,7 +197,7 @@ def main() -> None:
                 traffic = None
         roof.update({"traffic": traffic, "traffic_note": "bytes per step (92 launches), rocprofv3 PMC run of "
                      "bench.py --steps 1 --warmup 1 --no-post, see profiles/README.md" if traffic else None,
-                     "kernel": "conv_igemm_kernel (MFMA implicit-GEMM conv/convT family)",
+                     "kernel": "conv_halo_kernel + conv_igemm_kernel (MFMA conv / convT family)",
                      "launches_per_step": int(fam.sum()), "family_ms_per_step": round(fam_ms, 3),
                      "net_ms_per_step": round(net_ms, 3), "alg_bytes_per_step": fam_bytes,
                      "alg_flops_per_step": fam_flops, "tflops": round(ach_tf, 1),

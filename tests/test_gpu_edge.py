@@ -71,6 +71,28 @@ def test_network_sizes_against_oracle(shape):
         del be
 
 
+@pytest.mark.parametrize("shape", [(1, 64, 64), (3, 128, 64), (2, 320, 448)])
+def test_halo_kernel_forced_onto_small_maps_matches_oracle(shape, monkeypatch):
+    """The halo-tile conv kernel normally takes only maps with >= 1024 patches; forced onto tiny
+    ones (CTD_HALO_MIN_PATCHES=1) every 16x16 patch is partial: 2x2 ... 14x10 pixel maps, patches
+    hanging over the right / bottom edge, ConvTranspose phases on 2x2 inputs."""
+    ck = checkpoint(0)
+    x = gen_golden.make_input(33, shape)
+    ob, om, ol = OracleNet(ck)(x)
+    p = pkg()
+    be = p.backend.HipTextDetBackend(ck, device="cuda", precision="fp16")
+    ref = [t.clone() for t in be(x.cuda())]
+    monkeypatch.setenv("CTD_HALO_MIN_PATCHES", "1")
+    got = [t.clone() for t in be(x.cuda())]
+    torch.cuda.synchronize()
+    monkeypatch.delenv("CTD_HALO_MIN_PATCHES")
+    assert float((got[1].cpu() - om).abs().max()) < 3e-2
+    assert float((got[2].cpu() - ol).abs().max()) < 3e-2
+    assert float((got[0].cpu()[..., 4:] - ob[..., 4:]).abs().max()) < 3e-2
+    # same arithmetic up to the summation order of the K walk
+    assert float((got[1] - ref[1]).abs().max()) < 5e-3 and float((got[2] - ref[2]).abs().max()) < 5e-3
+
+
 def test_replanning_between_sizes_keeps_results():
     """A mixed-size stream re-plans the arena; going back to an earlier size reproduces its result."""
     be = pkg().backend.HipTextDetBackend(checkpoint(0), device="cuda", precision="fp16")

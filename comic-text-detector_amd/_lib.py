@@ -54,6 +54,10 @@ class CtdRule(C.Structure):
                 ("aux", C.c_int32)]
 
 
+class CtdBand(C.Structure):
+    _fields_ = [("win", C.c_int32), ("top", C.c_int32), ("mtop", C.c_int32)]
+
+
 # every symbol include/ctd_hip.h declares: (restype, argtypes)
 _vp, _i32, _i64, _f = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 SYMBOLS = {
@@ -76,6 +80,10 @@ SYMBOLS = {
     "ctd_win_hist": (_i32, [C.POINTER(CtdWindow), _i32, _vp, _vp]),
     "ctd_win_xor": (_i32, [C.POINTER(CtdWindow), _i32, C.POINTER(CtdRule), _i32, _vp, _vp]),
     "ctd_win_render": (_i32, [C.POINTER(CtdWindow), _i32, C.POINTER(CtdRule), C.POINTER(_i32), _i32, _vp, _i32, _vp]),
+    "ctd_win_accept": (_i32, [C.POINTER(CtdWindow), _i32, C.POINTER(CtdBand), _i32, _vp, _i32, _vp, _vp, _i32, _vp, _i32,
+                               _vp, _vp]),
+    "ctd_win_dilate": (_i32, [C.POINTER(CtdWindow), _i32, C.POINTER(_i32), _vp, _vp, _vp, _i32, _vp, _i32, _vp]),
+    "ctd_win_commit": (_i32, [C.POINTER(CtdWindow), _i32, C.POINTER(_i32), _vp, _i32, _vp, _i32, _vp]),
     "ctd_db_boxes": (_i32, [_vp, _vp, _vp, _i32, _vp, _vp, _i32, _i32, _i32, _i32, C.c_double, _vp, _vp, C.POINTER(_i32)]),
     "ctd_last_error": (C.c_char_p, []),
     "ctd_abi_version": (_i32, []),

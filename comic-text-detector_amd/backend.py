@@ -186,6 +186,28 @@ class HipTextDetBackend:
 
 
 # ---------------------------------------------------------------------------
+# device -> host copies through cached pinned buffers
+# ---------------------------------------------------------------------------
+
+_pinned: dict = {}
+
+
+def to_host(t: torch.Tensor, key: str) -> np.ndarray:
+    """Synchronous D2H copy of `t` into a cached page-locked buffer (pageable `.cpu()` copies of the
+    label / probability maps ran at a few GB/s and dominated the host tail).  The returned array
+    aliases the buffer of `key`: it is valid until the next `to_host` call with the same key."""
+    t = t.contiguous()
+    n = t.numel() * t.element_size()
+    buf = _pinned.get(key)
+    if buf is None or buf.numel() < n:
+        buf = torch.empty(max(n, 1 << 20), dtype=torch.uint8, pin_memory=True)
+        _pinned[key] = buf
+    view = buf[:n].view(t.dtype).view(t.shape)
+    view.copy_(t)
+    return view.numpy()
+
+
+# ---------------------------------------------------------------------------
 # post-processing kernels
 # ---------------------------------------------------------------------------
 

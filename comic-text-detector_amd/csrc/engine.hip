@@ -863,4 +863,56 @@ int ctd_win_render(const ctd_window* wins, int32_t n, const ctd_rule* bands, con
   return CTD_OK;
 }
 
+int ctd_win_accept(const ctd_window* wins, int32_t n, const ctd_band* bands, int32_t nbands, const int32_t* labels_dev,
+                   int32_t canvas_w, const int32_t* stats_dev, const uint8_t* allowed_dev, int32_t min_box,
+                   uint8_t* merged_dev, int32_t merged_w, uint32_t* counters_dev, void* stream) {
+  if (int rc = check_windows(wins, n)) return rc;
+  if (!bands || nbands < 1 || !labels_dev || !merged_dev || !counters_dev || (!stats_dev && !allowed_dev))
+    return fail(CTD_ERR_INVALID, "bad accept arguments");
+  int mp = 1;
+  for (int i = 0; i < nbands; ++i) {
+    if (bands[i].win < 0 || bands[i].win >= n || bands[i].top < 0 || bands[i].mtop < 0 ||
+        wins[bands[i].win].w > canvas_w || wins[bands[i].win].w > merged_w)
+      return fail(CTD_ERR_INVALID, "band " + std::to_string(i) + " is malformed");
+    mp = std::max(mp, wins[bands[i].win].w * wins[bands[i].win].h);
+  }
+  hipStream_t st = (hipStream_t)stream;
+  void *wd, *bd;
+  if (int rc = stage(0, wins, sizeof(ctd_window) * n, st, &wd)) return rc;
+  if (int rc = stage(1, bands, sizeof(ctd_band) * (size_t)nbands, st, &bd)) return rc;
+  launch_win_accept((const CtdWin*)wd, (const ctd_band*)bd, nbands, mp, labels_dev, canvas_w, stats_dev, allowed_dev,
+                    min_box, merged_dev, merged_w, counters_dev, st);
+  HIP_TRY(hipGetLastError());
+  return CTD_OK;
+}
+
+int ctd_win_dilate(const ctd_window* wins, int32_t n, const int32_t* mtops, const uint8_t* merged_in_dev,
+                   uint8_t* merged_out_dev, uint8_t* comp_dev, int32_t merged_w, uint32_t* count255_dev, int32_t dilate,
+                   void* stream) {
+  if (int rc = check_windows(wins, n)) return rc;
+  if (!mtops || !merged_in_dev || !merged_out_dev || !comp_dev || !count255_dev || merged_in_dev == merged_out_dev)
+    return fail(CTD_ERR_INVALID, "bad dilate arguments");
+  hipStream_t st = (hipStream_t)stream;
+  void *wd, *td;
+  if (int rc = stage(0, wins, sizeof(ctd_window) * n, st, &wd)) return rc;
+  if (int rc = stage(2, mtops, sizeof(int32_t) * (size_t)n, st, &td)) return rc;
+  launch_win_dilate((const CtdWin*)wd, (const int*)td, n, max_pixels(wins, n), merged_in_dev, merged_out_dev, comp_dev,
+                    merged_w, count255_dev, dilate, st);
+  HIP_TRY(hipGetLastError());
+  return CTD_OK;
+}
+
+int ctd_win_commit(const ctd_window* wins, int32_t n, const int32_t* mtops, const uint8_t* merged_dev, int32_t merged_w,
+                   uint8_t* page_dev, int32_t page_w, void* stream) {
+  if (int rc = check_windows(wins, n)) return rc;
+  if (!mtops || !merged_dev || !page_dev || ((uintptr_t)page_dev & 3)) return fail(CTD_ERR_INVALID, "bad commit arguments");
+  hipStream_t st = (hipStream_t)stream;
+  void *wd, *td;
+  if (int rc = stage(0, wins, sizeof(ctd_window) * n, st, &wd)) return rc;
+  if (int rc = stage(2, mtops, sizeof(int32_t) * (size_t)n, st, &td)) return rc;
+  launch_win_commit((const CtdWin*)wd, (const int*)td, n, max_pixels(wins, n), merged_dev, merged_w, page_dev, page_w, st);
+  HIP_TRY(hipGetLastError());
+  return CTD_OK;
+}
+
 }  // extern "C"

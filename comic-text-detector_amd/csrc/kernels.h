@@ -73,6 +73,13 @@ void launch_win_xor(const CtdWin* wins_dev, const CtdRule* rules_dev, int n, int
                     unsigned long long* sums_dev, hipStream_t st);
 void launch_win_render(const CtdWin* wins_dev, const CtdRule* rules_dev, const int* tops_dev, int nbands, int max_pix,
                        uint8_t* canvas_dev, int canvas_w, hipStream_t st);
+void launch_win_accept(const CtdWin* wins_dev, const ctd_band* bands_dev, int nbands, int max_pix, const int* labels,
+                       int canvas_w, const int* stats, const uint8_t* allowed, int min_box, uint8_t* merged, int merged_w,
+                       unsigned* counters, hipStream_t st);
+void launch_win_dilate(const CtdWin* wins_dev, const int* mtops_dev, int n, int max_pix, const uint8_t* in, uint8_t* out,
+                       uint8_t* comp, int merged_w, unsigned* count255, int dilate, hipStream_t st);
+void launch_win_commit(const CtdWin* wins_dev, const int* mtops_dev, int n, int max_pix, const uint8_t* merged, int merged_w,
+                       uint8_t* page, int page_w, hipStream_t st);
 
 // ---- mfma layout probe (selftest) -------------------------------------------
 void launch_mfma_probe(const half_t* a, const half_t* b, float* out, hipStream_t st);

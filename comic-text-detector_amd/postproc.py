@@ -72,10 +72,11 @@ class SegRepresenter:
         lab_f, n_f, st_f = BK.connected_components(bitmap, 0, 8, max_labels=cap)
         inv = (bitmap == 0).to(torch.uint8)
         lab_b, n_b, st_b = BK.connected_components(inv, 0, 4, max_labels=cap)
-        lab_f, lab_b = lab_f.cpu().numpy(), lab_b.cpu().numpy()
         n_f, n_b = n_f.cpu().numpy(), n_b.cpu().numpy()
-        st_f, st_b = st_f.cpu().numpy(), st_b.cpu().numpy()
-        prob = prob.cpu().numpy()
+        nmax_f, nmax_b = int(min(n_f.max(initial=0), cap)), int(min(n_b.max(initial=0), cap))
+        lab_f, lab_b = BK.to_host(lab_f, "db.lab_f"), BK.to_host(lab_b, "db.lab_b")
+        st_f, st_b = BK.to_host(st_f[:, :max(nmax_f, 1)], "db.st_f"), BK.to_host(st_b[:, :max(nmax_b, 1)], "db.st_b")
+        prob = BK.to_host(prob, "db.prob")
         boxes_batch, scores_batch = [], []
         for b in range(B):
             boxes, scores = self._page(prob[b], lab_f[b], st_f[b, : min(n_f[b], cap)], lab_b[b],

@@ -9,8 +9,11 @@ GPU / host split (one page = a few launches, independent of the number of text b
   host                 polarity (`minxor_thresh`), best Otsu channel, ordering by distance
   HIP  ctd_win_render  the chosen candidates as bands of one labelling canvas
   HIP  ctd_ccl         8-connected components of all candidates of all windows (one launch)
-  host                 accept / reject per component (bincount), 3x3 dilation, hole-fill threshold
+  HIP  ctd_win_accept  accept / reject per component, one round per candidate rank (count + apply)
+  HIP  ctd_win_dilate  3x3 dilation, complement canvas, set-pixel count per window
   HIP  ctd_ccl         components of the complements (hole filling, one launch)
+  host                 hole-fill area threshold per window from the component statistics
+  HIP  ctd_win_accept  hole-filling accept round;  ctd_win_commit  OR into the page mask
 
 Accept rule: a component is OR-ed into the merged mask iff, among its
 pixels not merged yet, more lie on predicted-text pixels than on predicted-background pixels --
@@ -89,8 +92,17 @@ def otsu_value(ch: np.ndarray) -> int:
 def topk_colors_from_hist(hist_sel: np.ndarray) -> List[float]:
     """`get_topk_masklist`'s colour pick (textmask.py:61-62, 16-27) from the integer histogram of
     the selected grey values: np.histogram(px, bins=255) only depends on the multiset of values."""
-    sel = np.repeat(np.arange(256, dtype=np.uint8), hist_sel.astype(np.int64))
-    counts, edges = np.histogram(sel, bins=255)
+    # np.histogram(px, bins=255) without materialising px: the bin of a value only depends on the
+    # value and on (min, max), so the grey levels present, weighted by their counts, give the same
+    # counts (exact in float64) and the same edges
+    hist_sel = np.asarray(hist_sel, np.int64)
+    present = np.nonzero(hist_sel)[0]
+    if present.size == 0:
+        counts, edges = np.histogram(np.zeros(0, np.uint8), bins=255)
+    else:
+        counts, edges = np.histogram(present.astype(np.uint8), bins=255, range=(int(present[0]), int(present[-1])),
+                                     weights=hist_sel[present].astype(np.float64))
+        counts = counts.astype(np.int64)
     order = np.argsort(-counts, kind="stable")
     colors, cnt = edges[order], counts[order]
     top = [colors[0]]
@@ -140,33 +152,8 @@ def candidate_masks(im: np.ndarray, msk: np.ndarray) -> List[Tuple[np.ndarray, i
 
 
 # --------------------------------------------------------------------------
-# GPU labelling of many small masks with one launch
+# canvas layout: windows / candidate masks stacked vertically, one labelling launch for all
 # --------------------------------------------------------------------------
-
-def _split_labels(labels: np.ndarray, stats: np.ndarray, shapes, tops):
-    """Canvas labels -> per band (local labels 1..n, local stats).  Bands are stacked vertically,
-    so the raster-order ids of a band form a contiguous range."""
-    out = []
-    for (h, w), top in zip(shapes, tops):
-        lab = labels[top: top + h, :w]
-        nz = lab[lab > 0]
-        if nz.size == 0:
-            out.append((np.zeros((h, w), np.int32), np.zeros((0, 5), np.int32)))
-            continue
-        lo, hi = int(nz.min()), int(nz.max())
-        st = stats[lo - 1: hi].copy()
-        st[:, 1] -= top
-        out.append((np.where(lab > 0, lab - (lo - 1), 0).astype(np.int32), st))
-    return out
-
-
-def _label_canvas(canvas: torch.Tensor, shapes, tops, connectivity: int, fg_upper: int):
-    cap = int(min(max(1024, fg_upper + 1), 1 << 20))
-    labels, n, stats = BK.connected_components(canvas, 0, connectivity, max_labels=cap)
-    labels = labels[0].cpu().numpy()
-    stats = stats[0, : min(int(n[0]), cap)].cpu().numpy()
-    return _split_labels(labels, stats, shapes, tops)
-
 
 def _band_layout(shapes):
     tops, y = [], 0
@@ -174,18 +161,6 @@ def _band_layout(shapes):
         tops.append(y)
         y += h + 1                        # an empty row keeps neighbouring bands apart
     return tops, y, max(w for _, w in shapes)
-
-
-def label_stack(masks: Sequence[np.ndarray], connectivity: int, device) -> List[Tuple[np.ndarray, np.ndarray]]:
-    """Labels host masks (foreground = non-zero) with ONE `ctd_ccl` launch."""
-    if not masks:
-        return []
-    shapes = [m.shape for m in masks]
-    tops, rows, wmax = _band_layout(shapes)
-    canvas = np.zeros((rows, wmax), np.uint8)
-    for m, top in zip(masks, tops):
-        canvas[top: top + m.shape[0], : m.shape[1]] = (m != 0)
-    return _label_canvas(torch.from_numpy(canvas).to(device), shapes, tops, connectivity, int(canvas.sum()))
 
 
 # --------------------------------------------------------------------------
@@ -250,11 +225,70 @@ def _gpu_candidates(img_gpu: torch.Tensor, mask_gpu: torch.Tensor, wins: Sequenc
     T = (C.c_int32 * len(bands))(*tops)
     canvas = torch.zeros((rows, wmax), dtype=torch.uint8, device=img_gpu.device)
     L.check(lib.ctd_win_render(W, n, Bd, T, len(bands), canvas.data_ptr(), wmax, stream), "ctd_win_render")
-    labelled = _label_canvas(canvas, shapes, tops, 8, sum(h * w for h, w in shapes))
-    per_win: List[list] = [[] for _ in range(n)]
-    for o, lab in zip(owner, labelled):
-        per_win[o].append(lab)
-    return per_win
+    cap = int(min(max(1024, sum(h * w for h, w in shapes) + 1), 1 << 20))
+    labels, nlab, stats = BK.connected_components(canvas, 0, 8, max_labels=cap)
+    return W, owner, tops, wmax, labels[0], min(int(nlab[0]), cap), stats[0]
+
+
+def _refine_gpu(img_gpu: torch.Tensor, mask_gpu: torch.Tensor, wins, refine_mode: int, out_shape) -> np.ndarray:
+    """Candidates, merge rounds, dilation, hole filling and the final OR on the device; the host only
+    sees the histograms, the xor sums and the component statistics of the hole-filling pass."""
+    lib = L.lib()
+    dev = img_gpu.device
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    n = len(wins)
+    W, owner, tops, wmax, labels, nlab, stats = _gpu_candidates(img_gpu, mask_gpu, wins)
+    shapes_w = [(y2 - y1, x2 - x1) for x1, y1, x2, y2 in wins]
+    mtops, mrows, mw = _band_layout(shapes_w)
+    MT = (C.c_int32 * n)(*mtops)
+    merged_a = torch.zeros((mrows, mw), dtype=torch.uint8, device=dev)
+    counters = torch.zeros((2 * (nlab + 1),), dtype=torch.int32, device=dev)
+    # merge rounds: candidate r of every window in parallel, candidates of one window in order (:93-107)
+    seen = [0] * n
+    rounds: List[list] = []
+    for j, o in enumerate(owner):
+        r = seen[o]
+        seen[o] += 1
+        while len(rounds) <= r:
+            rounds.append([])
+        rounds[r].append((o, tops[j], mtops[o]))
+    if nlab:
+        for bands in rounds:
+            Bd = (L.CtdBand * len(bands))()
+            for k, (o, top, mtop) in enumerate(bands):
+                Bd[k].win, Bd[k].top, Bd[k].mtop = o, top, mtop
+            L.check(lib.ctd_win_accept(W, n, Bd, len(bands), labels.data_ptr(), labels.shape[1], stats.data_ptr(), None, 3,
+                                       merged_a.data_ptr(), mw, counters.data_ptr(), stream), "ctd_win_accept")
+    merged_b = torch.empty_like(merged_a)
+    comp = torch.zeros_like(merged_a)
+    count255 = torch.zeros((n,), dtype=torch.int32, device=dev)
+    L.check(lib.ctd_win_dilate(W, n, MT, merged_a.data_ptr(), merged_b.data_ptr(), comp.data_ptr(), mw,
+                               count255.data_ptr(), 1 if refine_mode == REFINEMASK_INPAINT else 0, stream), "ctd_win_dilate")
+    # hole filling (:113-131): components of the complement, all but the largest area class allowed
+    cap2 = int(min(max(1024, sum(h * w for h, w in shapes_w) + 1), 1 << 20))
+    labels2, n2, stats2 = BK.connected_components(comp, 0, 8, max_labels=cap2)
+    n2 = min(int(n2[0]), cap2)
+    if n2:
+        st2 = stats2[0, :n2].cpu().numpy()
+        bg = count255.cpu().numpy().astype(np.int64)
+        owner2 = np.searchsorted(np.asarray(mtops), st2[:, 1], side="right") - 1
+        allowed = np.zeros(n2, np.uint8)
+        for i in range(n):
+            idx = np.nonzero(owner2 == i)[0]
+            if idx.size == 0:
+                continue
+            srt = np.sort(np.r_[bg[i], st2[idx, 4]])
+            allowed[idx] = st2[idx, 4] < srt[-2]
+        allowed_dev = torch.from_numpy(allowed).to(dev)
+        counters2 = torch.zeros((2 * (n2 + 1),), dtype=torch.int32, device=dev)
+        Bd = (L.CtdBand * n)()
+        for i in range(n):
+            Bd[i].win, Bd[i].top, Bd[i].mtop = i, mtops[i], mtops[i]
+        L.check(lib.ctd_win_accept(W, n, Bd, n, labels2[0].data_ptr(), labels2.shape[2], None, allowed_dev.data_ptr(), 0,
+                                   merged_b.data_ptr(), mw, counters2.data_ptr(), stream), "ctd_win_accept")
+    page = torch.zeros(out_shape, dtype=torch.uint8, device=dev)
+    L.check(lib.ctd_win_commit(W, n, MT, merged_b.data_ptr(), mw, page.data_ptr(), out_shape[1], stream), "ctd_win_commit")
+    return page.cpu().numpy()
 
 
 # --------------------------------------------------------------------------
@@ -288,25 +322,24 @@ def refine_mask(img: np.ndarray, pred_mask: np.ndarray, blk_list: Sequence[TextB
         x2, y2 = min(im_w - 1, x2 + pad), min(im_h - 1, y2 + pad)
         if x2 <= x1 or y2 <= y1:
             continue
-        msk = np.ascontiguousarray(pred_mask[y1:y2, x1:x2])
-        pred_bin = np.where(_morph(msk, _CROSS, erode=True) > 60, 255, 0).astype(np.uint8)   # (:85-89)
-        jobs.append(dict(win=(int(x1), int(y1), int(x2), int(y2)), pred=pred_bin))
+        jobs.append(dict(win=(int(x1), int(y1), int(x2), int(y2))))
     if not jobs:
         return refined
     if labeler is None:
         if gpu is None:
             gpu = (torch.from_numpy(np.ascontiguousarray(img)).to(device),
                    torch.from_numpy(np.ascontiguousarray(pred_mask)).to(device))
-        cand_labels = _gpu_candidates(gpu[0], gpu[1], [j["win"] for j in jobs])
-        labeler2 = lambda masks, conn: label_stack(masks, conn, device)     # noqa: E731
-    else:
-        cand_labels = []
-        for j in jobs:
-            x1, y1, x2, y2 = j["win"]
-            cands = candidate_masks(img[y1:y2, x1:x2], np.ascontiguousarray(pred_mask[y1:y2, x1:x2]))
-            cands.sort(key=lambda c: c[1])                                  # stable (:74)
-            cand_labels.append(labeler([c[0] for c in cands], 8))
-        labeler2 = labeler
+        return _refine_gpu(gpu[0], gpu[1], [j["win"] for j in jobs], refine_mode, pred_mask.shape)
+    # ---- numpy path of the CPU test-suite (injected labeller) ----
+    cand_labels = []
+    for j in jobs:
+        x1, y1, x2, y2 = j["win"]
+        msk = np.ascontiguousarray(pred_mask[y1:y2, x1:x2])
+        j["pred"] = np.where(_morph(msk, _CROSS, erode=True) > 60, 255, 0).astype(np.uint8)   # (:85-89)
+        cands = candidate_masks(img[y1:y2, x1:x2], msk)
+        cands.sort(key=lambda c: c[1])                                  # stable (:74)
+        cand_labels.append(labeler([c[0] for c in cands], 8))
+    labeler2 = labeler
     for j, labs in zip(jobs, cand_labels):
         merged = np.zeros_like(j["pred"])
         for labels, st in labs:

@@ -235,6 +235,39 @@ int ctd_win_xor(const ctd_window* wins, int32_t n, const ctd_rule* rules, int32_
 int ctd_win_render(const ctd_window* wins, int32_t n, const ctd_rule* bands, const int32_t* tops, int32_t nbands,
                    uint8_t* canvas_dev, int32_t canvas_w, void* stream);
 
+/* ---- merge stage of the mask refinement (reference utils/textmask.py:74-131) ---- */
+
+/* A band of a labelled canvas: window `win`, first row `top` in the label canvas, first row `mtop`
+ * in the merged-mask canvas (one band per window there). */
+typedef struct ctd_band {
+  int32_t win, top, mtop;
+} ctd_band;
+
+/* One accept round of `merge_mask_list` (textmask.py:93-107, and the hole-filling pass :113-131) for
+ * the given bands: a labelled component is OR-ed into the merged mask iff it is allowed and, among
+ * its pixels not merged yet, more lie on pred_bin = 255 than on pred_bin = 0 (pred_bin = 3x3 cross
+ * erosion of the window's mask > 60, :85-89) -- the reference's `xor_merged < xor_origin` test.
+ * Allowed: allowed_dev[label-1] != 0 when given, else bbox w*h >= min_box from stats_dev (:98-99).
+ * labels_dev (rows, canvas_w) i32 and stats_dev (nlab,5) i32 are `ctd_ccl` outputs; counters_dev
+ * = 2*(nlab+1) u32, zeroed by the caller before the first round of a canvas (labels are unique per
+ * band, so rounds do not collide).  wins / bands are HOST arrays. */
+int ctd_win_accept(const ctd_window* wins, int32_t n, const ctd_band* bands, int32_t nbands,
+                   const int32_t* labels_dev, int32_t canvas_w, const int32_t* stats_dev,
+                   const uint8_t* allowed_dev, int32_t min_box, uint8_t* merged_dev, int32_t merged_w,
+                   uint32_t* counters_dev, void* stream);
+
+/* merged_out = 3x3 rect dilation of merged_in inside each window (`dilate` != 0, REFINEMASK_INPAINT,
+ * textmask.py:110-111) or a copy; comp_dev = 255 - merged_out (the canvas of the hole-filling
+ * labelling, :113); count255_dev[win] += #pixels == 255 (the caller zeroes it).  mtops (n) HOST. */
+int ctd_win_dilate(const ctd_window* wins, int32_t n, const int32_t* mtops, const uint8_t* merged_in_dev,
+                   uint8_t* merged_out_dev, uint8_t* comp_dev, int32_t merged_w, uint32_t* count255_dev,
+                   int32_t dilate, void* stream);
+
+/* page[y1:y1+h, x1:x1+w] |= merged band of every window (textmask.py:167); page_dev must be 4-byte
+ * aligned (word-wide atomic OR: windows may overlap). */
+int ctd_win_commit(const ctd_window* wins, int32_t n, const int32_t* mtops, const uint8_t* merged_dev,
+                   int32_t merged_w, uint8_t* page_dev, int32_t page_w, void* stream);
+
 /* ---- host-side contour geometry of the DB text-line stage -------------- */
 
 /* `SegDetectorRepresenter.boxes_from_bitmap` (reference utils/db_utils.py:134-211) downstream of

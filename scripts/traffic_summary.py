@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Sum FETCH_SIZE / WRITE_SIZE of the conv_igemm_kernel dispatches of a bench.py run
+"""Sum FETCH_SIZE / WRITE_SIZE of the conv_halo_kernel + conv_igemm_kernel dispatches of a bench.py run
 (--steps 1 --warmup 1 => 3 forwards incl. the profile pass) and write traffic.json."""
 import collections
 import csv
@@ -12,7 +12,7 @@ tot = collections.defaultdict(lambda: [0.0, 0])
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
     for f in glob.glob(f"{out}/{c}/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(f)):
-            if "conv_igemm_kernel" in r["Kernel_Name"] and r["Counter_Name"] == c:
+            if ("conv_igemm_kernel" in r["Kernel_Name"] or "conv_halo_kernel" in r["Kernel_Name"]) and r["Counter_Name"] == c:
                 tot[c][0] += float(r["Counter_Value"])
                 tot[c][1] += 1
 n_fwd = 3

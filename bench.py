@@ -95,6 +95,8 @@ def main() -> None:
                          "give a noise bitmap, SURVEY 8(d)) or the network's own bitmap")
     ap.add_argument("--dump-ops", default="", help="write the per-op profile table to this file")
     ap.add_argument("--graph", action="store_true", help="replay the forward from a captured hipGraph")
+    ap.add_argument("--no-overlap", action="store_true",
+                    help="run NMS / CCL / record gather on the forward's stream instead of a second HIP stream")
     args = ap.parse_args()
 
     pkg = importlib.import_module("comic-text-detector_amd")
@@ -137,15 +139,32 @@ def main() -> None:
             maps.append((torch.nn.functional.max_pool2d(ink, 5, 1, 2)[0, 0] > 0).to(torch.uint8))
         ccl_in = torch.stack([maps[i % 4] for i in range(hi - lo)]).to(dev).contiguous()
 
+    def post(blks, bitmap):
+        dets, counts = BK.nms(blks, 0.4, 0.35)
+        labels, ncomp, stats = BK.connected_components(bitmap, 0, 8, max_labels=1024)
+        rec = D.pack_records(dets, counts)
+        return D.gather_records(rec, total_pages, rank, world)
+
+    # The post-processing kernels are small, latency-bound grids (NMS: one block per page); on a
+    # second HIP stream they run under the NEXT step's forward instead of after this one's.  The
+    # forward's outputs are fresh tensors per call, handed to the side stream with record_stream.
+    # (hipGraph replay writes static outputs, so it keeps everything on one stream.)
+    side = None if (args.no_overlap or args.graph or args.no_post) else torch.cuda.Stream(device=dev)
+
     def step():
         blks, mask, lines = run_net()
         if args.no_post:
             return None
-        dets, counts = BK.nms(blks, 0.4, 0.35)
-        labels, ncomp, stats = BK.connected_components(ccl_in if ccl_in is not None else be.bitmap, 0, 8,
-                                                       max_labels=1024)
-        rec = D.pack_records(dets, counts)
-        return D.gather_records(rec, total_pages, rank, world)
+        bitmap = ccl_in if ccl_in is not None else be.bitmap
+        if side is None:
+            return post(blks, bitmap)
+        done = torch.cuda.Event()
+        done.record()
+        with torch.cuda.stream(side):
+            side.wait_event(done)
+            blks.record_stream(side)
+            bitmap.record_stream(side)
+            return post(blks, bitmap)
 
     for _ in range(args.warmup):
         step()
@@ -231,7 +250,7 @@ def main() -> None:
                                    + ("" if args.no_post else f" + GPU NMS + CCL({args.ccl_input} bitmap)")
                                    + (" + RCCL all-gather of block records" if n_gpus > 1 else ""),
                        "global_batch": total_pages, "page": [S, S], "input": args.input,
-                       "precision": args.precision, "parallelism": f"dp{n_gpus} (pages sharded, no data-path "
+                       "precision": args.precision, "post_overlap": side is not None, "parallelism": f"dp{n_gpus} (pages sharded, no data-path "
                                                                    f"collective except the final record gather)"},
             "roofline": roof,
             "cpu_baseline": cpu,

@@ -118,3 +118,37 @@ def test_detector_on_page_of_another_size_matches_oracle():
     np.testing.assert_array_equal(m, ref[0])
     blocks_equal(blk_list, ref[2])
     np.testing.assert_array_equal(refined, ref[1])
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_refine_mask_gpu_merge_stage_on_adversarial_windows(seed):
+    """`refine_mask` through the GPU merge stage (ctd_win_hist/xor/render, ctd_ccl, ctd_win_accept /
+    dilate / commit) against the oracle on pages built to stress it: noisy colours (many small
+    components per candidate), blob masks, and text blocks that overlap each other, touch the page
+    border or are a few pixels thin -- the cases the text-like pages do not reach."""
+    p = pkg()
+    rng = np.random.RandomState(seed)
+    H, W = 384, 512
+    page = rng.randint(0, 256, (H, W, 3)).astype(np.uint8)
+    page[:, : W // 2] = (page[:, : W // 2] // 64) * 64                  # flat-ish colour regions on one half
+    mask = np.zeros((H, W), np.uint8)
+    for _ in range(60):
+        y, x = rng.randint(0, H), rng.randint(0, W)
+        hh, ww = rng.randint(2, 40), rng.randint(2, 60)
+        mask[y: y + hh, x: x + ww] = rng.randint(40, 256)
+    boxes = [[0, 0, 90, 70], [60, 40, 220, 160], [200, 100, 330, 230], [W - 120, H - 90, W, H],
+             [10, 300, 400, 306], [430, 5, 436, 200], [100, 100, 180, 150]]
+    for _ in range(5):
+        x1, y1 = rng.randint(0, W - 40), rng.randint(0, H - 40)
+        boxes.append([x1, y1, min(W, x1 + rng.randint(12, 200)), min(H, y1 + rng.randint(12, 150))])
+    blks = [p.textblock.TextBlock(b) for b in boxes]
+    rblks = [R.TextBlock(b) for b in boxes]
+    for mode in (0, 1):
+        got = p.textmask.refine_mask(page, mask, blks, mode, "cuda")
+        ref = R.refine_mask(page, mask, rblks, mode)
+        np.testing.assert_array_equal(got, ref)
+    m1, m2 = mask.copy(), mask.copy()
+    got = p.textmask.refine_undetected_mask(page, m1, p.textmask.refine_mask(page, mask, blks[:4], 0, "cuda"), blks[:4], 0, "cuda")
+    ref = R.refine_undetected_mask(page, m2, R.refine_mask(page, mask, rblks[:4], 0), rblks[:4], 0)
+    np.testing.assert_array_equal(got, ref)
+    np.testing.assert_array_equal(m1, m2)

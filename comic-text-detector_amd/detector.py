@@ -19,7 +19,8 @@ import torch
 from . import backend as BK
 from . import postproc as PP
 from .textblock import TextBlock, group_output
-from .textmask import REFINEMASK_ANNOTATION, REFINEMASK_INPAINT, refine_mask, refine_undetected_mask
+from .textmask import (REFINEMASK_ANNOTATION, REFINEMASK_INPAINT, refine_mask, refine_mask_batch,   # noqa: F401
+                       refine_undetected_mask)
 
 __all__ = ["TextDetector", "TextBlock", "REFINEMASK_INPAINT", "REFINEMASK_ANNOTATION"]
 
@@ -83,7 +84,7 @@ class TextDetector:
         ratios = [(im_w / (Wn - dw), im_h / (Hn - dh)) for im_h, im_w, dw, dh in metas]       # :148
         yolo = PP.postprocess_yolo(blks, self.conf_thresh, self.nms_thresh, ratios)             # :149
         boxes, scores = self.seg_rep(prob, bitmap)                                              # :158
-        out = []
+        masks, masks_gpu, blk_lists = [], [], []
         for b in range(B):
             im_h, im_w, dw, dh = metas[b]
             keep = scores[b] > 0.6                                          # box_thresh (:159-161)
@@ -99,12 +100,20 @@ class TextDetector:
             m = mask_u8[b, : Hn - dh, : Wn - dw]
             if (im_h, im_w) != (Hn - dh, Wn - dw):
                 m = BK.resize_linear_u8(m.contiguous(), (im_h, im_w))
-            m = m.cpu().numpy().copy()
-            blk_list = group_output(yolo[b], lines, im_w, im_h, m)          # :173
-            refined = refine_mask(pages[b], m, blk_list, refine_mode, self.net.device)        # :174
+            m = m.contiguous()
+            masks_gpu.append(m)
+            masks.append(BK.to_host(m, "tail.mask").copy())
+            blk_lists.append(group_output(yolo[b], lines, im_w, im_h, masks[b]))     # :173
+        # refine_mask (:174) for the whole batch: the windows of all pages share the launches
+        dev = self.net.device
+        gpu = [(torch.from_numpy(np.ascontiguousarray(pages[b])).to(dev), masks_gpu[b]) for b in range(B)]
+        refined = refine_mask_batch(pages, masks, blk_lists, refine_mode, dev, gpu)
+        out = []
+        for b in range(B):
+            r = refined[b]
             if keep_undetected_mask:
-                refined = refine_undetected_mask(pages[b], m, refined, blk_list, refine_mode, self.net.device)
-            out.append((m, refined, blk_list))
+                r = refine_undetected_mask(pages[b], masks[b], r, blk_lists[b], refine_mode, dev)
+            out.append((masks[b], r, blk_lists[b]))
         return out
 
     def __call__(self, img: np.ndarray, refine_mode=REFINEMASK_INPAINT, keep_undetected_mask=False):

@@ -167,18 +167,22 @@ def _band_layout(shapes):
 # GPU candidate path
 # --------------------------------------------------------------------------
 
-def _gpu_candidates(img_gpu: torch.Tensor, mask_gpu: torch.Tensor, wins: Sequence[Tuple[int, int, int, int]]):
-    """For every window (x1,y1,x2,y2): the ordered candidate masks as labelled components.
-    Returns per window a list of (labels, stats) in the reference's merge order."""
+def _gpu_candidates(pages, wins):
+    """pages[p] = (img_gpu (H,W,3) u8, mask_gpu (H,W) u8); wins[i] = (p, x1, y1, x2, y2).
+    Builds the window table, picks every window's candidate rules (top-k grey ranges, best Otsu
+    channel; polarity by xor distance), renders them in the reference's merge order into one canvas
+    and labels it.  Nothing but histograms and xor sums leaves the device."""
     lib = L.lib()
     n = len(wins)
-    stream = torch.cuda.current_stream(img_gpu.device).cuda_stream
+    dev = pages[0][0].device
+    stream = torch.cuda.current_stream(dev).cuda_stream
     W = (L.CtdWindow * n)()
-    for i, (x1, y1, x2, y2) in enumerate(wins):
+    for i, (p, x1, y1, x2, y2) in enumerate(wins):
+        img_gpu, mask_gpu = pages[p]
         W[i].img, W[i].mask = img_gpu.data_ptr(), mask_gpu.data_ptr()
         W[i].img_w, W[i].mask_w = img_gpu.shape[1], mask_gpu.shape[1]
         W[i].x1, W[i].y1, W[i].w, W[i].h = x1, y1, x2 - x1, y2 - y1
-    hist = torch.empty((n, 4, 256), dtype=torch.int32, device=img_gpu.device)
+    hist = torch.empty((n, 4, 256), dtype=torch.int32, device=dev)
     L.check(lib.ctd_win_hist(W, n, hist.data_ptr(), stream), "ctd_win_hist")
     hist = hist.cpu().numpy().astype(np.int64)
     # rules: 0..2 grey ranges (top-k colours), 3..5 Otsu thresholds of B, G, R
@@ -195,11 +199,11 @@ def _gpu_candidates(img_gpu: torch.Tensor, mask_gpu: torch.Tensor, wins: Sequenc
         for ch in range(3):
             r = R[i * 6 + 3 + ch]
             r.kind, r.lo = 1 + ch, float(otsu_from_hist(hist[i, 1 + ch]))
-    sums = torch.empty((n, 6), dtype=torch.int64, device=img_gpu.device)
+    sums = torch.empty((n, 6), dtype=torch.int64, device=dev)
     L.check(lib.ctd_win_xor(W, n, R, 6, sums.data_ptr(), stream), "ctd_win_xor")
     sums = sums.cpu().numpy()
     bands, shapes, owner = [], [], []
-    for i, (x1, y1, x2, y2) in enumerate(wins):
+    for i, (p, x1, y1, x2, y2) in enumerate(wins):
         npix = (x2 - x1) * (y2 - y1)
         cands = []
         for k in range(3):
@@ -223,22 +227,29 @@ def _gpu_candidates(img_gpu: torch.Tensor, mask_gpu: torch.Tensor, wins: Sequenc
     for j, (kind, lo, hi, inv, i) in enumerate(bands):
         Bd[j].kind, Bd[j].lo, Bd[j].hi, Bd[j].invert, Bd[j].aux = kind, lo, hi, inv, i
     T = (C.c_int32 * len(bands))(*tops)
-    canvas = torch.zeros((rows, wmax), dtype=torch.uint8, device=img_gpu.device)
+    canvas = torch.zeros((rows, wmax), dtype=torch.uint8, device=dev)
     L.check(lib.ctd_win_render(W, n, Bd, T, len(bands), canvas.data_ptr(), wmax, stream), "ctd_win_render")
-    cap = int(min(max(1024, sum(h * w for h, w in shapes) + 1), 1 << 20))
+    cap = _max_components(shapes)
     labels, nlab, stats = BK.connected_components(canvas, 0, 8, max_labels=cap)
-    return W, owner, tops, wmax, labels[0], min(int(nlab[0]), cap), stats[0]
+    return W, owner, tops, labels[0], min(int(nlab[0]), cap), stats[0]
 
 
-def _refine_gpu(img_gpu: torch.Tensor, mask_gpu: torch.Tensor, wins, refine_mode: int, out_shape) -> np.ndarray:
-    """Candidates, merge rounds, dilation, hole filling and the final OR on the device; the host only
-    sees the histograms, the xor sums and the component statistics of the hole-filling pass."""
+def _max_components(shapes) -> int:
+    """Upper bound of the 8-connected components of the stacked bands (one per 2x2 cell), so the
+    statistics buffer can never truncate."""
+    return max(1024, sum(((h + 1) // 2) * ((w + 1) // 2) for h, w in shapes) + 1)
+
+
+def _refine_gpu(pages, wins, refine_mode: int, out_shapes) -> List[np.ndarray]:
+    """Candidates, merge rounds, dilation, hole filling and the final OR on the device for the
+    windows of one or more pages at once; the host only sees the histograms, the xor sums and the
+    component statistics of the hole-filling pass.  Returns one refined mask per page."""
     lib = L.lib()
-    dev = img_gpu.device
+    dev = pages[0][0].device
     stream = torch.cuda.current_stream(dev).cuda_stream
     n = len(wins)
-    W, owner, tops, wmax, labels, nlab, stats = _gpu_candidates(img_gpu, mask_gpu, wins)
-    shapes_w = [(y2 - y1, x2 - x1) for x1, y1, x2, y2 in wins]
+    W, owner, tops, labels, nlab, stats = _gpu_candidates(pages, wins)
+    shapes_w = [(y2 - y1, x2 - x1) for _, x1, y1, x2, y2 in wins]
     mtops, mrows, mw = _band_layout(shapes_w)
     MT = (C.c_int32 * n)(*mtops)
     merged_a = torch.zeros((mrows, mw), dtype=torch.uint8, device=dev)
@@ -265,7 +276,7 @@ def _refine_gpu(img_gpu: torch.Tensor, mask_gpu: torch.Tensor, wins, refine_mode
     L.check(lib.ctd_win_dilate(W, n, MT, merged_a.data_ptr(), merged_b.data_ptr(), comp.data_ptr(), mw,
                                count255.data_ptr(), 1 if refine_mode == REFINEMASK_INPAINT else 0, stream), "ctd_win_dilate")
     # hole filling (:113-131): components of the complement, all but the largest area class allowed
-    cap2 = int(min(max(1024, sum(h * w for h, w in shapes_w) + 1), 1 << 20))
+    cap2 = _max_components(shapes_w)
     labels2, n2, stats2 = BK.connected_components(comp, 0, 8, max_labels=cap2)
     n2 = min(int(n2[0]), cap2)
     if n2:
@@ -273,8 +284,10 @@ def _refine_gpu(img_gpu: torch.Tensor, mask_gpu: torch.Tensor, wins, refine_mode
         bg = count255.cpu().numpy().astype(np.int64)
         owner2 = np.searchsorted(np.asarray(mtops), st2[:, 1], side="right") - 1
         allowed = np.zeros(n2, np.uint8)
+        order = np.argsort(owner2, kind="stable")
+        bounds = np.searchsorted(owner2[order], np.arange(n + 1))
         for i in range(n):
-            idx = np.nonzero(owner2 == i)[0]
+            idx = order[bounds[i]: bounds[i + 1]]
             if idx.size == 0:
                 continue
             srt = np.sort(np.r_[bg[i], st2[idx, 4]])
@@ -286,9 +299,22 @@ def _refine_gpu(img_gpu: torch.Tensor, mask_gpu: torch.Tensor, wins, refine_mode
             Bd[i].win, Bd[i].top, Bd[i].mtop = i, mtops[i], mtops[i]
         L.check(lib.ctd_win_accept(W, n, Bd, n, labels2[0].data_ptr(), labels2.shape[2], None, allowed_dev.data_ptr(), 0,
                                    merged_b.data_ptr(), mw, counters2.data_ptr(), stream), "ctd_win_accept")
-    page = torch.zeros(out_shape, dtype=torch.uint8, device=dev)
-    L.check(lib.ctd_win_commit(W, n, MT, merged_b.data_ptr(), mw, page.data_ptr(), out_shape[1], stream), "ctd_win_commit")
-    return page.cpu().numpy()
+    # OR into the page masks: one launch per page over that page's (contiguous) windows
+    out = []
+    first = 0
+    for p, shape in enumerate(out_shapes):
+        cnt = 0
+        while first + cnt < n and wins[first + cnt][0] == p:
+            cnt += 1
+        page = torch.zeros(shape, dtype=torch.uint8, device=dev)
+        if cnt:
+            Wp = C.cast(C.byref(W, first * C.sizeof(L.CtdWindow)), C.POINTER(L.CtdWindow))
+            MTp = C.cast(C.byref(MT, first * C.sizeof(C.c_int32)), C.POINTER(C.c_int32))
+            L.check(lib.ctd_win_commit(Wp, cnt, MTp, merged_b.data_ptr(), mw, page.data_ptr(), shape[1], stream),
+                    "ctd_win_commit")
+        out.append(page)
+        first += cnt
+    return [BK.to_host(t, "refine.page").copy() for t in out]
 
 
 # --------------------------------------------------------------------------
@@ -304,6 +330,66 @@ def _accept(labels: np.ndarray, pred_bin: np.ndarray, merged: np.ndarray, allowe
     merged[take[labels]] = 255
 
 
+def _block_windows(blk_list: Sequence[TextBlock], im_w: int, im_h: int) -> List[Tuple[int, int, int, int]]:
+    """`expand_textwindow(expand_r=16)` of every block (reference imgproc_utils.py:151-161, textmask.py:162-164)."""
+    wins = []
+    for blk in blk_list:
+        x1, y1, x2, y2 = blk.xyxy
+        w, h = x2 - x1, y2 - y1
+        pad = int(round((max(h, w) * 0.25 + min(h, w) * 0.75) / 16))
+        x1, y1 = max(0, x1 - pad), max(0, y1 - pad)
+        x2, y2 = min(im_w - 1, x2 + pad), min(im_h - 1, y2 + pad)
+        if x2 <= x1 or y2 <= y1:
+            continue
+        wins.append((int(x1), int(y1), int(x2), int(y2)))
+    return wins
+
+
+_GROUP_PIXELS = 2 << 20      # window pixels labelled per launch group (bounds the canvas / stats buffers)
+
+
+def refine_mask_batch(imgs: Sequence[np.ndarray], pred_masks: Sequence[np.ndarray],
+                      blk_lists: Sequence[Sequence[TextBlock]], refine_mode: int = REFINEMASK_INPAINT,
+                      device="cuda", gpu: Optional[Sequence[Tuple[torch.Tensor, torch.Tensor]]] = None) -> List[np.ndarray]:
+    """`refine_mask` (textmask.py:159-169) for several pages at once: the windows of all pages share
+    the launches (the reference calls it per page and labels per block and candidate).
+    gpu[p] = (page BGR u8, mask u8) already resident on the device (else they are uploaded)."""
+    n_pages = len(imgs)
+    out: List[Optional[np.ndarray]] = [None] * n_pages
+    group: List[int] = []
+    pix = 0
+
+    def flush():
+        nonlocal group, pix
+        if not group:
+            return
+        pages, wins, shapes = [], [], []
+        for k, p in enumerate(group):
+            if gpu is not None and gpu[p] is not None:
+                pages.append(gpu[p])
+            else:
+                pages.append((torch.from_numpy(np.ascontiguousarray(imgs[p])).to(device),
+                              torch.from_numpy(np.ascontiguousarray(pred_masks[p])).to(device)))
+            wins += [(k,) + w for w in page_wins[p]]
+            shapes.append(pred_masks[p].shape)
+        for p, m in zip(group, _refine_gpu(pages, wins, refine_mode, shapes)):
+            out[p] = m
+        group, pix = [], 0
+
+    page_wins = [_block_windows(blk_lists[p], imgs[p].shape[1], imgs[p].shape[0]) for p in range(n_pages)]
+    for p in range(n_pages):
+        if not page_wins[p]:
+            out[p] = np.zeros_like(pred_masks[p])
+            continue
+        npx = sum((x2 - x1) * (y2 - y1) for x1, y1, x2, y2 in page_wins[p])
+        if group and pix + npx > _GROUP_PIXELS:
+            flush()
+        group.append(p)
+        pix += npx
+    flush()
+    return out      # type: ignore[return-value]
+
+
 def refine_mask(img: np.ndarray, pred_mask: np.ndarray, blk_list: Sequence[TextBlock],
                 refine_mode: int = REFINEMASK_INPAINT, device="cuda", labeler=None,
                 gpu: Optional[Tuple[torch.Tensor, torch.Tensor]] = None) -> np.ndarray:
@@ -311,26 +397,14 @@ def refine_mask(img: np.ndarray, pred_mask: np.ndarray, blk_list: Sequence[TextB
     `gpu` = (page BGR u8, mask u8) already resident on the device (else they are uploaded).
     `labeler(masks, connectivity)`: the CPU test-suite injects its own labeller, which also
     selects the numpy candidate path (no GPU needed)."""
+    if labeler is None:
+        return refine_mask_batch([img], [pred_mask], [blk_list], refine_mode, device, None if gpu is None else [gpu])[0]
+    # ---- numpy path of the CPU test-suite (injected labeller) ----
     refined = np.zeros_like(pred_mask)
     im_h, im_w = img.shape[:2]
-    jobs = []
-    for blk in blk_list:
-        x1, y1, x2, y2 = blk.xyxy
-        w, h = x2 - x1, y2 - y1
-        pad = int(round((max(h, w) * 0.25 + min(h, w) * 0.75) / 16))       # expand_textwindow(expand_r=16)
-        x1, y1 = max(0, x1 - pad), max(0, y1 - pad)
-        x2, y2 = min(im_w - 1, x2 + pad), min(im_h - 1, y2 + pad)
-        if x2 <= x1 or y2 <= y1:
-            continue
-        jobs.append(dict(win=(int(x1), int(y1), int(x2), int(y2))))
+    jobs = [dict(win=w) for w in _block_windows(blk_list, im_w, im_h)]
     if not jobs:
         return refined
-    if labeler is None:
-        if gpu is None:
-            gpu = (torch.from_numpy(np.ascontiguousarray(img)).to(device),
-                   torch.from_numpy(np.ascontiguousarray(pred_mask)).to(device))
-        return _refine_gpu(gpu[0], gpu[1], [j["win"] for j in jobs], refine_mode, pred_mask.shape)
-    # ---- numpy path of the CPU test-suite (injected labeller) ----
     cand_labels = []
     for j in jobs:
         x1, y1, x2, y2 = j["win"]
@@ -348,7 +422,7 @@ def refine_mask(img: np.ndarray, pred_mask: np.ndarray, blk_list: Sequence[TextB
         if refine_mode == REFINEMASK_INPAINT:
             merged = _morph(merged, _RECT, erode=False)                                  # (:110-111)
         j["merged"] = merged
-    # hole filling on the complements (:113-131): second labelling launch
+    # hole filling on the complements (:113-131): second labelling pass
     lab2 = labeler2([255 - j["merged"] for j in jobs], 8)
     for j, (labels, st) in zip(jobs, lab2):
         merged = j["merged"]

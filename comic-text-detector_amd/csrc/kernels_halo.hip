@@ -42,6 +42,7 @@ __global__ __launch_bounds__(NTHR, 4) void conv_halo_kernel(ConvArgs a) {   // 4
   constexpr int OP = BN + 8;
   constexpr int LDS_OUT = BMH * OP;
   __shared__ __attribute__((aligned(16))) half_t lds[LDS_STAGE > LDS_OUT ? LDS_STAGE : LDS_OUT];
+  __shared__ __attribute__((aligned(16))) float bias_s[BN];   // this tile's biases, fetched under the K loop
   half_t* As = lds;               // [2][AROWS_PAD][32]
   half_t* Ws = lds + 2 * A_BUF;   // [2][BN][32]
 
@@ -79,6 +80,7 @@ __global__ __launch_bounds__(NTHR, 4) void conv_halo_kernel(ConvArgs a) {   // 4
   const int b = v / tilesY;
   const int n0 = tile_n * BN;
   const int y0 = tpy * THP, x0 = tpx * TWP;
+  if (threadIdx.x < BN) bias_s[threadIdx.x] = a.bias[n0 + threadIdx.x];   // visible after the prologue barrier
 
   int dy0 = a.dy0, dx0 = a.dx0, ooy = a.ooy, oox = a.oox;
   const half_t* __restrict__ wbase = (const half_t*)a.w;
@@ -225,8 +227,7 @@ __global__ __launch_bounds__(NTHR, 4) void conv_halo_kernel(ConvArgs a) {   // 4
         const int nl = (wn * TN + i) * 32 + 4 * hi;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-          const int n = n0 + nl + 8 * g;
-          const float4_t bv = *(const float4_t*)(a.bias + n);
+          const float4_t bv = *(const float4_t*)(bias_s + nl + 8 * g);
           float vv[4];
 #pragma unroll
           for (int e = 0; e < 4; ++e) vv[e] = ctd_act_fast<ACT>(acc[i][j][4 * g + e] + bv[e]);

@@ -46,6 +46,9 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_kernel(ConvArgs a) {
 
   constexpr int LDS_STAGE = 2 * (BM + BN) * LP, LDS_OUT = BM * (BN + 8);
   __shared__ __attribute__((aligned(16))) half_t lds[LDS_STAGE > LDS_OUT ? LDS_STAGE : LDS_OUT];
+  // this tile's biases, fetched while the K loop runs: as global loads in the epilogue they cost a
+  // cold round trip right before the stores
+  __shared__ __attribute__((aligned(16))) float bias_s[BN];
   half_t* As = lds;                 // [2][BM][LP]  pixels
   half_t* Ws = lds + 2 * BM * LP;   // [2][BN][LP]  weights
 
@@ -79,6 +82,7 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_kernel(ConvArgs a) {
   }
   const int n0 = tile_n * BN;
   const int m0 = tile_m * BM;
+  if (t < BN) bias_s[t] = a.bias[n0 + t];   // visible after the first barrier of the K loop
 
   // ---- phase (ConvTranspose 4x4 s2 p1 sub-pixel decomposition) --------------
   int dy0 = a.dy0, dx0 = a.dx0, ooy = a.ooy, oox = a.oox;
@@ -359,7 +363,7 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_kernel(ConvArgs a) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           const int n = n0 + nl + 8 * g;
-          const float4_t bv = *(const float4_t*)(a.bias + n);   // bias is padded to the N tile
+          const float4_t bv = *(const float4_t*)(bias_s + nl + 8 * g);   // bias is padded to the N tile
           float v[4];
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] = ctd_act_fast<ACT>(acc[i][j][4 * g + e] + bv[e]);

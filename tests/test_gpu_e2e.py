@@ -152,3 +152,30 @@ def test_refine_mask_gpu_merge_stage_on_adversarial_windows(seed):
     ref = R.refine_undetected_mask(page, m2, R.refine_mask(page, mask, rblks[:4], 0), rblks[:4], 0)
     np.testing.assert_array_equal(got, ref)
     np.testing.assert_array_equal(m1, m2)
+
+
+def test_refine_mask_batch_grouping_is_transparent():
+    """`refine_mask_batch` packs the windows of several pages into shared launches, in groups bounded
+    by `_GROUP_PIXELS`; one page per group and all pages in one group must give identical masks."""
+    p = pkg()
+    pages, masks, blks = [], [], []
+    for seed in range(3):
+        page, mask_u8, prob, b = fake_outputs(seed, 384 + 64 * seed)
+        boxes = [p.textblock.TextBlock([int(v) for v in bb]) for bb in b[0]]
+        pages.append(page)
+        masks.append(mask_u8)
+        blks.append(boxes)
+    blks.append([])                                               # a page without blocks
+    pages.append(pages[0])
+    masks.append(masks[0])
+    together = p.textmask.refine_mask_batch(pages, masks, blks, 0, "cuda")
+    old = p.textmask._GROUP_PIXELS
+    try:
+        p.textmask._GROUP_PIXELS = 1
+        apart = p.textmask.refine_mask_batch(pages, masks, blks, 0, "cuda")
+    finally:
+        p.textmask._GROUP_PIXELS = old
+    for a, b_, m, bl, pg in zip(together, apart, masks, blks, pages):
+        np.testing.assert_array_equal(a, b_)
+        np.testing.assert_array_equal(a, R.refine_mask(pg, m, [R.TextBlock(x.xyxy) for x in bl], 0))
+    assert not together[3].any()

@@ -22,16 +22,33 @@ LANG_LIST = ["eng", "ja", "unknown"]                 # textblock.py:9
 LANGCLS2IDX = {"eng": 0, "ja": 1, "unknown": 2}
 
 
+# Non-detection fields of the reference's result record (utils/textblock.py:24-86): the detector
+# never touches them, but `to_dict()` dumps every attribute in creation order and downstream callers
+# (OCR, translation, rendering) fill them.  (attribute, constructor keyword, default)
+_RECORD_TAIL = (
+    ("text", "text", None), ("prob", None, 1), ("translation", "translation", ""),
+    ("fg_r", "fg_r", 0), ("fg_g", "fg_g", 0), ("fg_b", "fg_b", 0),
+    ("bg_r", "bg_r", 0), ("bg_g", "bg_g", 0), ("bg_b", "bg_b", 0),
+    ("font_family", "font_family", ""), ("bold", "bold", False), ("underline", "underline", False),
+    ("italic", "italic", False), ("alpha", "alpha", 255), ("rich_text", "rich_text", ""),
+    ("line_spacing", "line_spacing", 1.0), ("_alignment", "alignment", -1), ("_target_lang", "target_lang", ""),
+    ("_bounding_rect", "_bounding_rect", None), ("default_stroke_width", "default_stroke_width", 0.2),
+    ("accumulate_color", "accumulate_color", True),
+)
+
+
 class TextBlock:
-    """Detection-relevant state of the reference's TextBlock (textblock.py:12-86)."""
+    """The reference's TextBlock record (textblock.py:12-86): detection state first, then the
+    fields later pipeline stages fill, in the reference's attribute order (that order is the key
+    order of the JSON record, `to_dict` :158-160)."""
 
     def __init__(self, xyxy: Sequence, lines: Optional[list] = None, language: str = "unknown",
                  vertical: bool = False, font_size: float = -1, distance=None, angle: int = 0, vec=None,
                  norm: float = -1, merged: bool = False, weight: float = -1, **kwargs):
         self.xyxy = [int(v) for v in xyxy]
         self.lines = [] if lines is None else lines
-        self.language = language
         self.vertical = vertical
+        self.language = language
         self.font_size = font_size
         self.distance = None if distance is None else np.array(distance, np.float64)
         self.angle = angle
@@ -39,8 +56,9 @@ class TextBlock:
         self.norm = norm
         self.merged = merged
         self.weight = weight
-        self.text: list = kwargs.get("text", [])
-        self.translation: str = kwargs.get("translation", "")
+        for attr, kw, default in _RECORD_TAIL:
+            v = kwargs.get(kw, default) if kw is not None else default
+            setattr(self, attr, [] if (attr == "text" and v is None) else v)
 
     # -- accessors the reference exposes ------------------------------------
     def lines_array(self, dtype=np.float64) -> np.ndarray:
@@ -77,21 +95,9 @@ class TextBlock:
             self.lines = np.array(self.lines, dtype=np.int32)[order].tolist()
 
     def to_dict(self) -> dict:
-        """JSON-friendly dump (the reference's `to_dict` + NumpyEncoder, textblock.py:158-160,
-        io_utils.py:16-27)."""
-        return {
-            "xyxy": [int(v) for v in self.xyxy],
-            "lines": np.asarray(self.lines).astype(int).tolist() if len(self.lines) else [],
-            "language": self.language,
-            "vertical": bool(self.vertical),
-            "font_size": float(self.font_size),
-            "distance": None if self.distance is None else np.asarray(self.distance).tolist(),
-            "angle": int(self.angle),
-            "vec": None if self.vec is None else np.asarray(self.vec).tolist(),
-            "norm": float(self.norm),
-            "merged": bool(self.merged),
-            "weight": float(self.weight),
-        }
+        """`copy.deepcopy(vars(self))` (textblock.py:158-160): every attribute, numpy values included;
+        `annotations.RecordEncoder` turns it into the reference's JSON."""
+        return copy.deepcopy(vars(self))
 
 
 # --------------------------------------------------------------------------

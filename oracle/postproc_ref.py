@@ -259,11 +259,15 @@ class TextBlock:
     """The fields of reference utils/textblock.py:12-86 that the detection path reads/writes."""
 
     def __init__(self, xyxy, lines=None, language="unknown", vertical=False, font_size=-1, distance=None,
-                 angle=0, vec=None, norm=-1, merged=False, weight=-1):
+                 angle=0, vec=None, norm=-1, merged=False, weight=-1, text=None, translation="",
+                 fg_r=0, fg_g=0, fg_b=0, bg_r=0, bg_g=0, bg_b=0, line_spacing=1., font_family="", bold=False,
+                 underline=False, italic=False, alignment=-1, alpha=255, rich_text="", _bounding_rect=None,
+                 accumulate_color=True, default_stroke_width=0.2, target_lang="", **kwargs):
+        # attribute creation order = key order of the JSON record (textblock.py:45-86)
         self.xyxy = [int(v) for v in xyxy]
         self.lines = [] if lines is None else lines
-        self.language = language
         self.vertical = vertical
+        self.language = language
         self.font_size = font_size
         self.distance = None if distance is None else np.array(distance, np.float64)
         self.angle = angle
@@ -271,6 +275,23 @@ class TextBlock:
         self.norm = norm
         self.merged = merged
         self.weight = weight
+        self.text = text if text is not None else []              # :58
+        self.prob = 1                                              # :59
+        self.translation = translation                             # :61
+        self.fg_r, self.fg_g, self.fg_b = fg_r, fg_g, fg_b          # :64-66
+        self.bg_r, self.bg_g, self.bg_b = bg_r, bg_g, bg_b          # :67-69
+        self.font_family = font_family                             # :72
+        self.bold = bold
+        self.underline = underline
+        self.italic = italic
+        self.alpha = alpha
+        self.rich_text = rich_text
+        self.line_spacing = line_spacing
+        self._alignment = alignment                                # :80
+        self._target_lang = target_lang
+        self._bounding_rect = _bounding_rect                       # :83
+        self.default_stroke_width = default_stroke_width
+        self.accumulate_color = accumulate_color
 
     def lines_array(self, dtype=np.float64):
         return np.array(self.lines, dtype=dtype)
@@ -298,17 +319,9 @@ class TextBlock:
             lines = np.array(self.lines, dtype=np.int32)
             self.lines = lines[idx].tolist()
 
-    def to_dict(self):
-        d = dict(vars(self))
-        for k in ("distance", "vec"):
-            if d[k] is not None:
-                d[k] = np.asarray(d[k]).tolist()
-        d["xyxy"] = [int(v) for v in self.xyxy]
-        d["lines"] = np.asarray(self.lines).astype(int).tolist() if len(self.lines) else []
-        for k in ("font_size", "norm", "weight", "angle"):
-            d[k] = float(d[k]) if isinstance(d[k], (float, np.floating)) else int(d[k])
-        d["vertical"] = bool(d["vertical"])
-        return d
+    def to_dict(self):                                             # textblock.py:158-160
+        import copy
+        return copy.deepcopy(vars(self))
 
 
 def union_area(bboxa, bboxb):

@@ -2,6 +2,8 @@
 block grouping -> mask refinement) against the oracle's restatement of reference
 inference.py:148-178, (a) on rendered text-like network outputs at 1024x1024 and
 (b) driven by the real HIP forward with seeded random weights at 256x256."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -179,3 +181,31 @@ def test_refine_mask_batch_grouping_is_transparent():
         np.testing.assert_array_equal(a, b_)
         np.testing.assert_array_equal(a, R.refine_mask(pg, m, [R.TextBlock(x.xyxy) for x in bl], 0))
     assert not together[3].any()
+
+
+def test_model2annotations_batch_driver_writes_the_reference_files(tmp_path):
+    """`model2annotations` (batched detect + threaded decode / write) leaves exactly the files the
+    reference's loop writes (inference.py:19-70), with the contents of single-page detector calls."""
+    from PIL import Image
+    p = pkg()
+    ann = p.annotations
+    src, out = tmp_path / "pages", tmp_path / "out"
+    src.mkdir()
+    names = ["p0.png", "p1.PNG", "scan.2.bmp"]
+    for i, nm in enumerate(names):
+        page = p.synth.text_like_page((512 + 64 * i, 448), seed=20 + i, n_blocks=6)
+        Image.fromarray(page[:, :, ::-1]).save(src / nm)
+    (src / "readme.txt").write_text("not an image")
+    ck = checkpoint(0)
+    det = p.detector.TextDetector(ck, input_size=512, device="cuda")
+    n = ann.model2annotations(ck, str(src), str(out), save_json=True, batch_size=2, detector=det)
+    assert n == 3
+    expect = {}
+    for nm in names:
+        img = ann.imread(str(src / nm))
+        mask, refined, blks = det(img, refine_mode=p.textmask.REFINEMASK_ANNOTATION, keep_undetected_mask=True)
+        expect.update(ann.page_files(str(out), nm, img, refined, blks, save_json=True))
+    assert sorted(os.listdir(out)) == sorted(os.path.basename(k) for k in expect)
+    for path, content in expect.items():
+        got = open(path, "rb").read()
+        assert got == (content if isinstance(content, bytes) else content.encode("utf8")), path

@@ -1,11 +1,17 @@
 """TEST INFRASTRUCTURE.  CPU restatement (numpy) of the reference's
 post-processing, written line-by-line against the reference sources.
 
+Pinning: the CONTROL FLOW restated here (`non_max_suppression`, `SegDetectorRepresenter`,
+`group_output`, `refine_mask`, `refine_undetected_mask`) is checked against the reference's OWN
+code, imported from /root/reference and run with functional stand-ins for the missing wheels
+(`ref_post_import.py`; tests/test_reference_pin.py in the build container, golden outputs
+tests/golden/post_seed*.npz + tests/test_oracle_post_golden.py everywhere).
+
 PARITY UNPINNED at the third-party boundary: `torchvision.ops.nms`,
-`cv2.connectedComponentsWithStats` etc. are not installed in the build
-container and the reference ships no tests / golden vectors, so these follow
-the published algorithms of those libraries and are cross-checked against
-scipy.ndimage / brute force only (tests/test_oracle_post.py).
+`cv2.connectedComponentsWithStats`, `findContours`, `minAreaRect`, Clipper offsets etc. are not
+installed in the build container and the reference ships no tests / golden vectors, so those
+primitives (`cv_ref.py` and the helpers below) follow the published algorithms of the libraries
+and are cross-checked against scipy.ndimage / brute force only (tests/test_post_host.py).
 """
 from __future__ import annotations
 

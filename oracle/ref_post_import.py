@@ -1,0 +1,231 @@
+"""TEST INFRASTRUCTURE.  Runs the reference's OWN post-processing code
+(`utils/yolov5_utils.py`, `utils/db_utils.py`, `utils/textblock.py`, `utils/textmask.py` under
+/root/reference, build container only) with FUNCTIONAL stand-ins for the third-party packages that
+are not installed here:
+
+    cv2          -> the OpenCV restatements of oracle/cv_ref.py, behind cv2's call signatures
+    shapely      -> Polygon.area / .length / .intersects from oracle/cv_ref.py
+    pyclipper    -> PyclipperOffset: integer-truncated input, round-join offset of a quad
+    torchvision  -> ops.nms from oracle/postproc_ref.py
+
+What this pins: the oracle's line-by-line restatement of the reference's control flow
+(`non_max_suppression`, `SegDetectorRepresenter`, `group_output`, `refine_mask`,
+`refine_undetected_mask`) against the reference's actual code -- both run on the same primitives,
+so any difference is a restatement error.  What it does NOT pin: the third-party primitives
+themselves (OpenCV rounding, Clipper's integer arcs, ...), which stay restated and unpinned
+(DESIGN.md section 5).  Nothing is copied from the reference; it is imported where it lies.
+"""
+from __future__ import annotations
+
+import sys
+import types
+
+import numpy as np
+
+from . import cv_ref as cv
+from . import postproc_ref as R
+from . import ref_import as RI
+
+
+# ---------------------------------------------------------------------------------- cv2 stand-in
+class _RotatedRect(tuple):
+    """((cx, cy), (w, h), angle) like cv2.minAreaRect, carrying the corner points for boxPoints."""
+    box: np.ndarray
+
+
+_offset_rects: dict = {}     # corners handed out by PyclipperOffset.Execute -> their (box, w, h)
+
+
+def _min_area_rect(points):
+    pts = np.asarray(points).reshape(-1, 2)
+    # The reference feeds Clipper's offset polygon straight into minAreaRect (db_utils.py:153-154).
+    # The stand-in's "polygon" is already that rectangle: hand it back unchanged instead of
+    # re-fitting its own four corners (which re-breaks corner-order ties on 45-degree boxes).
+    hit = _offset_rects.get(pts.astype(np.float64).tobytes()) if len(pts) == 4 else None
+    box, w, h = hit if hit is not None else cv.min_area_box(pts)
+    c = box.astype(np.float64).mean(0)
+    r = _RotatedRect(((float(c[0]), float(c[1])), (w, h), 0.0))
+    r.box = box
+    return r
+
+
+def _structuring_element(shape, ksize, anchor=None):
+    assert tuple(ksize) == (3, 3), "the reference only builds 3x3 elements"
+    return (cv.CROSS3 if shape == _CV.MORPH_ELLIPSE else cv.RECT3).astype(np.uint8)
+
+
+def _kernel(k):
+    k = np.asarray(k)
+    assert k.shape == (3, 3)
+    return k.astype(bool)
+
+
+def _threshold(src, thresh, maxval, typ):
+    if typ & _CV.THRESH_OTSU:
+        return cv.threshold_otsu(src)
+    return thresh, cv.threshold_binary(src, thresh, maxval)
+
+
+def _cvt_color(img, code):
+    if code == _CV.COLOR_BGR2GRAY:
+        return cv.cvt_bgr2gray(img)
+    if code == _CV.COLOR_BGR2RGB:
+        return np.ascontiguousarray(img[..., ::-1])
+    raise NotImplementedError(code)
+
+
+def _fill_poly(img, pts, color):
+    for poly in pts:
+        m = cv.fill_poly(img.shape[:2], np.asarray(poly).reshape(-1, 2))
+        img[m != 0] = color
+    return img
+
+
+def _ccws(img, connectivity=8, ltype=None):
+    n, lab, stats = R.connected_components_with_stats(img, connectivity)
+    return n, lab, stats, np.zeros((n, 2))
+
+
+def _find_contours(img, mode, method):
+    assert mode == _CV.RETR_LIST and method == _CV.CHAIN_APPROX_SIMPLE
+    return tuple(c.reshape(-1, 1, 2).astype(np.int32) for c in cv.find_contours(img)), None
+
+
+def _resize(img, size, interpolation=None):
+    return cv.resize_linear_u8(img, size)
+
+
+def _copy_make_border(im, top, bottom, left, right, border_type, value=0):
+    assert top == 0 and left == 0
+    shape = (im.shape[0] + bottom, im.shape[1] + right) + im.shape[2:]
+    out = np.zeros(shape, im.dtype)
+    out[...] = np.asarray(value, im.dtype) if np.ndim(value) else value
+    out[: im.shape[0], : im.shape[1]] = im
+    return out
+
+
+class _CV:
+    MORPH_RECT, MORPH_ELLIPSE = 0, 2
+    THRESH_BINARY, THRESH_OTSU = 0, 8
+    COLOR_BGR2GRAY, COLOR_BGR2RGB = 6, 4
+    RETR_LIST, CHAIN_APPROX_SIMPLE = 1, 2
+    CV_16U, CV_32S = 2, 4
+    INTER_LINEAR, BORDER_CONSTANT = 1, 0
+
+
+def _make_cv2() -> types.ModuleType:
+    m = types.ModuleType("cv2")
+    for k, v in vars(_CV).items():
+        if not k.startswith("_"):
+            setattr(m, k, v)
+    m.getStructuringElement = _structuring_element
+    m.dilate = lambda img, k, iterations=1: cv.dilate(img, _kernel(k), iterations)
+    m.erode = lambda img, k, iterations=1: cv.erode(img, _kernel(k), iterations)
+    m.bitwise_xor = lambda a, b: np.bitwise_xor(a, b)
+    m.bitwise_or = lambda a, b: np.bitwise_or(a, b)
+    m.bitwise_and = lambda a, b: np.bitwise_and(a, b)
+    m.threshold = _threshold
+    m.cvtColor = _cvt_color
+    m.inRange = lambda img, lo, hi: cv.in_range(img, lo, hi)
+    m.fillPoly = _fill_poly
+    m.connectedComponentsWithStats = _ccws
+    m.findContours = _find_contours
+    m.minAreaRect = _min_area_rect
+    m.boxPoints = lambda rect: rect.box
+    m.mean = lambda values, mask=None: (cv.masked_mean(values, mask), 0.0, 0.0, 0.0)
+    m.resize = _resize
+    m.copyMakeBorder = _copy_make_border
+    m.imshow = lambda *a, **k: None
+    m.setNumThreads = lambda *a, **k: None
+
+    def _other(name):          # constants only used as default arguments of functions that are not called
+        if name.startswith("__"):
+            raise AttributeError(name)
+        return 0
+    m.__getattr__ = _other
+    return m
+
+
+# ------------------------------------------------------------------------------ shapely stand-in
+class Polygon:
+    def __init__(self, pts):
+        self.pts = np.asarray(pts, np.float64).reshape(-1, 2)
+
+    @property
+    def area(self):
+        return cv.polygon_area(self.pts)
+
+    @property
+    def length(self):
+        return cv.polygon_length(self.pts)
+
+    def intersects(self, other):
+        return cv.polygons_intersect(self.pts, other.pts)
+
+
+# ---------------------------------------------------------------------------- pyclipper stand-in
+class PyclipperOffset:
+    """Round-join offset of one closed quad.  pyclipper casts the float corners to integers
+    (truncation); the min-area rectangle of the JT_ROUND offset is the calipers rectangle of that
+    integer quad grown by the distance, so its four corners stand for the offset polygon (the
+    reference only ever passes it to minAreaRect, db_utils.py:153-154)."""
+
+    def AddPath(self, path, join_type, end_type):
+        self.path = np.trunc(np.asarray(path, np.float64)).astype(np.int64)
+
+    def Execute(self, distance):
+        box, w, h = cv.min_area_box(self.path, float(distance))
+        corners = box.astype(np.float64)
+        if len(_offset_rects) > 4096:
+            _offset_rects.clear()
+        _offset_rects[corners.tobytes()] = (box, w, h)
+        return [corners.tolist()]
+
+
+_LOADED = None
+
+
+def load_reference_post():
+    """Returns a namespace with the reference's own functions / classes."""
+    global _LOADED
+    if _LOADED is not None:
+        return _LOADED
+    if not RI.reference_available():
+        raise RuntimeError("reference tree not present (build container only)")
+    import torch
+    RI._install_stubs()
+    saved = {k: sys.modules.get(k) for k in ("cv2", "shapely", "shapely.geometry", "pyclipper", "torchvision",
+                                             "torchvision.ops")}
+    sys.modules["cv2"] = _make_cv2()
+    sh, shg = types.ModuleType("shapely"), types.ModuleType("shapely.geometry")
+    shg.Polygon = Polygon
+    sh.geometry = shg
+    sys.modules["shapely"], sys.modules["shapely.geometry"] = sh, shg
+    pc = types.ModuleType("pyclipper")
+    pc.PyclipperOffset, pc.JT_ROUND, pc.ET_CLOSEDPOLYGON = PyclipperOffset, 1, 0
+    sys.modules["pyclipper"] = pc
+    tv, tvo = types.ModuleType("torchvision"), types.ModuleType("torchvision.ops")
+    tvo.nms = lambda boxes, scores, iou: torch.from_numpy(
+        R.torchvision_nms(boxes.cpu().numpy(), scores.cpu().numpy(), float(iou)).astype(np.int64))
+    tv.ops = tvo
+    sys.modules["torchvision"], sys.modules["torchvision.ops"] = tv, tvo
+    shadow = {k: sys.modules.pop(k) for k in list(sys.modules) if k in ("utils", "models") or
+              k.startswith(("utils.", "models."))}
+    sys.path.insert(0, RI.REFERENCE_ROOT)
+    try:
+        import utils.db_utils as DB
+        import utils.textblock as TB
+        import utils.textmask as TM
+        import utils.yolov5_utils as YU
+    finally:
+        sys.path.remove(RI.REFERENCE_ROOT)
+        for k in [k for k in sys.modules if k in ("utils", "models") or k.startswith(("utils.", "models."))]:
+            del sys.modules[k]
+        sys.modules.update(shadow)
+        for k, v in saved.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
+    _LOADED = types.SimpleNamespace(DB=DB, TB=TB, TM=TM, YU=YU)
+    return _LOADED

@@ -41,7 +41,16 @@ def main():
         rng = np.random.RandomState(100 + seed)
         yolo = random_blks(rng, 1, 2016, frac=0.1, size=512)
         nms = ref.YU.non_max_suppression(torch.from_numpy(yolo), 0.4, 0.35)[0].numpy()
+        # the whole TextDetector.__call__ on a page that needs a letterbox (network outputs fixed)
+        from test_reference_pin import letterboxed_case
+        lpage, lblks, lmask, llines, (dw, dh) = letterboxed_case(seed)
+        det = RP.reference_detector(ref, (torch.from_numpy(lblks.copy()), torch.from_numpy(lmask.copy()),
+                                          torch.from_numpy(llines.copy())), input_size=(512, 512))
+        dm, dr, db = det(lpage.copy(), refine_mode=seed % 2, keep_undetected_mask=bool(seed % 2))
+        det_records = json.dumps([b.to_dict() for b in db], ensure_ascii=False, cls=A.NumpyEncoder)
         np.savez_compressed(os.path.join(out_dir, f"post_seed{seed}.npz"), boxes=boxes[0], scores=scores[0],
+                            det_mask=dm, det_refined=np.packbits(dr > 0), det_dwdh=np.array([dw, dh]),
+                            det_records=np.frombuffer(det_records.encode("utf8"), np.uint8),
                             records=np.frombuffer(records.encode("utf8"), np.uint8),
                             refined_inpaint=np.packbits(refined[0] > 0), refined_annot=np.packbits(refined[1] > 0),
                             undetected=np.packbits(und > 0), mask_after_undetected=m2, nms=nms)

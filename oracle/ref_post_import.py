@@ -182,6 +182,21 @@ class PyclipperOffset:
         return [corners.tolist()]
 
 
+def reference_detector(ns, net_outputs, input_size=(1024, 1024)):
+    """The reference's `TextDetector` object without its constructor (which loads a checkpoint):
+    `net` returns the given (blks, mask, lines_map) torch tensors, everything else is the
+    reference's own `__call__` (inference.py:141-178)."""
+    det = ns.INF.TextDetector.__new__(ns.INF.TextDetector)
+    det.net = lambda img_in: net_outputs
+    det.backend = "torch"
+    det.input_size = input_size
+    det.device = "cpu"
+    det.half = False
+    det.conf_thresh, det.nms_thresh = 0.4, 0.35
+    det.seg_rep = ns.DB.SegDetectorRepresenter(thresh=0.3)
+    return det
+
+
 _LOADED = None
 
 
@@ -209,17 +224,24 @@ def load_reference_post():
         R.torchvision_nms(boxes.cpu().numpy(), scores.cpu().numpy(), float(iou)).astype(np.int64))
     tv.ops = tvo
     sys.modules["torchvision"], sys.modules["torchvision.ops"] = tv, tvo
-    shadow = {k: sys.modules.pop(k) for k in list(sys.modules) if k in ("utils", "models") or
-              k.startswith(("utils.", "models."))}
+    ours = ("utils", "models", "basemodel", "inference")
+    shadow = {k: sys.modules.pop(k) for k in list(sys.modules) if k in ours or k.startswith(("utils.", "models."))}
     sys.path.insert(0, RI.REFERENCE_ROOT)
+    # utils/io_utils.py:11-13 names aliases NumPy 2 removed; lend them for the import only
+    lent = [k for k in ("bool8", "float_") if not hasattr(np, k)]
+    for k in lent:
+        setattr(np, k, {"bool8": np.bool_, "float_": np.float64}[k])
     try:
         import utils.db_utils as DB
         import utils.textblock as TB
         import utils.textmask as TM
         import utils.yolov5_utils as YU
+        import inference as INF            # TextDetector.__call__, preprocess_img, postprocess_* (inference.py:72-178)
     finally:
+        for k in lent:
+            delattr(np, k)
         sys.path.remove(RI.REFERENCE_ROOT)
-        for k in [k for k in sys.modules if k in ("utils", "models") or k.startswith(("utils.", "models."))]:
+        for k in [k for k in sys.modules if k in ours or k.startswith(("utils.", "models."))]:
             del sys.modules[k]
         sys.modules.update(shadow)
         for k, v in saved.items():
@@ -227,5 +249,5 @@ def load_reference_post():
                 sys.modules.pop(k, None)
             else:
                 sys.modules[k] = v
-    _LOADED = types.SimpleNamespace(DB=DB, TB=TB, TM=TM, YU=YU)
+    _LOADED = types.SimpleNamespace(DB=DB, TB=TB, TM=TM, YU=YU, INF=INF)
     return _LOADED

@@ -39,3 +39,18 @@ def test_oracle_equals_reference_code_golden(seed):
     np.testing.assert_array_equal(m2, g["mask_after_undetected"])
     yolo = random_blks(np.random.RandomState(100 + seed), 1, 2016, frac=0.1, size=512)
     np.testing.assert_array_equal(R.non_max_suppression(yolo, 0.4, 0.35)[0], g["nms"])
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_oracle_detector_tail_equals_reference_call_golden(seed):
+    """`R.detector_tail` vs the reference's `TextDetector.__call__` (fixed network outputs) on a page
+    that needs a letterbox, mask crop and resize back to the page."""
+    from test_reference_pin import letterboxed_case
+    g = np.load(os.path.join(GOLD, f"post_seed{seed}.npz"))
+    page, blks, mask, lines_map, (dw, dh) = letterboxed_case(seed)
+    assert [dw, dh] == g["det_dwdh"].tolist()
+    m, r, b = R.detector_tail(page, blks, mask, lines_map, input_size=(512, 512), dw=dw, dh=dh,
+                              refine_mode=seed % 2, keep_undetected_mask=bool(seed % 2))
+    np.testing.assert_array_equal(m, g["det_mask"])
+    np.testing.assert_array_equal(np.packbits(r > 0), g["det_refined"])
+    assert json.dumps([x.to_dict() for x in b], ensure_ascii=False, cls=A.NumpyEncoder) == bytes(g["det_records"]).decode("utf8")

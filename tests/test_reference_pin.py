@@ -90,3 +90,48 @@ def test_speckle_bitmaps_equal_reference_code(ref):
         ob, os_ = R.seg_rep((H, W), pred.copy(), 0.3)
         np.testing.assert_array_equal(ob[0], tb[0])
         np.testing.assert_array_equal(os_[0], ts[0])
+
+
+def letterboxed_case(seed, im_hw=(420, 300), size=512):
+    """A page of another aspect ratio + network outputs that are consistent with its letterbox."""
+    from oracle import cv_ref as cv
+    from test_gpu_e2e import blks_tensor
+    page512, mask_u8, prob, blks = fake_outputs(seed, size)
+    im_h, im_w = im_hw
+    r = min(size / im_h, size / im_w)
+    nw, nh = int(round(im_w * r)), int(round(im_h * r))
+    page = cv.resize_linear_u8(np.ascontiguousarray(page512[:nh, :nw]), (im_w, im_h))
+    mask = mask_u8.astype(np.float32) / 255
+    mask[nh:], mask[:, nw:] = 0, 0
+    prob = prob.copy()
+    prob[nh:], prob[:, nw:] = 0.01, 0.01
+    keep = (blks[0][:, 2] <= nw) & (blks[0][:, 3] <= nh)
+    blks = tuple(b[keep] for b in blks)
+    return page, blks_tensor(blks), mask[None, None], np.stack([prob, np.zeros_like(prob)])[None], (size - nw, size - nh)
+
+
+@pytest.mark.parametrize("seed,keep", [(0, False), (1, True)])
+def test_whole_detector_call_equals_reference_code(ref, seed, keep):
+    """`TextDetector.__call__` of the reference (inference.py:141-178: preprocess_img + letterbox,
+    postprocess_yolo / postprocess_mask, crop + resize back, group_output, refine_mask, ...) on a
+    page that needs a real letterbox, with the network replaced by fixed outputs."""
+    from oracle import ref_post_import as RP
+    page, blks, mask, lines_map, (dw, dh) = letterboxed_case(seed)
+    det = RP.reference_detector(ref, (torch.from_numpy(blks.copy()), torch.from_numpy(mask.copy()),
+                                      torch.from_numpy(lines_map.copy())), input_size=(512, 512))
+    mode = 1 if keep else 0
+    tm, tr, tb = det(page.copy(), refine_mode=mode, keep_undetected_mask=keep)
+    # the letterbox geometry the reference derived is the one the outputs were built for
+    img_in, ratio, rdw, rdh = ref.INF.preprocess_img(page.copy(), input_size=(512, 512), device="cpu")
+    assert (rdw, rdh) == (dw, dh) and tuple(img_in.shape) == (1, 3, 512, 512)
+    om, orf, ob = R.detector_tail(page.copy(), blks.copy(), mask.copy(), lines_map.copy(), input_size=(512, 512),
+                                  dw=dw, dh=dh, refine_mode=mode, keep_undetected_mask=keep)
+    np.testing.assert_array_equal(om, tm)
+    np.testing.assert_array_equal(orf, tr)
+    same_blocks(ob, tb)
+    assert len(tb) > 0 and tr.any()
+    # preprocess_img itself: the oracle's letterbox + channel handling (App. C-1: the net sees BGR)
+    from oracle import cv_ref as cv
+    lb, _, (odw, odh) = cv.letterbox(page, (512, 512))
+    assert (odw, odh) == (dw, dh)
+    np.testing.assert_array_equal(img_in[0].numpy(), lb.transpose(2, 0, 1).astype(np.float32) / 255)

@@ -79,6 +79,32 @@ def cpu_baseline(pkg, ckpt, size: int, budget_s: float = 12.0, max_pages: int = 
                       f"{cores} threads"}
 
 
+def parity_sample(pkg, ckpt, be, page: torch.Tensor) -> dict:
+    """The second half of BASELINE's metric ("mask IoU vs ref") on ONE page of the benchmark input:
+    the HIP engine (as benchmarked) against the oracle forward (CPU fp32, bit-exact with the
+    reference's torch modules).  Seeded random weights put large parts of both maps near their
+    thresholds, so these IoUs are a worst case; the tolerance-level parity is in tests/."""
+    from oracle.net_ref import OracleNet
+    x = page[None].float().cpu() if page.dtype != torch.uint8 else (page[None].permute(0, 3, 1, 2).float() / 255).cpu()
+    _, om, ol = OracleNet(ckpt)(x)
+    blks, mask, lines = be(x.to(be.device))
+    torch.cuda.synchronize()
+    mask, lines = mask.cpu(), lines.cpu()
+    ou8, gu8 = (om[0, 0] * 255).to(torch.uint8), be.mask_u8[0].cpu()          # postprocess_mask: truncation
+    ob, gb = ol[0, 0] > 0.3, be.bitmap[0].cpu().bool()
+
+    def iou(a, b):
+        u = (a | b).sum().item()
+        return round((a & b).sum().item() / u, 6) if u else 1.0
+    return {"page": "first page of the benchmark batch, oracle = CPU fp32 restatement of the reference net",
+            "mask_abs_err_max": round(float((mask - om).abs().max()), 6),
+            "lines_abs_err_max": round(float((lines - ol).abs().max()), 6),
+            "mask_u8_differs_frac": round(float((ou8 != gu8).float().mean()), 6),
+            "mask_u8_max_level_diff": int((ou8.int() - gu8.int()).abs().max()),
+            "mask_iou_at_127": iou(ou8 > 127, gu8 > 127),
+            "line_bitmap_iou_at_0.3": iou(ob, gb)}
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -229,9 +255,13 @@ def main() -> None:
                     t = max(ms[i], 1e-6) * 1e-3
                     f.write(f"{nm}\t{cls[i]}\t{ms[i]:.4f}\t{fl[i] / 1e9:.3f}\t{by[i] / 1e6:.2f}\t"
                             f"{fl[i] / t / 1e12:.1f}\t{by[i] / t / 1e9:.1f}\n")
-        cpu = None
+        cpu = parity = None
         if not args.no_cpu_baseline and n_gpus == 1:
             cpu = cpu_baseline(pkg, ckpt, S)
+            try:
+                parity = parity_sample(pkg, ckpt, be, inp[0])
+            except Exception as e:                      # never lose the bench line to the extra check
+                parity = {"error": repr(e)}
         out = {
             "metric": "pages/sec at 1024x1024 bs=32",
             "value": round(total_pages * args.steps / dt, 2),
@@ -254,6 +284,7 @@ def main() -> None:
                                                                    f"collective except the final record gather)"},
             "roofline": roof,
             "cpu_baseline": cpu,
+            "parity": parity,
         }
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -202,3 +202,51 @@ def test_oracle_contours_and_cc_against_scipy():
     filled = sorted(int(cv.fill_poly(img.shape, c).sum()) for c in contours)
     for s in sizes:
         assert s in filled
+
+
+def _db_single_component(pts_mask, prob_val=0.9):
+    """Runs `ctd_db_boxes` on a bitmap given as a boolean array; returns (boxes, scores)."""
+    p = pkg()
+    H, W = pts_mask.shape
+    prob = np.where(pts_mask, prob_val, 0.05).astype(np.float32)
+    nf, lab_f, st_f = R.connected_components_with_stats(pts_mask.astype(np.uint8), 8)
+    nb, lab_b, st_b = R.connected_components_with_stats((~pts_mask).astype(np.uint8), 4)
+    return p.postproc.SegRepresenter()._page(prob, lab_f, st_f[1:], lab_b, st_b[1:], W, H)
+
+
+def test_db_boxes_geometric_invariants_on_random_blobs():
+    """Properties that hold whatever OpenCV's exact rounding is: the unclipped box of a solid
+    convex blob contains the blob, its area exceeds the blob's, it stays inside the map, and the
+    transposed blob gives a box of (nearly) the same area."""
+    rng = np.random.RandomState(5)
+    for _ in range(25):
+        H, W = 80, 96
+        m = np.zeros((H, W), bool)
+        cy, cx = rng.randint(20, H - 20), rng.randint(20, W - 20)
+        ry, rx = rng.randint(3, 12), rng.randint(3, 14)
+        yy, xx = np.mgrid[:H, :W]
+        ang = rng.uniform(0, np.pi)
+        u = (xx - cx) * np.cos(ang) + (yy - cy) * np.sin(ang)
+        v = -(xx - cx) * np.sin(ang) + (yy - cy) * np.cos(ang)
+        m[(u / rx) ** 2 + (v / ry) ** 2 <= 1] = True
+        boxes, scores = _db_single_component(m)
+        assert len(boxes) == 1 and scores[0] == pytest.approx(0.9, abs=1e-6)
+        box = boxes[0].astype(np.float64)
+        assert (box >= 0).all() and (box[:, 0] <= W).all() and (box[:, 1] <= H).all()
+        # every blob pixel lies inside the quad (cross products of a consistently oriented quad)
+        ys, xs = np.nonzero(m)
+        pts = np.stack([xs, ys], 1).astype(np.float64)
+        e = np.roll(box, -1, axis=0) - box
+        cr = e[:, None, 0] * (pts[None, :, 1] - box[:, None, 1]) - e[:, None, 1] * (pts[None, :, 0] - box[:, None, 0])
+        clipped = (box == 0).any() or (box[:, 0] == W).any() or (box[:, 1] == H).any()
+        if not clipped:
+            assert (cr >= -1e-9).all() or (cr <= 1e-9).all()
+        area = 0.5 * abs(np.dot(box[:, 0], np.roll(box[:, 1], -1)) - np.dot(box[:, 1], np.roll(box[:, 0], -1)))
+        assert area >= m.sum() or clipped
+        # the transposed bitmap gives a box of the same area up to rounding (the rectangle itself may
+        # differ: equal-area candidates are tie-broken in hull order, as in OpenCV)
+        tb, _ = _db_single_component(np.ascontiguousarray(m.T))
+        t = tb[0].astype(np.float64)
+        tarea = 0.5 * abs(np.dot(t[:, 0], np.roll(t[:, 1], -1)) - np.dot(t[:, 1], np.roll(t[:, 0], -1)))
+        if not clipped:
+            assert abs(tarea - area) <= 0.15 * area + 8

@@ -264,7 +264,8 @@ int ctd_win_dilate(const ctd_window* wins, int32_t n, const int32_t* mtops, cons
                    int32_t dilate, void* stream);
 
 /* page[y1:y1+h, x1:x1+w] |= merged band of every window (textmask.py:167); page_dev must be 4-byte
- * aligned (word-wide atomic OR: windows may overlap). */
+ * aligned and its allocation a multiple of 4 bytes (word-wide atomic OR: windows may overlap; the
+ * word holding the last pixels may reach up to 3 bytes past H*W). */
 int ctd_win_commit(const ctd_window* wins, int32_t n, const int32_t* mtops, const uint8_t* merged_dev,
                    int32_t merged_w, uint8_t* page_dev, int32_t page_w, void* stream);
 

@@ -178,8 +178,10 @@ static void run_case(const Case& cs, int B, bool timing) {
   // ST_ABL=1 appends ablations of the default kernel (wrong results by construction, timing only)
   // rot: 0 = default dispatch (halo kernel where it applies), 2 = implicit-GEMM kernel only, 1 = register staged
   const Var vars[] = {{"default", 32, 1, 0, 0}, {"igemm", 32, 1, 2, 0}, {"bk32/reg", 32, 1, 1, 0}, {"bk64/glds", 64, 1, 2, 0},
-                      {"noload", 32, 1, 0, 1}, {"nomfma", 32, 1, 0, 2}, {"nostore", 32, 1, 0, 4},
-                      {"loadonly", 32, 1, 0, 6}, {"mfmaonly", 32, 1, 0, 5}, {"phasemajor", 32, 1, 0, 8}, {"nofastpath", 32, 1, 0, 32}, {"noWloads", 32, 1, 0, 64}, {"noAloads", 32, 1, 0, 128}};
+                      // ablations of the implicit-GEMM kernel (rot 2 keeps the halo kernel out of the way)
+                      {"noload", 32, 1, 2, 1}, {"nomfma", 32, 1, 2, 2}, {"nostore", 32, 1, 2, 4},
+                      {"loadonly", 32, 1, 2, 6}, {"mfmaonly", 32, 1, 2, 5}, {"phasemajor", 32, 1, 2, 8},
+                      {"nofastpath", 32, 1, 2, 32}, {"noWloads", 32, 1, 2, 64}, {"noAloads", 32, 1, 2, 128}};
 
   const char* vsel = std::getenv("ST_VAR");   // ST_VAR=1: only variant index 1
   for (const Var& v : vars) {

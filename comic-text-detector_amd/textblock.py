@@ -190,12 +190,23 @@ def merge_textlines(blks: List[TextBlock]) -> List[TextBlock]:
     return out
 
 
+def _clone_without_lines(blk: TextBlock) -> TextBlock:
+    """`copy.deepcopy(blk)` followed by `.lines = [...]` (textblock.py:395-396,409-410) without
+    deep-copying the line list that is thrown away: every other mutable attribute gets its own copy."""
+    new = copy.copy(blk)
+    for k, v in vars(blk).items():
+        if k != "lines" and isinstance(v, (list, dict, np.ndarray)):
+            setattr(new, k, copy.deepcopy(v))
+    new.lines = []
+    return new
+
+
 def split_textblk(blk: TextBlock):
     """Split a vertical / Japanese block at line gaps (textblock.py:390-419)."""
     font, dist, lines = blk.font_size, blk.distance, blk.lines
     first = np.array(lines[0])
     lines.sort(key=lambda q: np.linalg.norm(np.array(q[0]) - first[0]))
-    cur = copy.deepcopy(blk)
+    cur = _clone_without_lines(blk)
     cur.lines = [first]
     parts = [cur]
     for j, line in enumerate(lines[1:]):
@@ -208,7 +219,7 @@ def split_textblk(blk: TextBlock):
                 if len(cur.lines) > 1 or gap > font:
                     split = abs(lines[j][0][1] - line[0][1]) > font
         if split:
-            cur = copy.deepcopy(cur)
+            cur = _clone_without_lines(cur)
             cur.lines = [line]
             parts.append(cur)
         else:

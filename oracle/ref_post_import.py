@@ -249,5 +249,18 @@ def load_reference_post():
                 sys.modules.pop(k, None)
             else:
                 sys.modules[k] = v
+    # `get_topk_color` orders the histogram bins with np.argsort's default (unstable) sort
+    # (textmask.py:17): the order of bins with EQUAL counts is implementation-defined (NumPy
+    # version, SIMD sort dispatch), SURVEY App. C-11.  The restatement and the product use a stable
+    # sort; give the reference's module the same tie order so everything else can be compared.
+    class _StableArgsortNumpy(types.ModuleType):
+        def __getattr__(self, name):
+            return getattr(np, name)
+
+        @staticmethod
+        def argsort(a, *args, **kw):
+            kw.setdefault("kind", "stable")
+            return np.argsort(a, *args, **kw)
+    TM.np = _StableArgsortNumpy("numpy")
     _LOADED = types.SimpleNamespace(DB=DB, TB=TB, TM=TM, YU=YU, INF=INF)
     return _LOADED

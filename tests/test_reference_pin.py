@@ -135,3 +135,35 @@ def test_whole_detector_call_equals_reference_code(ref, seed, keep):
     lb, _, (odw, odh) = cv.letterbox(page, (512, 512))
     assert (odw, odh) == (dw, dh)
     np.testing.assert_array_equal(img_in[0].numpy(), lb.transpose(2, 0, 1).astype(np.float32) / 255)
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_refine_mask_adversarial_windows_equal_reference_code(ref, seed):
+    """The scenario of tests/test_gpu_e2e.py::test_refine_mask_gpu_merge_stage_on_adversarial_windows
+    (noisy colours, blob masks, overlapping / border / thin blocks): oracle vs the reference's code,
+    so the GPU merge stage is compared with something that is itself pinned."""
+    rng = np.random.RandomState(seed)
+    H, W = 384, 512
+    page = rng.randint(0, 256, (H, W, 3)).astype(np.uint8)
+    page[:, : W // 2] = (page[:, : W // 2] // 64) * 64
+    mask = np.zeros((H, W), np.uint8)
+    for _ in range(60):
+        y, x = rng.randint(0, H), rng.randint(0, W)
+        hh, ww = rng.randint(2, 40), rng.randint(2, 60)
+        mask[y: y + hh, x: x + ww] = rng.randint(40, 256)
+    boxes = [[0, 0, 90, 70], [60, 40, 220, 160], [200, 100, 330, 230], [W - 120, H - 90, W, H],
+             [10, 300, 400, 306], [430, 5, 436, 200], [100, 100, 180, 150]]
+    for _ in range(5):
+        x1, y1 = rng.randint(0, W - 40), rng.randint(0, H - 40)
+        boxes.append([x1, y1, min(W, x1 + rng.randint(12, 200)), min(H, y1 + rng.randint(12, 150))])
+    ours = [R.TextBlock(b) for b in boxes]
+    theirs = [ref.TB.TextBlock(b) for b in boxes]
+    for mode in (0, 1):
+        np.testing.assert_array_equal(R.refine_mask(page, mask, ours, mode),
+                                      ref.TM.refine_mask(page, mask, theirs, refine_mode=mode))
+    m1, m2 = mask.copy(), mask.copy()
+    a = R.refine_undetected_mask(page, m1, R.refine_mask(page, mask, ours[:4], 0), ours[:4], 0)
+    b = ref.TM.refine_undetected_mask(page, m2, ref.TM.refine_mask(page, mask, theirs[:4], refine_mode=0), theirs[:4],
+                                      refine_mode=0)
+    np.testing.assert_array_equal(a, b)
+    np.testing.assert_array_equal(m1, m2)

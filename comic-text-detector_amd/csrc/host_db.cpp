@@ -147,6 +147,82 @@ double pairwise(const double* a, size_t n) {
   return pairwise(a, n2) + pairwise(a + n2, n - n2);
 }
 
+// `pyclipper.PyclipperOffset().AddPath(quad, JT_ROUND, ET_CLOSEDPOLYGON); Execute(delta)` for one convex
+// closed polygon and delta > 0 as Clipper 6.4.2 (the library pyclipper wraps) builds it: duplicate
+// stripping of `ClipperOffset::AddPath`, `FixOrientations`, the step count of `DoOffset` from the arc
+// tolerance (0.25), per-vertex `OffsetPoint` -> `DoRound`, every point rounded to the integer grid.
+// The closing `Clipper::Execute(ctUnion, pftPositive)` leaves the ring of a convex input as it is
+// (up to its start vertex and collinear points, irrelevant to the min-area rectangle taken next).
+inline long long clip_round(double v) { return v < 0 ? (long long)(v - 0.5) : (long long)(v + 0.5); }
+
+void clipper_offset_round(const long long (*in)[2], int n_in, double delta, std::vector<P>& out) {
+  out.clear();
+  long long poly[8][2];
+  int hi = n_in - 1;
+  while (hi > 0 && in[0][0] == in[hi][0] && in[0][1] == in[hi][1]) --hi;
+  int n = 0;
+  for (int i = 0; i <= hi && n < 8; ++i)
+    if (n == 0 || poly[n - 1][0] != in[i][0] || poly[n - 1][1] != in[i][1]) poly[n][0] = in[i][0], poly[n][1] = in[i][1], ++n;
+  if (n < 3) return;
+  double a = 0;
+  for (int i = 0, j = n - 1; i < n; j = i++) a += ((double)poly[j][0] + poly[i][0]) * ((double)poly[j][1] - poly[i][1]);
+  if (-a * 0.5 < 0)   // FixOrientations
+    for (int i = 0; i < n / 2; ++i) std::swap(poly[i][0], poly[n - 1 - i][0]), std::swap(poly[i][1], poly[n - 1 - i][1]);
+  const double kPi = 3.141592653589793238, kTwoPi = kPi * 2;
+  const double arc_tol = 0.25;
+  const double y = arc_tol > std::fabs(delta) * 0.25 ? std::fabs(delta) * 0.25 : arc_tol;
+  double steps = kPi / std::acos(1 - y / std::fabs(delta));
+  if (steps > std::fabs(delta) * kPi) steps = std::fabs(delta) * kPi;
+  double m_sin = std::sin(kTwoPi / steps);
+  const double m_cos = std::cos(kTwoPi / steps);
+  const double steps_per_rad = steps / kTwoPi;
+  if (delta < 0) m_sin = -m_sin;
+  double nx[8], ny[8];
+  for (int i = 0; i < n; ++i) {
+    const int k = (i + 1) % n;
+    double dx = (double)(poly[k][0] - poly[i][0]), dy = (double)(poly[k][1] - poly[i][1]);
+    const double f = 1.0 / std::sqrt(dx * dx + dy * dy);
+    dx *= f;
+    dy *= f;
+    nx[i] = dy, ny[i] = -dx;
+  }
+  auto emit = [&](int j, double X, double Y) {
+    out.push_back({(double)clip_round(poly[j][0] + X * delta), (double)clip_round(poly[j][1] + Y * delta)});
+  };
+  int k = n - 1;
+  for (int j = 0; j < n; ++j) {
+    double sin_a = nx[k] * ny[j] - nx[j] * ny[k];
+    bool done = false;
+    if (std::fabs(sin_a * delta) < 1.0) {
+      const double cos_a = nx[k] * nx[j] + ny[j] * ny[k];
+      if (cos_a > 0) {
+        emit(j, nx[k], ny[k]);
+        done = true;
+      }
+    } else if (sin_a > 1.0) sin_a = 1.0;
+    else if (sin_a < -1.0) sin_a = -1.0;
+    if (!done) {
+      if (sin_a * delta < 0) {
+        emit(j, nx[k], ny[k]);
+        out.push_back({(double)poly[j][0], (double)poly[j][1]});
+        emit(j, nx[j], ny[j]);
+      } else {   // DoRound
+        const double ang = std::atan2(sin_a, nx[k] * nx[j] + ny[k] * ny[j]);
+        const int nst = std::max((int)clip_round(steps_per_rad * std::fabs(ang)), 1);
+        double X = nx[k], Y = ny[k];
+        for (int i = 0; i < nst; ++i) {
+          emit(j, X, Y);
+          const double X2 = X;
+          X = X * m_cos - m_sin * Y;
+          Y = X2 * m_sin + Y * m_cos;
+        }
+        emit(j, nx[j], ny[j]);
+      }
+    }
+    k = j;
+  }
+}
+
 struct Item {
   long long key;
   int kind, label;
@@ -192,6 +268,36 @@ void filled_values(std::vector<uint8_t>& m, int rh, int rw, bool hole_border, co
     const uint8_t* mr = m.data() + (size_t)y * rw;
     for (int x = 0; x < rw; ++x)
       if (!(mr[x] & 4) || (mr[x] & 3) == 3) vals.push_back((double)pr[x]);
+  }
+}
+
+// unclip (db_utils.py:168-174) + get_mini_boxes (:154) + the rescale / clip of :158-163 for one
+// ordered mini box: distance = area * ratio / perimeter (shapely, float64 on the float32 corners),
+// pyclipper truncates the corners to integers, Clipper's round-join ring, its min-area rectangle.
+void unclip_to_box(const Pf box[4], double unclip_ratio, int W, int H, int16_t* out8, std::vector<P>& pts,
+                   std::vector<P>& h, std::vector<P>& tmp) {
+  const double bx[4] = {box[0].x, box[1].x, box[2].x, box[3].x}, by[4] = {box[0].y, box[1].y, box[2].y, box[3].y};
+  const double s1 = ((bx[0] * by[1] + bx[1] * by[2]) + bx[2] * by[3]) + bx[3] * by[0];
+  const double s2 = ((by[0] * bx[1] + by[1] * bx[2]) + by[2] * bx[3]) + by[3] * bx[0];
+  const double area = std::fabs(s1 - s2) * 0.5;
+  double perim = 0;
+  for (int k = 0; k < 4; ++k) perim += std::hypot(bx[(k + 1) & 3] - bx[k], by[(k + 1) & 3] - by[k]);
+  const double dist = area * unclip_ratio / perim;
+  long long q[4][2];
+  for (int k = 0; k < 4; ++k) q[k][0] = (long long)std::trunc(bx[k]), q[k][1] = (long long)std::trunc(by[k]);
+  clipper_offset_round(q, 4, dist, pts);
+  hull(pts, h, tmp);
+  Pf ub[4];
+  double bw, bh;
+  min_area_box(h, 0.0, ub, bw, bh);
+  order_box(ub);
+  for (int k = 0; k < 4; ++k) {
+    // dest size == bitmap size (reference inference.py:158): x / W * W in float32, round half even
+    float fx = nearbyintf(ub[k].x / (float)W * (float)W), fy = nearbyintf(ub[k].y / (float)H * (float)H);
+    fx = std::min(std::max(fx, 0.0f), (float)W);
+    fy = std::min(std::max(fy, 0.0f), (float)H);
+    out8[2 * k] = (int16_t)fx;
+    out8[2 * k + 1] = (int16_t)fy;
   }
 }
 
@@ -301,29 +407,7 @@ extern "C" int ctd_db_boxes(const float* prob, const int32_t* lab_f, const int32
       sum = i == 0 ? s : sum + s;
     }
     scores[idx] = (float)(sum / (double)vals.size());
-    // unclip (db_utils.py:168-174) + get_mini_boxes (:154): pyclipper truncates the corners to
-    // integers; the round-join offset's min-area rectangle = calipers rectangle + distance
-    const double bx[4] = {box[0].x, box[1].x, box[2].x, box[3].x}, by[4] = {box[0].y, box[1].y, box[2].y, box[3].y};
-    const double s1 = ((bx[0] * by[1] + bx[1] * by[2]) + bx[2] * by[3]) + bx[3] * by[0];
-    const double s2 = ((by[0] * bx[1] + by[1] * bx[2]) + by[2] * bx[3]) + by[3] * bx[0];
-    const double area = std::fabs(s1 - s2) * 0.5;
-    double perim = 0;
-    for (int k = 0; k < 4; ++k) perim += std::hypot(bx[(k + 1) & 3] - bx[k], by[(k + 1) & 3] - by[k]);
-    const double dist = area * unclip_ratio / perim;
-    pts.clear();
-    for (int k = 0; k < 4; ++k) pts.push_back({std::trunc(bx[k]), std::trunc(by[k])});
-    hull(pts, h, tmp);
-    Pf ub[4];
-    min_area_box(h, dist, ub, bw, bh);
-    order_box(ub);
-    for (int k = 0; k < 4; ++k) {
-      // dest size == bitmap size (reference inference.py:158): x / W * W in float32, round half even
-      float fx = nearbyintf(ub[k].x / (float)W * (float)W), fy = nearbyintf(ub[k].y / (float)H * (float)H);
-      fx = std::min(std::max(fx, 0.0f), (float)W);
-      fy = std::min(std::max(fy, 0.0f), (float)H);
-      boxes[(size_t)idx * 8 + 2 * k] = (int16_t)fx;
-      boxes[(size_t)idx * 8 + 2 * k + 1] = (int16_t)fy;
-    }
+    unclip_to_box(box, unclip_ratio, W, H, boxes + (size_t)idx * 8, pts, h, tmp);
   }
   return CTD_OK;
 }

@@ -2,7 +2,7 @@
 // SURVEY K14): every text-block window of a page batch is one entry of a window table; a
 // launch covers all windows (blockIdx.y = window).  Integer / comparison work on u8 pixels.
 //
-//   win_hist   : grey = BGR2GRAY (fixed point), msk eroded 3x3 (rect) inside the window;
+//   win_hist   : grey = BGR2GRAY (15-bit fixed point), msk eroded 3x3 (rect) inside the window;
 //                histograms: grey over pixels with eroded mask > 127 (textmask.py:60-61), and
 //                B, G, R over the whole window (Otsu, textmask.py:44-47)
 //   win_xor    : for up to 6 candidate rules per window (3 grey ranges, 3 channel thresholds)
@@ -15,7 +15,8 @@
 namespace {
 
 __device__ __forceinline__ int gray_of(const uint8_t* p) {
-  return ((int)p[0] * 1868 + (int)p[1] * 9617 + (int)p[2] * 4899 + 8192) >> 14;
+  // OpenCV 4.x RGB2Gray<uchar>: 15-bit coefficients (BY15, GY15, RY15), round to nearest
+  return ((int)p[0] * 3735 + (int)p[1] * 19235 + (int)p[2] * 9798 + 16384) >> 15;
 }
 
 __device__ __forceinline__ int erode_rect(const CtdWin& w, int x, int y) {
@@ -53,8 +54,8 @@ __global__ __launch_bounds__(256) void win_hist_kernel(const CtdWin* __restrict_
 }
 
 __device__ __forceinline__ bool rule_on(const CtdRule& r, const uint8_t* p) {
-  if (r.kind == 0) {                      // cv2.inRange(grey, lo, hi) with real-valued bounds
-    const float g = (float)gray_of(p);
+  if (r.kind == 0) {                      // cv2.inRange(grey, lo, hi): lo / hi are the integer bounds
+    const float g = (float)gray_of(p);   // cv2 derives from the scalars (cvRound, saturated; lo > hi = empty)
     return g >= r.lo && g <= r.hi;
   }
   return (float)p[r.kind - 1] > r.lo;      // threshold(channel, t, 255, BINARY): kind 1..3 = B,G,R

@@ -60,9 +60,18 @@ def _morph(img: np.ndarray, offsets, erode: bool) -> np.ndarray:
 
 
 def bgr2gray(img: np.ndarray) -> np.ndarray:
-    """cv2.cvtColor(BGR2GRAY), 8-bit fixed point (textmask.py:58)."""
+    """cv2.cvtColor(BGR2GRAY), OpenCV 4.x 15-bit fixed point (textmask.py:58)."""
     c = img.astype(np.int32)
-    return ((c[..., 0] * 1868 + c[..., 1] * 9617 + c[..., 2] * 4899 + 8192) >> 14).astype(np.uint8)
+    return ((c[..., 0] * 3735 + c[..., 1] * 19235 + c[..., 2] * 9798 + 16384) >> 15).astype(np.uint8)
+
+
+def inrange_bounds(lo: float, hi: float) -> Tuple[int, int]:
+    """Integer bounds cv2.inRange uses for double scalars on a u8 image: cvRound (half to even) of
+    both, the empty range when lb > ub, lb > 255 or ub < 0, else saturated to [0, 255]."""
+    ilo, ihi = int(np.rint(float(lo))), int(np.rint(float(hi)))
+    if ilo > ihi or ilo > 255 or ihi < 0:
+        return 1, 0
+    return max(ilo, 0), min(ihi, 255)
 
 
 def otsu_from_hist(hist: np.ndarray) -> int:
@@ -137,10 +146,11 @@ def candidate_masks(im: np.ndarray, msk: np.ndarray) -> List[Tuple[np.ndarray, i
         inv, d = _pick(int(np.where(on, 255 - m, m).sum()), m.size)
         return np.where(on != bool(inv), 255, 0).astype(np.uint8), d
 
-    g = grey.astype(np.float64)
+    g = grey.astype(np.int32)
     for c in top:
         hi = min(c + 30, 255)
-        out.append(add((g >= hi - 60) & (g <= hi)))
+        lb, ub = inrange_bounds(hi - 60, hi)
+        out.append(add((g >= lb) & (g <= ub)))
     best = None
     for ch in range(3):
         plane = im[..., ch]
@@ -193,7 +203,8 @@ def _gpu_candidates(pages, wins):
             r = R[i * 6 + k]
             if k < len(top):
                 hi = min(top[k] + 30, 255)
-                r.kind, r.lo, r.hi = 0, float(hi - 60), float(hi)
+                lb, ub = inrange_bounds(hi - 60, hi)
+                r.kind, r.lo, r.hi = 0, float(lb), float(ub)
             else:
                 r.kind = -1
         for ch in range(3):

@@ -22,10 +22,14 @@ import numpy as np
 # --------------------------------------------------------------------------
 
 def cvt_bgr2gray(img: np.ndarray) -> np.ndarray:
-    """cv2.cvtColor(BGR2GRAY) for uint8: fixed point, 14 fractional bits
-    (OpenCV color_rgb: B*1868 + G*9617 + R*4899 + 8192 >> 14)."""
+    """cv2.cvtColor(BGR2GRAY) for uint8: fixed point, 15 fractional bits
+    (OpenCV 4.x imgproc/src/color_rgb.simd.hpp `RGB2Gray<uchar>`: BY15 = 3735, GY15 = 19235,
+    RY15 = 9798, + (1 << 14) >> 15).  VERSION DEPENDENT: OpenCV 3.x and the first 4.x releases used
+    the 14-bit set (1868, 9617, 4899, >> 14); the two differ by one grey level on some coloured
+    pixels and agree on every grey pixel (B = G = R).  The reference asks for opencv-python>=4.1.2
+    (requirements.txt:3) without an upper bound; this restatement follows current 4.x."""
     b, g, r = img[..., 0].astype(np.int64), img[..., 1].astype(np.int64), img[..., 2].astype(np.int64)
-    return ((b * 1868 + g * 9617 + r * 4899 + (1 << 13)) >> 14).astype(np.uint8)
+    return ((b * 3735 + g * 19235 + r * 9798 + (1 << 14)) >> 15).astype(np.uint8)
 
 
 def threshold_binary(src: np.ndarray, thresh: float, maxval: int = 255) -> np.ndarray:
@@ -94,11 +98,22 @@ def dilate(img: np.ndarray, kernel: np.ndarray = RECT3, iterations: int = 1) -> 
     return img
 
 
+def in_range_bounds(lo: float, hi: float):
+    """Integer bounds cv2.inRange derives from double scalars for a CV_8U image (OpenCV
+    core/src/arithm.cpp `inRange`, scalar branch): both bounds are converted to int32 with
+    cvRound (round half to even); if lb > ub, lb > 255 or ub < 0 nothing matches; otherwise the
+    bounds saturate to [0, 255].  Returns (lb, ub) with lb > ub meaning the empty range."""
+    ilo, ihi = int(np.rint(float(lo))), int(np.rint(float(hi)))
+    if ilo > ihi or ilo > 255 or ihi < 0:
+        return 1, 0
+    return max(ilo, 0), min(ihi, 255)
+
+
 def in_range(img: np.ndarray, lo: float, hi: float) -> np.ndarray:
-    """cv2.inRange(img, lo, hi) with scalar (possibly fractional) bounds on uint8:
-    OpenCV rounds the bounds inwards (ceil/floor), i.e. the exact real comparison."""
-    v = img.astype(np.float64)
-    return np.where((v >= lo) & (v <= hi), 255, 0).astype(np.uint8)
+    """cv2.inRange(img, lo, hi) with scalar (possibly fractional) bounds on uint8."""
+    lb, ub = in_range_bounds(lo, hi)
+    v = img.astype(np.int64)
+    return np.where((v >= lb) & (v <= ub), 255, 0).astype(np.uint8)
 
 
 def _linear_coeffs(dst: int, src: int, zero_frac_at_edges: bool):
@@ -376,6 +391,104 @@ def masked_mean(values: np.ndarray, mask: np.ndarray) -> float:
     m = mask != 0
     c = int(m.sum())
     return float(values[m].astype(np.float64).sum() / c) if c else 0.0
+
+
+# --------------------------------------------------------------------------
+# Clipper polygon offset  (reference utils/db_utils.py:171-173: PyclipperOffset, JT_ROUND)
+# --------------------------------------------------------------------------
+
+def _clipper_round(v: float) -> int:
+    """Clipper 6.4.2 `Round`: half away from zero through a C cast."""
+    return int(v - 0.5) if v < 0 else int(v + 0.5)
+
+
+def clipper_offset_round(path, delta: float, arc_tolerance: float = 0.25) -> np.ndarray:
+    """`pyclipper.PyclipperOffset().AddPath(path, JT_ROUND, ET_CLOSEDPOLYGON); Execute(delta)` for ONE
+    convex closed polygon and delta > 0, following Clipper 6.4.2 (the library pyclipper wraps):
+    `ClipperOffset::AddPath` (duplicate stripping), `FixOrientations`, `DoOffset` (step count from the
+    arc tolerance, per-vertex `OffsetPoint` -> `DoRound`, every emitted point rounded to the integer
+    grid).  The final `Clipper::Execute(ctUnion, pftPositive)` only removes self-overlaps; for a
+    convex input the raw offset ring is already simple, so the ring itself is returned (the union may
+    rotate the start vertex or drop collinear points -- irrelevant to the min-area rectangle the
+    reference takes next, db_utils.py:154).  `path`: integer (x, y) vertices (pyclipper casts float
+    input to integers by truncation).  Returns (n, 2) int64."""
+    pts = [(int(x), int(y)) for x, y in np.asarray(path).reshape(-1, 2)]
+    hi = len(pts) - 1
+    while hi > 0 and pts[0] == pts[hi]:
+        hi -= 1
+    poly = [pts[0]]
+    for i in range(1, hi + 1):
+        if pts[i] != poly[-1]:
+            poly.append(pts[i])
+    n = len(poly)
+    if n < 3:
+        return np.zeros((0, 2), np.int64)
+    a = 0.0
+    j = n - 1
+    for i in range(n):
+        a += (float(poly[j][0]) + poly[i][0]) * (float(poly[j][1]) - poly[i][1])
+        j = i
+    if -a * 0.5 < 0:                       # FixOrientations: Orientation() == Area() >= 0
+        poly.reverse()
+    if arc_tolerance <= 0.0:
+        y = 0.25
+    elif arc_tolerance > abs(delta) * 0.25:
+        y = abs(delta) * 0.25
+    else:
+        y = arc_tolerance
+    steps = math.pi / math.acos(1 - y / abs(delta))
+    if steps > abs(delta) * math.pi:
+        steps = abs(delta) * math.pi
+    m_sin, m_cos = math.sin(2 * math.pi / steps), math.cos(2 * math.pi / steps)
+    steps_per_rad = steps / (2 * math.pi)
+    if delta < 0:
+        m_sin = -m_sin
+
+    def unit_normal(p1, p2):
+        if p1 == p2:
+            return (0.0, 0.0)
+        dx, dy = float(p2[0] - p1[0]), float(p2[1] - p1[1])
+        f = 1.0 / math.sqrt(dx * dx + dy * dy)
+        dx *= f
+        dy *= f
+        return (dy, -dx)
+
+    normals = [unit_normal(poly[i], poly[(i + 1) % n]) for i in range(n)]
+    out = []
+    k = n - 1
+    for j in range(n):
+        sin_a = normals[k][0] * normals[j][1] - normals[j][0] * normals[k][1]
+        done = False
+        if abs(sin_a * delta) < 1.0:
+            cos_a = normals[k][0] * normals[j][0] + normals[j][1] * normals[k][1]
+            if cos_a > 0:
+                out.append((_clipper_round(poly[j][0] + normals[k][0] * delta),
+                            _clipper_round(poly[j][1] + normals[k][1] * delta)))
+                done = True
+        elif sin_a > 1.0:
+            sin_a = 1.0
+        elif sin_a < -1.0:
+            sin_a = -1.0
+        if not done:
+            if sin_a * delta < 0:
+                out.append((_clipper_round(poly[j][0] + normals[k][0] * delta),
+                            _clipper_round(poly[j][1] + normals[k][1] * delta)))
+                out.append(poly[j])
+                out.append((_clipper_round(poly[j][0] + normals[j][0] * delta),
+                            _clipper_round(poly[j][1] + normals[j][1] * delta)))
+            else:                           # DoRound
+                ang = math.atan2(sin_a, normals[k][0] * normals[j][0] + normals[k][1] * normals[j][1])
+                nst = max(_clipper_round(steps_per_rad * abs(ang)), 1)
+                X, Y = normals[k]
+                for _ in range(nst):
+                    out.append((_clipper_round(poly[j][0] + X * delta), _clipper_round(poly[j][1] + Y * delta)))
+                    X2 = X
+                    X = X * m_cos - m_sin * Y
+                    Y = X2 * m_sin + Y * m_cos
+                out.append((_clipper_round(poly[j][0] + normals[j][0] * delta),
+                            _clipper_round(poly[j][1] + normals[j][1] * delta)))
+        k = j
+    return np.array(out, np.int64).reshape(-1, 2)
 
 
 # --------------------------------------------------------------------------

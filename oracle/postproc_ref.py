@@ -204,14 +204,13 @@ def box_score_fast(bitmap: np.ndarray, _box: np.ndarray) -> float:
 def unclip_box(points: np.ndarray, unclip_ratio: float = 1.5):
     """reference utils/db_utils.py:168-174 followed by get_mini_boxes (:154).
     distance = area * ratio / perimeter (shapely, float64); pyclipper truncates the float
-    corners to integers before offsetting (C cast in _to_clipper_path); the min-area rectangle
-    of the JT_ROUND offset polygon is the calipers rectangle of the truncated quad grown by
-    `distance` on every side.  UNPINNED: Clipper's integer arc approximation (arc tolerance
-    0.25) can move a side by <1 px before the final np.round."""
+    corners to integers before offsetting (C cast in _to_clipper_path); the JT_ROUND offset ring
+    is built the way Clipper 6.4.2 builds it (integer arc points, `cv.clipper_offset_round`) and its
+    min-area rectangle is taken."""
     pts = np.asarray(points, np.float32)
     distance = cv.polygon_area(pts) * unclip_ratio / cv.polygon_length(pts)
     ipts = np.trunc(pts.astype(np.float64)).astype(np.int64)
-    return get_mini_boxes(ipts, grow=distance)
+    return get_mini_boxes(cv.clipper_offset_round(ipts, distance))
 
 
 def boxes_from_bitmap(pred: np.ndarray, bitmap: np.ndarray, dest_width: int, dest_height: int,

@@ -33,16 +33,9 @@ class _RotatedRect(tuple):
     box: np.ndarray
 
 
-_offset_rects: dict = {}     # corners handed out by PyclipperOffset.Execute -> their (box, w, h)
-
-
 def _min_area_rect(points):
     pts = np.asarray(points).reshape(-1, 2)
-    # The reference feeds Clipper's offset polygon straight into minAreaRect (db_utils.py:153-154).
-    # The stand-in's "polygon" is already that rectangle: hand it back unchanged instead of
-    # re-fitting its own four corners (which re-breaks corner-order ties on 45-degree boxes).
-    hit = _offset_rects.get(pts.astype(np.float64).tobytes()) if len(pts) == 4 else None
-    box, w, h = hit if hit is not None else cv.min_area_box(pts)
+    box, w, h = cv.min_area_box(pts)
     c = box.astype(np.float64).mean(0)
     r = _RotatedRect(((float(c[0]), float(c[1])), (w, h), 0.0))
     r.box = box
@@ -165,21 +158,16 @@ class Polygon:
 
 # ---------------------------------------------------------------------------- pyclipper stand-in
 class PyclipperOffset:
-    """Round-join offset of one closed quad.  pyclipper casts the float corners to integers
-    (truncation); the min-area rectangle of the JT_ROUND offset is the calipers rectangle of that
-    integer quad grown by the distance, so its four corners stand for the offset polygon (the
-    reference only ever passes it to minAreaRect, db_utils.py:153-154)."""
+    """Round-join offset of one closed convex quad the way Clipper 6.4.2 (the library pyclipper
+    wraps) builds it: float corners cast to integers by truncation, integer arc points
+    (`cv_ref.clipper_offset_round`).  The reference only passes the ring to minAreaRect
+    (db_utils.py:153-154)."""
 
     def AddPath(self, path, join_type, end_type):
         self.path = np.trunc(np.asarray(path, np.float64)).astype(np.int64)
 
     def Execute(self, distance):
-        box, w, h = cv.min_area_box(self.path, float(distance))
-        corners = box.astype(np.float64)
-        if len(_offset_rects) > 4096:
-            _offset_rects.clear()
-        _offset_rects[corners.tobytes()] = (box, w, h)
-        return [corners.tolist()]
+        return [cv.clipper_offset_round(self.path, float(distance)).tolist()]
 
 
 def reference_detector(ns, net_outputs, input_size=(1024, 1024)):

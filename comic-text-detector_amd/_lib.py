@@ -58,6 +58,13 @@ class CtdBand(C.Structure):
     _fields_ = [("win", C.c_int32), ("top", C.c_int32), ("mtop", C.c_int32)]
 
 
+class CtdBlk(C.Structure):
+    _fields_ = [("xyxy", C.c_int32 * 4), ("language", C.c_int32), ("vertical", C.c_int32), ("angle", C.c_int32),
+                ("font_is_float", C.c_int32), ("font_size", C.c_double), ("vec", C.c_double * 2), ("norm", C.c_double),
+                ("weight", C.c_double), ("merged", C.c_int32), ("line_off", C.c_int32), ("n_lines", C.c_int32),
+                ("dist_off", C.c_int32), ("n_dist", C.c_int32), ("pad_", C.c_int32)]
+
+
 # every symbol include/ctd_hip.h declares: (restype, argtypes)
 _vp, _i32, _i64, _f = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 SYMBOLS = {
@@ -85,6 +92,8 @@ SYMBOLS = {
     "ctd_win_dilate": (_i32, [C.POINTER(CtdWindow), _i32, C.POINTER(_i32), _vp, _vp, _vp, _i32, _vp, _i32, _vp]),
     "ctd_win_commit": (_i32, [C.POINTER(CtdWindow), _i32, C.POINTER(_i32), _vp, _i32, _vp, _i32, _vp]),
     "ctd_db_boxes": (_i32, [_vp, _vp, _vp, _i32, _vp, _vp, _i32, _i32, _i32, _i32, C.c_double, _vp, _vp, C.POINTER(_i32)]),
+    "ctd_group_output": (_i32, [_vp, _vp, _i32, _vp, _i32, _i32, _i32, _vp, _i32, _vp, _i32, _vp, _i32, _vp, _i32,
+                                C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i32)]),
     "ctd_last_error": (C.c_char_p, []),
     "ctd_abi_version": (_i32, []),
     "ctd_device_info": (_i32, [_i32, C.c_char_p, C.POINTER(_i32), C.POINTER(_i64)]),

@@ -1,22 +1,20 @@
-"""Block / line grouping: host mirror of reference utils/textblock.py
-(`TextBlock` :12-160, `group_output` :421-508 and its helpers).  N is tiny
-(<= 300 blocks, <= 1000 lines per page), the arithmetic is scalar float64 with
-the reference's truncation points, so this stays on the host.
-
-The implementation is array-oriented where the reference loops (line -> block
-assignment is one broadcast; per-block geometry works on (n,4,2) arrays) but
-every decision threshold and rounding rule is the reference's; each function
-cites the lines it mirrors.
+"""`TextBlock` (the reference's result record, utils/textblock.py:12-265) and `group_output`
+(utils/textblock.py:421-508) on top of the native host code `ctd_group_output`
+(csrc/host_group.cpp): this module only turns the native records into the reference's Python
+objects.  N is tiny (<= 300 blocks, <= 1000 lines per page); the grouping itself -- line -> block
+assignment, orientation / font size / reading distance, splitting, merging of scattered lines,
+reading order, the margin of English lines -- is C++ with the reference's float64 operation order
+and truncation points.
 """
 from __future__ import annotations
 
 import copy
-import math
+import ctypes as C
 from typing import List, Optional, Sequence
 
 import numpy as np
 
-from . import geom
+from . import _lib as L
 
 LANG_LIST = ["eng", "ja", "unknown"]                 # textblock.py:9
 LANGCLS2IDX = {"eng": 0, "ja": 1, "unknown": 2}
@@ -37,10 +35,30 @@ _RECORD_TAIL = (
 )
 
 
+def rotate_polygons(center, polygons: np.ndarray, rotation, new_center=None, to_int: bool = True) -> np.ndarray:
+    """reference utils/imgproc_utils.py:68-84 (float32 arithmetic like the reference)."""
+    if new_center is None:
+        new_center = center
+    rotation = np.deg2rad(rotation)
+    s, c = np.sin(rotation), np.cos(rotation)
+    polygons = polygons.astype(np.float32)
+    polygons[:, 1::2] -= center[1]
+    polygons[:, ::2] -= center[0]
+    rotated = np.copy(polygons)
+    rotated[:, 1::2] = polygons[:, 1::2] * c - polygons[:, ::2] * s
+    rotated[:, ::2] = polygons[:, 1::2] * s + polygons[:, ::2] * c
+    rotated[:, 1::2] += new_center[1]
+    rotated[:, ::2] += new_center[0]
+    return rotated.astype(np.int64) if to_int else rotated
+
+
 class TextBlock:
-    """The reference's TextBlock record (textblock.py:12-86): detection state first, then the
+    """The reference's TextBlock record (textblock.py:12-265): detection state first, then the
     fields later pipeline stages fill, in the reference's attribute order (that order is the key
-    order of the JSON record, `to_dict` :158-160)."""
+    order of the JSON record, `to_dict` :158-160), with the reference's numpy-only methods.
+    `get_transformed_region` (:162-196, cv2.findHomography / warpPerspective) and
+    `visualize_textblocks` (:510-523, cv2 drawing) belong to the OCR / debugging side and are not
+    part of this package."""
 
     def __init__(self, xyxy: Sequence, lines: Optional[list] = None, language: str = "unknown",
                  vertical: bool = False, font_size: float = -1, distance=None, angle: int = 0, vec=None,
@@ -61,6 +79,10 @@ class TextBlock:
             setattr(self, attr, [] if (attr == "text" and v is None) else v)
 
     # -- accessors the reference exposes ------------------------------------
+    @property
+    def pts(self) -> np.ndarray:                                 # textblock.py:146-148
+        return self.lines_array()
+
     def lines_array(self, dtype=np.float64) -> np.ndarray:
         return np.array(self.lines, dtype=dtype)
 
@@ -94,6 +116,87 @@ class TextBlock:
             self.distance = self.distance[order]
             self.lines = np.array(self.lines, dtype=np.int32)[order].tolist()
 
+    def aspect_ratio(self) -> float:
+        """textblock.py:110-115."""
+        min_rect = self.min_rect()
+        mid = (min_rect[:, [1, 2, 3, 0]] + min_rect) / 2
+        return np.linalg.norm(mid[:, 2] - mid[:, 0]) / np.linalg.norm(mid[:, 1] - mid[:, 3])
+
+    def min_rect(self, rotate_back: bool = True) -> np.ndarray:
+        """textblock.py:121-134: bounding rectangle of the lines in the block's rotated frame."""
+        angled = self.angle != 0
+        center = self.center()
+        polygons = self.lines_array().reshape(-1, 8)
+        if angled:
+            polygons = rotate_polygons(center, polygons, self.angle)
+        min_x, min_y = polygons[:, ::2].min(), polygons[:, 1::2].min()
+        max_x, max_y = polygons[:, ::2].max(), polygons[:, 1::2].max()
+        min_bbox = np.array([[min_x, min_y, max_x, min_y, max_x, max_y, min_x, max_y]])
+        if angled and rotate_back:
+            min_bbox = rotate_polygons(center, min_bbox, -self.angle)
+        return min_bbox.reshape(-1, 4, 2).astype(np.int64)
+
+    def bounding_rect(self):
+        """textblock.py:136-144: Qt-style [x, y, w, h], ignoring the angle."""
+        if self._bounding_rect is None:
+            min_bbox = self.min_rect(rotate_back=False)[0]
+            x, y = min_bbox[0]
+            w, h = min_bbox[2] - min_bbox[0]
+            return [x, y, w, h]
+        return self._bounding_rect
+
+    def get_text(self) -> str:
+        """textblock.py:198-201."""
+        if isinstance(self.text, str):
+            return self.text
+        return " ".join(self.text).strip()
+
+    def set_font_colors(self, frgb, srgb, accumulate: bool = True) -> None:
+        """textblock.py:203-211."""
+        self.accumulate_color = accumulate
+        num_lines = len(self.lines) if accumulate and len(self.lines) > 0 else 1
+        self.fg_r, self.fg_g, self.fg_b = np.array(frgb) * num_lines
+        self.bg_r, self.bg_g, self.bg_b = np.array(srgb) * num_lines
+
+    def get_font_colors(self, bgr: bool = False):
+        """textblock.py:213-228."""
+        num_lines = len(self.lines)
+        frgb = np.array([self.fg_r, self.fg_g, self.fg_b])
+        brgb = np.array([self.bg_r, self.bg_g, self.bg_b])
+        if self.accumulate_color:
+            if num_lines > 0:
+                frgb = (frgb / num_lines).astype(np.int32)
+                brgb = (brgb / num_lines).astype(np.int32)
+                return (frgb[::-1], brgb[::-1]) if bgr else (frgb, brgb)
+            return [0, 0, 0], [0, 0, 0]
+        return frgb, brgb
+
+    def alignment(self) -> int:
+        """textblock.py:234-255: 0 left, 1 centre."""
+        if self._alignment >= 0:
+            return self._alignment
+        if self.vertical:
+            return 0
+        lines = self.lines_array()
+        if len(lines) == 1:
+            return 0
+        polygons = lines.reshape(-1, 8)
+        if self.angle != 0:
+            polygons = rotate_polygons((0, 0), polygons, self.angle)
+        polygons = polygons.reshape(-1, 4, 2)
+        left_std = np.std(polygons[:, 0, 0])
+        center_std = np.std((polygons[:, 0, 0] + polygons[:, 1, 0]) / 2)
+        return 0 if left_std < center_std else 1
+
+    def target_lang(self):
+        return self._target_lang
+
+    @property
+    def stroke_width(self):
+        """textblock.py:260-265."""
+        var = np.abs(np.array([self.fg_r, self.fg_g, self.fg_b]) - np.array([self.bg_r, self.bg_g, self.bg_b])).sum()
+        return self.default_stroke_width if var > 40 else 0
+
     def to_dict(self) -> dict:
         """`copy.deepcopy(vars(self))` (textblock.py:158-160): every attribute, numpy values included;
         `annotations.RecordEncoder` turns it into the reference's JSON."""
@@ -102,225 +205,59 @@ class TextBlock:
 
 # --------------------------------------------------------------------------
 
-def _mask_score(mask: Optional[np.ndarray], x1, y1, x2, y2) -> float:
-    """mean(mask[y1:y2, x1:x2]) / 255 with numpy's empty-slice behaviour (nan)."""
-    win = mask[y1:y2, x1:x2]
-    return float("nan") if win.size == 0 else float(win.mean()) / 255
-
-
-def examine_textblk(blk: TextBlock, im_w: int, im_h: int, sort: bool = False) -> None:
-    """Orientation, angle, font size and reading distance of a block (textblock.py:302-342)."""
-    L = blk.lines_array()                                      # (n,4,2)
-    mid = (np.roll(L, -1, axis=1) + L) / 2                     # midpoints of edges 0-1,1-2,2-3,3-0
-    v = (mid[:, 2] - mid[:, 0]).sum(0)                         # summed "vertical" vectors
-    h = (mid[:, 1] - mid[:, 3]).sum(0)
-    nv, nh = float(np.linalg.norm(v)), float(np.linalg.norm(h))
-    vertical = nv > nh if blk.language == "ja" else nv > nh * 2
-    centers = (L[:, 0] + L[:, 2]) / 2
-    if vertical:
-        pvec, pnorm = v, nv
-        d = centers - np.array([[im_w, 0]], np.float64)        # vertical manga text reads right-to-left
-        font = int(round(nh / len(L)))
+def blocks_from_records(recs, lines: np.ndarray, dist: np.ndarray) -> List[TextBlock]:
+    """Native records (`ctd_blk` array + line / distance pools) -> the reference's Python objects.
+    `TextBlock.distance` is re-evaluated from its two operands with numpy's own arccos / sin
+    (reference utils/textblock.py:327-328), so the record carries the bits the reference's numpy
+    expression gives on this machine (csrc/host_group.cpp decided with libm's)."""
+    if len(dist):
+        with np.errstate(divide="ignore", invalid="ignore"):
+            dval = np.abs(np.sin(np.arccos(np.ascontiguousarray(dist[:, 1]))) * np.ascontiguousarray(dist[:, 2]))
     else:
-        pvec, pnorm = h, nh
-        d = centers.astype(np.float64)
-        font = int(round(nv / len(L)))
-    angle = int(math.atan2(pvec[1], pvec[0]) / math.pi * 180)  # truncation (:326)
-    dist = np.linalg.norm(d, axis=1)
-    with np.errstate(divide="ignore", invalid="ignore"):
-        rad = np.arccos((d @ pvec) / (dist * pnorm))
-    blk.lines = L.astype(np.int32).tolist()
-    blk.distance = np.abs(np.sin(rad) * dist)
-    blk.angle = angle - 90 if vertical else angle
-    if abs(blk.angle) < 3:
-        blk.angle = 0
-    blk.font_size = font
-    blk.vertical = vertical
-    blk.vec = pvec
-    blk.norm = pnorm
-    if sort:
-        blk.sort_lines()
-
-
-def try_merge_textline(a: TextBlock, b: TextBlock, fntsize_tol: float = 1.3, distance_tol: float = 2) -> bool:
-    """textblock.py:344-373."""
-    if b.merged:
-        return False
-    with np.errstate(divide="ignore", invalid="ignore"):
-        ratio = a.font_size / b.font_size
-    na, nb = len(a), len(b)
-    avg = (a.font_size * na + b.font_size * nb) / (na + nb)
-    vsum = a.vec + b.vec
-    cosv = (a.vec @ b.vec) / a.norm / b.norm
-    gap = b.distance[-1] - a.distance[-1]
-    gap_p1 = np.linalg.norm(np.array(b.lines[-1][0]) - np.array(a.lines[-1][0]))
-    if not geom.quads_intersect(a.lines[-1], b.lines[-1]):
-        if ratio > fntsize_tol or 1 / ratio > fntsize_tol:
-            return False
-        if abs(cosv) < 0.866:
-            return False
-        if gap > distance_tol * avg or gap_p1 > avg * 2.5:
-            return False
-    a.lines.append(b.lines[0])
-    a.vec = vsum
-    a.angle = int(round(np.rad2deg(math.atan2(vsum[1], vsum[0]))))
-    if a.vertical:
-        a.angle -= 90
-    a.norm = np.linalg.norm(vsum)
-    a.distance = np.append(a.distance, b.distance[-1])
-    a.font_size = avg
-    b.merged = True
-    return True
-
-
-def merge_textlines(blks: List[TextBlock]) -> List[TextBlock]:
-    """Greedy merge of scattered single-line blocks (textblock.py:375-388)."""
-    if len(blks) < 2:
-        return blks
-    blks.sort(key=lambda t: t.distance[0])
+        dval = np.zeros((0,), np.float64)
     out = []
-    for i, cur in enumerate(blks):
-        if cur.merged:
-            continue
-        for other in blks[i + 1:]:
-            try_merge_textline(cur, other)
-        out.append(cur)
-    for t in out:
-        t.adjust_bbox(with_bbox=False)
+    for r in recs:
+        t = TextBlock(list(r.xyxy), lines[r.line_off: r.line_off + r.n_lines].reshape(-1, 4, 2).tolist(),
+                      language=LANG_LIST[r.language], vertical=bool(r.vertical),
+                      font_size=float(r.font_size) if r.font_is_float else int(r.font_size),
+                      distance=dval[r.dist_off: r.dist_off + r.n_dist], angle=int(r.angle),
+                      vec=(r.vec[0], r.vec[1]), norm=np.float64(r.norm), merged=bool(r.merged),
+                      weight=np.float64(r.weight))
+        out.append(t)
     return out
 
 
-def _clone_without_lines(blk: TextBlock) -> TextBlock:
-    """`copy.deepcopy(blk)` followed by `.lines = [...]` (textblock.py:395-396,409-410) without
-    deep-copying the line list that is thrown away: every other mutable attribute gets its own copy."""
-    new = copy.copy(blk)
-    for k, v in vars(blk).items():
-        if k != "lines" and isinstance(v, (list, dict, np.ndarray)):
-            setattr(new, k, copy.deepcopy(v))
-    new.lines = []
-    return new
-
-
-def split_textblk(blk: TextBlock):
-    """Split a vertical / Japanese block at line gaps (textblock.py:390-419)."""
-    font, dist, lines = blk.font_size, blk.distance, blk.lines
-    first = np.array(lines[0])
-    lines.sort(key=lambda q: np.linalg.norm(np.array(q[0]) - first[0]))
-    cur = _clone_without_lines(blk)
-    cur.lines = [first]
-    parts = [cur]
-    for j, line in enumerate(lines[1:]):
-        split = False
-        if not geom.quads_intersect(lines[j], line):
-            gap = abs(dist[j + 1] - dist[j])
-            if gap > font * 2:
-                split = True
-            elif blk.vertical and abs(blk.angle) < 15:
-                if len(cur.lines) > 1 or gap > font:
-                    split = abs(lines[j][0][1] - line[0][1]) > font
-        if split:
-            cur = _clone_without_lines(cur)
-            cur.lines = [line]
-            parts.append(cur)
-        else:
-            cur.lines.append(line)
-    if len(parts) > 1:
-        for p in parts:
-            p.adjust_bbox(with_bbox=False)
-        return True, parts
-    return False, parts
-
-
-def sort_textblk_list(blks: List[TextBlock], im_w: int, im_h: int) -> List[TextBlock]:
-    """4x3 reading-order grid, right-to-left when most blocks are Japanese (textblock.py:267-300)."""
-    if not blks:
-        return blks
-    box = np.array([t.xyxy for t in blks])
-    rtl = sum(t.language == "ja" for t in blks) > len(blks) / 2
-    full_w = im_w
-    if im_w > im_h:
-        im_w /= 2
-    gy, gx = 4, 3
-    area = im_h * im_w
-    cx = (box[:, 0] + box[:, 2]) / 2
-    if rtl:
-        cx = (full_w - cx) if im_w != full_w else (im_w - cx)
-    ix = (cx / im_w * gx).astype(np.int32)
-    cy = (box[:, 1] + box[:, 3]) / 2
-    iy = (cy / im_h * gy).astype(np.int32)
-    w = (iy * gx + ix) * area + 1.2 * (cx - ix * im_w / gx) + (cy - iy * im_h / gy)
-    if im_w != full_w:
-        w[ix >= gx] += area * gy * gx
-    for t, wt in zip(blks, w):
-        t.weight = wt
-    blks.sort(key=lambda t: t.weight)
-    return blks
+def group_output_native(blines: np.ndarray, cls: np.ndarray, lines, im_w: int, im_h: int,
+                        mask: Optional[np.ndarray] = None):
+    """One `ctd_group_output` call; returns (records, lines (n,8) i32, dist (m,3) f64)."""
+    lib = L.lib()
+    blines = np.ascontiguousarray(np.asarray(blines, np.int32).reshape(-1, 4))
+    cls = np.ascontiguousarray(np.asarray(cls, np.int32).reshape(-1))
+    lines = np.asarray(lines)
+    lines = np.ascontiguousarray(lines.astype(np.int32).reshape(-1, 8)) if lines.size else np.zeros((0, 8), np.int32)
+    nb, nl = len(blines), len(lines)
+    cap = nb + nl
+    dcap = cap * max(1, nl)
+    recs = (L.CtdBlk * max(cap, 1))()
+    lout = np.empty((max(cap, 1), 8), np.int32)
+    dout = np.empty((max(dcap, 1), 3), np.float64)
+    n_b, n_l, n_d = C.c_int32(), C.c_int32(), C.c_int32()
+    mptr, pitch = None, 0
+    if mask is not None:
+        if mask.dtype != np.uint8 or mask.ndim != 2 or mask.shape != (im_h, im_w):
+            raise ValueError("mask must be a uint8 (im_h, im_w) array")
+        mask = np.ascontiguousarray(mask)
+        mptr, pitch = mask.ctypes.data, mask.shape[1]
+    L.check(lib.ctd_group_output(blines.ctypes.data, cls.ctypes.data, nb, lines.ctypes.data, nl, int(im_w), int(im_h),
+                                 mptr, pitch, recs, cap, lout.ctypes.data, cap, dout.ctypes.data, dcap,
+                                 C.byref(n_b), C.byref(n_l), C.byref(n_d)), "ctd_group_output")
+    return recs[: n_b.value], lout[: n_l.value], dout[: n_d.value]
 
 
 def group_output(blks, lines, im_w: int, im_h: int, mask: Optional[np.ndarray] = None,
                  sort_blklist: bool = True) -> List[TextBlock]:
     """textblock.py:421-508.  blks = (blines (n,4) i32, cls (n,) i32, confs (n,)); lines (m,4,2) i32."""
-    blk_list = [TextBlock(bb, language=LANG_LIST[c]) for bb, c, _ in zip(*blks)]
-    scattered = {"ver": [], "hor": []}
-    bbox_thr, mask_thr = 0.4, 0.1
-    lines = np.asarray(lines)
-    if lines.size:
-        lo, hi = lines.min(1), lines.max(1)                               # (m,2) bbox of every line
-        if blk_list:
-            bx = np.array([t.xyxy for t in blk_list], np.float64)       # (n,4)
-            ix1 = np.maximum(bx[None, :, 0], lo[:, None, 0])
-            iy1 = np.maximum(bx[None, :, 1], lo[:, None, 1])
-            ix2 = np.minimum(bx[None, :, 2], hi[:, None, 0])
-            iy2 = np.minimum(bx[None, :, 3], hi[:, None, 1])
-            inter = np.where((iy2 < iy1) | (ix2 < ix1), -1.0, (iy2 - iy1) * (ix2 - ix1))   # imgproc_utils.py:13-20
-            area = ((hi[:, 1] - lo[:, 1]) * (hi[:, 0] - lo[:, 0])).astype(np.float64)
-            with np.errstate(divide="ignore", invalid="ignore"):
-                score = inter / area[:, None]                            # (m,n)
-        for i, line in enumerate(lines):
-            best, best_j = -1, -1
-            if blk_list:
-                for j in range(len(blk_list)):                             # first maximum, strict '<' (:440-442)
-                    if best < score[i, j]:
-                        best, best_j = score[i, j], j
-            if best > bbox_thr:
-                blk_list[best_j].lines.append(line)
-                continue
-            x1, y1, x2, y2 = lo[i, 0], lo[i, 1], hi[i, 0], hi[i, 1]
-            if mask is not None and _mask_score(mask, x1, y1, x2, y2) < mask_thr:
-                continue
-            t = TextBlock([x1, y1, x2, y2], [line])
-            examine_textblk(t, im_w, im_h, sort=False)
-            scattered["ver" if t.vertical else "hor"].append(t)
-
-    final: List[TextBlock] = []
-    for t in blk_list:
-        if not t.lines:
-            x1, y1, x2, y2 = t.xyxy
-            if mask is not None and _mask_score(mask, x1, y1, x2, y2) < mask_thr:
-                continue
-            t.lines = [[[x1, y1], [x2, y1], [x2, y2], [x1, y2]]]          # xywh2xyxypoly (imgproc_utils.py:31-37)
-        examine_textblk(t, im_w, im_h, sort=True)
-        parts, was_split = [t], False
-        if len(t.lines) > 1 and (t.language == "ja" or t.vertical):
-            was_split, parts = split_textblk(t)
-        if not was_split:
-            for p in parts:
-                p.adjust_bbox(with_bbox=True)
-        final += parts
-
-    final += merge_textlines(scattered["hor"])
-    final += merge_textlines(scattered["ver"])
-    if sort_blklist:
-        final = sort_textblk_list(final, im_w, im_h)
-
-    for t in final:                                                       # :492-506
-        if t.language == "eng" and not t.vertical and t.lines:
-            grow = max(int(t.font_size * 0.1), 2)
-            rad = np.deg2rad(t.angle)
-            shift = np.array([[[-1, -1], [1, -1], [1, 1], [-1, 1]]]) * np.array([[[np.sin(rad), np.cos(rad)]]]) * grow
-            q = t.lines_array() + shift
-            q[..., 0] = np.clip(q[..., 0], 0, im_w - 1)
-            q[..., 1] = np.clip(q[..., 1], 0, im_h - 1)
-            t.lines = q.astype(np.int64).tolist()
-            t.font_size += grow
-    return final
+    if not sort_blklist:
+        raise NotImplementedError("the detector always sorts the block list (reference inference.py:173)")
+    recs, lout, dout = group_output_native(blks[0], blks[1], lines, im_w, im_h, mask)
+    return blocks_from_records(recs, lout, dout)

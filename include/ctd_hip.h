@@ -287,6 +287,41 @@ int ctd_db_boxes(const float* prob, const int32_t* lab_f, const int32_t* st_f, i
                  const int32_t* st_b, int32_t n_b, int32_t W, int32_t H, int32_t max_candidates,
                  double unclip_ratio, int16_t* boxes, float* scores, int32_t* n_out);
 
+/* ---- host-side block / line grouping ------------------------------------- */
+
+/* One grouped text block: the detection fields of the reference's `TextBlock` record (reference
+ * utils/textblock.py:45-56).  Lines and distances live in pools: lines (n,4,2) i32 at line_off;
+ * `TextBlock.distance` at dist_off as triples (distance, c, d) with distance = |sin(arccos(c)) * d|
+ * (utils/textblock.py:327-328; c and d let the caller re-evaluate that expression with its own math
+ * library).  n_dist is NOT always n_lines: `split_textblk` hands every part the whole array of the
+ * block it came from (:395-396). */
+typedef struct ctd_blk {
+  int32_t xyxy[4];
+  int32_t language;      /* 0 eng, 1 ja, 2 unknown (reference utils/textblock.py:9) */
+  int32_t vertical;
+  int32_t angle;
+  int32_t font_is_float; /* Python type of font_size in the reference: int (0), float after a merge (1) */
+  double font_size;
+  double vec[2];
+  double norm;
+  double weight;
+  int32_t merged;
+  int32_t line_off, n_lines;
+  int32_t dist_off, n_dist;
+  int32_t pad_;
+} ctd_blk;
+
+/* `group_output` (reference utils/textblock.py:421-508, sort_blklist=True) for one page.  HOST memory
+ * only, no device work.  blines (n_blk,4) i32 / cls (n_blk) i32 = `postprocess_yolo`'s blocks (reference
+ * inference.py:101-114); lines (n_lines,4,2) i32 = the rescaled DB boxes (inference.py:166-172);
+ * mask (im_h rows of mask_pitch bytes) = the page-size u8 mask, or NULL (mask=None).
+ * Outputs: blocks in reading order; capacities blk_cap >= n_blk + n_lines, line_cap >= n_blk + n_lines,
+ * dist_cap >= (n_blk + n_lines) * max(1, n_lines) are always enough (CTD_ERR_NOMEM otherwise). */
+int ctd_group_output(const int32_t* blines, const int32_t* cls, int32_t n_blk, const int32_t* lines, int32_t n_lines,
+                     int32_t im_w, int32_t im_h, const uint8_t* mask, int32_t mask_pitch, ctd_blk* blks_out,
+                     int32_t blk_cap, int32_t* lines_out, int32_t line_cap, double* dist_out, int32_t dist_cap,
+                     int32_t* n_blk_out, int32_t* n_lines_out, int32_t* n_dist_out);
+
 /* ---- misc -------------------------------------------------------------- */
 const char* ctd_last_error(void);
 int32_t ctd_abi_version(void);

@@ -1,0 +1,124 @@
+"""`ctd_group_output` (native host code, csrc/host_group.cpp; runs without a GPU) against the oracle's
+restatement of reference utils/textblock.py:421-508 -- and, in the build container, against the
+reference's own `group_output` -- on randomised pages: rotated / vertical / horizontal line quads in
+clusters, yolo blocks around some clusters (all three languages), lines outside every block, blocks
+without lines, boxes reaching outside the page, empty inputs.  Strict comparison: every detection
+field of the record, `distance` / `vec` / `norm` / `weight` bit for bit, Python type of `font_size`."""
+import copy
+
+import numpy as np
+import pytest
+
+from conftest import pkg
+from oracle import postproc_ref as R
+from oracle import ref_import as RI
+
+
+def random_page(seed, im_w=None, im_h=None):
+    rng = np.random.RandomState(seed)
+    im_w = im_w or int(rng.choice([640, 1024, 1400]))
+    im_h = im_h or int(rng.choice([480, 1024, 1654]))
+    lines, blines, cls = [], [], []
+    for _ in range(rng.randint(0, 14)):
+        vertical = rng.rand() < 0.5
+        fs = rng.randint(8, 40)
+        n = rng.randint(1, 7)
+        length = rng.randint(30, 300)
+        x0, y0 = rng.randint(0, im_w - 40), rng.randint(0, im_h - 40)
+        ang = np.deg2rad(rng.choice([0, 0, 0, rng.uniform(-25, 25)]))
+        c, s = np.cos(ang), np.sin(ang)
+        quads = []
+        for i in range(n):
+            if rng.rand() < 0.15:
+                continue                                   # a gap -> split candidates
+            if vertical:
+                ox, oy, w, h = x0 - i * fs * rng.uniform(1.1, 2.8), y0 + rng.randint(-5, 5), fs, length * rng.uniform(0.5, 1)
+            else:
+                ox, oy, w, h = x0 + rng.randint(-5, 5), y0 + i * fs * rng.uniform(1.1, 2.8), length * rng.uniform(0.5, 1), fs
+            q = np.array([[0, 0], [w, 0], [w, h], [0, h]], np.float64)
+            q = q @ np.array([[c, s], [-s, c]]) + [ox, oy]
+            q[:, 0] = np.clip(q[:, 0], 0, im_w)
+            q[:, 1] = np.clip(q[:, 1], 0, im_h)
+            q = q.astype(np.int32)
+            if np.linalg.norm(q[1] - q[0]) < 4 or np.linalg.norm(q[3] - q[0]) < 4 or \
+               np.linalg.norm(q[2] - q[1]) < 4 or np.linalg.norm(q[3] - q[2]) < 4:
+                continue                                   # clipped flat at the page border: font size 0 crashes the reference
+            quads.append(q)
+        if not quads:
+            continue
+        lines += quads
+        if rng.rand() < 0.65:                               # a yolo block around (most of) the cluster
+            pts = np.concatenate(quads)
+            lo, hi = pts.min(0) + rng.randint(-12, 12, 2), pts.max(0) + rng.randint(-12, 12, 2)
+            blines.append([lo[0], lo[1], hi[0], hi[1]])
+            cls.append(rng.randint(0, 3))
+    for _ in range(rng.randint(0, 3)):                      # blocks without lines, partly outside the page
+        x, y = rng.randint(-30, im_w - 20), rng.randint(-30, im_h - 20)
+        blines.append([x, y, x + rng.randint(10, 200), y + rng.randint(10, 200)])
+        cls.append(rng.randint(0, 3))
+    order = rng.permutation(len(lines))
+    lines = np.array([lines[i] for i in order], np.int32).reshape(-1, 4, 2)
+    mask = np.zeros((im_h, im_w), np.uint8)
+    for q in lines:
+        if rng.rand() < 0.8:
+            lo, hi = q.min(0), q.max(0)
+            mask[lo[1]: hi[1], lo[0]: hi[0]] = rng.randint(20, 256)
+    for b in blines:
+        if rng.rand() < 0.5:
+            mask[max(b[1], 0): max(b[3], 0), max(b[0], 0): max(b[2], 0)] = rng.randint(20, 256)
+    blks = (np.array(blines, np.int32).reshape(-1, 4), np.array(cls, np.int32), np.ones(len(cls)))
+    return blks, lines, im_w, im_h, mask
+
+
+def same_blocks(ours, theirs):
+    assert len(ours) == len(theirs)
+    for a, b in zip(ours, theirs):
+        assert [int(v) for v in a.xyxy] == [int(v) for v in b.xyxy]
+        assert np.array_equal(np.asarray(a.lines), np.asarray(b.lines))
+        assert (a.language, bool(a.vertical), int(a.angle), bool(a.merged)) == \
+               (b.language, bool(b.vertical), int(b.angle), bool(b.merged))
+        assert float(a.font_size) == float(b.font_size)
+        assert isinstance(a.font_size, float) == isinstance(b.font_size, float)
+        np.testing.assert_array_equal(np.asarray(a.distance), np.asarray(b.distance))
+        np.testing.assert_array_equal(np.asarray(a.vec), np.asarray(b.vec))
+        assert float(a.norm) == float(b.norm) and float(a.weight) == float(b.weight)
+
+
+@pytest.mark.parametrize("seed", range(60))
+def test_native_group_output_equals_oracle(seed):
+    p = pkg()
+    blks, lines, im_w, im_h, mask = random_page(seed)
+    use_mask = mask if seed % 5 else None
+    got = p.textblock.group_output(copy.deepcopy(blks), lines.copy(), im_w, im_h, use_mask)
+    ref = R.group_output(copy.deepcopy(blks), lines.copy(), im_w, im_h, use_mask)
+    same_blocks(got, ref)
+
+
+def test_native_group_output_empty_inputs():
+    p = pkg()
+    none = (np.zeros((0, 4), np.int32), np.zeros((0,), np.int32), np.zeros((0,)))
+    assert p.textblock.group_output(none, [], 640, 480, np.zeros((480, 640), np.uint8)) == []
+    lines = np.array([[[10, 10], [100, 10], [100, 30], [10, 30]]], np.int32)
+    got = p.textblock.group_output(none, lines, 640, 480, None)
+    ref = R.group_output(none, lines, 640, 480, None)
+    same_blocks(got, ref)
+    # a wide page takes the two-page branch of the reading order (textblock.py:280-281)
+    blks, lines, im_w, im_h, mask = random_page(3, im_w=1800, im_h=900)
+    same_blocks(p.textblock.group_output(copy.deepcopy(blks), lines.copy(), im_w, im_h, mask),
+                R.group_output(copy.deepcopy(blks), lines.copy(), im_w, im_h, mask))
+
+
+@pytest.mark.skipif(not RI.reference_available(), reason="reference tree not present")
+@pytest.mark.parametrize("seed", range(0, 60, 3))
+def test_native_group_output_equals_reference_code(seed):
+    """The reference's OWN group_output (shapely stand-in = the oracle's polygon predicate)."""
+    from oracle import ref_post_import as RP
+    ref = RP.load_reference_post()
+    p = pkg()
+    blks, lines, im_w, im_h, mask = random_page(seed)
+    got = p.textblock.group_output(copy.deepcopy(blks), lines.copy(), im_w, im_h, mask)
+    with np.errstate(all="ignore"):
+        theirs = ref.TB.group_output(copy.deepcopy(blks), lines.copy(), im_w, im_h, mask)
+    same_blocks(got, theirs)
+    for a, b in zip(got, theirs):
+        assert type(a.font_size) is type(b.font_size)

@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, "libctd_hip.so")
 SELFTEST_PATH = os.path.join(_HERE, "ctd_selftest")
 
 # ---- constants mirrored from include/ctd_hip.h -------------------------------
-ABI_VERSION = 1
+ABI_VERSION = 2
 OK = 0
 PREC_F32, PREC_F16 = 0, 1
 ACT = {"none": 0, "silu": 1, "leaky": 2, "relu": 3, "sigmoid": 4}
@@ -44,18 +44,14 @@ class CtdOp(C.Structure):
     ]
 
 
-class CtdWindow(C.Structure):
-    _fields_ = [("img", C.c_void_p), ("mask", C.c_void_p), ("img_w", C.c_int32), ("mask_w", C.c_int32),
-                ("x1", C.c_int32), ("y1", C.c_int32), ("w", C.c_int32), ("h", C.c_int32)]
+class CtdTailPage(C.Structure):
+    _fields_ = [("img_dev", C.c_void_p), ("im_h", C.c_int32), ("im_w", C.c_int32), ("dw", C.c_int32), ("dh", C.c_int32)]
 
 
-class CtdRule(C.Structure):
-    _fields_ = [("kind", C.c_int32), ("lo", C.c_float), ("hi", C.c_float), ("invert", C.c_int32),
-                ("aux", C.c_int32)]
-
-
-class CtdBand(C.Structure):
-    _fields_ = [("win", C.c_int32), ("top", C.c_int32), ("mtop", C.c_int32)]
+class CtdTailParams(C.Structure):
+    _fields_ = [("conf_thresh", C.c_float), ("nms_thresh", C.c_float), ("box_thresh", C.c_float),
+                ("max_candidates", C.c_int32), ("unclip_ratio", C.c_double), ("refine", C.c_int32),
+                ("refine_mode", C.c_int32), ("keep_undetected_mask", C.c_int32), ("pad_", C.c_int32)]
 
 
 class CtdBlk(C.Structure):
@@ -84,14 +80,22 @@ SYMBOLS = {
     "ctd_ccl_workspace_bytes": (C.c_size_t, [_i32, _i32, _i32]),
     "ctd_ccl": (_i32, [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _i32, _vp, C.c_size_t, _vp]),
     "ctd_resize_linear_u8": (_i32, [_vp, _i32, _i32, _i32, _vp, _i32, _i32, _i32, _i32, _vp]),
-    "ctd_win_hist": (_i32, [C.POINTER(CtdWindow), _i32, _vp, _vp]),
-    "ctd_win_xor": (_i32, [C.POINTER(CtdWindow), _i32, C.POINTER(CtdRule), _i32, _vp, _vp]),
-    "ctd_win_render": (_i32, [C.POINTER(CtdWindow), _i32, C.POINTER(CtdRule), C.POINTER(_i32), _i32, _vp, _i32, _vp]),
-    "ctd_win_accept": (_i32, [C.POINTER(CtdWindow), _i32, C.POINTER(CtdBand), _i32, _vp, _i32, _vp, _vp, _i32, _vp, _i32,
-                               _vp, _vp]),
-    "ctd_win_dilate": (_i32, [C.POINTER(CtdWindow), _i32, C.POINTER(_i32), _vp, _vp, _vp, _i32, _vp, _i32, _vp]),
-    "ctd_win_commit": (_i32, [C.POINTER(CtdWindow), _i32, C.POINTER(_i32), _vp, _i32, _vp, _i32, _vp]),
     "ctd_db_boxes": (_i32, [_vp, _vp, _vp, _i32, _vp, _vp, _i32, _i32, _i32, _i32, C.c_double, _vp, _vp, C.POINTER(_i32)]),
+    "ctd_tail_create": (_i32, [C.POINTER(_vp), _i32]),
+    "ctd_tail_destroy": (None, [_vp]),
+    "ctd_tail_stream": (_vp, [_vp]),
+    "ctd_tail_run": (_i32, [_vp, _i32, _i32, _i32, _vp, _i32, _i32, _vp, _vp, _i64, _vp, C.POINTER(CtdTailPage),
+                            C.POINTER(CtdTailParams), _vp, _vp, _vp]),
+    "ctd_tail_db_boxes": (_i32, [_vp, _i32, _i32, _i32, _vp, _i64, _vp, _i32, C.c_double]),
+    "ctd_tail_refine": (_i32, [_vp, _i32, C.POINTER(CtdTailPage), _vp, _vp, _vp, _i32, _i32, _vp, _vp]),
+    "ctd_tail_page_counts": (_i32, [_vp, _i32, C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i32),
+                                    C.POINTER(_i32)]),
+    "ctd_tail_page_fetch": (_i32, [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "ctd_db_boxes_compact": (_i32, [_i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                                    _vp, _i32, C.c_double, _vp, _vp, C.POINTER(_i32)]),
+    "ctd_topk_colors": (_i32, [_vp, _vp]),
+    "ctd_otsu_from_hist": (_i32, [_vp]),
+    "ctd_inrange_bounds": (None, [C.c_double, C.c_double, C.POINTER(_i32), C.POINTER(_i32)]),
     "ctd_group_output": (_i32, [_vp, _vp, _i32, _vp, _i32, _i32, _i32, _vp, _i32, _vp, _i32, _vp, _i32, _vp, _i32,
                                 C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i32)]),
     "ctd_last_error": (C.c_char_p, []),

@@ -5,8 +5,6 @@
 
 #include "../../include/ctd_hip.h"
 
-typedef ctd_window CtdWin;
-typedef ctd_rule CtdRule;
 typedef _Float16 half_t;
 typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
 typedef _Float16 half4_t __attribute__((ext_vector_type(4)));

@@ -592,6 +592,8 @@ int prepare(ctd_engine* e, int B, int H, int W) {
 
 }  // namespace
 
+int ctd_fail_msg(int code, const std::string& msg) { return fail(code, msg); }
+
 extern "C" {
 
 const char* ctd_last_error(void) { return g_err.c_str(); }
@@ -773,144 +775,6 @@ int ctd_resize_linear_u8(const uint8_t* src_dev, int32_t sH, int32_t sW, int32_t
   if (C != 1 && C != 3) return fail(CTD_ERR_UNSUPPORTED, "resize: 1 or 3 channels");
   if (sH < 1 || sW < 1 || dH < 1 || dW < 1 || canvasH < dH || canvasW < dW) return fail(CTD_ERR_INVALID, "bad sizes");
   launch_resize_linear_u8(src_dev, sH, sW, C, dst_dev, dH, dW, canvasH, canvasW, (hipStream_t)stream);
-  HIP_TRY(hipGetLastError());
-  return CTD_OK;
-}
-
-// ---- per-window kernels: small host tables are staged in a growable device scratch --------
-namespace {
-struct Scratch {
-  void* p = nullptr;
-  size_t cap = 0;
-};
-thread_local Scratch g_tab[3];
-
-int stage(int slot, const void* host, size_t bytes, hipStream_t st, void** dev) {
-  Scratch& s = g_tab[slot];
-  // the previous call's kernels may still read the table: drain the stream before reuse
-  HIP_TRY(hipStreamSynchronize(st));
-  if (bytes > s.cap) {
-    if (s.p) HIP_TRY(hipFree(s.p));
-    s.p = nullptr;
-    s.cap = 0;
-    const size_t cap = std::max<size_t>(bytes * 2, 4096);
-    HIP_TRY(hipMalloc(&s.p, cap));
-    s.cap = cap;
-  }
-  HIP_TRY(hipMemcpyAsync(s.p, host, bytes, hipMemcpyHostToDevice, st));
-  *dev = s.p;
-  return CTD_OK;
-}
-
-int max_pixels(const ctd_window* w, int n) {
-  int m = 1;
-  for (int i = 0; i < n; ++i) m = std::max(m, w[i].w * w[i].h);
-  return m;
-}
-
-int check_windows(const ctd_window* w, int n) {
-  if (!w || n < 1) return fail(CTD_ERR_INVALID, "no windows");
-  for (int i = 0; i < n; ++i)
-    if (!w[i].img || !w[i].mask || w[i].w < 1 || w[i].h < 1 || w[i].x1 < 0 || w[i].y1 < 0 ||
-        w[i].x1 + w[i].w > w[i].img_w || w[i].x1 + w[i].w > w[i].mask_w)
-      return fail(CTD_ERR_INVALID, "window " + std::to_string(i) + " is malformed");
-  return CTD_OK;
-}
-}  // namespace
-
-int ctd_win_hist(const ctd_window* wins, int32_t n, uint32_t* hist_dev, void* stream) {
-  if (int rc = check_windows(wins, n)) return rc;
-  if (!hist_dev) return fail(CTD_ERR_INVALID, "null hist");
-  hipStream_t st = (hipStream_t)stream;
-  void* wd;
-  if (int rc = stage(0, wins, sizeof(ctd_window) * n, st, &wd)) return rc;
-  HIP_TRY(hipMemsetAsync(hist_dev, 0, (size_t)n * 1024 * sizeof(uint32_t), st));
-  launch_win_hist((const CtdWin*)wd, n, max_pixels(wins, n), hist_dev, st);
-  HIP_TRY(hipGetLastError());
-  return CTD_OK;
-}
-
-int ctd_win_xor(const ctd_window* wins, int32_t n, const ctd_rule* rules, int32_t nrules, uint64_t* sums_dev,
-                void* stream) {
-  if (int rc = check_windows(wins, n)) return rc;
-  if (!rules || !sums_dev || nrules < 1 || nrules > 6) return fail(CTD_ERR_INVALID, "bad rules");
-  hipStream_t st = (hipStream_t)stream;
-  void *wd, *rd;
-  if (int rc = stage(0, wins, sizeof(ctd_window) * n, st, &wd)) return rc;
-  if (int rc = stage(1, rules, sizeof(ctd_rule) * (size_t)n * nrules, st, &rd)) return rc;
-  HIP_TRY(hipMemsetAsync(sums_dev, 0, (size_t)n * nrules * sizeof(uint64_t), st));
-  launch_win_xor((const CtdWin*)wd, (const CtdRule*)rd, n, nrules, max_pixels(wins, n),
-                 (unsigned long long*)sums_dev, st);
-  HIP_TRY(hipGetLastError());
-  return CTD_OK;
-}
-
-int ctd_win_render(const ctd_window* wins, int32_t n, const ctd_rule* bands, const int32_t* tops, int32_t nbands,
-                   uint8_t* canvas_dev, int32_t canvas_w, void* stream) {
-  if (int rc = check_windows(wins, n)) return rc;
-  if (!bands || !tops || !canvas_dev || nbands < 1) return fail(CTD_ERR_INVALID, "bad bands");
-  for (int i = 0; i < nbands; ++i)
-    if (bands[i].aux < 0 || bands[i].aux >= n || wins[bands[i].aux].w > canvas_w || tops[i] < 0)
-      return fail(CTD_ERR_INVALID, "band " + std::to_string(i) + " is malformed");
-  hipStream_t st = (hipStream_t)stream;
-  void *wd, *rd, *td;
-  if (int rc = stage(0, wins, sizeof(ctd_window) * n, st, &wd)) return rc;
-  if (int rc = stage(1, bands, sizeof(ctd_rule) * (size_t)nbands, st, &rd)) return rc;
-  if (int rc = stage(2, tops, sizeof(int32_t) * (size_t)nbands, st, &td)) return rc;
-  launch_win_render((const CtdWin*)wd, (const CtdRule*)rd, (const int*)td, nbands, max_pixels(wins, n), canvas_dev,
-                    canvas_w, st);
-  HIP_TRY(hipGetLastError());
-  return CTD_OK;
-}
-
-int ctd_win_accept(const ctd_window* wins, int32_t n, const ctd_band* bands, int32_t nbands, const int32_t* labels_dev,
-                   int32_t canvas_w, const int32_t* stats_dev, const uint8_t* allowed_dev, int32_t min_box,
-                   uint8_t* merged_dev, int32_t merged_w, uint32_t* counters_dev, void* stream) {
-  if (int rc = check_windows(wins, n)) return rc;
-  if (!bands || nbands < 1 || !labels_dev || !merged_dev || !counters_dev || (!stats_dev && !allowed_dev))
-    return fail(CTD_ERR_INVALID, "bad accept arguments");
-  int mp = 1;
-  for (int i = 0; i < nbands; ++i) {
-    if (bands[i].win < 0 || bands[i].win >= n || bands[i].top < 0 || bands[i].mtop < 0 ||
-        wins[bands[i].win].w > canvas_w || wins[bands[i].win].w > merged_w)
-      return fail(CTD_ERR_INVALID, "band " + std::to_string(i) + " is malformed");
-    mp = std::max(mp, wins[bands[i].win].w * wins[bands[i].win].h);
-  }
-  hipStream_t st = (hipStream_t)stream;
-  void *wd, *bd;
-  if (int rc = stage(0, wins, sizeof(ctd_window) * n, st, &wd)) return rc;
-  if (int rc = stage(1, bands, sizeof(ctd_band) * (size_t)nbands, st, &bd)) return rc;
-  launch_win_accept((const CtdWin*)wd, (const ctd_band*)bd, nbands, mp, labels_dev, canvas_w, stats_dev, allowed_dev,
-                    min_box, merged_dev, merged_w, counters_dev, st);
-  HIP_TRY(hipGetLastError());
-  return CTD_OK;
-}
-
-int ctd_win_dilate(const ctd_window* wins, int32_t n, const int32_t* mtops, const uint8_t* merged_in_dev,
-                   uint8_t* merged_out_dev, uint8_t* comp_dev, int32_t merged_w, uint32_t* count255_dev, int32_t dilate,
-                   void* stream) {
-  if (int rc = check_windows(wins, n)) return rc;
-  if (!mtops || !merged_in_dev || !merged_out_dev || !comp_dev || !count255_dev || merged_in_dev == merged_out_dev)
-    return fail(CTD_ERR_INVALID, "bad dilate arguments");
-  hipStream_t st = (hipStream_t)stream;
-  void *wd, *td;
-  if (int rc = stage(0, wins, sizeof(ctd_window) * n, st, &wd)) return rc;
-  if (int rc = stage(2, mtops, sizeof(int32_t) * (size_t)n, st, &td)) return rc;
-  launch_win_dilate((const CtdWin*)wd, (const int*)td, n, max_pixels(wins, n), merged_in_dev, merged_out_dev, comp_dev,
-                    merged_w, count255_dev, dilate, st);
-  HIP_TRY(hipGetLastError());
-  return CTD_OK;
-}
-
-int ctd_win_commit(const ctd_window* wins, int32_t n, const int32_t* mtops, const uint8_t* merged_dev, int32_t merged_w,
-                   uint8_t* page_dev, int32_t page_w, void* stream) {
-  if (int rc = check_windows(wins, n)) return rc;
-  if (!mtops || !merged_dev || !page_dev || ((uintptr_t)page_dev & 3)) return fail(CTD_ERR_INVALID, "bad commit arguments");
-  hipStream_t st = (hipStream_t)stream;
-  void *wd, *td;
-  if (int rc = stage(0, wins, sizeof(ctd_window) * n, st, &wd)) return rc;
-  if (int rc = stage(2, mtops, sizeof(int32_t) * (size_t)n, st, &td)) return rc;
-  launch_win_commit((const CtdWin*)wd, (const int*)td, n, max_pixels(wins, n), merged_dev, merged_w, page_dev, page_w, st);
   HIP_TRY(hipGetLastError());
   return CTD_OK;
 }

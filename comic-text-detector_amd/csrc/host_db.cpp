@@ -411,3 +411,85 @@ extern "C" int ctd_db_boxes(const float* prob, const int32_t* lab_f, const int32
   }
   return CTD_OK;
 }
+
+// The same stage from the tables `launch_dbc` (csrc/kernels_tail.hip) compacts on the device: no label
+// image, no probability map.  Components are walked newest first (descending first pixel; labels are
+// already in first-pixel order, so this is a merge of the two label ranges from their ends).  A
+// contour's filled polygon is a subtree of the containment forest
+//     component -> the holes it rings -> the components inside those holes -> ...
+// and everything enclosed has a later first pixel than what encloses it, so one pass in that order has
+// every subtree sum complete when its root is reached:
+//     outer border of c : c + all holes ringed by c, each with everything inside it
+//     hole border of h  : h's border ring (pixels of the ringing component that 4-touch h) + h + everything inside h
+// Hull points are the row extremes of the component / of the ring.
+extern "C" int ctd_db_boxes_compact(int W, int H, int n_f, const int32_t* st_f, const int32_t* first_f,
+                                    const int32_t* par_f, const int32_t* off_f, const double* sum_f, int n_b,
+                                    const int32_t* st_b, const int32_t* first_b, const int32_t* par_b,
+                                    const int32_t* off_b, const double* sum_b, const double* ring_sum,
+                                    const int32_t* ring_cnt, const int32_t* row_lo, const int32_t* row_hi,
+                                    int max_candidates, double unclip_ratio, int16_t* boxes, float* scores, int* n_out) {
+  if (W <= 0 || H <= 0 || n_f < 0 || n_b < 0 || max_candidates < 0 || !boxes || !scores || !n_out ||
+      (n_f && (!st_f || !first_f || !par_f || !off_f || !sum_f)) ||
+      (n_b && (!st_b || !first_b || !par_b || !off_b || !sum_b || !ring_sum || !ring_cnt)) ||
+      ((n_f || n_b) && (!row_lo || !row_hi)))
+    return CTD_ERR_INVALID;
+  std::vector<double> acc_sf(n_f, 0.0), acc_sb(n_b, 0.0);
+  std::vector<long long> acc_nf(n_f, 0), acc_nb(n_b, 0);
+  std::vector<P> pts, h, tmp;
+  int n = 0;
+  int lf = n_f, lb = n_b;                    // next candidates: labels lf, lb (1-based), walking down
+  while (lb > 0 && par_b[lb - 1] <= 0) --lb;  // only holes have a border
+  while (n < max_candidates && (lf > 0 || lb > 0)) {
+    const long long kf = lf > 0 ? (long long)first_f[lf - 1] : -1;
+    const long long kb = lb > 0 ? (long long)first_b[lb - 1] - 1 : -1;
+    const bool take_hole = kb > kf;          // ties cannot happen: the pixel above a hole's first pixel belongs to its ring
+    double sum;
+    long long cnt;
+    pts.clear();
+    if (!take_hole) {
+      const int c = lf - 1;
+      --lf;
+      sum = sum_f[c] + acc_sf[c];
+      cnt = (long long)st_f[5 * c + 4] + acc_nf[c];
+      const int pb = par_f[c];
+      if (pb > 0 && pb <= n_b && par_b[pb - 1] > 0) acc_sb[pb - 1] += sum, acc_nb[pb - 1] += cnt;
+      const int y0 = st_f[5 * c + 1], rows = st_f[5 * c + 3];
+      for (int r = 0; r < rows; ++r) {
+        const int lo = row_lo[off_f[c] + r], hi = row_hi[off_f[c] + r];
+        if (hi < lo) continue;
+        pts.push_back({(double)lo, (double)(y0 + r)});
+        if (hi != lo) pts.push_back({(double)hi, (double)(y0 + r)});
+      }
+    } else {
+      const int c = lb - 1;
+      --lb;
+      while (lb > 0 && par_b[lb - 1] <= 0) --lb;
+      const double inner_s = sum_b[c] + acc_sb[c];
+      const long long inner_n = (long long)st_b[5 * c + 4] + acc_nb[c];
+      const int pf = par_b[c];
+      if (pf > 0 && pf <= n_f) acc_sf[pf - 1] += inner_s, acc_nf[pf - 1] += inner_n;
+      sum = inner_s + ring_sum[c];
+      cnt = inner_n + ring_cnt[c];
+      const int y0 = st_b[5 * c + 1] - 1, rows = st_b[5 * c + 3] + 2;
+      for (int r = 0; r < rows; ++r) {
+        const int lo = row_lo[off_b[c] + r], hi = row_hi[off_b[c] + r];
+        if (hi < lo) continue;
+        pts.push_back({(double)lo, (double)(y0 + r)});
+        if (hi != lo) pts.push_back({(double)hi, (double)(y0 + r)});
+      }
+    }
+    const int idx = n++;
+    std::memset(boxes + (size_t)idx * 8, 0, sizeof(int16_t) * 8);
+    scores[idx] = 0.f;
+    hull(pts, h, tmp);
+    Pf box[4];
+    double bw, bh;
+    min_area_box(h, 0.0, box, bw, bh);
+    if (std::min(bw, bh) < 2) continue;                              // db_utils.py:146-147
+    order_box(box);
+    scores[idx] = cnt > 0 ? (float)(sum / (double)cnt) : 0.f;
+    unclip_to_box(box, unclip_ratio, W, H, boxes + (size_t)idx * 8, pts, h, tmp);
+  }
+  *n_out = n;
+  return CTD_OK;
+}

@@ -59,27 +59,15 @@ size_t nms_workspace_bytes(int B, int rows);
 void launch_nms(const float* blks, int B, int rows, int no, float conf, float iou, int max_det, int max_nms,
                 float max_wh, float* dets, int* counts, void* ws, hipStream_t st);
 size_t ccl_workspace_bytes(int B, int H, int W);
+// invert: foreground = !(img > thresh); first (B,max_labels): linear index of every component's first pixel
+// in raster order (= its union-find root), or null
 void launch_ccl(const uint8_t* img, int B, int H, int W, int thresh, int conn, int* labels, int* n_out,
-                int* stats, int max_labels, void* ws, hipStream_t st);
+                int* stats, int max_labels, void* ws, hipStream_t st, int invert = 0, int* first = nullptr);
 
 // ---- kernels_pre.hip ----------------------------------------------------------
 // cv2.resize(INTER_LINEAR) u8 (C = 1 or 3) into the top-left (dH,dW) of a zero-padded canvas
 void launch_resize_linear_u8(const uint8_t* src, int sH, int sW, int C, uint8_t* dst, int dH, int dW, int canvasH,
                              int canvasW, hipStream_t st);
-
-// ---- kernels_win.hip : batched per-window kernels of the mask refinement -----------
-void launch_win_hist(const CtdWin* wins_dev, int n, int max_pix, unsigned* hist_dev, hipStream_t st);
-void launch_win_xor(const CtdWin* wins_dev, const CtdRule* rules_dev, int n, int nrules, int max_pix,
-                    unsigned long long* sums_dev, hipStream_t st);
-void launch_win_render(const CtdWin* wins_dev, const CtdRule* rules_dev, const int* tops_dev, int nbands, int max_pix,
-                       uint8_t* canvas_dev, int canvas_w, hipStream_t st);
-void launch_win_accept(const CtdWin* wins_dev, const ctd_band* bands_dev, int nbands, int max_pix, const int* labels,
-                       int canvas_w, const int* stats, const uint8_t* allowed, int min_box, uint8_t* merged, int merged_w,
-                       unsigned* counters, hipStream_t st);
-void launch_win_dilate(const CtdWin* wins_dev, const int* mtops_dev, int n, int max_pix, const uint8_t* in, uint8_t* out,
-                       uint8_t* comp, int merged_w, unsigned* count255, int dilate, hipStream_t st);
-void launch_win_commit(const CtdWin* wins_dev, const int* mtops_dev, int n, int max_pix, const uint8_t* merged, int merged_w,
-                       uint8_t* page, int page_w, hipStream_t st);
 
 // ---- mfma layout probe (selftest) -------------------------------------------
 void launch_mfma_probe(const half_t* a, const half_t* b, float* out, hipStream_t st);

@@ -204,7 +204,7 @@ __device__ __forceinline__ void lds_union(int* lp, int a, int b) {
 
 template <int CONN>
 __global__ __launch_bounds__(256) void ccl_local_kernel(const uint8_t* __restrict__ img, int* __restrict__ parent_all,
-                                                        int H, int W, int tiles_x, int tiles_y, int thresh) {
+                                                        int H, int W, int tiles_x, int tiles_y, int thresh, int invert) {
   __shared__ int lp[CT * CT];
   int bid = blockIdx.x;
   const int tx = bid % tiles_x;
@@ -217,7 +217,7 @@ __global__ __launch_bounds__(256) void ccl_local_kernel(const uint8_t* __restric
   for (int k = 0; k < CT * CT / 256; ++k) {
     const int li = threadIdx.x + 256 * k;
     const int gx = x0 + (li % CT), gy = y0 + (li / CT);
-    const bool fg = gx < W && gy < H && (int)img[base + (size_t)gy * W + gx] > thresh;
+    const bool fg = gx < W && gy < H && (((int)img[base + (size_t)gy * W + gx] > thresh) != (invert != 0));
     lp[li] = fg ? li : -1;
   }
   __syncthreads();
@@ -308,7 +308,7 @@ __device__ __forceinline__ int block_exclusive_scan(int v, int* sh, int* total) 
 // pass 1 (mode 0): count roots per chunk.  pass 3 (mode 1): assign raster-order ids to roots.
 __global__ __launch_bounds__(256) void ccl_rank_kernel(const int* __restrict__ parent_all, int hw, int nchunks,
                                                        int* __restrict__ chunk_cnt, int* __restrict__ ids_all,
-                                                       int mode) {
+                                                       int mode, int* __restrict__ first, int max_labels) {
   __shared__ int sh[4];
   const int b = blockIdx.x / nchunks, ch = blockIdx.x % nchunks;
   const int* parent = parent_all + (size_t)b * hw;
@@ -327,7 +327,10 @@ __global__ __launch_bounds__(256) void ccl_rank_kernel(const int* __restrict__ p
     int* ids = ids_all + (size_t)b * hw;
     for (int j = 0; j < RK_PER_T; ++j) {
       const int p = p0 + j;
-      if (p < hw && parent[p] == p) ids[p] = ++id;
+      if (p < hw && parent[p] == p) {
+        ids[p] = ++id;
+        if (first && id <= max_labels) first[(size_t)b * max_labels + id - 1] = p;   // root = first pixel in raster order
+      }
     }
   }
 }
@@ -438,7 +441,7 @@ size_t ccl_workspace_bytes(int B, int H, int W) {
 }
 
 void launch_ccl(const uint8_t* img, int B, int H, int W, int thresh, int conn, int* labels, int* n_out, int* stats,
-                int max_labels, void* ws, hipStream_t st) {
+                int max_labels, void* ws, hipStream_t st, int invert, int* first) {
   const int hw = H * W;
   const long long total = (long long)B * hw;
   const int nchunks = (hw + RK_CHUNK - 1) / RK_CHUNK;
@@ -448,17 +451,19 @@ void launch_ccl(const uint8_t* img, int B, int H, int W, int thresh, int conn, i
   const int tiles_x = (W + CT - 1) / CT, tiles_y = (H + CT - 1) / CT;
   if (conn == 8) {
     hipLaunchKernelGGL((ccl_local_kernel<8>), dim3(B * tiles_x * tiles_y), dim3(256), 0, st, img, labels, H, W, tiles_x,
-                       tiles_y, thresh);
+                       tiles_y, thresh, invert);
     hipLaunchKernelGGL((ccl_border_kernel<8>), dim3(g), dim3(256), 0, st, labels, B, H, W);
   } else {
     hipLaunchKernelGGL((ccl_local_kernel<4>), dim3(B * tiles_x * tiles_y), dim3(256), 0, st, img, labels, H, W, tiles_x,
-                       tiles_y, thresh);
+                       tiles_y, thresh, invert);
     hipLaunchKernelGGL((ccl_border_kernel<4>), dim3(g), dim3(256), 0, st, labels, B, H, W);
   }
   hipLaunchKernelGGL(ccl_flatten_kernel, dim3(g), dim3(256), 0, st, labels, total, hw);
-  hipLaunchKernelGGL(ccl_rank_kernel, dim3(B * nchunks), dim3(256), 0, st, labels, hw, nchunks, chunk_cnt, ids, 0);
+  hipLaunchKernelGGL(ccl_rank_kernel, dim3(B * nchunks), dim3(256), 0, st, labels, hw, nchunks, chunk_cnt, ids, 0,
+                     (int*)nullptr, 0);
   hipLaunchKernelGGL(ccl_scan_chunks_kernel, dim3(B), dim3(256), 0, st, chunk_cnt, nchunks, n_out);
-  hipLaunchKernelGGL(ccl_rank_kernel, dim3(B * nchunks), dim3(256), 0, st, labels, hw, nchunks, chunk_cnt, ids, 1);
+  hipLaunchKernelGGL(ccl_rank_kernel, dim3(B * nchunks), dim3(256), 0, st, labels, hw, nchunks, chunk_cnt, ids, 1,
+                     first, max_labels);
   if (stats)
     hipLaunchKernelGGL(ccl_stats_init_kernel, dim3(grid_for((long long)B * max_labels)), dim3(256), 0, st, stats,
                        (long long)B * max_labels, H, W);

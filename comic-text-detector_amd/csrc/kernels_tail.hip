@@ -1,0 +1,469 @@
+// Device kernels of the detector tail (reference inference.py:148-178 after the network):
+//
+//  * DB text-line stage (reference utils/db_utils.py:123-211): after the two labelling passes
+//    (`launch_ccl`: 8-connected foreground, 4-connected background) the per-contour quantities the
+//    host geometry needs are compacted here, so no label image or probability map leaves the GPU:
+//      - containment links (which hole a component sits in, which component rings a hole),
+//      - sum of the probability map per component / per hole / per hole-border ring,
+//      - leftmost and rightmost pixel of every component (and ring) per row: the convex hull of a
+//        pixel set is the hull of its row extremes.
+//  * mask refinement (reference utils/textmask.py:29-131): batched per-window kernels;
+//    every text-block window of a page batch is one entry of a window table, candidate masks and
+//    merged masks live as bands of packed canvases that `launch_ccl` labels in one launch.
+//
+// Integer / comparison work on u8 and i32 pixels: HBM- and latency-bound, no MFMA.
+#include <hip/amd_detail/amd_hip_unsafe_atomics.h>
+
+#include "tail.h"
+
+namespace {
+
+inline int grid_for(long long total, int block = 256) {
+  long long g = (total + block - 1) / block;
+  if (g > 256LL * 32) g = 256LL * 32;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+// ======================================================================================================
+// DB stage
+// ======================================================================================================
+__global__ __launch_bounds__(256) void dbc_prep_kernel(DbcTables t) {
+  const int b = blockIdx.y, l = blockIdx.x * 256 + threadIdx.x;
+  const int hw = t.H * t.W;
+  const int nf = min(t.n_f[b], t.cap), nb = min(t.n_b[b], t.cap);
+  const size_t r = (size_t)b * t.cap + l;
+  if (l < nf) {
+    const int p = t.first_f[r];
+    t.par_f[r] = (p % t.W) > 0 ? t.lab_b[(size_t)b * hw + p - 1] : 0;
+    t.off_f[r] = t.st_f[r * 5 + 3];
+  }
+  if (l < nb) {
+    const int* s = t.st_b + r * 5;
+    const bool hole = s[0] > 0 && s[1] > 0 && s[0] + s[2] < t.W && s[1] + s[3] < t.H;   // does not touch the frame
+    t.par_b[r] = hole ? t.lab_f[(size_t)b * hw + t.first_b[r] - 1] : 0;
+    t.off_b[r] = hole ? s[3] + 2 : 0;
+  }
+}
+
+__device__ __forceinline__ int block_excl_scan(int v, int* sh, int* total) {   // 256 threads
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  int incl = v;
+  for (int off = 1; off < 64; off <<= 1) {
+    const int u = __shfl_up(incl, off);
+    if (lane >= off) incl += u;
+  }
+  if (lane == 63) sh[w] = incl;
+  __syncthreads();
+  int base = 0;
+  for (int i = 0; i < w; ++i) base += sh[i];
+  *total = sh[0] + sh[1] + sh[2] + sh[3];
+  __syncthreads();
+  return base + incl - v;
+}
+
+// row-table offsets: exclusive scan over [heights of the components | heights + 2 of the holes]
+__global__ __launch_bounds__(256) void dbc_scan_kernel(DbcTables t) {
+  __shared__ int sh[4];
+  const int b = blockIdx.x;
+  const int nf = min(t.n_f[b], t.cap), nb = min(t.n_b[b], t.cap);
+  int carry = 0;
+  for (int pass = 0; pass < 2; ++pass) {
+    int* a = (pass ? t.off_b : t.off_f) + (size_t)b * t.cap;
+    const int n = pass ? nb : nf;
+    for (int base = 0; base < n; base += 256) {
+      const int i = base + threadIdx.x;
+      const int v = i < n ? a[i] : 0;
+      int total;
+      const int e = block_excl_scan(v, sh, &total);
+      if (i < n) a[i] = carry + e;
+      carry += total;
+    }
+  }
+  if (threadIdx.x == 0) {
+    int* h = t.hdr + b * 4;
+    h[0] = nf, h[1] = nb, h[2] = carry;
+    h[3] = (t.n_f[b] > t.cap || t.n_b[b] > t.cap || carry > t.rcap) ? 1 : 0;
+  }
+}
+
+__global__ void dbc_init_kernel(DbcTables t) {
+  const long long total = (long long)t.B * t.rcap;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int b = (int)(i / t.rcap), r = (int)(i % t.rcap);
+    if (r < t.hdr[b * 4 + 2]) t.row_lo[i] = 0x7fffffff, t.row_hi[i] = -1;
+  }
+}
+
+__global__ __launch_bounds__(256) void dbc_accum_kernel(DbcTables t) {
+  const int hw = t.H * t.W;
+  const long long total = (long long)t.B * hw;
+  const long long span = (long long)gridDim.x * 256;
+  const int lane = threadIdx.x & 63;
+  for (long long i0 = (long long)blockIdx.x * 256; i0 < total; i0 += span) {
+    const long long i = i0 + threadIdx.x;
+    const bool live = i < total;
+    const int b = live ? (int)(i / hw) : 0, p = live ? (int)(i % hw) : 0;
+    const int x = p % t.W, y = p / t.W;
+    const int lf = live ? t.lab_f[i] : 0, lb = live ? t.lab_b[i] : 0;
+    const int key = lf > 0 ? lf : -lb;
+    const double pr = live ? (double)t.prob[(long long)b * t.prob_stride + p] : 0.0;
+    // horizontal runs of one label inside the wave: the first lane of a run acts for it
+    const int prev = __shfl_up(key, 1);
+    const bool head = lane == 0 || prev != key || x == 0;
+    const unsigned long long heads = __ballot(head);
+    const unsigned long long later = lane == 63 ? 0ull : (heads >> (lane + 1));
+    const int len = later ? __ffsll((long long)later) : 64 - lane;
+    double ps = pr;
+    for (int off = 1; off < 64; off <<= 1) {
+      const double u = __shfl_up(ps, off);
+      if (lane >= off) ps += u;
+    }
+    const double s_tail = __shfl(ps, lane + len - 1);
+    const double s_prev = __shfl_up(ps, 1);
+    const double run = s_tail - (lane > 0 ? s_prev : 0.0);
+    if (!live || t.hdr[b * 4 + 3]) continue;          // overflowed page: the host takes the label-image path
+    const size_t cb = (size_t)b * t.cap, rb = (size_t)b * t.rcap;
+    if (lf > 0 && lf <= t.cap) {
+      if (head) {
+        unsafeAtomicAdd(t.sum_f + cb + lf - 1, run);
+        const int row = t.off_f[cb + lf - 1] + (y - t.st_f[(cb + lf - 1) * 5 + 1]);
+        atomicMin(t.row_lo + rb + row, x);
+        atomicMax(t.row_hi + rb + row, x + len - 1);
+      }
+      // border ring of a hole: foreground pixels of the ringing component that 4-touch the hole
+      int seen[4];
+      int ns = 0;
+      const int dq[4] = {-1, 1, -t.W, t.W};
+      const bool ok[4] = {x > 0, x + 1 < t.W, y > 0, y + 1 < t.H};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        if (!ok[k]) continue;
+        const int hb = t.lab_b[i + dq[k]];
+        if (hb <= 0 || hb > t.cap || t.par_b[cb + hb - 1] != lf) continue;
+        bool dup = false;
+        for (int j = 0; j < ns; ++j) dup |= seen[j] == hb;
+        if (dup) continue;
+        seen[ns++] = hb;
+        unsafeAtomicAdd(t.ring_sum + cb + hb - 1, pr);
+        atomicAdd(t.ring_cnt + cb + hb - 1, 1);
+        const int row = t.off_b[cb + hb - 1] + (y - (t.st_b[(cb + hb - 1) * 5 + 1] - 1));
+        atomicMin(t.row_lo + rb + row, x);
+        atomicMax(t.row_hi + rb + row, x);
+      }
+    } else if (head && lb > 0 && lb <= t.cap && t.par_b[cb + lb - 1] > 0) {
+      unsafeAtomicAdd(t.sum_b + cb + lb - 1, run);
+    }
+  }
+}
+
+// ======================================================================================================
+// mask refinement
+// ======================================================================================================
+__device__ __forceinline__ int gray_of(const uint8_t* p) {
+  // OpenCV 4.x RGB2Gray<uchar>: 15-bit coefficients (BY15, GY15, RY15), round to nearest
+  return ((int)p[0] * 3735 + (int)p[1] * 19235 + (int)p[2] * 9798 + 16384) >> 15;
+}
+
+__device__ __forceinline__ int erode_rect(const TWin& w, int x, int y) {
+  int m = 255;
+  for (int dy = -1; dy <= 1; ++dy) {
+    const int yy = y + dy;
+    if (yy < 0 || yy >= w.h) continue;
+    for (int dx = -1; dx <= 1; ++dx) {
+      const int xx = x + dx;
+      if (xx < 0 || xx >= w.w) continue;
+      m = min(m, (int)w.mask[(size_t)(w.y1 + yy) * w.mask_w + w.x1 + xx]);
+    }
+  }
+  return m;
+}
+
+// grey over pixels whose 3x3-eroded mask > 127 (textmask.py:58-61) and B, G, R of the whole window (Otsu, :44-47)
+__global__ __launch_bounds__(256) void tw_hist_kernel(const TWin* __restrict__ wins, unsigned* __restrict__ hist) {
+  __shared__ unsigned h[4 * 256];
+  const TWin w = wins[blockIdx.y];
+  for (int i = threadIdx.x; i < 1024; i += 256) h[i] = 0;
+  __syncthreads();
+  const int npix = w.w * w.h;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < npix; i += gridDim.x * 256) {
+    const int x = i % w.w, y = i / w.w;
+    const uint8_t* p = w.img + ((size_t)(w.y1 + y) * w.img_w + w.x1 + x) * 3;
+    atomicAdd(&h[256 + p[0]], 1u);
+    atomicAdd(&h[512 + p[1]], 1u);
+    atomicAdd(&h[768 + p[2]], 1u);
+    if (erode_rect(w, x, y) > 127) atomicAdd(&h[gray_of(p)], 1u);
+  }
+  __syncthreads();
+  unsigned* out = hist + (size_t)blockIdx.y * 1024;
+  for (int i = threadIdx.x; i < 1024; i += 256)
+    if (h[i]) atomicAdd(out + i, h[i]);
+}
+
+// kind 0: cv2.inRange(grey, lo, hi) with the integer bounds cv2 derives from the scalars (lo > hi: empty);
+// kind 1..3: threshold(channel B/G/R, lo, 255, THRESH_BINARY)
+__device__ __forceinline__ bool rule_on(int kind, int lo, int hi, const uint8_t* p) {
+  if (kind == 0) {
+    const int g = gray_of(p);
+    return g >= lo && g <= hi;
+  }
+  return (int)p[kind - 1] > lo;
+}
+
+// xor distance sum(cand ? 255 - m : m) of the 6 candidate rules of every window (textmask.py:36-37)
+__global__ __launch_bounds__(256) void tw_xor_kernel(const TWin* __restrict__ wins, const TRule* __restrict__ rules,
+                                                     unsigned long long* __restrict__ sums) {
+  __shared__ unsigned long long red[4];
+  const TWin w = wins[blockIdx.y];
+  TRule rs[6];
+  for (int k = 0; k < 6; ++k) rs[k] = rules[(size_t)blockIdx.y * 6 + k];
+  unsigned long long acc[6] = {0, 0, 0, 0, 0, 0};
+  const int npix = w.w * w.h;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < npix; i += gridDim.x * 256) {
+    const int x = i % w.w, y = i / w.w;
+    const uint8_t* p = w.img + ((size_t)(w.y1 + y) * w.img_w + w.x1 + x) * 3;
+    const int m = w.mask[(size_t)(w.y1 + y) * w.mask_w + w.x1 + x];
+#pragma unroll
+    for (int k = 0; k < 6; ++k)
+      if (rs[k].kind >= 0) acc[k] += rule_on(rs[k].kind, rs[k].lo, rs[k].hi, p) ? (255 - m) : m;
+  }
+  for (int k = 0; k < 6; ++k) {
+    unsigned long long v = acc[k];
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const unsigned long long s = red[0] + red[1] + red[2] + red[3];
+      if (s) atomicAdd(sums + (size_t)blockIdx.y * 6 + k, s);
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void tw_render_kernel(const TWin* __restrict__ wins, const TBand* __restrict__ bands,
+                                                        uint8_t* __restrict__ canvas, int canvas_w) {
+  const TBand bd = bands[blockIdx.y];
+  const TWin w = wins[bd.win];
+  const int npix = w.w * w.h;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < npix; i += gridDim.x * 256) {
+    const int x = i % w.w, y = i / w.w;
+    const uint8_t* p = w.img + ((size_t)(w.y1 + y) * w.img_w + w.x1 + x) * 3;
+    const bool on = rule_on(bd.kind, bd.lo, bd.hi, p) != (bd.invert != 0);
+    canvas[(size_t)(bd.cy + y) * canvas_w + bd.cx + x] = on ? 255 : 0;
+  }
+}
+
+// pred_bin of merge_mask_list (:85-89): 3x3 cross erosion of the window's mask, > 60 -> 255
+__device__ __forceinline__ bool pred_on(const TWin& w, int x, int y) {
+  int m = w.mask[(size_t)(w.y1 + y) * w.mask_w + w.x1 + x];
+  if (y > 0) m = min(m, (int)w.mask[(size_t)(w.y1 + y - 1) * w.mask_w + w.x1 + x]);
+  if (y + 1 < w.h) m = min(m, (int)w.mask[(size_t)(w.y1 + y + 1) * w.mask_w + w.x1 + x]);
+  if (x > 0) m = min(m, (int)w.mask[(size_t)(w.y1 + y) * w.mask_w + w.x1 + x - 1]);
+  if (x + 1 < w.w) m = min(m, (int)w.mask[(size_t)(w.y1 + y) * w.mask_w + w.x1 + x + 1]);
+  return m > 60;
+}
+
+// counters[2l] / [2l+1]: pixels of component l not merged yet that are predicted text / background
+__global__ __launch_bounds__(256) void tw_accept_count_kernel(const TWin* __restrict__ wins, const TBand* __restrict__ bands,
+                                                              int round, const int* __restrict__ labels, int canvas_w,
+                                                              int max_labels, const uint8_t* __restrict__ merged,
+                                                              int merged_w, unsigned* __restrict__ counters) {
+  const TBand bd = bands[blockIdx.y];
+  if (round >= 0 && bd.round != round) return;
+  const TWin w = wins[bd.win];
+  const int npix = w.w * w.h;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < npix; i += gridDim.x * 256) {
+    const int x = i % w.w, y = i / w.w;
+    const int l = labels[(size_t)(bd.cy + y) * canvas_w + bd.cx + x];
+    if (l > 0 && l <= max_labels && merged[(size_t)(w.my + y) * merged_w + w.mx + x] == 0)
+      atomicAdd(counters + 2 * (size_t)l + (pred_on(w, x, y) ? 0 : 1), 1u);
+  }
+}
+
+// OR a component into the merged mask iff its bbox has >= min_box pixels (:98-99) and it lowers the
+// xor distance to pred_bin (on > off, the reference's `xor_merged < xor_origin`)
+__global__ __launch_bounds__(256) void tw_accept_apply_kernel(const TWin* __restrict__ wins, const TBand* __restrict__ bands,
+                                                              int round, const int* __restrict__ labels, int canvas_w,
+                                                              const int* __restrict__ stats, int max_labels, int min_box,
+                                                              uint8_t* __restrict__ merged, int merged_w,
+                                                              const unsigned* __restrict__ counters) {
+  const TBand bd = bands[blockIdx.y];
+  if (round >= 0 && bd.round != round) return;
+  const TWin w = wins[bd.win];
+  const int npix = w.w * w.h;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < npix; i += gridDim.x * 256) {
+    const int x = i % w.w, y = i / w.w;
+    const int l = labels[(size_t)(bd.cy + y) * canvas_w + bd.cx + x];
+    if (l <= 0 || l > max_labels) continue;
+    const bool ok = stats[(size_t)(l - 1) * 5 + 2] * stats[(size_t)(l - 1) * 5 + 3] >= min_box;
+    if (ok && counters[2 * (size_t)l] > counters[2 * (size_t)l + 1]) merged[(size_t)(w.my + y) * merged_w + w.mx + x] = 255;
+  }
+}
+
+// 3x3 rect dilation inside the window (REFINEMASK_INPAINT, textmask.py:110-111) or a copy; also the
+// complement canvas for the hole-filling labelling (:113) and the count of set pixels per window
+__global__ __launch_bounds__(256) void tw_dilate_kernel(const TWin* __restrict__ wins, const uint8_t* __restrict__ in,
+                                                        uint8_t* __restrict__ out, uint8_t* __restrict__ comp, int merged_w,
+                                                        unsigned* __restrict__ count255, int dilate) {
+  __shared__ unsigned red[4];
+  const TWin w = wins[blockIdx.y];
+  const int npix = w.w * w.h;
+  unsigned cnt = 0;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < npix; i += gridDim.x * 256) {
+    const int x = i % w.w, y = i / w.w;
+    int m = in[(size_t)(w.my + y) * merged_w + w.mx + x];
+    if (dilate) {
+      for (int dy = -1; dy <= 1; ++dy) {
+        const int yy = y + dy;
+        if (yy < 0 || yy >= w.h) continue;
+        for (int dx = -1; dx <= 1; ++dx) {
+          const int xx = x + dx;
+          if (xx < 0 || xx >= w.w) continue;
+          m = max(m, (int)in[(size_t)(w.my + yy) * merged_w + w.mx + xx]);
+        }
+      }
+    }
+    out[(size_t)(w.my + y) * merged_w + w.mx + x] = (uint8_t)m;
+    comp[(size_t)(w.my + y) * merged_w + w.mx + x] = (uint8_t)(255 - m);
+    cnt += m == 255;
+  }
+  for (int off = 32; off > 0; off >>= 1) cnt += __shfl_down(cnt, off);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = cnt;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned s = red[0] + red[1] + red[2] + red[3];
+    if (s) atomicAdd(count255 + blockIdx.y, s);
+  }
+}
+
+// Hole filling (:113-131): components of the complement with area < the second largest entry of
+// sorted({set-pixel count} U {component areas}) may be OR-ed in.  pass 0: maximum; pass 1: multiplicity
+// of the maximum and the runner-up; pass 2: on / off counters; pass 3: apply.
+// top2 (n,3) = [maximum, multiplicity - 1, runner-up], all three initialised to -1 by the caller
+// (one memset); a window without any entry besides its background keeps runner-up -1: nothing is filled.
+__global__ __launch_bounds__(256) void tw_holes_kernel(const TWin* __restrict__ wins, int pass, const int* __restrict__ labels2,
+                                                       const int* __restrict__ stats2, const int* __restrict__ first2,
+                                                       int max_labels, const unsigned* __restrict__ count255,
+                                                       int* __restrict__ top2, uint8_t* __restrict__ merged, int merged_w,
+                                                       unsigned* __restrict__ counters2) {
+  const TWin w = wins[blockIdx.y];
+  int* tp = top2 + (size_t)blockIdx.y * 3;
+  const int npix = w.w * w.h;
+  if (pass <= 1 && blockIdx.x == 0 && threadIdx.x == 0) {      // the background entry: pixels already set
+    const int a = (int)count255[blockIdx.y];
+    if (pass == 0) atomicMax(tp, a);
+    else if (a == tp[0]) atomicAdd(tp + 1, 1);
+    else atomicMax(tp + 2, a);
+  }
+  const int m1 = pass >= 1 ? tp[0] : 0;
+  const int thr = pass == 3 ? (tp[1] >= 1 ? tp[0] : tp[2]) : 0;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < npix; i += gridDim.x * 256) {
+    const int x = i % w.w, y = i / w.w;
+    const size_t ci = (size_t)(w.my + y) * merged_w + w.mx + x;
+    const int l = labels2[ci];
+    if (l <= 0 || l > max_labels) continue;
+    const int area = stats2[(size_t)(l - 1) * 5 + 4];
+    if (pass <= 1) {
+      if (first2[l - 1] != (int)ci) continue;                  // one representative pixel per component
+      if (pass == 0) atomicMax(tp, area);
+      else if (area == m1) atomicAdd(tp + 1, 1);
+      else atomicMax(tp + 2, area);
+    } else if (pass == 2) {
+      if (merged[ci] == 0) atomicAdd(counters2 + 2 * (size_t)l + (pred_on(w, x, y) ? 0 : 1), 1u);
+    } else {
+      if (area < thr && counters2[2 * (size_t)l] > counters2[2 * (size_t)l + 1]) merged[ci] = 255;
+    }
+  }
+}
+
+// refined[y1:y2, x1:x2] |= merged (textmask.py:167); windows may overlap -> word-wide atomic OR
+__global__ __launch_bounds__(256) void tw_commit_kernel(const TWin* __restrict__ wins, const uint8_t* __restrict__ merged,
+                                                        int merged_w) {
+  const TWin w = wins[blockIdx.y];
+  const int npix = w.w * w.h;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < npix; i += gridDim.x * 256) {
+    const int x = i % w.w, y = i / w.w;
+    const unsigned v = merged[(size_t)(w.my + y) * merged_w + w.mx + x];
+    if (!v) continue;
+    const size_t idx = (size_t)(w.y1 + y) * w.out_w + w.x1 + x;
+    uint8_t* a = w.out + (idx & ~(size_t)3);
+    // the page buffers are 4-byte aligned and padded to a multiple of 4 bytes
+    atomicOr((unsigned*)a, v << (8 * (idx & 3)));
+  }
+}
+
+__global__ void mask_clear_where_kernel(uint8_t* __restrict__ mask, const uint8_t* __restrict__ refined, long long n, int thr) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+    if ((int)refined[i] > thr) mask[i] = 0;
+}
+
+__global__ void copy2d_u8_kernel(const uint8_t* __restrict__ src, int spitch, uint8_t* __restrict__ dst, int dpitch, int rows,
+                                 int cols) {
+  const long long n = (long long)rows * cols;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const int y = (int)(i / cols), x = (int)(i % cols);
+    dst[(size_t)y * dpitch + x] = src[(size_t)y * spitch + x];
+  }
+}
+
+inline int win_gx(int max_pix) { return max(1, min(64, (max_pix + 4095) / 4096)); }
+
+}  // namespace
+
+void launch_dbc(const DbcTables& t, hipStream_t st) {
+  hipLaunchKernelGGL(dbc_prep_kernel, dim3((t.cap + 255) / 256, t.B), dim3(256), 0, st, t);
+  hipLaunchKernelGGL(dbc_scan_kernel, dim3(t.B), dim3(256), 0, st, t);
+  hipLaunchKernelGGL(dbc_init_kernel, dim3(grid_for((long long)t.B * t.rcap)), dim3(256), 0, st, t);
+  hipLaunchKernelGGL(dbc_accum_kernel, dim3(grid_for((long long)t.B * t.H * t.W)), dim3(256), 0, st, t);
+}
+
+void launch_tw_hist(const TWin* wins, int n, int max_pix, unsigned* hist, hipStream_t st) {
+  hipLaunchKernelGGL(tw_hist_kernel, dim3(win_gx(max_pix), n), dim3(256), 0, st, wins, hist);
+}
+
+void launch_tw_xor(const TWin* wins, const TRule* rules, int n, int max_pix, unsigned long long* sums, hipStream_t st) {
+  hipLaunchKernelGGL(tw_xor_kernel, dim3(win_gx(max_pix), n), dim3(256), 0, st, wins, rules, sums);
+}
+
+void launch_tw_render(const TWin* wins, const TBand* bands, int nbands, int max_pix, uint8_t* canvas, int canvas_w,
+                      hipStream_t st) {
+  hipLaunchKernelGGL(tw_render_kernel, dim3(win_gx(max_pix), nbands), dim3(256), 0, st, wins, bands, canvas, canvas_w);
+}
+
+void launch_tw_accept(const TWin* wins, const TBand* bands, int nbands, int max_pix, int round, const int* labels,
+                      int canvas_w, const int* stats, int max_labels, int min_box, uint8_t* merged, int merged_w,
+                      unsigned* counters, hipStream_t st) {
+  const dim3 g(win_gx(max_pix), nbands);
+  hipLaunchKernelGGL(tw_accept_count_kernel, g, dim3(256), 0, st, wins, bands, round, labels, canvas_w, max_labels, merged,
+                     merged_w, counters);
+  hipLaunchKernelGGL(tw_accept_apply_kernel, g, dim3(256), 0, st, wins, bands, round, labels, canvas_w, stats, max_labels,
+                     min_box, merged, merged_w, counters);
+}
+
+void launch_tw_dilate(const TWin* wins, int n, int max_pix, const uint8_t* in, uint8_t* out, uint8_t* comp, int merged_w,
+                      unsigned* count255, int dilate, hipStream_t st) {
+  hipLaunchKernelGGL(tw_dilate_kernel, dim3(win_gx(max_pix), n), dim3(256), 0, st, wins, in, out, comp, merged_w, count255,
+                     dilate);
+}
+
+void launch_tw_holes(const TWin* wins, int n, int max_pix, const int* labels2, const int* stats2, const int* first2,
+                     int max_labels, const unsigned* count255, int* top2, uint8_t* merged, int merged_w,
+                     unsigned* counters2, hipStream_t st) {
+  const dim3 g(win_gx(max_pix), n);
+  for (int pass = 0; pass < 4; ++pass)
+    hipLaunchKernelGGL(tw_holes_kernel, g, dim3(256), 0, st, wins, pass, labels2, stats2, first2, max_labels, count255, top2,
+                       merged, merged_w, counters2);
+}
+
+void launch_tw_commit(const TWin* wins, int n, int max_pix, const uint8_t* merged, int merged_w, hipStream_t st) {
+  hipLaunchKernelGGL(tw_commit_kernel, dim3(win_gx(max_pix), n), dim3(256), 0, st, wins, merged, merged_w);
+}
+
+void launch_mask_clear_where(uint8_t* mask, const uint8_t* refined, long long n, int thr, hipStream_t st) {
+  hipLaunchKernelGGL(mask_clear_where_kernel, dim3(grid_for(n)), dim3(256), 0, st, mask, refined, n, thr);
+}
+
+void launch_copy2d_u8(const uint8_t* src, int spitch, uint8_t* dst, int dpitch, int rows, int cols, hipStream_t st) {
+  hipLaunchKernelGGL(copy2d_u8_kernel, dim3(grid_for((long long)rows * cols)), dim3(256), 0, st, src, spitch, dst, dpitch,
+                     rows, cols);
+}

@@ -1,0 +1,805 @@
+// The detector tail: everything `TextDetector.__call__` does after `self.net(img_in)` (reference
+// inference.py:148-178) for a whole batch of pages, driven natively:
+//
+//   postprocess_yolo   (inference.py:101-114)   launch_nms                      + host unpack
+//   postprocess_mask   (:85-99)                 fused in the network epilogue (mask_u8)
+//   SegDetectorRepresenter (utils/db_utils.py)  launch_ccl x2 + launch_dbc       + host hull / calipers / unclip
+//   crop + resize of the mask (:164-165)        copy2d / resize_linear_u8
+//   group_output       (utils/textblock.py)     host (csrc/host_group.cpp)
+//   refine_mask        (utils/textmask.py)      tw_* kernels + launch_ccl x2     + host colour / threshold picks
+//   refine_undetected_mask (:135-156)           mask_clear_where + launch_ccl    + host block test + a 2nd refine pass
+//
+// One `ctd_tail` object owns a HIP stream, grow-only device and pinned-host buffers and the results of
+// its last run.  A run enqueues every kernel of a stage for ALL pages of the batch, then waits once
+// for the few KB the host decisions of the next stage need (5 stream synchronisations per batch, none
+// per page, block or window).  Objects are independent: several of them can run on different host threads
+// (the C ABI is called without the Python interpreter lock), so the tail of batch k overlaps the
+// network forward of batch k+1 (comic-text-detector_amd/detector.py `detect_stream`).
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "host_refine.h"
+#include "kernels.h"
+#include "tail.h"
+
+int ctd_fail_msg(int code, const std::string& msg);   // engine.hip: sets the thread-local error text
+
+#define T_TRY(expr)                                                                                  \
+  do {                                                                                               \
+    hipError_t e_ = (expr);                                                                          \
+    if (e_ != hipSuccess) return ctd_fail_msg(CTD_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+  } while (0)
+
+namespace {
+
+struct DevBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+  int get(size_t bytes, void** out) {
+    if (bytes > cap) {
+      if (p) (void)hipFree(p);
+      p = nullptr, cap = 0;
+      const size_t want = bytes + bytes / 4 + 4096;
+      hipError_t e = hipMalloc(&p, want);
+      if (e != hipSuccess) return ctd_fail_msg(CTD_ERR_NOMEM, std::string("hipMalloc: ") + hipGetErrorString(e));
+      cap = want;
+    }
+    *out = p;
+    return CTD_OK;
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr, cap = 0;
+  }
+};
+
+struct PinBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+  int get(size_t bytes, void** out) {
+    if (bytes > cap) {
+      if (p) (void)hipHostFree(p);
+      p = nullptr, cap = 0;
+      const size_t want = bytes + bytes / 4 + 4096;
+      hipError_t e = hipHostMalloc(&p, want, hipHostMallocDefault);
+      if (e != hipSuccess) return ctd_fail_msg(CTD_ERR_NOMEM, std::string("hipHostMalloc: ") + hipGetErrorString(e));
+      cap = want;
+    }
+    *out = p;
+    return CTD_OK;
+  }
+  void release() {
+    if (p) (void)hipHostFree(p);
+    p = nullptr, cap = 0;
+  }
+};
+
+#define GET(buf, bytes, type, var) \
+  type* var;                       \
+  if (int rc_ = (buf).get((bytes), (void**)&var)) return rc_
+
+struct PageOut {
+  std::vector<ctd_blk> blks;
+  std::vector<int32_t> lines;   // (n,8)
+  std::vector<double> dist;     // (m,3)
+  std::vector<int16_t> db_boxes;   // every contour's box (n,4,2) as `seg_rep` returns them
+  std::vector<float> db_scores;
+  std::vector<int32_t> yolo;    // (n,4) blines, then cls in yolo_cls, confs
+  std::vector<int32_t> yolo_cls;
+  std::vector<float> yolo_conf;
+};
+
+struct WinReq {
+  int page, x1, y1, x2, y2;
+};
+
+constexpr int kMaxDet = 300;
+constexpr int kCompCap = 1 << 16;   // components per polarity and page the compact DB path holds
+constexpr int kRowCap = 1 << 18;    // row-table entries per page
+
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+}  // namespace
+
+struct ctd_tail {
+  int device = 0;
+  hipStream_t st = nullptr;
+  // device
+  DevBuf d_dets, d_nms_ws, d_lab_f, d_lab_b, d_ccl_ws, d_ccl_small, d_dbc_i, d_dbc_d, d_rows, d_pmask, d_refined;
+  DevBuf d_wins, d_rules, d_bands, d_hist, d_sums, d_canvas, d_clab, d_cstats, d_cnt, d_merged, d_mlab, d_mstats, d_cnt2, d_small, d_crop;
+  // pinned host
+  PinBuf h_dets, h_hdr, h_tab, h_pmask, h_refined, h_hist, h_sums, h_wins, h_rules, h_bands, h_small, h_lab;
+  // per-run state
+  int B = 0;
+  std::vector<ctd_tail_page> pages;
+  std::vector<size_t> poff;           // byte offset of page b in the page-mask / refined buffers
+  size_t ptotal = 0;
+  std::vector<PageOut> out;
+  double ms_stage[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+};
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------------
+// packing of rectangles into a canvas of fixed width: shelves, one empty column / row between bands
+// ---------------------------------------------------------------------------------------------------
+struct Packed {
+  std::vector<int> x, y;
+  int W = 0, H = 0;
+};
+void shelf_pack(const std::vector<int>& w, const std::vector<int>& h, int min_width, Packed& out) {
+  const int n = (int)w.size();
+  out.x.assign(n, 0);
+  out.y.assign(n, 0);
+  int cw = min_width;
+  for (int i = 0; i < n; ++i) cw = std::max(cw, w[i]);
+  std::vector<int> order(n);
+  for (int i = 0; i < n; ++i) order[i] = i;
+  std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return h[a] > h[b]; });
+  int x = 0, y = 0, shelf = 0;
+  for (int i : order) {
+    if (x > 0 && x + w[i] > cw) {
+      y += shelf + 1;
+      x = 0;
+      shelf = 0;
+    }
+    out.x[i] = x, out.y[i] = y;
+    x += w[i] + 1;
+    shelf = std::max(shelf, h[i]);
+  }
+  out.W = cw;
+  out.H = y + shelf;
+}
+
+// expand_textwindow(expand_r=16) of a block box (reference utils/imgproc_utils.py:151-161, utils/textmask.py:162)
+bool block_window(const int32_t* xyxy, int im_w, int im_h, WinReq& wq) {
+  int x1 = xyxy[0], y1 = xyxy[1], x2 = xyxy[2], y2 = xyxy[3];
+  const int w = x2 - x1, h = y2 - y1;
+  const int pad = (int)std::nearbyint(((double)std::max(h, w) * 0.25 + (double)std::min(h, w) * 0.75) / 16);
+  x1 = std::max(0, x1 - pad), y1 = std::max(0, y1 - pad);
+  x2 = std::min(im_w - 1, x2 + pad), y2 = std::min(im_h - 1, y2 + pad);
+  if (x2 <= x1 || y2 <= y1) return false;
+  wq.x1 = x1, wq.y1 = y1, wq.x2 = x2, wq.y2 = y2;
+  return true;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// refine_mask for a list of windows over the pages of the batch (reference utils/textmask.py:159-169):
+// ORs the merged window masks into the refined page buffers on the device.
+// ---------------------------------------------------------------------------------------------------
+int refine_windows(ctd_tail* t, const std::vector<WinReq>& reqs, int refine_mode) {
+  const int n = (int)reqs.size();
+  if (n == 0) return CTD_OK;
+  hipStream_t st = t->st;
+  GET(t->d_pmask, 0, uint8_t, pmask);
+  GET(t->d_refined, 0, uint8_t, refined);
+  // ---- window table: merged-canvas positions are known up front
+  std::vector<int> ww(n), wh(n);
+  int max_pix = 1;
+  for (int i = 0; i < n; ++i) {
+    ww[i] = reqs[i].x2 - reqs[i].x1, wh[i] = reqs[i].y2 - reqs[i].y1;
+    max_pix = std::max(max_pix, ww[i] * wh[i]);
+  }
+  Packed pm;
+  shelf_pack(ww, wh, 2048, pm);
+  GET(t->h_wins, sizeof(TWin) * n, TWin, hw);
+  for (int i = 0; i < n; ++i) {
+    const ctd_tail_page& pg = t->pages[reqs[i].page];
+    TWin& w = hw[i];
+    w.img = pg.img_dev;
+    w.mask = pmask + t->poff[reqs[i].page];
+    w.out = refined + t->poff[reqs[i].page];
+    w.img_w = pg.im_w, w.mask_w = pg.im_w, w.out_w = pg.im_w;
+    w.x1 = reqs[i].x1, w.y1 = reqs[i].y1, w.w = ww[i], w.h = wh[i];
+    w.mx = pm.x[i], w.my = pm.y[i];
+  }
+  GET(t->d_wins, sizeof(TWin) * n, TWin, dw);
+  T_TRY(hipMemcpyAsync(dw, hw, sizeof(TWin) * n, hipMemcpyHostToDevice, st));
+  // ---- histograms -> rules
+  GET(t->d_hist, (size_t)n * 1024 * 4, unsigned, dhist);
+  GET(t->h_hist, (size_t)n * 1024 * 4, uint32_t, hhist);
+  T_TRY(hipMemsetAsync(dhist, 0, (size_t)n * 1024 * 4, st));
+  launch_tw_hist(dw, n, max_pix, dhist, st);
+  T_TRY(hipMemcpyAsync(hhist, dhist, (size_t)n * 1024 * 4, hipMemcpyDeviceToHost, st));
+  T_TRY(hipStreamSynchronize(st));
+  GET(t->h_rules, sizeof(RRule) * 6 * n, RRule, hrules);
+  for (int i = 0; i < n; ++i) refine_rules(hhist + (size_t)i * 1024, hrules + (size_t)i * 6);
+  static_assert(sizeof(RRule) == sizeof(TRule), "rule layouts must agree");
+  GET(t->d_rules, sizeof(TRule) * 6 * n, TRule, drules);
+  T_TRY(hipMemcpyAsync(drules, hrules, sizeof(TRule) * 6 * n, hipMemcpyHostToDevice, st));
+  // ---- xor distances -> polarity and merge order
+  GET(t->d_sums, (size_t)n * 6 * 8, unsigned long long, dsums);
+  GET(t->h_sums, (size_t)n * 6 * 8, uint64_t, hsums);
+  T_TRY(hipMemsetAsync(dsums, 0, (size_t)n * 6 * 8, st));
+  launch_tw_xor(dw, drules, n, max_pix, dsums, st);
+  T_TRY(hipMemcpyAsync(hsums, dsums, (size_t)n * 6 * 8, hipMemcpyDeviceToHost, st));
+  T_TRY(hipStreamSynchronize(st));
+  std::vector<TBand> bands;
+  std::vector<int> bw, bh;
+  int rounds = 0;
+  for (int i = 0; i < n; ++i) {
+    RCand c[4];
+    const int nc = refine_candidates(hrules + (size_t)i * 6, hsums + (size_t)i * 6, (long long)ww[i] * wh[i], c);
+    rounds = std::max(rounds, nc);
+    for (int r = 0; r < nc; ++r) {
+      const RRule& rl = hrules[(size_t)i * 6 + c[r].rule];
+      TBand b;
+      b.win = i, b.cx = b.cy = 0, b.kind = rl.kind, b.lo = rl.lo, b.hi = rl.hi, b.invert = c[r].invert, b.round = r;
+      bands.push_back(b);
+      bw.push_back(ww[i]);
+      bh.push_back(wh[i]);
+    }
+  }
+  const int nbands = (int)bands.size();
+  Packed pc;
+  shelf_pack(bw, bh, 2048, pc);
+  long long bound1 = 1, bound2 = 1;                      // 8-connected components: at most one per 2x2 cell
+  for (int j = 0; j < nbands; ++j) {
+    bands[j].cx = pc.x[j], bands[j].cy = pc.y[j];
+    bound1 += (long long)((bw[j] + 1) / 2) * ((bh[j] + 1) / 2);
+  }
+  for (int i = 0; i < n; ++i) bound2 += (long long)((ww[i] + 1) / 2) * ((wh[i] + 1) / 2);
+  if ((long long)pc.W * pc.H >= (1LL << 30) || (long long)pm.W * pm.H >= (1LL << 30) || bound1 >= (1LL << 28))
+    return ctd_fail_msg(CTD_ERR_UNSUPPORTED, "refine: too many window pixels in one batch");
+  const int cap1 = (int)bound1, cap2 = (int)bound2;
+  GET(t->h_bands, sizeof(TBand) * nbands, TBand, hb);
+  std::memcpy(hb, bands.data(), sizeof(TBand) * nbands);
+  GET(t->d_bands, sizeof(TBand) * nbands, TBand, db);
+  T_TRY(hipMemcpyAsync(db, hb, sizeof(TBand) * nbands, hipMemcpyHostToDevice, st));
+  // ---- candidates rendered into one canvas, one labelling launch, merge rounds
+  const size_t cpx = (size_t)pc.W * pc.H, mpx = (size_t)pm.W * pm.H;
+  GET(t->d_canvas, cpx, uint8_t, canvas);
+  GET(t->d_clab, cpx * 4, int, clab);
+  GET(t->d_cstats, (size_t)cap1 * 5 * 4, int, cstats);
+  GET(t->d_ccl_ws, ccl_workspace_bytes(1, std::max(pc.H, pm.H), std::max(pc.W, pm.W)), uint8_t, ws);
+  GET(t->d_cnt, ((size_t)cap1 + 1) * 8, unsigned, counters);
+  GET(t->d_merged, mpx * 3, uint8_t, merged_a);
+  uint8_t* merged_b = merged_a + mpx;
+  uint8_t* comp = merged_a + 2 * mpx;
+  GET(t->d_small, (size_t)n * 16 + 64, int, small);       // [n2 (1) | pad | count255 (n) | top2 (n,3)]
+  int* n_dev = small;
+  unsigned* count255 = (unsigned*)(small + 16);
+  int* top2 = small + 16 + n;
+  T_TRY(hipMemsetAsync(canvas, 0, cpx, st));
+  T_TRY(hipMemsetAsync(merged_a, 0, mpx * 3, st));
+  T_TRY(hipMemsetAsync(counters, 0, ((size_t)cap1 + 1) * 8, st));
+  T_TRY(hipMemsetAsync(count255, 0, (size_t)n * 4, st));
+  T_TRY(hipMemsetAsync(top2, 0xFF, (size_t)n * 12, st));
+  launch_tw_render(dw, db, nbands, max_pix, canvas, pc.W, st);
+  launch_ccl(canvas, 1, pc.H, pc.W, 0, 8, clab, n_dev, cstats, cap1, ws, st);
+  for (int r = 0; r < rounds; ++r)
+    launch_tw_accept(dw, db, nbands, max_pix, r, clab, pc.W, cstats, cap1, 3, merged_a, pm.W, counters, st);
+  launch_tw_dilate(dw, n, max_pix, merged_a, merged_b, comp, pm.W, count255, refine_mode == 0 ? 1 : 0, st);
+  // ---- hole filling on the complement, then the OR into the pages
+  GET(t->d_mlab, mpx * 4, int, mlab);
+  GET(t->d_mstats, (size_t)cap2 * 6 * 4, int, mstats);
+  int* mfirst = mstats + (size_t)cap2 * 5;
+  GET(t->d_cnt2, ((size_t)cap2 + 1) * 8, unsigned, counters2);
+  T_TRY(hipMemsetAsync(counters2, 0, ((size_t)cap2 + 1) * 8, st));
+  launch_ccl(comp, 1, pm.H, pm.W, 0, 8, mlab, n_dev, mstats, cap2, ws, st, 0, mfirst);
+  launch_tw_holes(dw, n, max_pix, mlab, mstats, mfirst, cap2, count255, top2, merged_b, pm.W, counters2, st);
+  launch_tw_commit(dw, n, max_pix, merged_b, pm.W, st);
+  T_TRY(hipGetLastError());
+  return CTD_OK;
+}
+
+// Page-mask / refined buffers: page b at byte offset poff[b], im_h * im_w bytes, padded to 256.
+int layout_pages(ctd_tail* t, int B, const ctd_tail_page* pages) {
+  t->B = B;
+  t->pages.assign(pages, pages + B);
+  t->poff.resize(B);
+  size_t off = 0;
+  for (int b = 0; b < B; ++b) {
+    if (pages[b].im_h < 1 || pages[b].im_w < 1) return ctd_fail_msg(CTD_ERR_INVALID, "bad page size");
+    t->poff[b] = off;
+    off += align_up((size_t)pages[b].im_h * pages[b].im_w + 4, 256);
+  }
+  t->ptotal = off;
+  t->out.assign(B, PageOut());
+  return CTD_OK;
+}
+
+// refine_undetected_mask (reference utils/textmask.py:135-156) for every page of the batch: the masks are
+// edited in place on the device, components of what is left become extra blocks when no detected
+// block covers half of their box, and those blocks get their own refine pass.
+int undetected_pass(ctd_tail* t, const std::vector<std::vector<int32_t>>& blk_xyxy, int refine_mode) {
+  hipStream_t st = t->st;
+  const int B = t->B;
+  GET(t->d_pmask, 0, uint8_t, pmask);
+  GET(t->d_refined, 0, uint8_t, refined);
+  launch_mask_clear_where(pmask, refined, (long long)t->ptotal, 30, st);
+  // labelling page by page (pages may differ in size); stats rows are downloaded per page
+  const int cap = kCompCap;
+  size_t max_px = 0;
+  for (int b = 0; b < B; ++b) max_px = std::max(max_px, (size_t)t->pages[b].im_h * t->pages[b].im_w);
+  GET(t->d_lab_f, max_px * 4, int, lab);
+  GET(t->d_ccl_ws, ccl_workspace_bytes(1, 1, (int)max_px), uint8_t, ws);
+  GET(t->d_ccl_small, (size_t)B * 4 + (size_t)B * cap * 5 * 4, int, nst);
+  int* n_dev = nst;
+  int* st_dev = nst + B;
+  GET(t->h_small, (size_t)B * 4, int, n_host);
+  for (int b = 0; b < B; ++b)
+    launch_ccl(pmask + t->poff[b], 1, t->pages[b].im_h, t->pages[b].im_w, 30, 4, lab, n_dev + b,
+               st_dev + (size_t)b * cap * 5, cap, ws, st);
+  T_TRY(hipMemcpyAsync(n_host, n_dev, (size_t)B * 4, hipMemcpyDeviceToHost, st));
+  T_TRY(hipStreamSynchronize(st));
+  int nmax = 0;
+  for (int b = 0; b < B; ++b) nmax = std::max(nmax, std::min(n_host[b], cap));
+  std::vector<WinReq> reqs;
+  if (nmax > 0) {
+    GET(t->h_tab, (size_t)B * nmax * 5 * 4, int, sth);
+    T_TRY(hipMemcpy2DAsync(sth, (size_t)nmax * 20, st_dev, (size_t)cap * 20, (size_t)nmax * 20, B, hipMemcpyDeviceToHost, st));
+    T_TRY(hipStreamSynchronize(st));
+    for (int b = 0; b < B; ++b) {
+      const int n = std::min(n_host[b], cap);
+      const int im_w = t->pages[b].im_w, im_h = t->pages[b].im_h;
+      const int* s = sth + (size_t)b * nmax * 5;
+      long long fg = 0;
+      for (int l = 0; l < n; ++l) fg += s[5 * l + 4];
+      // the reference's stats include the background row 0; `valid_labels[1:]` drops the FIRST row with
+      // area > 50, which is the background whenever that has more than 50 pixels (:139-142)
+      bool first_dropped = false;
+      if ((long long)im_w * im_h - fg > 50) first_dropped = true;
+      const std::vector<int32_t>& bx = blk_xyxy[b];
+      for (int l = 0; l < n; ++l) {
+        if (s[5 * l + 4] <= 50) continue;
+        if (!first_dropped) {
+          first_dropped = true;
+          continue;
+        }
+        const int x = s[5 * l], y = s[5 * l + 1], w = s[5 * l + 2], h = s[5 * l + 3];
+        long long best = -1;
+        for (size_t k = 0; k + 3 < bx.size(); k += 4) {
+          const int ix1 = std::max(bx[k], x), iy1 = std::max(bx[k + 1], y);
+          const int ix2 = std::min(bx[k + 2], x + w), iy2 = std::min(bx[k + 3], y + h);
+          const long long sc = (iy2 < iy1 || ix2 < ix1) ? -1 : (long long)(iy2 - iy1) * (ix2 - ix1);
+          best = std::max(best, sc);
+        }
+        if ((double)best / (double)w / (double)h < 0.5) {
+          const int32_t q[4] = {x, y, x + w, y + h};
+          WinReq wq;
+          wq.page = b;
+          if (block_window(q, im_w, im_h, wq)) reqs.push_back(wq);
+        }
+      }
+    }
+  }
+  return refine_windows(t, reqs, refine_mode);
+}
+
+// device -> host of the page-size outputs, then into the caller's arrays
+int download_pages(ctd_tail* t, bool mask_too, uint8_t* const* mask_out, uint8_t* const* refined_out) {
+  hipStream_t st = t->st;
+  GET(t->d_pmask, 0, uint8_t, pmask);
+  GET(t->d_refined, 0, uint8_t, refined);
+  GET(t->h_pmask, t->ptotal, uint8_t, hm);
+  GET(t->h_refined, t->ptotal, uint8_t, hr);
+  if (mask_too && mask_out) T_TRY(hipMemcpyAsync(hm, pmask, t->ptotal, hipMemcpyDeviceToHost, st));
+  if (refined_out) T_TRY(hipMemcpyAsync(hr, refined, t->ptotal, hipMemcpyDeviceToHost, st));
+  T_TRY(hipStreamSynchronize(st));
+  for (int b = 0; b < t->B; ++b) {
+    const size_t nb = (size_t)t->pages[b].im_h * t->pages[b].im_w;
+    if (mask_out && mask_out[b]) std::memcpy(mask_out[b], hm + t->poff[b], nb);
+    if (refined_out && refined_out[b]) std::memcpy(refined_out[b], hr + t->poff[b], nb);
+  }
+  return CTD_OK;
+}
+
+
+// ---------------------------------------------------------------------------------------------------
+// DB text-line stage (reference utils/db_utils.py:32-211) for a batch: `db_enqueue` launches the two
+// labelling passes and the contour-table kernels and starts the download of the per-page counts;
+// after the caller's stream synchronisation `db_collect` fetches the tables at their actual sizes and
+// runs the host geometry, filling PageOut::db_boxes / db_scores of every page.
+// ---------------------------------------------------------------------------------------------------
+struct DbStage {
+  int B = 0, Hn = 0, Wn = 0;
+  const float* prob = nullptr;
+  long long prob_stride = 0;
+  int *lab_f = nullptr, *lab_b = nullptr, *n_f = nullptr, *n_b = nullptr, *st_f = nullptr, *st_b = nullptr;
+  int *first_f = nullptr, *first_b = nullptr, *par_f = nullptr, *par_b = nullptr, *off_f = nullptr, *off_b = nullptr;
+  int *hdr = nullptr, *ring_cnt = nullptr, *row_lo = nullptr, *row_hi = nullptr;
+  double *sum_f = nullptr, *sum_b = nullptr, *ring_sum = nullptr;
+  int* hhdr = nullptr;
+};
+
+int db_enqueue(ctd_tail* t, DbStage& d, int B, int Hn, int Wn, const float* prob_dev, long long prob_stride,
+               const uint8_t* bitmap_dev) {
+  hipStream_t st = t->st;
+  const size_t hw = (size_t)Hn * Wn;
+  const int cap = kCompCap, rcap = kRowCap;
+  d.B = B, d.Hn = Hn, d.Wn = Wn, d.prob = prob_dev, d.prob_stride = prob_stride;
+  GET(t->d_lab_f, (size_t)B * hw * 4, int, lab_f);
+  GET(t->d_lab_b, (size_t)B * hw * 4, int, lab_b);
+  GET(t->d_ccl_ws, ccl_workspace_bytes(B, Hn, Wn), uint8_t, ccl_ws);
+  // int tables: n_f, n_b (B each) | st_f, st_b (B,cap,5) | first, par, off x2 (B,cap) | hdr (B,4) | ring_cnt (B,cap)
+  const size_t bc = (size_t)B * cap;
+  GET(t->d_dbc_i, (2 * (size_t)B + 10 * bc + 6 * bc + 4 * (size_t)B + bc) * 4, int, ti);
+  d.lab_f = lab_f, d.lab_b = lab_b;
+  d.n_f = ti;
+  d.n_b = d.n_f + B;
+  d.st_f = d.n_b + B;
+  d.st_b = d.st_f + 5 * bc;
+  d.first_f = d.st_b + 5 * bc;
+  d.first_b = d.first_f + bc;
+  d.par_f = d.first_b + bc;
+  d.par_b = d.par_f + bc;
+  d.off_f = d.par_b + bc;
+  d.off_b = d.off_f + bc;
+  d.hdr = d.off_b + bc;
+  d.ring_cnt = d.hdr + 4 * (size_t)B;
+  GET(t->d_dbc_d, 3 * bc * 8, double, td);
+  d.sum_f = td, d.sum_b = td + bc, d.ring_sum = td + 2 * bc;
+  GET(t->d_rows, 2 * (size_t)B * rcap * 4, int, rows);
+  d.row_lo = rows, d.row_hi = rows + (size_t)B * rcap;
+  launch_ccl(bitmap_dev, B, Hn, Wn, 0, 8, lab_f, d.n_f, d.st_f, cap, ccl_ws, st, 0, d.first_f);
+  launch_ccl(bitmap_dev, B, Hn, Wn, 0, 4, lab_b, d.n_b, d.st_b, cap, ccl_ws, st, 1, d.first_b);
+  T_TRY(hipMemsetAsync(td, 0, 3 * bc * 8, st));
+  T_TRY(hipMemsetAsync(d.ring_cnt, 0, bc * 4, st));
+  DbcTables dt;
+  dt.B = B, dt.H = Hn, dt.W = Wn, dt.cap = cap, dt.rcap = rcap;
+  dt.prob = prob_dev, dt.prob_stride = prob_stride;
+  dt.lab_f = lab_f, dt.lab_b = lab_b, dt.n_f = d.n_f, dt.n_b = d.n_b, dt.st_f = d.st_f, dt.st_b = d.st_b;
+  dt.first_f = d.first_f, dt.first_b = d.first_b, dt.par_f = d.par_f, dt.par_b = d.par_b, dt.off_f = d.off_f;
+  dt.off_b = d.off_b, dt.hdr = d.hdr, dt.row_lo = d.row_lo, dt.row_hi = d.row_hi, dt.sum_f = d.sum_f, dt.sum_b = d.sum_b;
+  dt.ring_sum = d.ring_sum, dt.ring_cnt = d.ring_cnt;
+  launch_dbc(dt, st);
+  GET(t->h_hdr, (size_t)B * 4 * 4, int, hhdr);
+  d.hhdr = hhdr;
+  T_TRY(hipMemcpyAsync(hhdr, d.hdr, (size_t)B * 16, hipMemcpyDeviceToHost, st));
+  T_TRY(hipGetLastError());
+  return CTD_OK;
+}
+
+int db_collect(ctd_tail* t, const DbStage& d, const ctd_tail_params* prm) {
+  hipStream_t st = t->st;
+  const int B = d.B, Hn = d.Hn, Wn = d.Wn, cap = kCompCap, rcap = kRowCap;
+  const size_t hw = (size_t)Hn * Wn;
+  const int* hhdr = d.hhdr;
+  int nfm = 0, nbm = 0, rwm = 0;
+  for (int b = 0; b < B; ++b)
+    nfm = std::max(nfm, hhdr[4 * b]), nbm = std::max(nbm, hhdr[4 * b + 1]), rwm = std::max(rwm, std::min(hhdr[4 * b + 2], rcap));
+  // pinned layout: per table a (B, max) block
+  const size_t nf = (size_t)std::max(nfm, 1), nb = (size_t)std::max(nbm, 1), nr = (size_t)std::max(rwm, 1);
+  const size_t tab_bytes = (size_t)B * (nf * (5 + 3) * 4 + nf * 8 + nb * (5 + 3 + 1) * 4 + nb * 16 + nr * 8) + 14 * 8;
+  GET(t->h_tab, tab_bytes + 256, uint8_t, tab);
+  uint8_t* cur = tab;
+  auto take = [&](size_t bytes) {
+    uint8_t* p = cur;
+    cur += align_up(bytes, 8);
+    return p;
+  };
+  int* h_st_f = (int*)take((size_t)B * nf * 20);
+  int* h_first_f = (int*)take((size_t)B * nf * 4);
+  int* h_par_f = (int*)take((size_t)B * nf * 4);
+  int* h_off_f = (int*)take((size_t)B * nf * 4);
+  double* h_sum_f = (double*)take((size_t)B * nf * 8);
+  int* h_st_b = (int*)take((size_t)B * nb * 20);
+  int* h_first_b = (int*)take((size_t)B * nb * 4);
+  int* h_par_b = (int*)take((size_t)B * nb * 4);
+  int* h_off_b = (int*)take((size_t)B * nb * 4);
+  int* h_ring_cnt = (int*)take((size_t)B * nb * 4);
+  double* h_sum_b = (double*)take((size_t)B * nb * 8);
+  double* h_ring_sum = (double*)take((size_t)B * nb * 8);
+  int* h_row_lo = (int*)take((size_t)B * nr * 4);
+  int* h_row_hi = (int*)take((size_t)B * nr * 4);
+  auto d2h = [&](void* dst, const void* src, size_t elem, size_t n_used, size_t n_cap) -> hipError_t {
+    return hipMemcpy2DAsync(dst, n_used * elem, src, n_cap * elem, n_used * elem, B, hipMemcpyDeviceToHost, st);
+  };
+  if (nfm > 0) {
+    T_TRY(d2h(h_st_f, d.st_f, 20, nf, cap));
+    T_TRY(d2h(h_first_f, d.first_f, 4, nf, cap));
+    T_TRY(d2h(h_par_f, d.par_f, 4, nf, cap));
+    T_TRY(d2h(h_off_f, d.off_f, 4, nf, cap));
+    T_TRY(d2h(h_sum_f, d.sum_f, 8, nf, cap));
+  }
+  if (nbm > 0) {
+    T_TRY(d2h(h_st_b, d.st_b, 20, nb, cap));
+    T_TRY(d2h(h_first_b, d.first_b, 4, nb, cap));
+    T_TRY(d2h(h_par_b, d.par_b, 4, nb, cap));
+    T_TRY(d2h(h_off_b, d.off_b, 4, nb, cap));
+    T_TRY(d2h(h_ring_cnt, d.ring_cnt, 4, nb, cap));
+    T_TRY(d2h(h_sum_b, d.sum_b, 8, nb, cap));
+    T_TRY(d2h(h_ring_sum, d.ring_sum, 8, nb, cap));
+  }
+  if (rwm > 0) {
+    T_TRY(d2h(h_row_lo, d.row_lo, 4, nr, rcap));
+    T_TRY(d2h(h_row_hi, d.row_hi, 4, nr, rcap));
+  }
+  T_TRY(hipStreamSynchronize(st));
+  const int maxc = std::max(prm->max_candidates, 0);
+  std::vector<int16_t> boxes((size_t)std::max(maxc, 1) * 8);
+  std::vector<float> scores((size_t)std::max(maxc, 1));
+  for (int b = 0; b < B; ++b) {
+    PageOut& po = t->out[b];
+    int nbox = 0;
+    if (!hhdr[4 * b + 3]) {
+      if (int rc = ctd_db_boxes_compact(Wn, Hn, hhdr[4 * b], h_st_f + (size_t)b * nf * 5, h_first_f + (size_t)b * nf,
+                                        h_par_f + (size_t)b * nf, h_off_f + (size_t)b * nf, h_sum_f + (size_t)b * nf,
+                                        hhdr[4 * b + 1], h_st_b + (size_t)b * nb * 5, h_first_b + (size_t)b * nb,
+                                        h_par_b + (size_t)b * nb, h_off_b + (size_t)b * nb, h_sum_b + (size_t)b * nb,
+                                        h_ring_sum + (size_t)b * nb, h_ring_cnt + (size_t)b * nb, h_row_lo + (size_t)b * nr,
+                                        h_row_hi + (size_t)b * nr, maxc, prm->unclip_ratio, boxes.data(), scores.data(), &nbox))
+        return ctd_fail_msg(rc, "ctd_db_boxes_compact failed");
+    } else {
+      // more components than the compact tables hold (a noise bitmap): label images to the host
+      std::vector<int32_t> lab_host_f(hw), lab_host_b(hw);
+      std::vector<float> prob_h(hw);
+      int nfb[2];
+      T_TRY(hipMemcpyAsync(nfb, d.n_f + b, 4, hipMemcpyDeviceToHost, st));
+      T_TRY(hipMemcpyAsync(nfb + 1, d.n_b + b, 4, hipMemcpyDeviceToHost, st));
+      T_TRY(hipMemcpyAsync(lab_host_f.data(), d.lab_f + (size_t)b * hw, hw * 4, hipMemcpyDeviceToHost, st));
+      T_TRY(hipMemcpyAsync(lab_host_b.data(), d.lab_b + (size_t)b * hw, hw * 4, hipMemcpyDeviceToHost, st));
+      T_TRY(hipMemcpyAsync(prob_h.data(), d.prob + (size_t)b * d.prob_stride, hw * 4, hipMemcpyDeviceToHost, st));
+      T_TRY(hipStreamSynchronize(st));
+      // stats beyond `cap` rows were dropped on the device: recompute them from the labels
+      std::vector<int32_t> sf((size_t)nfb[0] * 5), sb((size_t)nfb[1] * 5);
+      auto stats_of = [&](const std::vector<int32_t>& lab, std::vector<int32_t>& s, int n) {
+        for (int l = 0; l < n; ++l) {
+          int32_t* q = s.data() + 5 * (size_t)l;
+          q[0] = Wn, q[1] = Hn, q[2] = -1, q[3] = -1, q[4] = 0;
+        }
+        for (int y = 0; y < Hn; ++y)
+          for (int x = 0; x < Wn; ++x) {
+            const int l = lab[(size_t)y * Wn + x];
+            if (l <= 0 || l > n) continue;
+            int32_t* q = s.data() + 5 * (size_t)(l - 1);
+            q[0] = std::min(q[0], x), q[1] = std::min(q[1], y), q[2] = std::max(q[2], x), q[3] = std::max(q[3], y), ++q[4];
+          }
+        for (int l = 0; l < n; ++l) {
+          int32_t* q = s.data() + 5 * (size_t)l;
+          q[2] -= q[0] - 1, q[3] -= q[1] - 1;
+        }
+      };
+      stats_of(lab_host_f, sf, nfb[0]);
+      stats_of(lab_host_b, sb, nfb[1]);
+      if (int rc = ctd_db_boxes(prob_h.data(), lab_host_f.data(), sf.data(), nfb[0], lab_host_b.data(), sb.data(), nfb[1], Wn, Hn,
+                                maxc, prm->unclip_ratio, boxes.data(), scores.data(), &nbox))
+        return ctd_fail_msg(rc, "ctd_db_boxes failed");
+    }
+    po.db_boxes.assign(boxes.begin(), boxes.begin() + (size_t)nbox * 8);
+    po.db_scores.assign(scores.begin(), scores.begin() + nbox);
+  }
+  return CTD_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ctd_tail_create(ctd_tail** out, int32_t device) {
+  if (!out) return ctd_fail_msg(CTD_ERR_INVALID, "null out");
+  T_TRY(hipSetDevice(device));
+  ctd_tail* t = new ctd_tail();
+  t->device = device;
+  int lo = 0, hi = 0;
+  (void)hipDeviceGetStreamPriorityRange(&lo, &hi);   // hi = numerically lowest = highest priority
+  if (hipStreamCreateWithPriority(&t->st, hipStreamNonBlocking, hi) != hipSuccess) {
+    delete t;
+    return ctd_fail_msg(CTD_ERR_HIP, "hipStreamCreateWithPriority failed");
+  }
+  *out = t;
+  return CTD_OK;
+}
+
+void ctd_tail_destroy(ctd_tail* t) {
+  if (!t) return;
+  (void)hipSetDevice(t->device);
+  if (t->st) {
+    (void)hipStreamSynchronize(t->st);
+    (void)hipStreamDestroy(t->st);
+  }
+  DevBuf* dv[] = {&t->d_dets, &t->d_nms_ws, &t->d_lab_f, &t->d_lab_b, &t->d_ccl_ws, &t->d_ccl_small, &t->d_dbc_i, &t->d_dbc_d,
+                  &t->d_rows, &t->d_pmask, &t->d_refined, &t->d_wins, &t->d_rules, &t->d_bands, &t->d_hist, &t->d_sums,
+                  &t->d_canvas, &t->d_clab, &t->d_cstats, &t->d_cnt, &t->d_merged, &t->d_mlab, &t->d_mstats, &t->d_cnt2,
+                  &t->d_small, &t->d_crop};
+  for (DevBuf* d : dv) d->release();
+  PinBuf* pv[] = {&t->h_dets, &t->h_hdr, &t->h_tab, &t->h_pmask, &t->h_refined, &t->h_hist, &t->h_sums, &t->h_wins,
+                  &t->h_rules, &t->h_bands, &t->h_small, &t->h_lab};
+  for (PinBuf* p : pv) p->release();
+  delete t;
+}
+
+void* ctd_tail_stream(ctd_tail* t) { return t ? (void*)t->st : nullptr; }
+
+int ctd_tail_run(ctd_tail* t, int32_t B, int32_t Hn, int32_t Wn, const float* blks_dev, int32_t rows, int32_t no,
+                 const uint8_t* mask_u8_dev, const float* prob_dev, int64_t prob_stride, const uint8_t* bitmap_dev,
+                 const ctd_tail_page* pages, const ctd_tail_params* prm, uint8_t* const* mask_out,
+                 uint8_t* const* refined_out, void* ready_event) {
+  if (!t || !blks_dev || !mask_u8_dev || !prob_dev || !bitmap_dev || !pages || !prm || B < 1 || Hn < 1 || Wn < 1 ||
+      rows < 1 || no < 6)
+    return ctd_fail_msg(CTD_ERR_INVALID, "ctd_tail_run: bad arguments");
+  T_TRY(hipSetDevice(t->device));
+  hipStream_t st = t->st;
+  if (ready_event) T_TRY(hipStreamWaitEvent(st, (hipEvent_t)ready_event, 0));
+  if (int rc = layout_pages(t, B, pages)) return rc;
+  for (int b = 0; b < B; ++b)
+    if (pages[b].dw < 0 || pages[b].dh < 0 || pages[b].dw >= Wn || pages[b].dh >= Hn || (prm->refine && !pages[b].img_dev))
+      return ctd_fail_msg(CTD_ERR_INVALID, "ctd_tail_run: bad page record");
+  const size_t hw = (size_t)Hn * Wn;
+
+  // ================= stage 1: NMS, two labelling passes, contour tables, page masks =================
+  GET(t->d_dets, (size_t)B * kMaxDet * 6 * 4 + (size_t)B * 4, float, dets);
+  int* counts = (int*)(dets + (size_t)B * kMaxDet * 6);
+  GET(t->d_nms_ws, nms_workspace_bytes(B, rows), uint8_t, nms_ws);
+  launch_nms(blks_dev, B, rows, no, prm->conf_thresh, prm->nms_thresh, kMaxDet, 30000, 4096.f, dets, counts, nms_ws, st);
+  GET(t->h_dets, (size_t)B * kMaxDet * 6 * 4 + (size_t)B * 4, float, hdets);
+  T_TRY(hipMemcpyAsync(hdets, dets, (size_t)B * kMaxDet * 6 * 4 + (size_t)B * 4, hipMemcpyDeviceToHost, st));
+  DbStage db;
+  if (int rc = db_enqueue(t, db, B, Hn, Wn, prob_dev, prob_stride, bitmap_dev)) return rc;
+
+  // page masks: crop of the letterbox padding, resize to the page (inference.py:164-165)
+  GET(t->d_pmask, t->ptotal, uint8_t, pmask);
+  GET(t->d_refined, t->ptotal, uint8_t, refined);
+  T_TRY(hipMemsetAsync(refined, 0, t->ptotal, st));
+  size_t crop_px = 1;                       // pages whose letterbox padded the right side are cropped into a dense
+  for (int b = 0; b < B; ++b)               // temporary first (one buffer: the stream runs the pages in order)
+    if (pages[b].dw > 0) crop_px = std::max(crop_px, (size_t)(Hn - pages[b].dh) * (Wn - pages[b].dw));
+  GET(t->d_crop, crop_px, uint8_t, tmp);
+  for (int b = 0; b < B; ++b) {
+    const ctd_tail_page& pg = pages[b];
+    const int ch = Hn - pg.dh, cw = Wn - pg.dw;
+    const uint8_t* src = mask_u8_dev + (size_t)b * hw;
+    uint8_t* dst = pmask + t->poff[b];
+    if (pg.im_h == ch && pg.im_w == cw) {
+      launch_copy2d_u8(src, Wn, dst, cw, ch, cw, st);
+    } else if (cw != Wn) {                  // the resize kernel reads a dense source
+      launch_copy2d_u8(src, Wn, tmp, cw, ch, cw, st);
+      launch_resize_linear_u8(tmp, ch, cw, 1, dst, pg.im_h, pg.im_w, pg.im_h, pg.im_w, st);
+    } else {
+      launch_resize_linear_u8(src, ch, cw, 1, dst, pg.im_h, pg.im_w, pg.im_h, pg.im_w, st);
+    }
+  }
+  GET(t->h_pmask, t->ptotal, uint8_t, hpmask);
+  T_TRY(hipMemcpyAsync(hpmask, pmask, t->ptotal, hipMemcpyDeviceToHost, st));
+  T_TRY(hipStreamSynchronize(st));                                     // sync 1: counts are known
+
+  // ================= stage 2: contour geometry on the host, grouping =================
+  if (int rc = db_collect(t, db, prm)) return rc;                      // sync 2 inside: the sized tables
+  std::vector<WinReq> reqs;
+  std::vector<std::vector<int32_t>> blk_xyxy(B);
+  std::vector<int32_t> lines;
+  for (int b = 0; b < B; ++b) {
+    const ctd_tail_page& pg = pages[b];
+    PageOut& po = t->out[b];
+    const double rx = (double)pg.im_w / (double)(Wn - pg.dw), ry = (double)pg.im_h / (double)(Hn - pg.dh);   // :148
+    // ---- postprocess_yolo (:101-114): float32 scale, truncation to int32
+    const int nd = std::min(std::max(((const int*)(hdets + (size_t)B * kMaxDet * 6))[b], 0), kMaxDet);
+    po.yolo.resize((size_t)nd * 4);
+    po.yolo_cls.resize(nd);
+    po.yolo_conf.resize(nd);
+    const float frx = (float)rx, fry = (float)ry;
+    for (int i = 0; i < nd; ++i) {
+      const float* d = hdets + ((size_t)b * kMaxDet + i) * 6;
+      po.yolo[4 * i] = (int32_t)(d[0] * frx), po.yolo[4 * i + 1] = (int32_t)(d[1] * fry);
+      po.yolo[4 * i + 2] = (int32_t)(d[2] * frx), po.yolo[4 * i + 3] = (int32_t)(d[3] * fry);
+      po.yolo_cls[i] = (int32_t)d[5];
+      po.yolo_conf[i] = d[4];
+    }
+    // ---- lines = boxes with score > box_thresh, mapped to the page (:159-172)
+    lines.clear();
+    const int nbox = (int)po.db_scores.size();
+    for (int i = 0; i < nbox; ++i) {
+      if (!(po.db_scores[i] > prm->box_thresh)) continue;
+      for (int k = 0; k < 4; ++k) {
+        lines.push_back((int32_t)((double)po.db_boxes[(size_t)i * 8 + 2 * k] * rx));
+        lines.push_back((int32_t)((double)po.db_boxes[(size_t)i * 8 + 2 * k + 1] * ry));
+      }
+    }
+    // ---- group_output (:173)
+    const int nl = (int)lines.size() / 8;
+    const int bcap = nd + nl, dcap = std::max(1, bcap) * std::max(1, nl);
+    po.blks.resize(std::max(bcap, 1));
+    po.lines.resize((size_t)std::max(bcap, 1) * 8);
+    po.dist.resize((size_t)std::max(dcap, 1) * 3);
+    int nb_out = 0, nl_out = 0, nd_out = 0;
+    if (int rc = ctd_group_output(po.yolo.data(), po.yolo_cls.data(), nd, lines.data(), nl, pg.im_w, pg.im_h,
+                                  hpmask + t->poff[b], pg.im_w, po.blks.data(), bcap, po.lines.data(), bcap, po.dist.data(),
+                                  dcap, &nb_out, &nl_out, &nd_out))
+      return ctd_fail_msg(rc, "ctd_group_output failed");
+    po.blks.resize(nb_out);
+    po.lines.resize((size_t)nl_out * 8);
+    po.dist.resize((size_t)nd_out * 3);
+    for (const ctd_blk& k : po.blks) {
+      WinReq wq;
+      wq.page = b;
+      if (block_window(k.xyxy, pg.im_w, pg.im_h, wq)) reqs.push_back(wq);
+      blk_xyxy[b].insert(blk_xyxy[b].end(), k.xyxy, k.xyxy + 4);
+    }
+  }
+
+  // ================= stage 3: mask refinement =================
+  if (prm->refine) {
+    if (int rc = refine_windows(t, reqs, prm->refine_mode)) return rc;
+    if (prm->keep_undetected_mask)
+      if (int rc = undetected_pass(t, blk_xyxy, prm->refine_mode)) return rc;
+  }
+  if (prm->refine && prm->keep_undetected_mask) return download_pages(t, true, mask_out, refined_out);
+  // the mask was not edited: the early download is the result
+  if (int rc = download_pages(t, false, nullptr, prm->refine ? refined_out : nullptr)) return rc;
+  if (mask_out)
+    for (int b = 0; b < B; ++b)
+      if (mask_out[b]) std::memcpy(mask_out[b], hpmask + t->poff[b], (size_t)pages[b].im_h * pages[b].im_w);
+  return CTD_OK;
+}
+
+int ctd_tail_db_boxes(ctd_tail* t, int32_t B, int32_t Hn, int32_t Wn, const float* prob_dev, int64_t prob_stride,
+                      const uint8_t* bitmap_dev, int32_t max_candidates, double unclip_ratio) {
+  if (!t || !prob_dev || !bitmap_dev || B < 1 || Hn < 1 || Wn < 1) return ctd_fail_msg(CTD_ERR_INVALID, "bad arguments");
+  T_TRY(hipSetDevice(t->device));
+  t->B = B;
+  t->out.assign(B, PageOut());
+  DbStage db;
+  if (int rc = db_enqueue(t, db, B, Hn, Wn, prob_dev, prob_stride, bitmap_dev)) return rc;
+  T_TRY(hipStreamSynchronize(t->st));
+  ctd_tail_params prm;
+  std::memset(&prm, 0, sizeof(prm));
+  prm.max_candidates = max_candidates;
+  prm.unclip_ratio = unclip_ratio;
+  return db_collect(t, db, &prm);
+}
+
+int ctd_tail_refine(ctd_tail* t, int32_t n_pages, const ctd_tail_page* pages, const uint8_t* const* masks_host,
+                    const int32_t* blk_xyxy, const int32_t* blk_counts, int32_t refine_mode, int32_t keep_undetected_mask,
+                    uint8_t* const* mask_out, uint8_t* const* refined_out) {
+  if (!t || n_pages < 1 || !pages || !masks_host || !blk_counts || !refined_out)
+    return ctd_fail_msg(CTD_ERR_INVALID, "ctd_tail_refine: bad arguments");
+  T_TRY(hipSetDevice(t->device));
+  hipStream_t st = t->st;
+  if (int rc = layout_pages(t, n_pages, pages)) return rc;
+  GET(t->d_pmask, t->ptotal, uint8_t, pmask);
+  GET(t->d_refined, t->ptotal, uint8_t, refined);
+  GET(t->h_pmask, t->ptotal, uint8_t, hpmask);
+  T_TRY(hipMemsetAsync(refined, 0, t->ptotal, st));
+  std::memset(hpmask, 0, t->ptotal);
+  std::vector<WinReq> reqs;
+  std::vector<std::vector<int32_t>> bxy(n_pages);
+  const int32_t* q = blk_xyxy;
+  for (int b = 0; b < n_pages; ++b) {
+    if (!pages[b].img_dev || !masks_host[b]) return ctd_fail_msg(CTD_ERR_INVALID, "ctd_tail_refine: null page");
+    std::memcpy(hpmask + t->poff[b], masks_host[b], (size_t)pages[b].im_h * pages[b].im_w);
+    for (int k = 0; k < blk_counts[b]; ++k, q += 4) {
+      WinReq wq;
+      wq.page = b;
+      if (block_window(q, pages[b].im_w, pages[b].im_h, wq)) reqs.push_back(wq);
+      bxy[b].insert(bxy[b].end(), q, q + 4);
+    }
+  }
+  T_TRY(hipMemcpyAsync(pmask, hpmask, t->ptotal, hipMemcpyHostToDevice, st));
+  if (int rc = refine_windows(t, reqs, refine_mode)) return rc;
+  if (keep_undetected_mask)
+    if (int rc = undetected_pass(t, bxy, refine_mode)) return rc;
+  return download_pages(t, keep_undetected_mask != 0, mask_out, refined_out);
+}
+
+int ctd_tail_page_counts(const ctd_tail* t, int32_t page, int32_t* n_blocks, int32_t* n_lines, int32_t* n_dist,
+                         int32_t* n_db_boxes, int32_t* n_yolo) {
+  if (!t || page < 0 || page >= (int)t->out.size()) return ctd_fail_msg(CTD_ERR_INVALID, "bad page index");
+  const PageOut& po = t->out[page];
+  if (n_blocks) *n_blocks = (int32_t)po.blks.size();
+  if (n_lines) *n_lines = (int32_t)(po.lines.size() / 8);
+  if (n_dist) *n_dist = (int32_t)(po.dist.size() / 3);
+  if (n_db_boxes) *n_db_boxes = (int32_t)po.db_scores.size();
+  if (n_yolo) *n_yolo = (int32_t)po.yolo_cls.size();
+  return CTD_OK;
+}
+
+int ctd_tail_page_fetch(const ctd_tail* t, int32_t page, ctd_blk* blocks, int32_t* lines, double* dist, int16_t* db_boxes,
+                        float* db_scores, int32_t* yolo_xyxy, int32_t* yolo_cls, float* yolo_conf) {
+  if (!t || page < 0 || page >= (int)t->out.size()) return ctd_fail_msg(CTD_ERR_INVALID, "bad page index");
+  const PageOut& po = t->out[page];
+  if (blocks && !po.blks.empty()) std::memcpy(blocks, po.blks.data(), po.blks.size() * sizeof(ctd_blk));
+  if (lines && !po.lines.empty()) std::memcpy(lines, po.lines.data(), po.lines.size() * 4);
+  if (dist && !po.dist.empty()) std::memcpy(dist, po.dist.data(), po.dist.size() * 8);
+  if (db_boxes && !po.db_boxes.empty()) std::memcpy(db_boxes, po.db_boxes.data(), po.db_boxes.size() * 2);
+  if (db_scores && !po.db_scores.empty()) std::memcpy(db_scores, po.db_scores.data(), po.db_scores.size() * 4);
+  if (yolo_xyxy && !po.yolo.empty()) std::memcpy(yolo_xyxy, po.yolo.data(), po.yolo.size() * 4);
+  if (yolo_cls && !po.yolo_cls.empty()) std::memcpy(yolo_cls, po.yolo_cls.data(), po.yolo_cls.size() * 4);
+  if (yolo_conf && !po.yolo_conf.empty()) std::memcpy(yolo_conf, po.yolo_conf.data(), po.yolo_conf.size() * 4);
+  return CTD_OK;
+}
+
+}  // extern "C"

@@ -1,35 +1,47 @@
 """`TextDetector`: mirror of the reference's L4 API (reference inference.py:116-178)
-on top of the HIP backend.
+on top of the HIP backend and the native tail.
 
     det = TextDetector(model_path_or_ckpt, input_size=1024, device='cuda')
     mask, mask_refined, blk_list = det(img_bgr_uint8, refine_mode, keep_undetected_mask)
 
-Same constructor arguments, same call signature, same return triple as the
-reference.  `detect_batch(pages)` is the batched form the reference lacks (it is
-bs=1 only): one fused forward + one NMS + two labelling
-launches for the whole batch, then the per-page grouping / refinement.
+Same call signature and return triple as the reference; same constructor keywords.  Deviation of the
+defaults: `device='cuda'` (there is no CPU path; the reference defaults to 'cpu').  `half=False` is the
+reference's default AND its behaviour (its `TextDetBase` always runs fp32, inference.py:129): the
+exact-fp32 engine; `half=True` selects the fp16-operand / fp32-accumulate MFMA engine (BASELINE
+configs[2]) whose maps differ from fp32 by <1e-3 (see DESIGN.md section 5 for the measured effect on
+boxes and masks).
+
+`detect_batch(pages)` is the batched form the reference lacks (it is bs=1 only): one
+fused forward and ONE native tail call for the whole batch.  `detect_stream(batches)` pipelines batches:
+the tail of batch k runs on worker threads (own HIP stream, interpreter lock released) under the
+forward of batch k+1.
 """
 from __future__ import annotations
 
-from typing import List, Sequence, Tuple, Union
+from collections import deque
+from concurrent.futures import ThreadPoolExecutor
+from typing import Iterable, Iterator, List, Sequence, Tuple, Union
 
 import numpy as np
 import torch
 
 from . import backend as BK
 from . import postproc as PP
-from .textblock import TextBlock, group_output
+from .tail import thread_tail
+from .textblock import TextBlock
 from .textmask import (REFINEMASK_ANNOTATION, REFINEMASK_INPAINT, refine_mask, refine_mask_batch,   # noqa: F401
                        refine_undetected_mask)
 
 __all__ = ["TextDetector", "TextBlock", "REFINEMASK_INPAINT", "REFINEMASK_ANNOTATION"]
+
+Page = Union[np.ndarray, torch.Tensor]
 
 
 class TextDetector:
     lang_list = ["eng", "ja", "unknown"]                      # inference.py:117
     langcls2idx = {"eng": 0, "ja": 1, "unknown": 2}
 
-    def __init__(self, model_path: Union[str, dict], input_size=1024, device="cuda", half=True,
+    def __init__(self, model_path: Union[str, dict], input_size=1024, device="cuda", half=False,
                  nms_thresh=0.35, conf_thresh=0.4, mask_thresh=0.3, act="leaky"):
         if isinstance(input_size, int):
             input_size = (input_size, input_size)
@@ -48,73 +60,81 @@ class TextDetector:
     #    (ctd_resize_linear_u8); the /255 and the layout change are fused into the stem kernel.
     #    Channel order: BGR2RGB (:74) followed by [::-1] (:77) = the net consumes BGR planes,
     #    and the per-channel resize commutes with the swaps, so the BGR page is resized as is.
-    def _prepare(self, pages: Sequence[np.ndarray]):
+    def _prepare(self, pages: Sequence[Page]):
         Hn, Wn = self.input_size[1], self.input_size[0]
-        canv, metas = [], []
+        dev = self.net.device
+        gpu, metas = [], []
         for p in pages:
-            if p.dtype != np.uint8 or p.ndim != 3 or p.shape[2] != 3:
-                raise ValueError("pages must be uint8 BGR (H,W,3) arrays")
-            im_h, im_w = p.shape[:2]
+            if isinstance(p, torch.Tensor):
+                if p.dtype != torch.uint8 or p.dim() != 3 or p.shape[2] != 3:
+                    raise ValueError("pages must be uint8 BGR (H,W,3)")
+                src = p.to(dev).contiguous()
+            else:
+                if p.dtype != np.uint8 or p.ndim != 3 or p.shape[2] != 3:
+                    raise ValueError("pages must be uint8 BGR (H,W,3) arrays")
+                src = torch.from_numpy(np.ascontiguousarray(p)).to(dev)
+            im_h, im_w = src.shape[:2]
             r = min(Hn / im_h, Wn / im_w)
             nw, nh = int(round(im_w * r)), int(round(im_h * r))
-            dw, dh = int(Wn - nw), int(Hn - nh)
-            src = torch.from_numpy(np.ascontiguousarray(p)).to(self.net.device)
-            canv.append(BK.resize_linear_u8(src, (nh, nw), (Hn, Wn)))
-            metas.append((im_h, im_w, dw, dh))
-        return torch.stack(canv), metas
+            gpu.append(src)
+            metas.append((im_h, im_w, int(Wn - nw), int(Hn - nh)))
+        if all(m == (Hn, Wn, 0, 0) for m in metas):             # nothing to resize (letterbox: shape == new_unpad)
+            x = torch.stack(gpu)
+        else:
+            x = torch.stack([g if m == (Hn, Wn, 0, 0) else BK.resize_linear_u8(g, (Hn - m[3], Wn - m[2]), (Hn, Wn))
+                             for g, m in zip(gpu, metas)])
+        return x, gpu, metas
+
+    def _forward(self, pages: Sequence[Page]):
+        x, gpu, metas = self._prepare(pages)
+        blks, mask, lines_map = self.net.forward_u8(x)                      # the seam (inference.py:146)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.net.device))
+        return dict(gpu=gpu, metas=metas, blks=blks, mask_u8=self.net.mask_u8, lines_map=lines_map,
+                    bitmap=self.net.bitmap, ev=ev, keep=(mask, x))
+
+    def _tail(self, job, refine_mode, keep_undetected_mask):
+        return thread_tail(self.net.device).run(job["gpu"], job["metas"], job["blks"], job["mask_u8"], job["lines_map"],
+                                                job["bitmap"], self.conf_thresh, self.nms_thresh, 0.6, True, refine_mode,
+                                                keep_undetected_mask, job["ev"])
 
     @torch.no_grad()
-    def detect_batch(self, pages: Sequence[np.ndarray], refine_mode=REFINEMASK_INPAINT,
+    def detect_batch(self, pages: Sequence[Page], refine_mode=REFINEMASK_INPAINT,
                      keep_undetected_mask=False) -> List[Tuple[np.ndarray, np.ndarray, List[TextBlock]]]:
-        x, metas = self._prepare(pages)
-        blks, mask, lines_map = self.net.forward_u8(x)                      # the seam (inference.py:146)
-        return self.tail_batch(pages, blks, self.net.mask_u8, lines_map[:, 0], self.net.bitmap, refine_mode,
-                               keep_undetected_mask, metas)
+        return self._tail(self._forward(pages), refine_mode, keep_undetected_mask)
 
-    def tail_batch(self, pages: Sequence[np.ndarray], blks: torch.Tensor, mask_u8: torch.Tensor,
-                   prob: torch.Tensor, bitmap: torch.Tensor, refine_mode=REFINEMASK_INPAINT,
-                   keep_undetected_mask=False, metas=None):
+    @torch.no_grad()
+    def detect_stream(self, batches: Iterable[Sequence[Page]], refine_mode=REFINEMASK_INPAINT,
+                      keep_undetected_mask=False, workers: int = 2, depth: int = 3) -> Iterator[list]:
+        """Yields `detect_batch(batch)` for every batch, in order, with up to `depth` batches in flight:
+        the forward of the next batches is launched while `workers` threads run the tails of earlier ones."""
+        pool = ThreadPoolExecutor(max_workers=max(1, workers), thread_name_prefix="ctd-tail")
+        pending = deque()
+        try:
+            for batch in batches:
+                job = self._forward(batch)
+                pending.append(pool.submit(self._tail, job, refine_mode, keep_undetected_mask))
+                while len(pending) >= depth:
+                    yield pending.popleft().result()
+            while pending:
+                yield pending.popleft().result()
+        finally:
+            pool.shutdown(wait=True)
+
+    def tail_batch(self, pages: Sequence[Page], blks: torch.Tensor, mask_u8: torch.Tensor, prob: torch.Tensor,
+                   bitmap: torch.Tensor, refine_mode=REFINEMASK_INPAINT, keep_undetected_mask=False, metas=None,
+                   want_extras: bool = False):
         """Everything after the network (inference.py:148-178) for a batch whose network outputs are
         already on the GPU: blks (B,rows,no) f32, mask_u8 (B,H,W) u8, prob = lines_map[:,0] (B,H,W) f32,
         bitmap (B,H,W) u8.  metas[b] = (im_h, im_w, dw, dh) of the letterbox (default: no resize)."""
-        B = len(pages)
-        Hn, Wn = self.input_size[1], self.input_size[0]
-        if metas is None:
-            metas = [(p.shape[0], p.shape[1], 0, 0) for p in pages]
-        ratios = [(im_w / (Wn - dw), im_h / (Hn - dh)) for im_h, im_w, dw, dh in metas]       # :148
-        yolo = PP.postprocess_yolo(blks, self.conf_thresh, self.nms_thresh, ratios)             # :149
-        boxes, scores = self.seg_rep(prob, bitmap)                                              # :158
-        masks, masks_gpu, blk_lists = [], [], []
-        for b in range(B):
-            im_h, im_w, dw, dh = metas[b]
-            keep = scores[b] > 0.6                                          # box_thresh (:159-161)
-            lines = boxes[b][keep]
-            if lines.size == 0:
-                lines = []
-            else:
-                lines = lines.astype(np.float64)
-                lines[..., 0] *= ratios[b][0]
-                lines[..., 1] *= ratios[b][1]
-                lines = lines.astype(np.int32)
-            # fused postprocess_mask (:156), crop of the padding (:164), resize to the page (:165)
-            m = mask_u8[b, : Hn - dh, : Wn - dw]
-            if (im_h, im_w) != (Hn - dh, Wn - dw):
-                m = BK.resize_linear_u8(m.contiguous(), (im_h, im_w))
-            m = m.contiguous()
-            masks_gpu.append(m)
-            masks.append(BK.to_host(m, "tail.mask").copy())
-            blk_lists.append(group_output(yolo[b], lines, im_w, im_h, masks[b]))     # :173
-        # refine_mask (:174) for the whole batch: the windows of all pages share the launches
         dev = self.net.device
-        gpu = [(torch.from_numpy(np.ascontiguousarray(pages[b])).to(dev), masks_gpu[b]) for b in range(B)]
-        refined = refine_mask_batch(pages, masks, blk_lists, refine_mode, dev, gpu)
-        out = []
-        for b in range(B):
-            r = refined[b]
-            if keep_undetected_mask:
-                r = refine_undetected_mask(pages[b], masks[b], r, blk_lists[b], refine_mode, dev)
-            out.append((masks[b], r, blk_lists[b]))
-        return out
+        gpu = [p.to(dev).contiguous() if isinstance(p, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(p)).to(dev)
+               for p in pages]
+        if metas is None:
+            metas = [(g.shape[0], g.shape[1], 0, 0) for g in gpu]
+        torch.cuda.current_stream(dev).synchronize()
+        return thread_tail(dev).run(gpu, metas, blks, mask_u8, prob, bitmap, self.conf_thresh, self.nms_thresh, 0.6, True,
+                                    refine_mode, keep_undetected_mask, None, want_extras)
 
     def __call__(self, img: np.ndarray, refine_mode=REFINEMASK_INPAINT, keep_undetected_mask=False):
         return self.detect_batch([img], refine_mode, keep_undetected_mask)[0]

@@ -1,11 +1,12 @@
-"""Post-processing of the detector outputs: the host mirror of the reference's
-second-level seams, driving the HIP kernels for the O(pixels)
-work and doing the O(#boxes) scalar geometry on the host.
+"""Post-processing of the detector outputs, stage by stage: the host mirror of the reference's
+second-level seams.  `TextDetector` runs all of them in one native call
+(`tail.Tail.run`); the pieces here serve callers and tests that want one stage.
 
-  postprocess_yolo      reference inference.py:101-114      -> ctd_nms (HIP)
-  SegRepresenter        reference utils/db_utils.py:32-211  -> ctd_ccl (HIP) x2 + ctd_db_boxes (native host geometry)
-  group_output          reference utils/textblock.py:421-508 -> textblock.py (host, tiny N)
-  refine_mask           reference utils/textmask.py:159-169  -> textmask.py
+  postprocess_yolo      reference inference.py:101-114      -> ctd_nms (HIP) + the float32 rescale
+  SegRepresenter        reference utils/db_utils.py:32-211  -> ctd_tail_db_boxes: 2x labelling + contour tables on
+                                                              the GPU, hull / min-area rectangle / unclip on the host
+  group_output          reference utils/textblock.py:421-508 -> textblock.py (ctd_group_output, native host)
+  refine_mask           reference utils/textmask.py:159-169  -> textmask.py (ctd_tail_refine)
 
 Nothing here imports `oracle/`.
 """
@@ -20,11 +21,8 @@ import torch
 
 from . import _lib as L
 from . import backend as BK
+from .tail import thread_tail
 
-
-# --------------------------------------------------------------------------
-# YOLO blocks
-# --------------------------------------------------------------------------
 
 def postprocess_yolo(blks: torch.Tensor, conf_thresh: float, nms_thresh: float, resize_ratios):
     """blks (B,rows,no) on the GPU -> per page (blines i32 (n,4), cls i32 (n,), confs f32 (n,)).
@@ -42,21 +40,19 @@ def postprocess_yolo(blks: torch.Tensor, conf_thresh: float, nms_thresh: float, 
     return out
 
 
-# --------------------------------------------------------------------------
-# DB text lines: bitmap -> boxes
-# --------------------------------------------------------------------------
-
 class SegRepresenter:
     """`SegDetectorRepresenter` (reference utils/db_utils.py:32-69) for the box output.
 
-    The reference walks `cv2.findContours(RETR_LIST)` contours: one per 8-connected
-    foreground component (its outer border) and one per enclosed 4-connected background
-    region (a hole border).  The same set is obtained here from two GPU labelling passes
-    (`ctd_ccl`, 8-connectivity on the bitmap, 4-connectivity on its complement):
+    The reference walks `cv2.findContours(RETR_LIST)` contours: one per 8-connected foreground
+    component (its outer border) and one per enclosed 4-connected background region (a hole border).
+    The same set comes from two GPU labelling passes (8-connectivity on the bitmap, 4-connectivity on
+    its complement); per contour the GPU also compacts what the host geometry needs -- the row
+    extremes (hull points), the sums of the probability map, the containment links
+    (csrc/kernels_tail.hip `launch_dbc`) -- so no label image or probability map is downloaded:
       * min-area rectangle of a contour = that of its component's pixels (outer) or of the
-        hole grown by its 4-neighbourhood (hole border pixels);
+        ringing component's pixels that 4-touch the hole (hole border);
       * `box_score_fast` fills the contour polygon = the component with everything it
-        encloses (outer) / the hole, its border ring and any islands inside (hole).
+        encloses (outer) / the hole, its border ring and everything inside the hole (hole border).
     """
 
     def __init__(self, thresh=0.3, max_candidates=1000, unclip_ratio=1.5):
@@ -67,25 +63,10 @@ class SegRepresenter:
     def __call__(self, prob: torch.Tensor, bitmap: torch.Tensor) -> Tuple[List[np.ndarray], List[np.ndarray]]:
         """prob (B,H,W) f32 cuda (lines_map[:,0]); bitmap (B,H,W) u8 cuda (prob > thresh, fused
         in the DB tail kernel).  Returns per page boxes int16 (n,4,2) and scores f32 (n,)."""
-        B, H, W = bitmap.shape
-        cap = 1 << 16
-        lab_f, n_f, st_f = BK.connected_components(bitmap, 0, 8, max_labels=cap)
-        inv = (bitmap == 0).to(torch.uint8)
-        lab_b, n_b, st_b = BK.connected_components(inv, 0, 4, max_labels=cap)
-        n_f, n_b = n_f.cpu().numpy(), n_b.cpu().numpy()
-        nmax_f, nmax_b = int(min(n_f.max(initial=0), cap)), int(min(n_b.max(initial=0), cap))
-        lab_f, lab_b = BK.to_host(lab_f, "db.lab_f"), BK.to_host(lab_b, "db.lab_b")
-        st_f, st_b = BK.to_host(st_f[:, :max(nmax_f, 1)], "db.st_f"), BK.to_host(st_b[:, :max(nmax_b, 1)], "db.st_b")
-        prob = BK.to_host(prob, "db.prob")
-        boxes_batch, scores_batch = [], []
-        for b in range(B):
-            boxes, scores = self._page(prob[b], lab_f[b], st_f[b, : min(n_f[b], cap)], lab_b[b],
-                                       st_b[b, : min(n_b[b], cap)], W, H)
-            boxes_batch.append(boxes)
-            scores_batch.append(scores)
-        return boxes_batch, scores_batch
+        return thread_tail(bitmap.device).db_boxes(prob, bitmap, self.max_candidates, self.unclip_ratio)
 
-    # one page ---------------------------------------------------------------
+    # one page from host label images (the path the tail falls back to when a bitmap has more
+    # components than the compact tables hold) ---------------------------------------------------
     def _page(self, prob, lab_f, st_f, lab_b, st_b, W, H):
         """Contours -> boxes for one page: `ctd_db_boxes` (native host geometry, csrc/host_db.cpp)."""
         lib = L.lib()

@@ -1,0 +1,162 @@
+"""`Tail`: Python handle of the native detector tail (`ctd_tail_*`, csrc/tail.hip) -- everything
+`TextDetector.__call__` does after `self.net(img_in)` (reference inference.py:148-178) for a batch of
+pages in ONE native call: NMS, DB boxes, mask crop / resize, `group_output`, `refine_mask`,
+`refine_undetected_mask`.  The call releases the interpreter lock, owns its HIP stream and buffers, and
+different `Tail` objects may run on different threads (`TextDetector.detect_stream` overlaps the tail of
+batch k with the network forward of batch k+1 that way).  This module only marshals arguments and turns
+the native records into the reference's Python objects.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import threading
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib as L
+from .textblock import TextBlock, blocks_from_records
+
+
+class Tail:
+    def __init__(self, device: torch.device):
+        self._lib = L.lib()
+        self.device = torch.device(device)
+        h = C.c_void_p()
+        L.check(self._lib.ctd_tail_create(C.byref(h), self.device.index or 0), "ctd_tail_create")
+        self._h = h
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            try:
+                self._lib.ctd_tail_destroy(h)
+            except Exception:
+                pass
+            self._h = None
+
+    # -- helpers --------------------------------------------------------------------------------
+    @staticmethod
+    def _page_table(pages_gpu: Sequence[Optional[torch.Tensor]], metas):
+        n = len(metas)
+        tab = (L.CtdTailPage * n)()
+        for b, (im_h, im_w, dw, dh) in enumerate(metas):
+            pg = pages_gpu[b] if pages_gpu is not None else None
+            if pg is not None:
+                if not pg.is_cuda or pg.dtype != torch.uint8 or tuple(pg.shape) != (im_h, im_w, 3) or not pg.is_contiguous():
+                    raise ValueError("pages must be contiguous uint8 (im_h, im_w, 3) GPU tensors")
+                tab[b].img_dev = pg.data_ptr()
+            tab[b].im_h, tab[b].im_w, tab[b].dw, tab[b].dh = int(im_h), int(im_w), int(dw), int(dh)
+        return tab
+
+    def _blocks(self, b: int) -> Tuple[List[TextBlock], dict]:
+        lib = self._lib
+        nb, nl, nd, nx, ny = (C.c_int32() for _ in range(5))
+        L.check(lib.ctd_tail_page_counts(self._h, b, C.byref(nb), C.byref(nl), C.byref(nd), C.byref(nx), C.byref(ny)),
+                "ctd_tail_page_counts")
+        recs = (L.CtdBlk * max(nb.value, 1))()
+        lines = np.empty((nl.value, 8), np.int32)
+        dist = np.empty((nd.value, 3), np.float64)
+        boxes = np.empty((nx.value, 4, 2), np.int16)
+        scores = np.empty((nx.value,), np.float32)
+        yx = np.empty((ny.value, 4), np.int32)
+        yc = np.empty((ny.value,), np.int32)
+        yf = np.empty((ny.value,), np.float32)
+        L.check(lib.ctd_tail_page_fetch(self._h, b, recs, lines.ctypes.data, dist.ctypes.data, boxes.ctypes.data,
+                                        scores.ctypes.data, yx.ctypes.data, yc.ctypes.data, yf.ctypes.data),
+                "ctd_tail_page_fetch")
+        extras = {"db_boxes": boxes, "db_scores": scores, "yolo": (yx, yc, np.round(yf, 3))}
+        return blocks_from_records(recs[: nb.value], lines, dist), extras
+
+    # -- the whole tail ---------------------------------------------------------------------------
+    def run(self, pages_gpu: Sequence[torch.Tensor], metas, blks: torch.Tensor, mask_u8: torch.Tensor,
+            lines_map: torch.Tensor, bitmap: torch.Tensor, conf_thresh=0.4, nms_thresh=0.35, box_thresh=0.6,
+            refine: bool = True, refine_mode: int = 0, keep_undetected_mask: bool = False,
+            ready_event: Optional[torch.cuda.Event] = None, want_extras: bool = False):
+        """metas[b] = (im_h, im_w, dw, dh); blks (B,rows,no) f32, mask_u8 (B,Hn,Wn) u8, lines_map (B,2,Hn,Wn) f32
+        or its plane 0 (B,Hn,Wn), bitmap (B,Hn,Wn) u8 -- all on the GPU.  Returns per page
+        (mask, mask_refined, blk_list[, extras]) as the reference's `TextDetector.__call__` does."""
+        B = len(metas)
+        for tns in (blks, mask_u8, lines_map, bitmap):
+            if not tns.is_cuda:
+                raise L.CtdError("Tail.run: the network outputs must live on the GPU")
+        blks = blks.contiguous()
+        mask_u8 = mask_u8.contiguous()
+        bitmap = bitmap.contiguous()
+        Hn, Wn = mask_u8.shape[-2:]
+        if lines_map.dtype != torch.float32 or lines_map.stride(-1) != 1 or lines_map.stride(-2) != Wn:
+            lines_map = lines_map.float().contiguous()
+        prob_stride = lines_map.stride(0)
+        tab = self._page_table(pages_gpu, metas)
+        prm = L.CtdTailParams(conf_thresh, nms_thresh, box_thresh, 1000, 1.5, int(bool(refine)), int(refine_mode),
+                              int(bool(keep_undetected_mask)), 0)
+        masks = [np.empty((m[0], m[1]), np.uint8) for m in metas]
+        refined = [np.empty((m[0], m[1]), np.uint8) for m in metas] if refine else [None] * B
+        mptr = (C.c_void_p * B)(*[m.ctypes.data for m in masks])
+        rptr = (C.c_void_p * B)(*[r.ctypes.data for r in refined]) if refine else None
+        ev = C.c_void_p(ready_event.cuda_event) if ready_event is not None else None
+        L.check(self._lib.ctd_tail_run(self._h, B, Hn, Wn, blks.data_ptr(), blks.shape[1], blks.shape[2],
+                                       mask_u8.data_ptr(), lines_map.data_ptr(), prob_stride, bitmap.data_ptr(), tab,
+                                       C.byref(prm), mptr, rptr, ev), "ctd_tail_run")
+        out = []
+        for b in range(B):
+            blk_list, extras = self._blocks(b)
+            out.append((masks[b], refined[b], blk_list, extras) if want_extras else (masks[b], refined[b], blk_list))
+        return out
+
+    # -- SegDetectorRepresenter alone -----------------------------------------------------------------
+    def db_boxes(self, prob: torch.Tensor, bitmap: torch.Tensor, max_candidates=1000, unclip_ratio=1.5):
+        B, Hn, Wn = bitmap.shape
+        prob = prob.float().contiguous()
+        bitmap = bitmap.contiguous()
+        torch.cuda.current_stream(self.device).synchronize()
+        L.check(self._lib.ctd_tail_db_boxes(self._h, B, Hn, Wn, prob.data_ptr(), prob.stride(0), bitmap.data_ptr(),
+                                            int(max_candidates), float(unclip_ratio)), "ctd_tail_db_boxes")
+        boxes, scores = [], []
+        for b in range(B):
+            nx = C.c_int32()
+            L.check(self._lib.ctd_tail_page_counts(self._h, b, None, None, None, C.byref(nx), None), "ctd_tail_page_counts")
+            bx = np.empty((nx.value, 4, 2), np.int16)
+            sc = np.empty((nx.value,), np.float32)
+            L.check(self._lib.ctd_tail_page_fetch(self._h, b, None, None, None, bx.ctypes.data, sc.ctypes.data, None, None,
+                                                  None), "ctd_tail_page_fetch")
+            boxes.append(bx)
+            scores.append(sc)
+        return boxes, scores
+
+    # -- refine_mask (+ refine_undetected_mask) alone ------------------------------------------------
+    def refine(self, pages_gpu: Sequence[torch.Tensor], masks: Sequence[np.ndarray], boxes: Sequence[Sequence],
+               refine_mode: int = 0, keep_undetected_mask: bool = False):
+        """masks[b]: host uint8 (im_h, im_w); boxes[b]: the blocks' xyxy.  Returns (refined, masks_after)."""
+        n = len(masks)
+        metas = [(m.shape[0], m.shape[1], 0, 0) for m in masks]
+        tab = self._page_table(pages_gpu, metas)
+        masks = [np.ascontiguousarray(m, np.uint8) for m in masks]
+        xy = np.ascontiguousarray(np.array([list(map(int, bb)) for pb in boxes for bb in pb], np.int32).reshape(-1, 4))
+        cnt = np.array([len(pb) for pb in boxes], np.int32)
+        refined = [np.empty_like(m) for m in masks]
+        after = [np.empty_like(m) for m in masks] if keep_undetected_mask else None
+        inp = (C.c_void_p * n)(*[m.ctypes.data for m in masks])
+        rptr = (C.c_void_p * n)(*[r.ctypes.data for r in refined])
+        aptr = (C.c_void_p * n)(*[a.ctypes.data for a in after]) if after is not None else None
+        torch.cuda.current_stream(self.device).synchronize()        # the pages were uploaded on torch's stream
+        L.check(self._lib.ctd_tail_refine(self._h, n, tab, inp, xy.ctypes.data if len(xy) else None, cnt.ctypes.data,
+                                          int(refine_mode), int(bool(keep_undetected_mask)), aptr, rptr), "ctd_tail_refine")
+        return refined, (after if after is not None else masks)
+
+
+_tls = threading.local()
+
+
+def thread_tail(device) -> Tail:
+    """One `Tail` per (host thread, device): its stream and buffers are not shared."""
+    device = torch.device(device)
+    if device.index is None:
+        device = torch.device("cuda", torch.cuda.current_device())
+    pool = getattr(_tls, "pool", None)
+    if pool is None:
+        pool = _tls.pool = {}
+    if device.index not in pool:
+        pool[device.index] = Tail(device)
+    return pool[device.index]

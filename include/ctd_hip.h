@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define CTD_ABI_VERSION 1
+#define CTD_ABI_VERSION 2
 
 /* ---- error codes ------------------------------------------------------ */
 #define CTD_OK 0
@@ -199,75 +199,71 @@ int ctd_ccl(const uint8_t* img_dev, int32_t B, int32_t H, int32_t W, int32_t thr
 int ctd_resize_linear_u8(const uint8_t* src_dev, int32_t sH, int32_t sW, int32_t C, uint8_t* dst_dev,
                          int32_t dH, int32_t dW, int32_t canvasH, int32_t canvasW, void* stream);
 
-/* ---- per-window kernels of the mask refinement (reference utils/textmask.py:29-71) ---- */
+/* ---- the detector tail ------------------------------------------------------ */
 
-/* One text-block window of a page: both images live on the device. */
-typedef struct ctd_window {
-  const uint8_t* img;  /* page, BGR u8 interleaved, row = img_w * 3 bytes          */
-  const uint8_t* mask; /* predicted mask of the page, u8, row = mask_w bytes        */
-  int32_t img_w, mask_w;
-  int32_t x1, y1, w, h; /* window [x1, x1+w) x [y1, y1+h) (reference textmask.py:162-164) */
-} ctd_window;
+/* Everything `TextDetector.__call__` does after `self.net(img_in)` (reference inference.py:148-178) for a
+ * whole batch of pages, driven natively: NMS + `postprocess_yolo` (inference.py:101-114), the DB
+ * text-line stage (`SegDetectorRepresenter`, utils/db_utils.py:32-211: two labelling passes and contour
+ * tables on the GPU, hull / min-area rectangle / unclip on the host), the mask crop + resize
+ * (inference.py:164-165), `group_output` (utils/textblock.py:421-508), `refine_mask` and
+ * `refine_undetected_mask` (utils/textmask.py:135-169: histograms, xor distances, candidate masks,
+ * labelling, merge rounds, dilation, hole filling and the final OR on the GPU; colour / threshold picks
+ * on the host).  A `ctd_tail` owns a HIP stream and its buffers; different objects may run concurrently
+ * from different host threads.  All calls are synchronous: results are complete on return. */
+typedef struct ctd_tail ctd_tail;
 
-/* A candidate-mask rule: kind -1 unused; 0 = cv2.inRange(grey, lo, hi);
- * 1/2/3 = threshold(channel B/G/R, lo, 255, THRESH_BINARY).  `invert` selects the negative
- * (255 - mask), `aux` = window index (render only). */
-typedef struct ctd_rule {
-  int32_t kind;
-  float lo, hi;
-  int32_t invert;
-  int32_t aux;
-} ctd_rule;
+typedef struct ctd_tail_page {
+  const uint8_t* img_dev; /* the page as the caller passed it: BGR u8 (im_h, im_w, 3) on the device      */
+  int32_t im_h, im_w;     /* page size                                                                    */
+  int32_t dw, dh;         /* right / bottom letterbox padding of the network input (inference.py:143)     */
+} ctd_tail_page;
 
-/* hist_dev (n,4,256) u32: [0] grey (BGR2GRAY) of the pixels whose 3x3-eroded mask > 127
- * (textmask.py:58-61), [1..3] B, G, R of the whole window (Otsu input, textmask.py:44-47).
- * `wins` is a HOST array (copied internally). */
-int ctd_win_hist(const ctd_window* wins, int32_t n, uint32_t* hist_dev, void* stream);
+typedef struct ctd_tail_params {
+  float conf_thresh, nms_thresh; /* reference inference.py:121 defaults 0.4 / 0.35                        */
+  float box_thresh;              /* DB line score threshold, 0.6 (inference.py:159)                       */
+  int32_t max_candidates;        /* 1000 (utils/db_utils.py:33)                                           */
+  double unclip_ratio;           /* 1.5                                                                   */
+  int32_t refine;                /* 0: stop after group_output                                            */
+  int32_t refine_mode;           /* REFINEMASK_INPAINT 0 / REFINEMASK_ANNOTATION 1 (utils/textmask.py:13) */
+  int32_t keep_undetected_mask;  /* run refine_undetected_mask (inference.py:175-176)                     */
+  int32_t pad_;
+} ctd_tail_params;
 
-/* sums_dev (n,nrules) u64: sum over the window of (rule(pixel) ? 255 - m : m), the xor distance
- * of `minxor_thresh` (textmask.py:36-37); nrules <= 6; rules is a HOST array (n*nrules). */
-int ctd_win_xor(const ctd_window* wins, int32_t n, const ctd_rule* rules, int32_t nrules, uint64_t* sums_dev,
-                void* stream);
+int ctd_tail_create(ctd_tail** out, int32_t device);
+void ctd_tail_destroy(ctd_tail* t);
+void* ctd_tail_stream(ctd_tail* t); /* the hipStream_t the tail's kernels run on */
 
-/* Renders nbands candidate masks {0,255} into a (rows, canvas_w) u8 canvas: band k uses window
- * bands[k].aux with rule bands[k] and starts at row tops[k], left aligned.  The canvas feeds
- * ctd_ccl (reference textmask.py:93).  bands / tops are HOST arrays. */
-int ctd_win_render(const ctd_window* wins, int32_t n, const ctd_rule* bands, const int32_t* tops, int32_t nbands,
-                   uint8_t* canvas_dev, int32_t canvas_w, void* stream);
+/* Network outputs of a batch (all on the device): blks (B,rows,no) f32, mask_u8 (B,Hn,Wn) u8 =
+ * `postprocess_mask` (fused in the engine), prob = plane 0 of lines_map (page b at prob_dev +
+ * b * prob_stride floats), bitmap (B,Hn,Wn) u8 = prob > 0.3.  mask_out[b] / refined_out[b]: host arrays of
+ * im_h * im_w bytes (the `mask` and `mask_refined` the reference returns; entries or the arrays may be NULL).
+ * ready_event: a hipEvent_t recorded after the network on its stream (waited for on the tail's stream), or
+ * NULL if the outputs are already complete.  Blocks: ctd_tail_page_counts / ctd_tail_page_fetch. */
+int ctd_tail_run(ctd_tail* t, int32_t B, int32_t Hn, int32_t Wn, const float* blks_dev, int32_t rows, int32_t no,
+                 const uint8_t* mask_u8_dev, const float* prob_dev, int64_t prob_stride, const uint8_t* bitmap_dev,
+                 const ctd_tail_page* pages, const ctd_tail_params* prm, uint8_t* const* mask_out,
+                 uint8_t* const* refined_out, void* ready_event);
 
-/* ---- merge stage of the mask refinement (reference utils/textmask.py:74-131) ---- */
+/* The DB text-line stage alone (`SegDetectorRepresenter.__call__`, reference utils/db_utils.py:40-69): boxes and
+ * scores of every contour of every page, read back with ctd_tail_page_counts / ctd_tail_page_fetch. */
+int ctd_tail_db_boxes(ctd_tail* t, int32_t B, int32_t Hn, int32_t Wn, const float* prob_dev, int64_t prob_stride,
+                      const uint8_t* bitmap_dev, int32_t max_candidates, double unclip_ratio);
 
-/* A band of a labelled canvas: window `win`, first row `top` in the label canvas, first row `mtop`
- * in the merged-mask canvas (one band per window there). */
-typedef struct ctd_band {
-  int32_t win, top, mtop;
-} ctd_band;
+/* `refine_mask` (+ `refine_undetected_mask`) alone for given pages, page-size masks (HOST) and block boxes
+ * (blk_xyxy: all pages' (x1,y1,x2,y2) concatenated, blk_counts[b] per page).  mask_out receives the masks
+ * as `refine_undetected_mask` edits them in place (may be NULL). */
+int ctd_tail_refine(ctd_tail* t, int32_t n_pages, const ctd_tail_page* pages, const uint8_t* const* masks_host,
+                    const int32_t* blk_xyxy, const int32_t* blk_counts, int32_t refine_mode, int32_t keep_undetected_mask,
+                    uint8_t* const* mask_out, uint8_t* const* refined_out);
 
-/* One accept round of `merge_mask_list` (textmask.py:93-107, and the hole-filling pass :113-131) for
- * the given bands: a labelled component is OR-ed into the merged mask iff it is allowed and, among
- * its pixels not merged yet, more lie on pred_bin = 255 than on pred_bin = 0 (pred_bin = 3x3 cross
- * erosion of the window's mask > 60, :85-89) -- the reference's `xor_merged < xor_origin` test.
- * Allowed: allowed_dev[label-1] != 0 when given, else bbox w*h >= min_box from stats_dev (:98-99).
- * labels_dev (rows, canvas_w) i32 and stats_dev (nlab,5) i32 are `ctd_ccl` outputs; counters_dev
- * = 2*(nlab+1) u32, zeroed by the caller before the first round of a canvas (labels are unique per
- * band, so rounds do not collide).  wins / bands are HOST arrays. */
-int ctd_win_accept(const ctd_window* wins, int32_t n, const ctd_band* bands, int32_t nbands,
-                   const int32_t* labels_dev, int32_t canvas_w, const int32_t* stats_dev,
-                   const uint8_t* allowed_dev, int32_t min_box, uint8_t* merged_dev, int32_t merged_w,
-                   uint32_t* counters_dev, void* stream);
-
-/* merged_out = 3x3 rect dilation of merged_in inside each window (`dilate` != 0, REFINEMASK_INPAINT,
- * textmask.py:110-111) or a copy; comp_dev = 255 - merged_out (the canvas of the hole-filling
- * labelling, :113); count255_dev[win] += #pixels == 255 (the caller zeroes it).  mtops (n) HOST. */
-int ctd_win_dilate(const ctd_window* wins, int32_t n, const int32_t* mtops, const uint8_t* merged_in_dev,
-                   uint8_t* merged_out_dev, uint8_t* comp_dev, int32_t merged_w, uint32_t* count255_dev,
-                   int32_t dilate, void* stream);
-
-/* page[y1:y1+h, x1:x1+w] |= merged band of every window (textmask.py:167); page_dev must be 4-byte
- * aligned and its allocation a multiple of 4 bytes (word-wide atomic OR: windows may overlap; the
- * word holding the last pixels may reach up to 3 bytes past H*W). */
-int ctd_win_commit(const ctd_window* wins, int32_t n, const int32_t* mtops, const uint8_t* merged_dev,
-                   int32_t merged_w, uint8_t* page_dev, int32_t page_w, void* stream);
+/* Results of the last ctd_tail_run for one page: grouped blocks (ctd_blk, below) with their line and distance
+ * pools, every DB contour box (n,4,2) i16 + score as `SegDetectorRepresenter.__call__` returns them, and the
+ * NMS blocks (xyxy i32, class, confidence) as `postprocess_yolo` returns them.  Any output may be NULL. */
+int ctd_tail_page_counts(const ctd_tail* t, int32_t page, int32_t* n_blocks, int32_t* n_lines, int32_t* n_dist,
+                         int32_t* n_db_boxes, int32_t* n_yolo);
+struct ctd_blk;
+int ctd_tail_page_fetch(const ctd_tail* t, int32_t page, struct ctd_blk* blocks, int32_t* lines, double* dist,
+                        int16_t* db_boxes, float* db_scores, int32_t* yolo_xyxy, int32_t* yolo_cls, float* yolo_conf);
 
 /* ---- host-side contour geometry of the DB text-line stage -------------- */
 
@@ -286,6 +282,27 @@ int ctd_win_commit(const ctd_window* wins, int32_t n, const int32_t* mtops, cons
 int ctd_db_boxes(const float* prob, const int32_t* lab_f, const int32_t* st_f, int32_t n_f, const int32_t* lab_b,
                  const int32_t* st_b, int32_t n_b, int32_t W, int32_t H, int32_t max_candidates,
                  double unclip_ratio, int16_t* boxes, float* scores, int32_t* n_out);
+
+/* The same stage (`boxes_from_bitmap`, reference utils/db_utils.py:123-211) from tables compacted on the
+ * DEVICE, so that no label image or probability map is downloaded (csrc/kernels_tail.hip `launch_dbc`, driven
+ * by `ctd_tail_run`).  HOST memory only.  Per polarity (f = 8-connected foreground components, b =
+ * 4-connected background components; labels 1..n in first-pixel order, row l-1 of every table):
+ *   st_*    (n,5) [x,y,w,h,area]            first_* (n) linear index of the component's first pixel
+ *   par_f   (n_f) background label left of the first pixel (0 at the page edge)
+ *   par_b   (n_b) foreground label left of the first pixel if the component is a HOLE (does not touch the
+ *                 page frame), else 0
+ *   off_f   (n_f) first entry of the component's h rows in row_lo / row_hi (leftmost / rightmost x per row)
+ *   off_b   (n_b) first entry of the h + 2 rows of a hole's border ring (the ringing component's pixels that
+ *                 4-touch the hole), rows y - 1 .. y + h
+ *   sum_f / sum_b  sum of the probability map over the component / the hole
+ *   ring_sum / ring_cnt  sum of the probability map over the border ring / its pixel count
+ * Outputs as `ctd_db_boxes`. */
+int ctd_db_boxes_compact(int32_t W, int32_t H, int32_t n_f, const int32_t* st_f, const int32_t* first_f,
+                         const int32_t* par_f, const int32_t* off_f, const double* sum_f, int32_t n_b,
+                         const int32_t* st_b, const int32_t* first_b, const int32_t* par_b, const int32_t* off_b,
+                         const double* sum_b, const double* ring_sum, const int32_t* ring_cnt, const int32_t* row_lo,
+                         const int32_t* row_hi, int32_t max_candidates, double unclip_ratio, int16_t* boxes,
+                         float* scores, int32_t* n_out);
 
 /* ---- host-side block / line grouping ------------------------------------- */
 
@@ -321,6 +338,18 @@ int ctd_group_output(const int32_t* blines, const int32_t* cls, int32_t n_blk, c
                      int32_t im_w, int32_t im_h, const uint8_t* mask, int32_t mask_pitch, ctd_blk* blks_out,
                      int32_t blk_cap, int32_t* lines_out, int32_t line_cap, double* dist_out, int32_t dist_cap,
                      int32_t* n_blk_out, int32_t* n_lines_out, int32_t* n_dist_out);
+
+/* ---- host decisions of the mask refinement (exposed for tests; HOST memory, no device work) ---- */
+
+/* np.histogram(px, bins=255) + get_topk_color(k=3, color_var=10, bin_tol=0.001) (reference
+ * utils/textmask.py:16-27,61-62) from the 256-bin histogram of the selected grey pixels; writes up to 3
+ * colours (left bin edges, float64) and returns how many. */
+int ctd_topk_colors(const int64_t* hist256, double* colors3);
+/* Threshold picked by cv2.threshold(.., THRESH_OTSU) (reference utils/textmask.py:47) from a 256-bin histogram. */
+int ctd_otsu_from_hist(const int64_t* hist256);
+/* Integer bounds cv2.inRange(u8, lo, hi) derives from double scalars (reference utils/textmask.py:68);
+ * lb > ub on return = the empty range. */
+void ctd_inrange_bounds(double lo, double hi, int32_t* lb, int32_t* ub);
 
 /* ---- misc -------------------------------------------------------------- */
 const char* ctd_last_error(void);

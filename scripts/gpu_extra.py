@@ -41,47 +41,25 @@ for B in (1, 4):
 
 from test_post_host import fake_outputs          # noqa: E402
 from test_gpu_e2e import blks_tensor             # noqa: E402
-det = pkg.detector.TextDetector(ck, input_size=1024, device="cuda")
+det = pkg.detector.TextDetector(ck, input_size=1024, device="cuda", half=True)
+NP = int(os.environ.get("EXTRA_PAGES", "32"))
 pages, args = [], []
-for s in range(4):
-    page, mask_u8, prob, blks = fake_outputs(s, 1024)
-    pages.append(page)
+for s in range(NP):
+    page, mask_u8, prob, blks = fake_outputs(s % 8, 1024)
+    pages.append(torch.from_numpy(page).cuda())
     args.append((blks_tensor(blks), mask_u8, prob, (prob > 0.3).astype(np.uint8)))
 bt = torch.from_numpy(np.concatenate([a[0] for a in args])).cuda()
 mu = torch.from_numpy(np.stack([a[1] for a in args])).cuda()
 pr = torch.from_numpy(np.stack([a[2] for a in args])).cuda()
 bm = torch.from_numpy(np.stack([a[3] for a in args])).cuda()
-det.tail_batch(pages, bt, mu, pr, bm, keep_undetected_mask=True)
-t0 = time.perf_counter()
-res = det.tail_batch(pages, bt, mu, pr, bm, keep_undetected_mask=True)
-out["tail_ms_per_page_textlike_1024"] = round((time.perf_counter() - t0) / 4 * 1e3, 1)
-out["tail_blocks_per_page"] = [len(r[2]) for r in res]
-
-# per-stage split of the same tail (host wall clock, device synchronised at the stage ends)
-from importlib import import_module                  # noqa: E402
-PP = pkg.postproc
-stage = {}
-
-
-def clock(name, fn):
+for keep in (False, True):
+    det.tail_batch(pages, bt, mu, pr, bm, keep_undetected_mask=keep)
     torch.cuda.synchronize()
-    t = time.perf_counter()
-    r = fn()
-    torch.cuda.synchronize()
-    stage[name] = stage.get(name, 0.0) + (time.perf_counter() - t) * 1e3 / 4
-    return r
-
-
-ratios = [(1.0, 1.0)] * 4
-yolo = clock("nms+unpack", lambda: PP.postprocess_yolo(bt, det.conf_thresh, det.nms_thresh, ratios))
-boxes, scores = clock("db_boxes(ccl x2 + download + ctd_db_boxes)", lambda: det.seg_rep(pr, bm))
-for b in range(4):
-    lines = boxes[b][scores[b] > 0.6].astype(np.int32)
-    m = clock("mask download", lambda: mu[b].cpu().numpy().copy())
-    blk = clock("group_output", lambda: pkg.textblock.group_output(yolo[b], lines, 1024, 1024, m))
-    ref = clock("refine_mask", lambda: pkg.textmask.refine_mask(pages[b], m, blk, 0, "cuda"))
-    clock("refine_undetected_mask", lambda: pkg.textmask.refine_undetected_mask(pages[b], m, ref, blk, 0, "cuda"))
-out["tail_stage_ms_per_page"] = {k: round(v, 2) for k, v in stage.items()}
+    t0 = time.perf_counter()
+    for _ in range(3):
+        res = det.tail_batch(pages, bt, mu, pr, bm, keep_undetected_mask=keep)
+    out[f"tail_ms_per_page_textlike_1024_b{NP}_keep{int(keep)}"] = round((time.perf_counter() - t0) / 3 / NP * 1e3, 3)
+out["tail_blocks_per_page"] = [len(r[2]) for r in res][:8]
 
 be32 = pkg.backend.HipTextDetBackend(ck, precision="fp32")
 x = torch.rand(8, 3, 1024, 1024).cuda()

@@ -124,8 +124,8 @@ def test_detector_on_page_of_another_size_matches_oracle():
 
 @pytest.mark.parametrize("seed", [0, 1, 2])
 def test_refine_mask_gpu_merge_stage_on_adversarial_windows(seed):
-    """`refine_mask` through the GPU merge stage (ctd_win_hist/xor/render, ctd_ccl, ctd_win_accept /
-    dilate / commit) against the oracle on pages built to stress it: noisy colours (many small
+    """`refine_mask` through the native tail (tw_hist / xor / render, ccl, tw_accept / dilate / holes /
+    commit) against the oracle on pages built to stress it: noisy colours (many small
     components per candidate), blob masks, and text blocks that overlap each other, touch the page
     border or are a few pixels thin -- the cases the text-like pages do not reach."""
     p = pkg()
@@ -156,9 +156,9 @@ def test_refine_mask_gpu_merge_stage_on_adversarial_windows(seed):
     np.testing.assert_array_equal(m1, m2)
 
 
-def test_refine_mask_batch_grouping_is_transparent():
-    """`refine_mask_batch` packs the windows of several pages into shared launches, in groups bounded
-    by `_GROUP_PIXELS`; one page per group and all pages in one group must give identical masks."""
+def test_refine_mask_batch_equals_single_pages():
+    """`refine_mask_batch` packs the windows of several pages (of different sizes) into shared canvases
+    and launches; every page must come out as from its own call, and as from the oracle."""
     p = pkg()
     pages, masks, blks = [], [], []
     for seed in range(3):
@@ -171,16 +171,55 @@ def test_refine_mask_batch_grouping_is_transparent():
     pages.append(pages[0])
     masks.append(masks[0])
     together = p.textmask.refine_mask_batch(pages, masks, blks, 0, "cuda")
-    old = p.textmask._GROUP_PIXELS
-    try:
-        p.textmask._GROUP_PIXELS = 1
-        apart = p.textmask.refine_mask_batch(pages, masks, blks, 0, "cuda")
-    finally:
-        p.textmask._GROUP_PIXELS = old
-    for a, b_, m, bl, pg in zip(together, apart, masks, blks, pages):
-        np.testing.assert_array_equal(a, b_)
+    for a, m, bl, pg in zip(together, masks, blks, pages):
+        np.testing.assert_array_equal(a, p.textmask.refine_mask(pg, m, bl, 0, "cuda"))
         np.testing.assert_array_equal(a, R.refine_mask(pg, m, [R.TextBlock(x.xyxy) for x in bl], 0))
     assert not together[3].any()
+
+
+def test_db_stage_on_device_tables_matches_oracle_and_falls_back_on_overflow():
+    """`SegRepresenter` (two labelling passes + contour tables on the GPU, geometry on the host) against the
+    oracle's contour walk on speckle maps; a map with more components than the compact tables hold takes
+    the label-image path and must give the same answer."""
+    from scipy import ndimage
+    p = pkg()
+    rep = p.postproc.SegRepresenter()
+    probs = []
+    for seed in range(4):
+        rng = np.random.RandomState(200 + seed)
+        pr = ndimage.uniform_filter(rng.rand(192, 256), 1 + seed).astype(np.float32)
+        probs.append((pr - pr.min()) / (pr.max() - pr.min()) * 0.62)
+    prob = torch.from_numpy(np.stack(probs)).cuda()
+    boxes, scores = rep(prob, (prob > 0.3).to(torch.uint8))
+    for b in range(4):
+        rb, rs = R.boxes_from_bitmap(probs[b], probs[b] > 0.3, 256, 192)
+        np.testing.assert_array_equal(boxes[b], rb)
+        np.testing.assert_allclose(scores[b], rs, rtol=0, atol=1e-6)
+    # > 65536 single-pixel components + one solid block
+    big = np.full((516, 516), 0.05, np.float32)
+    big[::2, ::2] = 0.9
+    big[100:140, 200:330] = 0.95
+    bt = torch.from_numpy(big)[None].cuda()
+    boxes, scores = rep(bt, (bt > 0.3).to(torch.uint8))
+    rb, rs = R.boxes_from_bitmap(big, big > 0.3, 516, 516)
+    np.testing.assert_array_equal(boxes[0], rb)
+    np.testing.assert_allclose(scores[0], rs, rtol=0, atol=1e-6)
+
+
+def test_detect_stream_equals_detect_batch():
+    """The pipelined form (tails on worker threads under the next forward) returns what detect_batch returns."""
+    size = 256
+    p = pkg()
+    det = detector(size)
+    batches = [[p.synth.text_like_page((size, size), 30 + 3 * k + j, n_blocks=4) for j in range(3)] for k in range(4)]
+    want = [det.detect_batch(b) for b in batches]
+    got = list(det.detect_stream(batches, workers=2, depth=3))
+    assert len(got) == len(want)
+    for gb, wb in zip(got, want):
+        for (m, r, bl), (m1, r1, bl1) in zip(gb, wb):
+            np.testing.assert_array_equal(m, m1)
+            np.testing.assert_array_equal(r, r1)
+            blocks_equal(bl, bl1)
 
 
 def test_model2annotations_batch_driver_writes_the_reference_files(tmp_path):

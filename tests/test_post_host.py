@@ -1,7 +1,6 @@
-"""Host logic of the post-processing mirror (textblock / textmask / geom / SegRepresenter)
-against the oracle restatement, on CPU.  GPU labelling is replaced by a scipy labeller
-(test infrastructure) so only the host arithmetic is under test here; the GPU kernels
-themselves are checked in tests/test_gpu_post.py and end-to-end in tests/test_gpu_e2e.py."""
+"""Native host code of the post-processing (csrc/host_db.cpp, host_group.cpp, host_refine.cpp: no
+device work, runs without a GPU) against the oracle restatement.  The GPU kernels are checked in
+tests/test_gpu_post.py and end-to-end in tests/test_gpu_e2e.py."""
 import copy
 
 import numpy as np
@@ -10,14 +9,6 @@ import pytest
 from conftest import pkg
 from oracle import cv_ref as cv
 from oracle import postproc_ref as R
-
-
-def scipy_labeler(masks, connectivity):
-    out = []
-    for m in masks:
-        n, lab, stats = R.connected_components_with_stats(m, connectivity)
-        out.append((lab.astype(np.int32), stats[1:].astype(np.int32)))
-    return out
 
 
 def fake_outputs(seed=0, size=512):
@@ -48,7 +39,7 @@ def blocks_equal(a, b):
 
 
 @pytest.mark.parametrize("seed", [0, 1, 2])
-def test_db_boxes_group_output_refine_match_oracle(seed):
+def test_db_boxes_group_output_match_oracle(seed):
     p = pkg()
     page, mask_u8, prob, blks = fake_outputs(seed)
     H, W = prob.shape
@@ -67,17 +58,6 @@ def test_db_boxes_group_output_refine_match_oracle(seed):
     got = p.textblock.group_output(copy.deepcopy(blks), lines.copy(), W, H, mask_u8)
     ref = R.group_output(copy.deepcopy(blks), lines.copy(), W, H, mask_u8)
     blocks_equal(got, ref)
-    # --- mask refinement (both modes) + undetected-mask pass
-    for mode in (0, 1):
-        a = p.textmask.refine_mask(page, mask_u8, got, mode, labeler=scipy_labeler)
-        b = R.refine_mask(page, mask_u8, ref, mode)
-        np.testing.assert_array_equal(a, b)
-    m1, m2 = mask_u8.copy(), mask_u8.copy()
-    a = p.textmask.refine_undetected_mask(page, m1, p.textmask.refine_mask(page, mask_u8, got, 1, labeler=scipy_labeler),
-                                          got[: len(got) // 2], 1, labeler=scipy_labeler)
-    b = R.refine_undetected_mask(page, m2, R.refine_mask(page, mask_u8, ref, 1), ref[: len(ref) // 2], 1)
-    np.testing.assert_array_equal(a, b)
-    np.testing.assert_array_equal(m1, m2)          # the in-place mutation of mask_pred is mirrored too
 
 
 @pytest.mark.parametrize("case", ["noise", "holes", "thin", "empty", "full", "cap"])
@@ -172,18 +152,44 @@ def test_group_output_hand_built_scenes():
     assert p.textblock.group_output((np.zeros((0, 4), np.int32), np.zeros(0, np.int32), np.zeros(0)), [], W, H, mask) == []
 
 
-def test_geometry_primitives_match_oracle():
-    p = pkg()
+def test_refine_host_decisions_match_oracle():
+    """csrc/host_refine.cpp: the colour pick (np.histogram(bins=255) + get_topk_color), the Otsu threshold
+    and the cv2.inRange bounds against the oracle's restatements, on random and degenerate histograms."""
+    import ctypes as C
+    lib = pkg()._lib.lib()
     rng = np.random.RandomState(3)
-    for _ in range(200):
-        q1 = rng.randint(0, 50, (4, 2))
-        q2 = rng.randint(0, 50, (4, 2))
-        assert p.geom.quads_intersect(q1, q2) == cv.polygons_intersect(q1, q2)
-    img = rng.randint(0, 256, (40, 60, 3)).astype(np.uint8)
-    np.testing.assert_array_equal(p.textmask.bgr2gray(img), cv.cvt_bgr2gray(img))
-    for _ in range(20):
-        ch = rng.randint(0, 256, (30, 30)).astype(np.uint8) // rng.randint(1, 5)
-        assert p.textmask.otsu_value(ch) == cv.otsu_threshold_value(ch)
+    for it in range(300):
+        kind = it % 6
+        if kind == 0:
+            px = rng.randint(0, 256, rng.randint(1, 4000)).astype(np.uint8)
+        elif kind == 1:
+            px = np.clip(rng.normal(rng.randint(20, 230), rng.uniform(1, 40), rng.randint(1, 5000)), 0, 255).astype(np.uint8)
+        elif kind == 2:
+            px = np.r_[np.full(rng.randint(1, 900), rng.randint(0, 256)), rng.randint(0, 256, rng.randint(0, 30))].astype(np.uint8)
+        elif kind == 3:
+            px = np.full(rng.randint(1, 50), rng.randint(0, 256), np.uint8)          # min == max
+        elif kind == 4:
+            px = np.zeros(0, np.uint8)                                               # nothing selected
+        else:
+            lo = rng.randint(0, 200)
+            px = rng.randint(lo, lo + rng.randint(2, 56), rng.randint(1, 3000)).astype(np.uint8)
+        hist = np.bincount(px, minlength=256).astype(np.int64)
+        out = np.zeros(3, np.float64)
+        n = lib.ctd_topk_colors(hist.ctypes.data, out.ctypes.data)
+        counts, edges = np.histogram(px, bins=255)
+        ref = R.get_topk_color(edges, counts, k=3, color_var=10)
+        assert n == len(ref)
+        np.testing.assert_array_equal(out[:n], np.asarray(ref, np.float64))
+        if len(px):
+            assert lib.ctd_otsu_from_hist(hist.ctypes.data) == cv.otsu_threshold_value(px)
+    for lo, hi in [(7.4, 67.4), (7.5, 67.5), (8.5, 68.5), (-12.3, 47.7), (195.0, 255), (-70.2, -10.2), (254.6, 255),
+                   (300.0, 360.0), (100.5, 100.4), (0.5, 0.5), (-0.5, 0.49)] + [tuple(rng.uniform(-80, 300, 2)) for _ in range(50)]:
+        lb, ub = C.c_int32(), C.c_int32()
+        lib.ctd_inrange_bounds(lo, hi, C.byref(lb), C.byref(ub))
+        rl, ru = cv.in_range_bounds(lo, hi)
+        assert (lb.value > ub.value) == (rl > ru)
+        if rl <= ru:
+            assert (lb.value, ub.value) == (rl, ru)
 
 
 def test_oracle_contours_and_cc_against_scipy():

@@ -86,6 +86,7 @@ SYMBOLS = {
     "ctd_tail_stream": (_vp, [_vp]),
     "ctd_tail_run": (_i32, [_vp, _i32, _i32, _i32, _vp, _i32, _i32, _vp, _vp, _i64, _vp, C.POINTER(CtdTailPage),
                             C.POINTER(CtdTailParams), _vp, _vp, _vp]),
+    "ctd_tail_timings": (_i32, [_vp, C.POINTER(C.c_double)]),
     "ctd_tail_db_boxes": (_i32, [_vp, _i32, _i32, _i32, _vp, _i64, _vp, _i32, C.c_double]),
     "ctd_tail_refine": (_i32, [_vp, _i32, C.POINTER(CtdTailPage), _vp, _vp, _vp, _i32, _i32, _vp, _vp]),
     "ctd_tail_page_counts": (_i32, [_vp, _i32, C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i32),

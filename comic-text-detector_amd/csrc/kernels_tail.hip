@@ -263,7 +263,9 @@ __device__ __forceinline__ bool pred_on(const TWin& w, int x, int y) {
   return m > 60;
 }
 
-// counters[2l] / [2l+1]: pixels of component l not merged yet that are predicted text / background
+// counters[2l] / [2l+1]: pixels of component l not merged yet that are predicted text / background.
+// Consecutive lanes walk consecutive pixels of a window row: runs of one (label, prediction) inside a
+// wave are counted by their first lane (a candidate's big components would otherwise serialise on two words).
 __global__ __launch_bounds__(256) void tw_accept_count_kernel(const TWin* __restrict__ wins, const TBand* __restrict__ bands,
                                                               int round, const int* __restrict__ labels, int canvas_w,
                                                               int max_labels, const uint8_t* __restrict__ merged,
@@ -272,11 +274,24 @@ __global__ __launch_bounds__(256) void tw_accept_count_kernel(const TWin* __rest
   if (round >= 0 && bd.round != round) return;
   const TWin w = wins[bd.win];
   const int npix = w.w * w.h;
-  for (int i = blockIdx.x * 256 + threadIdx.x; i < npix; i += gridDim.x * 256) {
-    const int x = i % w.w, y = i / w.w;
-    const int l = labels[(size_t)(bd.cy + y) * canvas_w + bd.cx + x];
-    if (l > 0 && l <= max_labels && merged[(size_t)(w.my + y) * merged_w + w.mx + x] == 0)
-      atomicAdd(counters + 2 * (size_t)l + (pred_on(w, x, y) ? 0 : 1), 1u);
+  const int lane = threadIdx.x & 63;
+  for (int i0 = blockIdx.x * 256; i0 < npix; i0 += gridDim.x * 256) {
+    const int i = i0 + threadIdx.x;
+    int key = 0;                                    // 0: nothing to count; else 2 * label + (pred ? 0 : 1)
+    if (i < npix) {
+      const int x = i % w.w, y = i / w.w;
+      const int l = labels[(size_t)(bd.cy + y) * canvas_w + bd.cx + x];
+      if (l > 0 && l <= max_labels && merged[(size_t)(w.my + y) * merged_w + w.mx + x] == 0)
+        key = 2 * l + (pred_on(w, x, y) ? 0 : 1);
+    }
+    const int prev = __shfl_up(key, 1);
+    const bool head = lane == 0 || prev != key;
+    const unsigned long long heads = __ballot(head);
+    if (head && key) {
+      const unsigned long long later = lane == 63 ? 0ull : (heads >> (lane + 1));
+      const int len = later ? __ffsll((long long)later) : 64 - lane;
+      atomicAdd(counters + (size_t)key, (unsigned)len);
+    }
   }
 }
 
@@ -356,7 +371,7 @@ __global__ __launch_bounds__(256) void tw_holes_kernel(const TWin* __restrict__ 
     else atomicMax(tp + 2, a);
   }
   const int m1 = pass >= 1 ? tp[0] : 0;
-  const int thr = pass == 3 ? (tp[1] >= 1 ? tp[0] : tp[2]) : 0;
+  const int thr = pass >= 2 ? (tp[1] >= 1 ? tp[0] : tp[2]) : 0;
   for (int i = blockIdx.x * 256 + threadIdx.x; i < npix; i += gridDim.x * 256) {
     const int x = i % w.w, y = i / w.w;
     const size_t ci = (size_t)(w.my + y) * merged_w + w.mx + x;
@@ -369,7 +384,9 @@ __global__ __launch_bounds__(256) void tw_holes_kernel(const TWin* __restrict__ 
       else if (area == m1) atomicAdd(tp + 1, 1);
       else atomicMax(tp + 2, area);
     } else if (pass == 2) {
-      if (merged[ci] == 0) atomicAdd(counters2 + 2 * (size_t)l + (pred_on(w, x, y) ? 0 : 1), 1u);
+      // only components that may be filled are counted: the big ones (the window's real background) would
+      // serialise every pixel of the window on two counters
+      if (area < thr && merged[ci] == 0) atomicAdd(counters2 + 2 * (size_t)l + (pred_on(w, x, y) ? 0 : 1), 1u);
     } else {
       if (area < thr && counters2[2 * (size_t)l] > counters2[2 * (size_t)l + 1]) merged[ci] = 255;
     }

@@ -16,9 +16,12 @@
 // (the C ABI is called without the Python interpreter lock), so the tail of batch k overlaps the
 // network forward of batch k+1 (comic-text-detector_amd/detector.py `detect_stream`).
 #include <algorithm>
+#include <atomic>
+#include <chrono>
 #include <cmath>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "host_refine.h"
@@ -102,6 +105,30 @@ constexpr int kRowCap = 1 << 18;    // row-table entries per page
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
+// The per-page / per-window host work of a batch is independent: a few short-lived threads per call
+// (a GPU host has cores to spare; the Python caller holds none of them while inside this library).
+template <class F>
+void parallel_for(int n, int max_threads, F f) {
+  const int nt = std::min(max_threads, n);
+  if (nt <= 1) {
+    for (int i = 0; i < n; ++i) f(i);
+    return;
+  }
+  std::atomic<int> next{0};
+  auto work = [&]() {
+    for (int i; (i = next.fetch_add(1)) < n;) f(i);
+  };
+  std::vector<std::thread> th;
+  th.reserve(nt - 1);
+  for (int k = 1; k < nt; ++k) th.emplace_back(work);
+  work();
+  for (auto& x : th) x.join();
+}
+
+inline double now_ms() {
+  return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
 }  // namespace
 
 struct ctd_tail {
@@ -118,7 +145,12 @@ struct ctd_tail {
   std::vector<size_t> poff;           // byte offset of page b in the page-mask / refined buffers
   size_t ptotal = 0;
   std::vector<PageOut> out;
-  double ms_stage[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  // host wall clock of the last run, ms: [0] enqueue of stage 1, [1] wait for stage 1, [2] table download +
+  // contour geometry, [3] yolo unpack + group_output, [4] refine: histograms, [5] refine: xor sums, [6] refine:
+  // enqueue of the merge stage, [7] undetected pass, [8] final wait + copies, [9] total
+  double ms_stage[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  double ms_db_wait = 0;              // inside [2]: waiting for the table download
+  int host_threads = 8;               // threads of the per-page / per-window host loops
 };
 
 namespace {
@@ -204,9 +236,11 @@ int refine_windows(ctd_tail* t, const std::vector<WinReq>& reqs, int refine_mode
   T_TRY(hipMemsetAsync(dhist, 0, (size_t)n * 1024 * 4, st));
   launch_tw_hist(dw, n, max_pix, dhist, st);
   T_TRY(hipMemcpyAsync(hhist, dhist, (size_t)n * 1024 * 4, hipMemcpyDeviceToHost, st));
+  const double tr0 = now_ms();
   T_TRY(hipStreamSynchronize(st));
+  const double tr1 = now_ms();
   GET(t->h_rules, sizeof(RRule) * 6 * n, RRule, hrules);
-  for (int i = 0; i < n; ++i) refine_rules(hhist + (size_t)i * 1024, hrules + (size_t)i * 6);
+  parallel_for(n, t->host_threads, [&](int i) { refine_rules(hhist + (size_t)i * 1024, hrules + (size_t)i * 6); });
   static_assert(sizeof(RRule) == sizeof(TRule), "rule layouts must agree");
   GET(t->d_rules, sizeof(TRule) * 6 * n, TRule, drules);
   T_TRY(hipMemcpyAsync(drules, hrules, sizeof(TRule) * 6 * n, hipMemcpyHostToDevice, st));
@@ -216,7 +250,9 @@ int refine_windows(ctd_tail* t, const std::vector<WinReq>& reqs, int refine_mode
   T_TRY(hipMemsetAsync(dsums, 0, (size_t)n * 6 * 8, st));
   launch_tw_xor(dw, drules, n, max_pix, dsums, st);
   T_TRY(hipMemcpyAsync(hsums, dsums, (size_t)n * 6 * 8, hipMemcpyDeviceToHost, st));
+  const double tr2 = now_ms();
   T_TRY(hipStreamSynchronize(st));
+  const double tr3 = now_ms();
   std::vector<TBand> bands;
   std::vector<int> bw, bh;
   int rounds = 0;
@@ -283,6 +319,9 @@ int refine_windows(ctd_tail* t, const std::vector<WinReq>& reqs, int refine_mode
   launch_tw_holes(dw, n, max_pix, mlab, mstats, mfirst, cap2, count255, top2, merged_b, pm.W, counters2, st);
   launch_tw_commit(dw, n, max_pix, merged_b, pm.W, st);
   T_TRY(hipGetLastError());
+  t->ms_stage[4] += tr1 - tr0;
+  t->ms_stage[5] += tr3 - tr2;
+  t->ms_stage[6] += (now_ms() - tr3) + (tr2 - tr1);
   return CTD_OK;
 }
 
@@ -370,24 +409,20 @@ int undetected_pass(ctd_tail* t, const std::vector<std::vector<int32_t>>& blk_xy
   return refine_windows(t, reqs, refine_mode);
 }
 
-// device -> host of the page-size outputs, then into the caller's arrays
+// device -> host of the page-size outputs, straight into the caller's arrays (page-locked arrays make
+// these DMA transfers; comic-text-detector_amd/tail.py allocates them pinned)
 int download_pages(ctd_tail* t, bool mask_too, uint8_t* const* mask_out, uint8_t* const* refined_out) {
   hipStream_t st = t->st;
   GET(t->d_pmask, 0, uint8_t, pmask);
   GET(t->d_refined, 0, uint8_t, refined);
-  GET(t->h_pmask, t->ptotal, uint8_t, hm);
-  GET(t->h_refined, t->ptotal, uint8_t, hr);
-  if (mask_too && mask_out) T_TRY(hipMemcpyAsync(hm, pmask, t->ptotal, hipMemcpyDeviceToHost, st));
-  if (refined_out) T_TRY(hipMemcpyAsync(hr, refined, t->ptotal, hipMemcpyDeviceToHost, st));
-  T_TRY(hipStreamSynchronize(st));
   for (int b = 0; b < t->B; ++b) {
     const size_t nb = (size_t)t->pages[b].im_h * t->pages[b].im_w;
-    if (mask_out && mask_out[b]) std::memcpy(mask_out[b], hm + t->poff[b], nb);
-    if (refined_out && refined_out[b]) std::memcpy(refined_out[b], hr + t->poff[b], nb);
+    if (mask_too && mask_out && mask_out[b]) T_TRY(hipMemcpyAsync(mask_out[b], pmask + t->poff[b], nb, hipMemcpyDeviceToHost, st));
+    if (refined_out && refined_out[b]) T_TRY(hipMemcpyAsync(refined_out[b], refined + t->poff[b], nb, hipMemcpyDeviceToHost, st));
   }
+  T_TRY(hipStreamSynchronize(st));
   return CTD_OK;
 }
-
 
 // ---------------------------------------------------------------------------------------------------
 // DB text-line stage (reference utils/db_utils.py:32-211) for a batch: `db_enqueue` launches the two
@@ -509,22 +544,36 @@ int db_collect(ctd_tail* t, const DbStage& d, const ctd_tail_params* prm) {
     T_TRY(d2h(h_row_lo, d.row_lo, 4, nr, rcap));
     T_TRY(d2h(h_row_hi, d.row_hi, 4, nr, rcap));
   }
+  const double td0 = now_ms();
   T_TRY(hipStreamSynchronize(st));
+  t->ms_db_wait = now_ms() - td0;
   const int maxc = std::max(prm->max_candidates, 0);
-  std::vector<int16_t> boxes((size_t)std::max(maxc, 1) * 8);
-  std::vector<float> scores((size_t)std::max(maxc, 1));
-  for (int b = 0; b < B; ++b) {
+  std::atomic<int> err{CTD_OK};
+  parallel_for(B, t->host_threads, [&](int b) {
+    if (hhdr[4 * b + 3]) return;                        // overflowed page: handled below, one at a time
     PageOut& po = t->out[b];
+    po.db_boxes.assign((size_t)std::max(maxc, 1) * 8, 0);
+    po.db_scores.assign((size_t)std::max(maxc, 1), 0.f);
     int nbox = 0;
-    if (!hhdr[4 * b + 3]) {
-      if (int rc = ctd_db_boxes_compact(Wn, Hn, hhdr[4 * b], h_st_f + (size_t)b * nf * 5, h_first_f + (size_t)b * nf,
+    const int rc = ctd_db_boxes_compact(Wn, Hn, hhdr[4 * b], h_st_f + (size_t)b * nf * 5, h_first_f + (size_t)b * nf,
                                         h_par_f + (size_t)b * nf, h_off_f + (size_t)b * nf, h_sum_f + (size_t)b * nf,
                                         hhdr[4 * b + 1], h_st_b + (size_t)b * nb * 5, h_first_b + (size_t)b * nb,
                                         h_par_b + (size_t)b * nb, h_off_b + (size_t)b * nb, h_sum_b + (size_t)b * nb,
                                         h_ring_sum + (size_t)b * nb, h_ring_cnt + (size_t)b * nb, h_row_lo + (size_t)b * nr,
-                                        h_row_hi + (size_t)b * nr, maxc, prm->unclip_ratio, boxes.data(), scores.data(), &nbox))
-        return ctd_fail_msg(rc, "ctd_db_boxes_compact failed");
-    } else {
+                                        h_row_hi + (size_t)b * nr, maxc, prm->unclip_ratio, po.db_boxes.data(),
+                                        po.db_scores.data(), &nbox);
+    if (rc) err = rc;
+    po.db_boxes.resize((size_t)nbox * 8);
+    po.db_scores.resize(nbox);
+  });
+  if (err) return ctd_fail_msg(err, "ctd_db_boxes_compact failed");
+  std::vector<int16_t> boxes((size_t)std::max(maxc, 1) * 8);
+  std::vector<float> scores((size_t)std::max(maxc, 1));
+  for (int b = 0; b < B; ++b) {
+    if (!hhdr[4 * b + 3]) continue;
+    PageOut& po = t->out[b];
+    int nbox = 0;
+    {
       // more components than the compact tables hold (a noise bitmap): label images to the host
       std::vector<int32_t> lab_host_f(hw), lab_host_b(hw);
       std::vector<float> prob_h(hw);
@@ -614,6 +663,8 @@ int ctd_tail_run(ctd_tail* t, int32_t B, int32_t Hn, int32_t Wn, const float* bl
     return ctd_fail_msg(CTD_ERR_INVALID, "ctd_tail_run: bad arguments");
   T_TRY(hipSetDevice(t->device));
   hipStream_t st = t->st;
+  const double t0 = now_ms();
+  for (double& v : t->ms_stage) v = 0;
   if (ready_event) T_TRY(hipStreamWaitEvent(st, (hipEvent_t)ready_event, 0));
   if (int rc = layout_pages(t, B, pages)) return rc;
   for (int b = 0; b < B; ++b)
@@ -655,10 +706,13 @@ int ctd_tail_run(ctd_tail* t, int32_t B, int32_t Hn, int32_t Wn, const float* bl
   }
   GET(t->h_pmask, t->ptotal, uint8_t, hpmask);
   T_TRY(hipMemcpyAsync(hpmask, pmask, t->ptotal, hipMemcpyDeviceToHost, st));
+  const double t1 = now_ms();
   T_TRY(hipStreamSynchronize(st));                                     // sync 1: counts are known
+  const double t2 = now_ms();
 
   // ================= stage 2: contour geometry on the host, grouping =================
   if (int rc = db_collect(t, db, prm)) return rc;                      // sync 2 inside: the sized tables
+  const double t3 = now_ms();
   std::vector<WinReq> reqs;
   std::vector<std::vector<int32_t>> blk_xyxy(B);
   std::vector<int32_t> lines;
@@ -712,17 +766,37 @@ int ctd_tail_run(ctd_tail* t, int32_t B, int32_t Hn, int32_t Wn, const float* bl
   }
 
   // ================= stage 3: mask refinement =================
+  const double t4 = now_ms();
+  double t5 = t4;
   if (prm->refine) {
     if (int rc = refine_windows(t, reqs, prm->refine_mode)) return rc;
-    if (prm->keep_undetected_mask)
+    t5 = now_ms();
+    if (prm->keep_undetected_mask) {
+      const double k4 = t->ms_stage[4], k5 = t->ms_stage[5], k6 = t->ms_stage[6];
       if (int rc = undetected_pass(t, blk_xyxy, prm->refine_mode)) return rc;
+      t->ms_stage[4] = k4, t->ms_stage[5] = k5, t->ms_stage[6] = k6;
+    }
   }
-  if (prm->refine && prm->keep_undetected_mask) return download_pages(t, true, mask_out, refined_out);
-  // the mask was not edited: the early download is the result
-  if (int rc = download_pages(t, false, nullptr, prm->refine ? refined_out : nullptr)) return rc;
-  if (mask_out)
-    for (int b = 0; b < B; ++b)
-      if (mask_out[b]) std::memcpy(mask_out[b], hpmask + t->poff[b], (size_t)pages[b].im_h * pages[b].im_w);
+  const double t6 = now_ms();
+  int rc = CTD_OK;
+  if (prm->refine && prm->keep_undetected_mask) {
+    rc = download_pages(t, true, mask_out, refined_out);
+  } else {   // the mask was not edited: the early download is the result
+    rc = download_pages(t, false, nullptr, prm->refine ? refined_out : nullptr);
+    if (!rc && mask_out)
+      for (int b = 0; b < B; ++b)
+        if (mask_out[b]) std::memcpy(mask_out[b], hpmask + t->poff[b], (size_t)pages[b].im_h * pages[b].im_w);
+  }
+  const double t7 = now_ms();
+  t->ms_stage[0] = t1 - t0, t->ms_stage[1] = t2 - t1, t->ms_stage[2] = t3 - t2, t->ms_stage[3] = t4 - t3;
+  t->ms_stage[7] = t6 - t5, t->ms_stage[8] = t7 - t6, t->ms_stage[9] = t7 - t0;
+  return rc;
+}
+
+int ctd_tail_timings(const ctd_tail* t, double* ms10) {   // 11 entries
+  if (!t || !ms10) return ctd_fail_msg(CTD_ERR_INVALID, "null argument");
+  std::memcpy(ms10, t->ms_stage, sizeof(t->ms_stage));
+  ms10[10] = t->ms_db_wait;
   return CTD_OK;
 }
 

@@ -70,6 +70,55 @@ def unpack_records(rec: torch.Tensor):
     return dets, counts, lines, line_counts
 
 
+# ---- the grouped result of a page (the reference's final `blk_list`, inference.py:173) -----------------
+MAX_BLK = MAX_DET + MAX_LINES      # group_output yields at most one block per yolo box + one per unassigned line
+BLK_F = 12                          # xyxy(4), language, vertical, angle, font_size, n_lines, norm, vec(2)
+
+
+def pack_results(results, device=None) -> torch.Tensor:
+    """`detect_batch` results [(mask, mask_refined, blk_list), ...] -> one fixed-size f64 record per page:
+    [n_blk, n_lines, blocks MAX_BLK x 12, lines MAX_BLK x 8 (4 points, in block order)].  float64 holds
+    every field exactly (coordinates and angles are integers, font sizes / norms are doubles).  Masks stay
+    on the rank that produced them."""
+    import numpy as np
+    from .textblock import LANGCLS2IDX
+    rec = np.zeros((len(results), 2 + MAX_BLK * (BLK_F + 8)), np.float64)
+    for p, r in enumerate(results):
+        blks = r[2]
+        if not blks:
+            continue
+        head = np.array([[*b.xyxy, LANGCLS2IDX[b.language], bool(b.vertical), b.angle, b.font_size, len(b.lines), b.norm,
+                          b.vec[0], b.vec[1]] for b in blks], np.float64)
+        lines = [np.asarray(b.lines, np.float64).reshape(-1, 8) for b in blks if len(b.lines)]
+        lines = np.concatenate(lines) if lines else np.zeros((0, 8))
+        rec[p, 0], rec[p, 1] = len(blks), len(lines)
+        rec[p, 2: 2 + head.size] = head.ravel()
+        lb = 2 + MAX_BLK * BLK_F
+        rec[p, lb: lb + lines.size] = lines.ravel()
+    out = torch.from_numpy(rec)
+    return out.to(device) if device is not None else out
+
+
+def unpack_results(rec: torch.Tensor):
+    """Inverse of pack_results: per page a list of dicts (xyxy, language, vertical, angle, font_size, norm, vec, lines)."""
+    from .textblock import LANG_LIST
+    rec = rec.cpu()
+    out = []
+    for p in range(rec.shape[0]):
+        nb = int(rec[p, 0])
+        blks, nl = [], 0
+        for i in range(nb):
+            f = rec[p, 2 + i * BLK_F: 2 + (i + 1) * BLK_F].tolist()
+            n = int(f[8])
+            lb = 2 + MAX_BLK * BLK_F + nl * 8
+            lines = rec[p, lb: lb + 8 * n].reshape(n, 4, 2).to(torch.int64).tolist()
+            nl += n
+            blks.append(dict(xyxy=[int(v) for v in f[:4]], language=LANG_LIST[int(f[4])], vertical=bool(f[5]),
+                             angle=int(f[6]), font_size=f[7], norm=f[9], vec=[f[10], f[11]], lines=lines))
+        out.append(blks)
+    return out
+
+
 def gather_records(rec: torch.Tensor, n_total: int, rank: int, world: int) -> torch.Tensor:
     """All-gather the per-page records; returns (n_total, R) in global page order on
     every rank.  Shards may differ by one page, so each rank pads to the largest shard."""

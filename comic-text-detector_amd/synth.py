@@ -127,3 +127,30 @@ def text_like_page(size_hw=(1024, 1024), seed: int = 0, n_blocks: int = 18) -> n
                     else:
                         img[sy:min(sy + fs // 2, cy + fs - 2), sx:sx + max(2, fs // 8)] = rng.randint(0, 40)
     return img
+
+
+def text_like_outputs(seed: int = 0, size: int = 1024, n_blocks: int = 10):
+    """A synthetic page together with network outputs a trained detector would plausibly give for it,
+    rendered from the page's ink: `mask_u8` (ink dilated by 1 px, 0.9 * 255), `prob` (ink dilated by
+    4 px: 0.9 inside, 0.05 outside), and yolo blocks (boxes of the ink dilated by 10 px, random class and
+    confidence) packed as a Detect tensor (1, rows, 7) whose NMS gives those blocks back.  Release weights
+    are not available offline and random weights give noise maps, so tests and the end-to-end
+    bench feed the tail with these.  Returns (page BGR u8, blks f32 (1,rows,7), mask_u8, prob f32, bitmap u8)."""
+    from scipy import ndimage
+    page = text_like_page((size, size), seed, n_blocks=n_blocks)
+    ink = page.min(axis=2) < 60
+    mask_u8 = (ndimage.maximum_filter(ink.astype(np.uint8) * 255, size=3, mode="constant").astype(np.float32) / 255
+               * 0.9 * 255).astype(np.uint8)
+    blob = ndimage.maximum_filter(ink.astype(np.uint8), size=9, mode="constant")
+    prob = (blob * 0.85 + 0.05).astype(np.float32)
+    big = ndimage.maximum_filter(ink.astype(np.uint8), size=21, mode="constant")
+    lab, n = ndimage.label(big, structure=np.ones((3, 3)))
+    rng = np.random.RandomState(seed)
+    rows = 4096
+    blks = np.zeros((1, rows, 7), np.float32)
+    for i, sl in enumerate(ndimage.find_objects(lab)[: rows]):
+        x1, y1, x2, y2 = sl[1].start, sl[0].start, sl[1].stop, sl[0].stop
+        c, s = int(rng.randint(0, 2)), float(np.round(rng.uniform(0.5, 1), 3))
+        blks[0, i] = [(x1 + x2) / 2, (y1 + y2) / 2, x2 - x1, y2 - y1, 0.99, 0.0, 0.0]
+        blks[0, i, 5 + c] = s / 0.99
+    return page, blks, mask_u8, prob, (prob > 0.3).astype(np.uint8)

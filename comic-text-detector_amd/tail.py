@@ -19,6 +19,21 @@ from . import _lib as L
 from .textblock import TextBlock, blocks_from_records
 
 
+def _pinned_u8(h: int, w: int) -> np.ndarray:
+    return torch.empty((h, w), dtype=torch.uint8, pin_memory=True).numpy()
+
+
+def _pinned_pages(shapes) -> List[np.ndarray]:
+    """One page-locked allocation for a batch of u8 pages, handed out as per-page views."""
+    sizes = [h * w for h, w in shapes]
+    buf = torch.empty((sum(sizes),), dtype=torch.uint8, pin_memory=True).numpy()
+    out, off = [], 0
+    for (h, w), n in zip(shapes, sizes):
+        out.append(buf[off: off + n].reshape(h, w))
+        off += n
+    return out
+
+
 class Tail:
     def __init__(self, device: torch.device):
         self._lib = L.lib()
@@ -50,7 +65,7 @@ class Tail:
             tab[b].im_h, tab[b].im_w, tab[b].dw, tab[b].dh = int(im_h), int(im_w), int(dw), int(dh)
         return tab
 
-    def _blocks(self, b: int) -> Tuple[List[TextBlock], dict]:
+    def _blocks(self, b: int, want_extras: bool = False) -> Tuple[List[TextBlock], Optional[dict]]:
         lib = self._lib
         nb, nl, nd, nx, ny = (C.c_int32() for _ in range(5))
         L.check(lib.ctd_tail_page_counts(self._h, b, C.byref(nb), C.byref(nl), C.byref(nd), C.byref(nx), C.byref(ny)),
@@ -58,6 +73,10 @@ class Tail:
         recs = (L.CtdBlk * max(nb.value, 1))()
         lines = np.empty((nl.value, 8), np.int32)
         dist = np.empty((nd.value, 3), np.float64)
+        if not want_extras:
+            L.check(lib.ctd_tail_page_fetch(self._h, b, recs, lines.ctypes.data, dist.ctypes.data, None, None, None, None,
+                                            None), "ctd_tail_page_fetch")
+            return blocks_from_records(recs[: nb.value], lines, dist), None
         boxes = np.empty((nx.value, 4, 2), np.int16)
         scores = np.empty((nx.value,), np.float32)
         yx = np.empty((ny.value, 4), np.int32)
@@ -91,8 +110,9 @@ class Tail:
         tab = self._page_table(pages_gpu, metas)
         prm = L.CtdTailParams(conf_thresh, nms_thresh, box_thresh, 1000, 1.5, int(bool(refine)), int(refine_mode),
                               int(bool(keep_undetected_mask)), 0)
-        masks = [np.empty((m[0], m[1]), np.uint8) for m in metas]
-        refined = [np.empty((m[0], m[1]), np.uint8) for m in metas] if refine else [None] * B
+        # page-locked result arrays (torch's caching host allocator): the tail DMAs straight into them
+        masks = _pinned_pages([(m[0], m[1]) for m in metas])
+        refined = _pinned_pages([(m[0], m[1]) for m in metas]) if refine else [None] * B
         mptr = (C.c_void_p * B)(*[m.ctypes.data for m in masks])
         rptr = (C.c_void_p * B)(*[r.ctypes.data for r in refined]) if refine else None
         ev = C.c_void_p(ready_event.cuda_event) if ready_event is not None else None
@@ -101,9 +121,17 @@ class Tail:
                                        C.byref(prm), mptr, rptr, ev), "ctd_tail_run")
         out = []
         for b in range(B):
-            blk_list, extras = self._blocks(b)
+            blk_list, extras = self._blocks(b, want_extras)
             out.append((masks[b], refined[b], blk_list, extras) if want_extras else (masks[b], refined[b], blk_list))
         return out
+
+    def timings(self) -> dict:
+        """Host wall clock (ms) of the stages of the last `run`."""
+        ms = (C.c_double * 11)()
+        L.check(self._lib.ctd_tail_timings(self._h, ms), "ctd_tail_timings")
+        keys = ("enqueue1", "wait1", "db_tables+geometry", "yolo+group_output", "refine_wait_hist", "refine_wait_xor",
+                "refine_host+enqueue", "undetected", "final_wait+copies", "total", "db_table_wait")
+        return {k: round(v, 3) for k, v in zip(keys, ms)}
 
     # -- SegDetectorRepresenter alone -----------------------------------------------------------------
     def db_boxes(self, prob: torch.Tensor, bitmap: torch.Tensor, max_candidates=1000, unclip_ratio=1.5):
@@ -135,8 +163,8 @@ class Tail:
         masks = [np.ascontiguousarray(m, np.uint8) for m in masks]
         xy = np.ascontiguousarray(np.array([list(map(int, bb)) for pb in boxes for bb in pb], np.int32).reshape(-1, 4))
         cnt = np.array([len(pb) for pb in boxes], np.int32)
-        refined = [np.empty_like(m) for m in masks]
-        after = [np.empty_like(m) for m in masks] if keep_undetected_mask else None
+        refined = [_pinned_u8(*m.shape) for m in masks]
+        after = [_pinned_u8(*m.shape) for m in masks] if keep_undetected_mask else None
         inp = (C.c_void_p * n)(*[m.ctypes.data for m in masks])
         rptr = (C.c_void_p * n)(*[r.ctypes.data for r in refined])
         aptr = (C.c_void_p * n)(*[a.ctypes.data for a in after]) if after is not None else None

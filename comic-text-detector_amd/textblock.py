@@ -205,6 +205,20 @@ class TextBlock:
 
 # --------------------------------------------------------------------------
 
+_TAIL_DEFAULTS = tuple((attr, default) for attr, _, default in _RECORD_TAIL)
+
+
+def _fast_block(xyxy, lines, language, vertical, font_size, distance, angle, vec, norm, merged, weight) -> TextBlock:
+    """`TextBlock(...)` without the keyword plumbing: the attribute dict in the reference's creation order."""
+    t = TextBlock.__new__(TextBlock)
+    d = {"xyxy": xyxy, "lines": lines, "vertical": vertical, "language": language, "font_size": font_size,
+         "distance": distance, "angle": angle, "vec": vec, "norm": norm, "merged": merged, "weight": weight}
+    for attr, default in _TAIL_DEFAULTS:
+        d[attr] = [] if attr == "text" else default
+    t.__dict__ = d
+    return t
+
+
 def blocks_from_records(recs, lines: np.ndarray, dist: np.ndarray) -> List[TextBlock]:
     """Native records (`ctd_blk` array + line / distance pools) -> the reference's Python objects.
     `TextBlock.distance` is re-evaluated from its two operands with numpy's own arccos / sin
@@ -216,14 +230,13 @@ def blocks_from_records(recs, lines: np.ndarray, dist: np.ndarray) -> List[TextB
     else:
         dval = np.zeros((0,), np.float64)
     out = []
+    all_lines = lines.reshape(-1, 4, 2).tolist()
     for r in recs:
-        t = TextBlock(list(r.xyxy), lines[r.line_off: r.line_off + r.n_lines].reshape(-1, 4, 2).tolist(),
-                      language=LANG_LIST[r.language], vertical=bool(r.vertical),
-                      font_size=float(r.font_size) if r.font_is_float else int(r.font_size),
-                      distance=dval[r.dist_off: r.dist_off + r.n_dist], angle=int(r.angle),
-                      vec=(r.vec[0], r.vec[1]), norm=np.float64(r.norm), merged=bool(r.merged),
-                      weight=np.float64(r.weight))
-        out.append(t)
+        lo, do = r.line_off, r.dist_off
+        out.append(_fast_block(list(r.xyxy), all_lines[lo: lo + r.n_lines], LANG_LIST[r.language], bool(r.vertical),
+                               float(r.font_size) if r.font_is_float else int(r.font_size),
+                               dval[do: do + r.n_dist].copy(), int(r.angle), np.array((r.vec[0], r.vec[1]), np.float64),
+                               np.float64(r.norm), bool(r.merged), np.float64(r.weight)))
     return out
 
 

@@ -244,6 +244,13 @@ int ctd_tail_run(ctd_tail* t, int32_t B, int32_t Hn, int32_t Wn, const float* bl
                  const ctd_tail_page* pages, const ctd_tail_params* prm, uint8_t* const* mask_out,
                  uint8_t* const* refined_out, void* ready_event);
 
+/* Host wall clock of the stages of the last ctd_tail_run in ms: [0] enqueue of NMS / labelling / contour tables /
+ * page masks, [1] wait for them, [2] table download + contour geometry, [3] yolo unpack + group_output,
+ * [4] refine: wait for the histograms, [5] refine: wait for the xor sums, [6] refine: host decisions + enqueue,
+ * [7] refine_undetected_mask, [8] final wait + copies, [9] total, [10] the part of [2] spent waiting for the
+ * table download.  ms must hold 11 doubles. */
+int ctd_tail_timings(const ctd_tail* t, double* ms);
+
 /* The DB text-line stage alone (`SegDetectorRepresenter.__call__`, reference utils/db_utils.py:40-69): boxes and
  * scores of every contour of every page, read back with ctd_tail_page_counts / ctd_tail_page_fetch. */
 int ctd_tail_db_boxes(ctd_tail* t, int32_t B, int32_t Hn, int32_t Wn, const float* prob_dev, int64_t prob_stride,

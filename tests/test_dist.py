@@ -75,3 +75,58 @@ def test_shard_range_partitions_everything():
             assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
             sizes = [b - a for a, b in spans]
             assert max(sizes) - min(sizes) <= 1
+
+
+# ---- the whole N>1 data path on CPU: shard -> per-page grouping (native host code) -> gather of the block records
+
+
+def _page_blocks(i):
+    """The grouped block list of global page i (native `ctd_group_output`, host only)."""
+    from test_group_native import random_page
+    p = pkg()
+    blks, lines, im_w, im_h, mask = random_page(500 + i)
+    return p.textblock.group_output(blks, lines, im_w, im_h, mask)
+
+
+def _worker_blocks(rank, world, port, n_total, q):
+    import sys
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    D = pkg().dist
+    r, lr, w = D.init("gloo")
+    lo, hi = D.shard_range(n_total, r, w)
+    results = [(None, None, _page_blocks(i)) for i in range(lo, hi)]          # this rank's pages
+    allrec = D.gather_records(D.pack_results(results), n_total, r, w)
+    got = D.unpack_results(allrec)
+    ok = len(got) == n_total
+    for i in range(n_total):
+        ref = _page_blocks(i)
+        ok &= len(got[i]) == len(ref)
+        for a, b in zip(got[i], ref):
+            ok &= a["xyxy"] == [int(v) for v in b.xyxy] and a["lines"] == [[[int(x) for x in pt] for pt in ln] for ln in b.lines]
+            ok &= (a["language"], a["vertical"], a["angle"]) == (b.language, bool(b.vertical), int(b.angle))
+            ok &= a["font_size"] == float(b.font_size) and a["norm"] == float(b.norm) and a["vec"] == [float(v) for v in b.vec]
+    q.put((rank, bool(ok), tuple(allrec.shape)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_total", [6, 5])
+def test_gloo_world2_grouped_blocks_gathered_equal_single_process(n_total):
+    """Every rank ends up with the final block list of EVERY page (SURVEY 8(e) record: blocks + their
+    lines), identical to what one process computes -- also with an uneven split."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_blocks, args=(r, 2, port, n_total, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank, ok, shape in res:
+        assert ok, f"rank {rank}: gathered block lists differ from the single-process result"
+        assert shape[0] == n_total

@@ -154,3 +154,32 @@ def text_like_outputs(seed: int = 0, size: int = 1024, n_blocks: int = 10):
         blks[0, i] = [(x1 + x2) / 2, (y1 + y2) / 2, x2 - x1, y2 - y1, 0.99, 0.0, 0.0]
         blks[0, i, 5 + c] = s / 0.99
     return page, blks, mask_u8, prob, (prob > 0.3).astype(np.uint8)
+
+
+def make_blob_checkpoint(seed: int = 0) -> dict:
+    """`make_checkpoint(seed)` with the LAST layers of the two sigmoid heads re-shaped so that the maps are
+    decisive blobs instead of mid-grey noise: the transposed-conv taps of the DB tail and of the UNet's final
+    layer are tied (a random ConvT 2x2 / 4x4 gives every sub-pixel position its own weight, i.e. a period-4
+    texture of isolated pixels), the final logits are amplified and the DB bias is shifted so that ~15 % of a
+    page lies above the 0.3 threshold; the final UNet weights alternate in sign so its (bias-free) logit is
+    centred.  Still random weights in the reference's checkpoint format -- but their outputs have contours,
+    boxes above the score threshold, text lines and blocks, so the WHOLE detector (network + tail) can be
+    compared end to end between engines (tests/test_gpu_accept.py, bench.py `parity`)."""
+    ck = make_checkpoint(seed)
+
+    def tie(w):      # (cin, cout, k, k): one value for every tap of a (cin, cout) pair
+        return (w.mean(dim=(2, 3), keepdim=True) * w.shape[2]).expand_as(w).clone()
+
+    td, ts = ck["text_det"], ck["text_seg"]
+    for br in ("binarize", "thresh"):
+        td[f"{br}.3.weight"] = tie(td[f"{br}.3.weight"])
+        td[f"{br}.6.weight"] = tie(td[f"{br}.6.weight"])
+    gain = 6.0
+    b0 = float(td["binarize.6.bias"])
+    td["binarize.6.weight"] = td["binarize.6.weight"] * gain
+    td["binarize.6.bias"] = torch.tensor([gain * b0 - gain * 1.2 + math.log(0.3 / 0.7)], dtype=torch.float32)
+    w = tie(ts["upconv6.0.weight"]) * 2.0
+    sign = torch.ones(w.shape[0])
+    sign[1::2] = -1.0
+    ts["upconv6.0.weight"] = w * sign.view(-1, 1, 1, 1)
+    return ck

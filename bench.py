@@ -302,8 +302,9 @@ def main() -> None:
                 except Exception:
                     traffic = None
         roof.update({"traffic": traffic, "traffic_note": tnote,
-                     "kernel": "conv_halo_kernel + conv_igemm_kernel (MFMA conv / convT family)" if (cls[fam] != 3).any()
-                     else "conv_direct / convt_direct (exact-fp32 VALU kernels)",
+                     "kernel": ("conv_direct / convt_direct (exact-fp32 VALU kernels)" if not (cls[fam] != 3).any() else
+                                "conv_f32_mfma_kernel (f32-operand MFMA conv / convT family)" if args.precision == "fp32" else
+                                "conv_halo_kernel + conv_igemm_kernel (MFMA conv / convT family)"),
                      "launches_per_step": int(fam.sum()), "family_ms_per_step": round(fam_ms, 3),
                      "net_ms_per_step": round(net_ms, 3), "alg_bytes_per_step": fam_bytes,
                      "alg_flops_per_step": fam_flops, "tflops": round(ach_tf, 1),

@@ -77,6 +77,7 @@ SYMBOLS = {
     "ctd_engine_workspace_bytes": (_i64, [_vp]),
     "ctd_nms_workspace_bytes": (C.c_size_t, [_i32, _i32]),
     "ctd_nms": (_i32, [_vp, _i32, _i32, _i32, _f, _f, _i32, _i32, _f, _vp, _vp, _vp, C.c_size_t, _vp]),
+    "ctd_db_step": (_i32, [_vp, _i32, _i32, _i32, _f, _vp, _vp, _f, _vp]),
     "ctd_ccl_workspace_bytes": (C.c_size_t, [_i32, _i32, _i32]),
     "ctd_ccl": (_i32, [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _i32, _vp, C.c_size_t, _vp]),
     "ctd_resize_linear_u8": (_i32, [_vp, _i32, _i32, _i32, _vp, _i32, _i32, _i32, _i32, _vp]),

@@ -32,7 +32,8 @@ def _load_ckpt(model: Union[str, dict]) -> dict:
 
 class HipTextDetBackend:
     def __init__(self, model: Union[str, dict], device: Union[str, int, torch.device] = "cuda",
-                 precision: str = "fp16", act: str = "leaky", bitmap_thresh: float = 0.3):
+                 precision: str = "fp16", act: str = "leaky", bitmap_thresh: float = 0.3, step_eval: bool = False,
+                 db_k: float = 50.0):
         if not torch.cuda.is_available():
             raise L.CtdError("HipTextDetBackend needs a ROCm GPU (MI355X); there is no CPU fallback")
         dev = torch.device(device)
@@ -42,6 +43,9 @@ class HipTextDetBackend:
         self.prec = {"fp16": L.PREC_F16, "fp32": L.PREC_F32}[precision]
         self.precision = precision
         self._lib = L.lib()
+        # `DBHead.forward(step_eval=True)` (reference basemodel.py:121-122): `lines_map` becomes the (B,1,H,W)
+        # differentiable-binarisation map step_function(shrink, thresh) (:159-160, k = 50)
+        self.step_eval, self.db_k, self.bitmap_thresh = bool(step_eval), float(db_k), float(bitmap_thresh)
         ckpt = _load_ckpt(model)
         self.program = graph.lower(ckpt, self.prec, act=act, bitmap_thresh=bitmap_thresh)
         T, O, blob = graph.to_ctypes(self.program)
@@ -108,6 +112,11 @@ class HipTextDetBackend:
         else:
             L.check(self._lib.ctd_engine_forward(*args), "ctd_engine_forward")
         self.mask_u8, self.bitmap = outs[3], outs[4]
+        if self.step_eval:
+            step = torch.empty((B, 1, H, W), dtype=torch.float32, device=self.device)
+            L.check(self._lib.ctd_db_step(outs[2].data_ptr(), B, H, W, self.db_k, step.data_ptr(), outs[4].data_ptr(),
+                                          self.bitmap_thresh, stream), "ctd_db_step")
+            return outs[0], outs[1], step
         return outs[0], outs[1], outs[2]
 
     # -- the seam ---------------------------------------------------------------
@@ -183,6 +192,42 @@ class HipTextDetBackend:
 
     def workspace_bytes(self) -> int:
         return int(self._lib.ctd_engine_workspace_bytes(self._h))
+
+
+class HipTextDetDNN:
+    """The reference's OTHER backend object behind the same seam: `TextDetBaseDNN` (reference
+    basemodel.py:246-256), the OpenCV-DNN runner of the exported ONNX file whose tensors are named
+    `images` -> `blk`, `seg`, `det` (utils/export.py:43-44).  Same constructor and call contract:
+    `TextDetBaseDNN(input_size, model_path)(im_in)` takes the letterboxed uint8 HWC image that
+    `preprocess_img(..., to_tensor=False)` hands it (inference.py:72-83), scales it by 1/255 like
+    `cv2.dnn.blobFromImage` (no channel swap, no mean) and returns numpy `(blks, mask, lines_map)`.
+    `model_path` is the reference's checkpoint dict / .pt file (there is no ONNX parser here: the graph
+    is the one `graph.lower` builds from the checkpoint, which is what the ONNX file was exported from)."""
+
+    output_names = ("blk", "seg", "det")          # utils/export.py:44
+    input_name = "images"                         # utils/export.py:43
+
+    def __init__(self, input_size: int, model_path: Union[str, dict], device="cuda", precision: str = "fp32",
+                 act: str = "leaky"):
+        self.input_size = input_size
+        self.net = HipTextDetBackend(model_path, device=device, precision=precision, act=act)
+        self.uoln = list(self.output_names)       # getUnconnectedOutLayersNames()
+
+    def forward_named(self, images: np.ndarray) -> dict:
+        """{'images': (B,3,H,W) float32 in [0,1]} -> {'blk': .., 'seg': .., 'det': ..} as numpy arrays."""
+        x = torch.from_numpy(np.ascontiguousarray(images, np.float32)).to(self.net.device)
+        outs = self.net(x)
+        torch.cuda.current_stream(self.net.device).synchronize()
+        return {k: v.cpu().numpy() for k, v in zip(self.output_names, outs)}
+
+    def __call__(self, im_in: np.ndarray):
+        if im_in.dtype != np.uint8 or im_in.ndim != 3 or im_in.shape[2] != 3:
+            raise ValueError("im_in must be a uint8 (H,W,3) image")
+        if im_in.shape[0] != self.input_size or im_in.shape[1] != self.input_size:
+            raise ValueError("blobFromImage would rescale: pass the letterboxed input_size x input_size image")
+        blob = (im_in.astype(np.float32) * np.float32(1 / 255.0)).transpose(2, 0, 1)[None]     # scalefactor = 1/255
+        out = self.forward_named(blob)
+        return out["blk"], out["seg"], out["det"]
 
 
 # ---------------------------------------------------------------------------

@@ -71,6 +71,7 @@ struct ctd_engine {
   int pB = 0, pH = 0, pW = 0;  // current plan
   bool no_reuse = false;
   bool w_tiled = true;   // tile-major MFMA weight packing (CTD_W_TILED=0 disables)
+  bool f32_mfma = true;  // fp32 engine: f32-operand MFMA kernel (CTD_F32_MFMA=0: exact-order direct kernels only)
   int det_rows_per_unit = 0;
   int det_no = 0;
   void* zeros = nullptr;  // 256 B of zeros (padding source of the LDS-DMA loads)
@@ -142,6 +143,23 @@ int pack_op(ctd_engine* e, OpState& s, const float* P, int64_t nP) {
       }
       if (e->tensors[o.dst].t.dtype != 0 && f16)
         return fail(CTD_ERR_UNSUPPORTED, "f32 destination needs the MFMA path");
+      // fp32 engine: f32-operand MFMA (kernels_f32.hip) when a K step of 16 channels never crosses a tap
+      auto al4 = [&](int id, int coff) { return e->tensors[id].t.channels % 4 == 0 && coff % 4 == 0; };
+      if (!f16 && e->f32_mfma && o.src0_c % 16 == 0 && (o.src1 < 0 || o.src1_c % 16 == 0) && al4(o.src0, o.src0_coff) &&
+          (o.src1 < 0 || al4(o.src1, o.src1_coff)) && al4(o.dst, o.dst_coff) && (o.res < 0 || al4(o.res, o.res_coff))) {
+        s.impl = IMPL_IGEMM;
+        const int bn = f32_mfma_ntile(N);
+        s.npad = (N + bn - 1) / bn * bn;
+        const int K = k * k * cin;
+        std::vector<float> wp((size_t)s.npad * K, 0.f);
+        for (int n = 0; n < N; ++n)
+          for (int c = 0; c < cin; ++c)
+            for (int ky = 0; ky < k; ++ky)
+              for (int kx = 0; kx < k; ++kx)
+                wp[(size_t)n * K + (size_t)(ky * k + kx) * cin + c] = W[(((size_t)n * cin + c) * k + ky) * k + kx];
+        if (int rc = upload(e, wp, &s.w_dev)) return rc;
+        return pack_bias(s.npad);
+      }
       s.impl = IMPL_DIRECT;
       s.npad = N;
       std::vector<float> wp((size_t)k * k * cin * N);
@@ -183,6 +201,28 @@ int pack_op(ctd_engine* e, OpState& s, const float* P, int64_t nP) {
         }
         std::vector<half_t> wp;
         igemm_pack_weights(lg.data(), 4, N, K, bn, s.bk, e->w_tiled, wp);
+        if (int rc = upload(e, wp, &s.w_dev)) return rc;
+        return pack_bias(s.npad);
+      }
+      if (!f16 && e->f32_mfma && k == 4 && o.stride == 2 && o.pad == 1 && cin % 16 == 0 && N >= 16 &&
+          t0.channels % 4 == 0 && o.src0_coff % 4 == 0 && td.channels % 4 == 0 && o.dst_coff % 4 == 0) {
+        s.impl = IMPL_IGEMM_T;
+        const int bn = f32_mfma_ntile(N);
+        s.npad = (N + bn - 1) / bn * bn;
+        const int K = 4 * cin;
+        std::vector<float> wp((size_t)4 * s.npad * K, 0.f);
+        for (int ph = 0; ph < 4; ++ph) {
+          const int py = ph >> 1, px = ph & 1;
+          for (int ty = 0; ty < 2; ++ty)
+            for (int tx = 0; tx < 2; ++tx) {
+              const int dy = (py ? 0 : -1) + ty, dx = (px ? 0 : -1) + tx;
+              const int ky = py + 1 - 2 * dy, kx = px + 1 - 2 * dx;
+              for (int n = 0; n < N; ++n)
+                for (int c = 0; c < cin; ++c)
+                  wp[((size_t)ph * s.npad + n) * K + (size_t)(ty * 2 + tx) * cin + c] =
+                      W[(((size_t)c * N + n) * 4 + ky) * 4 + kx];
+            }
+        }
         if (int rc = upload(e, wp, &s.w_dev)) return rc;
         return pack_bias(s.npad);
       }
@@ -481,7 +521,7 @@ int plan(ctd_engine* e, int B, int H, int W) {
         // every input pixel meets k*k taps
         s.flops = 2.0 * (double)B * a.Hin * a.Win * o.k * o.k * cin * a.N;
       }
-      if ((s.impl == IMPL_IGEMM || s.impl == IMPL_IGEMM_T) && !igemm_supported(a))
+      if ((s.impl == IMPL_IGEMM || s.impl == IMPL_IGEMM_T) && !(f16 ? igemm_supported(a) : conv_f32_mfma_supported(a)))
         return fail(CTD_ERR_UNSUPPORTED, "op " + std::to_string(i) + ": shape rejected by the MFMA kernel");
       const double es = f16 ? 2 : 4;
       s.bytes = ((double)B * a.s0.H * a.s0.W * a.s0.c + (o.src1 >= 0 ? (double)B * a.s1.H * a.s1.W * a.s1.c : 0)) * es +
@@ -523,11 +563,13 @@ int launch_op(ctd_engine* e, int i, const Outs& x, hipStream_t st) {
       break;
     }
     case CTD_OP_CONV:
-      if (s.impl == IMPL_IGEMM) launch_conv_igemm(s.args, e->tensors[o.dst].esize == 4, st);
+      if (s.impl == IMPL_IGEMM && !f16) launch_conv_f32_mfma(s.args, st);
+      else if (s.impl == IMPL_IGEMM) launch_conv_igemm(s.args, e->tensors[o.dst].esize == 4, st);
       else launch_conv_direct(s.args, f16, st);
       break;
     case CTD_OP_CONVT:
-      if (s.impl == IMPL_IGEMM_T) launch_conv_igemm(s.args, false, st);
+      if (s.impl == IMPL_IGEMM_T && !f16) launch_conv_f32_mfma(s.args, st);
+      else if (s.impl == IMPL_IGEMM_T) launch_conv_igemm(s.args, false, st);
       else launch_convt_direct(s.args, f16, st);
       break;
     case CTD_OP_MAXPOOL: {
@@ -621,7 +663,7 @@ int ctd_engine_create(ctd_engine** out, const ctd_tensor* tensors, int32_t n_ten
   e->device = device;
   e->prec = precision;
   e->no_reuse = std::getenv("CTD_NO_REUSE") != nullptr;
-
+  if (const char* v = std::getenv("CTD_F32_MFMA")) e->f32_mfma = std::atoi(v) != 0;
 
   e->tensors.resize(n_tensors);
   for (int i = 0; i < n_tensors; ++i) e->tensors[i].t = tensors[i];
@@ -750,6 +792,14 @@ int ctd_nms(const float* blks_dev, int32_t B, int32_t rows, int32_t no, float co
   if (ws_bytes < nms_workspace_bytes(B, rows)) return fail(CTD_ERR_INVALID, "workspace too small");
   launch_nms(blks_dev, B, rows, no, conf_thres, iou_thres, max_det, max_nms, max_wh, dets_dev, counts_dev, ws_dev,
              (hipStream_t)stream);
+  HIP_TRY(hipGetLastError());
+  return CTD_OK;
+}
+
+int ctd_db_step(const float* lines_dev, int32_t B, int32_t H, int32_t W, float k, float* out_dev, uint8_t* bitmap_dev,
+                float thresh, void* stream) {
+  if (!lines_dev || !out_dev || B < 1 || H < 1 || W < 1) return fail(CTD_ERR_INVALID, "ctd_db_step: bad arguments");
+  launch_db_step(lines_dev, k, out_dev, bitmap_dev, thresh, B, H, W, (hipStream_t)stream);
   HIP_TRY(hipGetLastError());
   return CTD_OK;
 }

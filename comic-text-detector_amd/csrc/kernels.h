@@ -24,6 +24,10 @@ void launch_detect_decode(const void* raw, int pitch, bool raw_f16, float* blks,
 void launch_export_plane(const void* src, int pitch, bool f16, float* out, int nplanes, int plane, uint8_t* u8,
                          int u8_mode, float thresh, int B, int H, int W, hipStream_t st);
 
+// DBHead.step_function on the two planes of lines_map (B,2,H,W) -> out (B,1,H,W) f32 (+ bitmap u8 = out > thresh)
+void launch_db_step(const float* lines, float k, float* out, uint8_t* bitmap, float thresh, int B, int H, int W,
+                    hipStream_t st);
+
 // ---- kernels_igemm.hip : MFMA implicit-GEMM conv (fp16 in, fp32 acc) ------
 // weights: half [nphase][Npad][K], K index = (ty*KW+tx)*(c0+c1) + c
 extern int g_igemm_occ_lo;
@@ -34,6 +38,12 @@ void igemm_pack_weights(const float* logical, int nphase, int N, int K, int bn, 
 bool igemm_supported(const ConvArgs& a);
 int igemm_ntile(int N);  // N tile the dispatcher will use (weights must be padded to it)
 void launch_conv_igemm(const ConvArgs& a, bool dst_f32, hipStream_t st);   // dispatches to the halo kernel when it applies
+
+// ---- kernels_f32.hip : f32-operand MFMA implicit-GEMM conv (the exact-fp32 engine) ----
+// weights: f32 [nphase][Npad][K], K index = (ty*KW+tx)*(c0+c1) + c; bias f32 padded to Npad
+int f32_mfma_ntile(int N);
+bool conv_f32_mfma_supported(const ConvArgs& a);
+void launch_conv_f32_mfma(const ConvArgs& a, hipStream_t st);
 
 // ---- kernels_halo.hip : halo-tile MFMA conv (stride-1 3x3, ConvTranspose phases) ----
 extern int g_conv_halo;   // 0 disables (selftest A/B)

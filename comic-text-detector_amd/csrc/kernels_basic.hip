@@ -298,6 +298,26 @@ void launch_detect_decode(const void* raw, int pitch, bool raw_f16, float* blks,
                        rows_total, row_off, B, ny, nx, na, no, stride, anchors_px);
 }
 
+// DBHead.step_function (reference basemodel.py:159-160): 1 / (1 + exp(-k (shrink - thresh))) of the two planes of
+// `lines_map`, the map `DBHead.forward(step_eval=True)` returns (basemodel.py:121-122), plus its bitmap (> thresh)
+__global__ void db_step_kernel(const float* __restrict__ lines, float k, float* __restrict__ out,
+                               uint8_t* __restrict__ bitmap, float thresh, int B, int hw) {
+  const long long total = (long long)B * hw;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const long long b = i / hw, p = i % hw;
+    const float x = lines[(b * 2) * hw + p], y = lines[(b * 2 + 1) * hw + p];
+    const float v = 1.0f / (1.0f + expf(-k * (x - y)));
+    out[i] = v;
+    if (bitmap) bitmap[i] = v > thresh ? 1 : 0;
+  }
+}
+
+void launch_db_step(const float* lines, float k, float* out, uint8_t* bitmap, float thresh, int B, int H, int W,
+                    hipStream_t st) {
+  hipLaunchKernelGGL(db_step_kernel, dim3(grid_for((long long)B * H * W)), dim3(256), 0, st, lines, k, out, bitmap, thresh,
+                     B, H * W);
+}
+
 void launch_export_plane(const void* src, int pitch, bool f16, float* out, int nplanes, int plane, uint8_t* u8,
                          int u8_mode, float thresh, int B, int H, int W, hipStream_t st) {
   const int g = grid_for((long long)B * H * W);

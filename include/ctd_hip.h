@@ -188,6 +188,13 @@ int ctd_ccl(const uint8_t* img_dev, int32_t B, int32_t H, int32_t W, int32_t thr
             int32_t connectivity, int32_t* labels_dev, int32_t* n_dev, int32_t* stats_dev,
             int32_t max_labels, void* ws_dev, size_t ws_bytes, void* stream);
 
+/* `DBHead.step_function` (reference basemodel.py:159-160), the differentiable binarisation
+ * 1 / (1 + exp(-k (P - T))) of the shrink map P and the threshold map T = the two planes of `lines_map`
+ * (B,2,H,W); out (B,1,H,W) f32 is what `DBHead.forward(step_eval=True)` returns (basemodel.py:121-122);
+ * bitmap (B,H,W) u8 = out > thresh, or NULL.  k = 50 in the reference (basemodel.py:84). */
+int ctd_db_step(const float* lines_dev, int32_t B, int32_t H, int32_t W, float k, float* out_dev, uint8_t* bitmap_dev,
+                float thresh, void* stream);
+
 /* ---- pre / post resampling ---------------------------------------------- */
 
 /* cv2.resize(src, (dW,dH), INTER_LINEAR) for uint8 images with C = 1 or 3 interleaved

@@ -180,6 +180,12 @@ class OracleNet:
             lines = self.det(*feats2)
         return blks, mask, lines
 
+    @staticmethod
+    def step_function(lines: torch.Tensor, k: float = 50.0) -> torch.Tensor:
+        """`DBHead.step_function(shrink_maps, threshold_maps)` (reference basemodel.py:159-160), what
+        `DBHead.forward(step_eval=True)` returns (:121-122): (B,2,H,W) -> (B,1,H,W)."""
+        return torch.reciprocal(1 + torch.exp(-k * (lines[:, 0:1] - lines[:, 1:2])))
+
     def forward_with_taps(self, x: torch.Tensor):
         with torch.no_grad():
             blks, feats = self.yolo(x.float())

@@ -159,3 +159,55 @@ def test_hipgraph_replay_matches_eager():
     out2 = [t.clone() for t in replay()]
     torch.cuda.synchronize()
     assert torch.equal(out2[1][0], eager[1][1]) and torch.equal(out2[1][1], eager[1][0])
+
+
+@pytest.mark.parametrize("prec,tol", [("fp32", 2e-3), ("fp16", 2e-1)])
+def test_db_step_function_matches_oracle(prec, tol):
+    """N8: `DBHead.forward(step_eval=True)` = step_function(shrink, thresh), k = 50 (reference
+    basemodel.py:121-122,159-160) through `ctd_db_step`.  k amplifies the map error 12.5x at the steepest point."""
+    p = pkg()
+    ck = checkpoint(0)
+    be = p.backend.HipTextDetBackend(ck, device="cuda", precision=prec, step_eval=True)
+    x = torch.rand(2, 3, 128, 192, generator=torch.Generator().manual_seed(5))
+    blks, mask, step = be(x.cuda())
+    torch.cuda.synchronize()
+    _, _, ol = OracleNet(ck)(x)
+    ref = OracleNet.step_function(ol, 50.0)
+    assert step.shape == ref.shape == (2, 1, 128, 192)
+    assert float((step.cpu() - ref).abs().max()) < tol
+    assert float((step.cpu() - ref).abs().mean()) < tol / 20
+    # the exact relation on the engine's OWN planes (the kernel itself, no network error)
+    be2 = backend(prec)
+    _, _, lines = be2(x.cuda())
+    own = torch.reciprocal(1 + torch.exp(-50.0 * (lines[:, 0:1] - lines[:, 1:2])))
+    torch.testing.assert_close(step, own, rtol=1e-5, atol=1e-6)
+    assert torch.equal(be.bitmap.bool(), step[:, 0] > 0.3)
+
+
+def test_checkpoint_file_and_onnx_contract_entry(tmp_path):
+    """f-3: the reference's weight FILE (`torch.save` of the dict, basemodel.py:212) loaded by path, and the
+    `TextDetBaseDNN`-style entry (uint8 HWC in, numpy out, tensors named images -> blk / seg / det,
+    utils/export.py:43-44, basemodel.py:246-256)."""
+    p = pkg()
+    ck = checkpoint(0)
+    path = str(tmp_path / "comictextdetector.pt")
+    torch.save(ck, path)
+    det = p.detector.TextDetector(path, input_size=256, device="cuda", half=False)
+    page = p.synth.text_like_page((256, 256), 5, n_blocks=4)
+    m0, r0, b0 = det(page)
+    m1, r1, b1 = p.detector.TextDetector(ck, input_size=256, device="cuda", half=False)(page)
+    np.testing.assert_array_equal(m0, m1)
+    np.testing.assert_array_equal(r0, r1)
+    assert len(b0) == len(b1)
+    dnn = p.backend.HipTextDetDNN(256, path)
+    assert (dnn.input_name, tuple(dnn.uoln)) == ("images", ("blk", "seg", "det"))
+    im_in = page[:, :, ::-1].copy()                       # preprocess_img(..., to_tensor=False): RGB uint8 HWC
+    blks, mask, lines = dnn(im_in)
+    x = torch.from_numpy(im_in.transpose(2, 0, 1)[None].astype(np.float32) * np.float32(1 / 255.0))
+    ob, om, ol = OracleNet(ck)(x)
+    assert isinstance(blks, np.ndarray) and mask.shape == (1, 1, 256, 256) and lines.shape == (1, 2, 256, 256)
+    np.testing.assert_allclose(mask, om.numpy(), rtol=0, atol=2e-5)
+    np.testing.assert_allclose(lines, ol.numpy(), rtol=0, atol=2e-5)
+    named = dnn.forward_named(x.numpy())
+    assert sorted(named) == ["blk", "det", "seg"]
+    np.testing.assert_array_equal(named["seg"], mask)

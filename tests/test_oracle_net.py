@@ -48,3 +48,21 @@ def test_synthetic_checkpoint_is_in_reference_format():
     ref = ReferenceNet(checkpoint(3))
     n = sum(p.numel() for m in (ref.blk_det, ref.text_seg, ref.text_det) for p in m.parameters())
     assert 23.0e6 < n < 23.8e6     # SURVEY: 23.4 M params
+
+
+@pytest.mark.skipif(not reference_available(), reason="reference tree only exists in the build container")
+def test_oracle_step_function_equals_reference_dbhead_step_eval():
+    """`DBHead.forward(step_eval=True)` (reference basemodel.py:121-122,159-160) vs the restated step function
+    applied to the oracle's two DB planes."""
+    from oracle.ref_import import ReferenceNet
+    ck = checkpoint(0)
+    x = torch.rand(1, 3, 128, 128, generator=torch.Generator().manual_seed(11))
+    ref = ReferenceNet(ck)
+    with torch.no_grad():
+        blks, feats = ref.blk_det(x, detect=True)
+        mask, feats2 = ref.text_seg(*feats, forward_mode=ref._mode)
+        theirs = ref.text_det(*feats2, step_eval=True)
+    _, _, lines = OracleNet(ck)(x)
+    ours = OracleNet.step_function(lines, k=ref.text_det.k)
+    assert theirs.shape == ours.shape == (1, 1, 128, 128)
+    assert torch.equal(theirs, ours)

@@ -145,7 +145,9 @@ int pack_op(ctd_engine* e, OpState& s, const float* P, int64_t nP) {
         return fail(CTD_ERR_UNSUPPORTED, "f32 destination needs the MFMA path");
       // fp32 engine: f32-operand MFMA (kernels_f32.hip) when a K step of 16 channels never crosses a tap
       auto al4 = [&](int id, int coff) { return e->tensors[id].t.channels % 4 == 0 && coff % 4 == 0; };
-      if (!f16 && e->f32_mfma && o.src0_c % 16 == 0 && (o.src1 < 0 || o.src1_c % 16 == 0) && al4(o.src0, o.src0_coff) &&
+      const bool ch_ok = (o.src0_c % 16 == 0 && (o.src1 < 0 || o.src1_c % 16 == 0)) ||
+                         (o.src0_c == 4 && o.src1 < 0 && (k * k) % 4 == 0);     // 4-channel source: one tap per 16-B chunk
+      if (!f16 && e->f32_mfma && ch_ok && al4(o.src0, o.src0_coff) &&
           (o.src1 < 0 || al4(o.src1, o.src1_coff)) && al4(o.dst, o.dst_coff) && (o.res < 0 || al4(o.res, o.res_coff))) {
         s.impl = IMPL_IGEMM;
         const int bn = f32_mfma_ntile(N);
@@ -204,8 +206,8 @@ int pack_op(ctd_engine* e, OpState& s, const float* P, int64_t nP) {
         if (int rc = upload(e, wp, &s.w_dev)) return rc;
         return pack_bias(s.npad);
       }
-      if (!f16 && e->f32_mfma && k == 4 && o.stride == 2 && o.pad == 1 && cin % 16 == 0 && N >= 16 &&
-          t0.channels % 4 == 0 && o.src0_coff % 4 == 0 && td.channels % 4 == 0 && o.dst_coff % 4 == 0) {
+      if (!f16 && e->f32_mfma && k == 4 && o.stride == 2 && o.pad == 1 && cin % 16 == 0 &&
+          t0.channels % 4 == 0 && o.src0_coff % 4 == 0 && (N < 4 || (td.channels % 4 == 0 && o.dst_coff % 4 == 0))) {
         s.impl = IMPL_IGEMM_T;
         const int bn = f32_mfma_ntile(N);
         s.npad = (N + bn - 1) / bn * bn;
@@ -552,8 +554,9 @@ int launch_op(ctd_engine* e, int i, const Outs& x, hipStream_t st) {
   switch (o.kind) {
     case CTD_OP_INPUT: {
       void* d = tptr(o.dst, 0);
-      if (x.in_fmt == CTD_IN_NCHW_F32) launch_input_nchw((const float*)x.input, d, B, H, W, f16, st);
-      else launch_input_u8((const uint8_t*)x.input, d, B, H, W, f16, st);
+      const int pitch = e->tensors[o.dst].t.channels;
+      if (x.in_fmt == CTD_IN_NCHW_F32) launch_input_nchw((const float*)x.input, d, pitch, B, H, W, f16, st);
+      else launch_input_u8((const uint8_t*)x.input, d, pitch, B, H, W, f16, st);
       break;
     }
     case CTD_OP_STEM: {

@@ -9,8 +9,9 @@
 void launch_conv_direct(const ConvArgs& a, bool f16, hipStream_t st);
 // generic transposed conv; weights f32 [k*k][cin][N]; a.stride = s, a.dy0 = pad, a.KH = k
 void launch_convt_direct(const ConvArgs& a, bool f16, hipStream_t st);
-void launch_input_nchw(const float* in, void* dst, int B, int H, int W, bool f16, hipStream_t st);
-void launch_input_u8(const uint8_t* in, void* dst, int B, int H, int W, bool f16, hipStream_t st);
+// dst: NHWC with `pitch` >= 3 channels per pixel; channels 3.. are zero filled
+void launch_input_nchw(const float* in, void* dst, int pitch, int B, int H, int W, bool f16, hipStream_t st);
+void launch_input_u8(const uint8_t* in, void* dst, int pitch, int B, int H, int W, bool f16, hipStream_t st);
 void launch_maxpool(const void* src, int pitchS, void* dst, int pitchD, int C, int B, int H, int W, int k,
                     bool f16, hipStream_t st);
 void launch_avgpool2(const void* src, int pitchS, void* dst, int pitchD, int C, int B, int Ho, int Wo,

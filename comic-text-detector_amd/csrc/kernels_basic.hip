@@ -90,27 +90,34 @@ __global__ __launch_bounds__(256) void convt_direct_kernel(ConvArgs a) {
 
 // reference inference.py:77-82: the net sees (B,3,H,W) f32 in [0,1]
 template <typename T>
-__global__ void input_nchw_kernel(const float* __restrict__ in, T* __restrict__ dst, int B, int H, int W) {
+__global__ void input_nchw_kernel(const float* __restrict__ in, T* __restrict__ dst, int pitch, int B, int H, int W) {
   const long long hw = (long long)H * W;
   const long long total = (long long)B * hw;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
        i += (long long)gridDim.x * blockDim.x) {
     const long long b = i / hw, p = i % hw;
     const float* src = in + b * 3 * hw + p;
-    T* d = dst + i * 3;
+    T* d = dst + i * pitch;
     d[0] = from_f<T>(src[0]);
     d[1] = from_f<T>(src[hw]);
     d[2] = from_f<T>(src[2 * hw]);
+    for (int c = 3; c < pitch; ++c) d[c] = from_f<T>(0.f);   // padding channels (the f32 MFMA stem reads 4)
   }
 }
 
 // u8 page in the channel order the net consumes; x/255 as float32 like
 // `astype(np.float32) / 255` (reference inference.py:78)
 template <typename T>
-__global__ void input_u8_kernel(const uint8_t* __restrict__ in, T* __restrict__ dst, long long total3) {
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total3;
-       i += (long long)gridDim.x * blockDim.x)
-    dst[i] = from_f<T>((float)in[i] / 255.0f);
+__global__ void input_u8_kernel(const uint8_t* __restrict__ in, T* __restrict__ dst, int pitch, long long total) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const uint8_t* s = in + i * 3;
+    T* d = dst + i * pitch;
+    d[0] = from_f<T>((float)s[0] / 255.0f);
+    d[1] = from_f<T>((float)s[1] / 255.0f);
+    d[2] = from_f<T>((float)s[2] / 255.0f);
+    for (int c = 3; c < pitch; ++c) d[c] = from_f<T>(0.f);
+  }
 }
 
 // nn.MaxPool2d(k, stride 1, pad k/2) (reference common.py:188); padding is -inf
@@ -249,17 +256,17 @@ void launch_convt_direct(const ConvArgs& a, bool f16, hipStream_t st) {
   else hipLaunchKernelGGL((convt_direct_kernel<float, true>), dim3(g), dim3(256), 0, st, a);
 }
 
-void launch_input_nchw(const float* in, void* dst, int B, int H, int W, bool f16, hipStream_t st) {
+void launch_input_nchw(const float* in, void* dst, int pitch, int B, int H, int W, bool f16, hipStream_t st) {
   const int g = grid_for((long long)B * H * W);
-  if (f16) hipLaunchKernelGGL((input_nchw_kernel<half_t>), dim3(g), dim3(256), 0, st, in, (half_t*)dst, B, H, W);
-  else hipLaunchKernelGGL((input_nchw_kernel<float>), dim3(g), dim3(256), 0, st, in, (float*)dst, B, H, W);
+  if (f16) hipLaunchKernelGGL((input_nchw_kernel<half_t>), dim3(g), dim3(256), 0, st, in, (half_t*)dst, pitch, B, H, W);
+  else hipLaunchKernelGGL((input_nchw_kernel<float>), dim3(g), dim3(256), 0, st, in, (float*)dst, pitch, B, H, W);
 }
 
-void launch_input_u8(const uint8_t* in, void* dst, int B, int H, int W, bool f16, hipStream_t st) {
-  const long long t = (long long)B * H * W * 3;
+void launch_input_u8(const uint8_t* in, void* dst, int pitch, int B, int H, int W, bool f16, hipStream_t st) {
+  const long long t = (long long)B * H * W;
   const int g = grid_for(t);
-  if (f16) hipLaunchKernelGGL((input_u8_kernel<half_t>), dim3(g), dim3(256), 0, st, in, (half_t*)dst, t);
-  else hipLaunchKernelGGL((input_u8_kernel<float>), dim3(g), dim3(256), 0, st, in, (float*)dst, t);
+  if (f16) hipLaunchKernelGGL((input_u8_kernel<half_t>), dim3(g), dim3(256), 0, st, in, (half_t*)dst, pitch, t);
+  else hipLaunchKernelGGL((input_u8_kernel<float>), dim3(g), dim3(256), 0, st, in, (float*)dst, pitch, t);
 }
 
 void launch_maxpool(const void* src, int pitchS, void* dst, int pitchD, int C, int B, int H, int W, int k,

@@ -8,8 +8,9 @@
 //
 // Covers Conv k x k stride 1/2 (+ folded BN, activation, residual), two concatenated sources, nearest x2
 // upsampled sources, and ConvTranspose 4x4/s2/p1 as four 2x2-tap phase GEMMs -- the ops of the fp32
-// program whose channel counts are multiples of 16; the 3-channel stem and the 1-channel tails stay on the
-// direct kernels (kernels_basic.hip).
+// program whose channel counts are multiples of 16, plus the stem (the image is stored with a zero 4th
+// channel so that one tap is one 16-B chunk; K = 36 taps x 4); the 2x2 transposed convs of the DB tail stay
+// on the direct kernels (kernels_basic.hip).
 //
 // Tiling: 256 threads = 4 waves, block tile BN x 128 pixels, K step 16 floats (64-B LDS rows, XOR-swizzled
 // 16-B chunks, double buffered, register-staged global loads).  The weights are the MFMA A operand, the
@@ -85,11 +86,13 @@ __global__ __launch_bounds__(256) void conv_f32_mfma_kernel(ConvArgs a) {
   float4_t ra[AROWS], rw[WROWS];
   auto load_tile = [&](int ks) {
     const int k0 = ks * FBK;
-    const int tap = k0 / Ct, cc = k0 - tap * Ct;       // a K step never crosses a tap: Ct % 16 == 0
+    // Ct % 16 == 0: a K step stays inside one tap.  Ct == 4 (the stem's zero-padded image): one tap per 16-B chunk.
+    const int tap = Ct == 4 ? ks * 4 + seg : k0 / Ct;
+    const int cc = Ct == 4 ? 0 : k0 - tap * Ct;
     const int ty = tap / a.KW, tx = tap - ty * a.KW;
     const bool first = cc < a.s0.c;
     const SrcView& s = first ? a.s0 : a.s1;
-    const int ch = (first ? cc : cc - a.s0.c) + seg * 4;
+    const int ch = Ct == 4 ? 0 : (first ? cc : cc - a.s0.c) + seg * 4;
 #pragma unroll
     for (int i = 0; i < AROWS; ++i) {
       const int iy = poy[i] * a.stride + dy0 + ty, ix = pox[i] * a.stride + dx0 + tx;
@@ -210,8 +213,8 @@ int f32_mfma_ntile(int N) { return N > 64 ? 128 : (N > 32 ? 64 : 32); }
 
 // f32 sources / destination with 16-B aligned channel rows, channel counts multiples of 16
 bool conv_f32_mfma_supported(const ConvArgs& a) {
-  if (a.s0.c % FBK || a.s1.c % FBK) return false;
-  if (a.s0.pitch % 4 || (a.s1.c && a.s1.pitch % 4) || a.pitchD % 4) return false;
+  if (!(a.s0.c == 4 && a.s1.c == 0) && (a.s0.c % FBK || a.s1.c % FBK)) return false;
+  if (a.s0.pitch % 4 || (a.s1.c && a.s1.pitch % 4) || (a.N >= 4 && a.pitchD % 4)) return false;
   if (a.res && a.pitchR % 4) return false;
   if (a.K % FBK) return false;
   return a.nphase == 1 || a.nphase == 4;

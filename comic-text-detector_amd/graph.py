@@ -216,9 +216,12 @@ def lower(ckpt: dict, precision: int, act: str = "leaky", bitmap_thresh: float =
                             w_off=prog.param(w), b_off=prog.param(b), name=cs.prefix)
                     v = View(t, 0, cs.c2, 1)
                 else:
-                    t_in = prog.tensor(3, 0, 0, "input")
+                    # the image is stored with a zero 4th channel (16-B pixels): the f32 MFMA kernel takes one tap
+                    # per 16-B chunk; the matching weight channel is zero
+                    t_in = prog.tensor(4, 0, 0, "input")
                     prog.op(L.OP_INPUT, dst=t_in, name="input")
-                    v = prog.conv([View(t_in, 0, 3, 0)], w, b, cs.k, cs.s, cs.p, cs.act, name=cs.prefix)
+                    w4 = np.concatenate([w, np.zeros_like(w[:, :1])], 1) if w.shape[1] == 3 else w
+                    v = prog.conv([View(t_in, 0, w4.shape[1], 0)], w4, b, cs.k, cs.s, cs.p, cs.act, name=cs.prefix)
             else:
                 v = ylo.conv(src, cs)
             cur = [v]

@@ -56,7 +56,8 @@ def run_program(prog, x: torch.Tensor, bitmap_thresh: float = 0.3):
     for o in prog.ops:
         k = o["kind"]
         if k == L.OP_INPUT:
-            tens(o["dst"])[:] = x
+            tens(o["dst"])[:] = 0           # channels beyond the image's 3 are zero padding
+            tens(o["dst"])[:, :3] = x
         elif k == L.OP_STEM:
             w = par(o["w_off"], o["cout"] * 3 * 36).view(o["cout"], 3, 6, 6)
             b = par(o["b_off"], o["cout"])

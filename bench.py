@@ -145,6 +145,91 @@ def parity_sample(pkg, ckpt, be, page: torch.Tensor) -> dict:
                     "fp32-oracle end-to-end box / mask IoU: tests/test_gpu_accept.py"}
 
 
+def mixed_stream(args, pkg, D, BK, det, rank, world, dev) -> None:
+    """BASELINE configs[4]: a seeded stream of pages of three sizes, batched dynamically per size bucket under a
+    fixed pixel budget, every bucket's forward captured ONCE into a hipGraph (largest bucket first, so the
+    arena never moves) and replayed in steady state; GPU NMS after every replay.  A step = one pass over the
+    whole stream shard of this rank.  Reported: pages/s, and what (re)planning + capturing a bucket costs."""
+    be = det.net
+    sizes = (640, 1024, 1536)
+    budget = 32 * 1024 * 1024                     # pixels per batch: 81 -> 64 @ 640, 32 @ 1024, 14 @ 1536
+    cap = {s: max(1, min(64, budget // (s * s))) for s in sizes}
+    n_stream = 512 * world
+    rng = np.random.RandomState(2024)
+    stream = rng.choice(sizes, size=n_stream, p=[0.3, 0.5, 0.2])
+    lo, hi = D.shard_range(n_stream, rank, world)
+    mine = stream[lo:hi]
+    # dynamic batching: pages are taken in stream order, a bucket is flushed when it is full (and at the end)
+    batches, open_b = [], {s: 0 for s in sizes}
+    for s in mine:
+        open_b[s] += 1
+        if open_b[s] == cap[s]:
+            batches.append((int(s), cap[s]))
+            open_b[s] = 0
+    for s in sizes:
+        if open_b[s]:
+            batches.append((int(s), open_b[s]))
+    shapes = sorted({b for b in batches}, key=lambda t: -t[0] * t[0] * t[1])
+    graphs, setup = {}, {}
+    for s, n in shapes:                            # one eager pass over every bucket: the arena reaches its final size
+        be.forward_u8(torch.zeros((n, s, s, 3), dtype=torch.uint8, device=dev))
+    for s, n in shapes:                            # ... so no capture below can move it (stale-graph guard)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        static_in, replay = be.capture(n, s, s, "u8")
+        torch.cuda.synchronize()
+        setup[f"{n}x{s}x{s}"] = round((time.perf_counter() - t0) * 1e3, 2)
+        static_in.copy_(pkg.synth.throughput_pages(n, s, seed=s + n).to(dev))
+        graphs[(s, n)] = replay
+
+    def run_steps(k):
+        for _ in range(k):
+            for key in batches:
+                blks, _, _ = graphs[key]()
+                BK.nms(blks, 0.4, 0.35)
+
+    run_steps(args.warmup)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run_steps(args.steps)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    # eager comparison on this rank (re-plans on every size change)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for s, n in batches:
+        be.forward_u8(pkg.synth.throughput_pages(1, s, seed=1).to(dev).expand(n, s, s, 3).contiguous())
+    torch.cuda.synchronize()
+    eager = time.perf_counter() - t1
+    if rank == 0:
+        mpix = float(sum(s * s * n for s, n in batches)) / 1e6
+        out = {"metric": "pages/sec, mixed-size stream (640/1024/1536), hipGraph steady state", "unit": "pages/s",
+               "value": round(n_stream * args.steps / dt, 2), "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+               "vs_baseline": None, "dtype": "f16" if args.precision == "fp16" else "f32", "data": "synthetic",
+               "config": {"workload": "BASELINE configs[4]: seeded stream of 512 pages per GPU, sizes 640/1024/1536 drawn "
+                                      "30/50/20 %, dynamic batches under a 32 Mpixel budget per batch, one hipGraph per "
+                                      "(size, batch) bucket captured once (largest first), forward + GPU NMS per batch",
+                          "pages_per_step": int(n_stream), "batches_per_step_rank0": len(batches),
+                          "bucket_caps": {str(k): v for k, v in cap.items()}, "mpixels_per_step_rank0": round(mpix, 1),
+                          "mpixels_per_s_rank0": round(mpix * args.steps / dt, 1), "precision": args.precision},
+               "plan_and_capture_ms": setup,
+               "eager_replanning_ms_per_step_rank0": round(eager * 1e3, 2),
+               "roofline": None, "cpu_baseline": None}
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -153,10 +238,12 @@ def main() -> None:
     ap.add_argument("--batch", type=int, default=32, help="pages per GPU per step")
     ap.add_argument("--size", type=int, default=1024)
     ap.add_argument("--precision", default="fp16", choices=["fp16", "fp32"])
-    ap.add_argument("--mode", default="e2e", choices=["e2e", "net"],
-                    help="e2e: forward + the whole native tail (default); net: forward + GPU NMS only")
-    ap.add_argument("--workers", type=int, default=2, help="tail worker threads (e2e)")
-    ap.add_argument("--depth", type=int, default=3, help="batches in flight (e2e)")
+    ap.add_argument("--mode", default="e2e", choices=["e2e", "net", "mixed"],
+                    help="e2e: forward + the whole native tail (default); net: forward + GPU NMS only; mixed: BASELINE "
+                         "configs[4], a seeded stream of 640 / 1024 / 1536 pages, dynamic batches, one captured "
+                         "hipGraph per size bucket (forward + NMS)")
+    ap.add_argument("--workers", type=int, default=3, help="tail worker threads (e2e)")
+    ap.add_argument("--depth", type=int, default=4, help="batches in flight (e2e)")
     ap.add_argument("--keep-undetected", action="store_true", help="also run refine_undetected_mask in the tail")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dump-ops", default="", help="write the per-op profile table to this file")
@@ -177,6 +264,8 @@ def main() -> None:
     B, S = args.batch, args.size
     det = DET.TextDetector(ckpt, input_size=S, device=dev, half=args.precision == "fp16")
     be = det.net
+    if args.mode == "mixed":
+        return mixed_stream(args, pkg, D, BK, det, rank, world, dev)
     total_pages = B * n_gpus                      # weak scaling: fixed per-GPU work
     lo, hi = D.shard_range(total_pages, rank, world)
     nloc = hi - lo

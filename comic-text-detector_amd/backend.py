@@ -154,12 +154,19 @@ class HipTextDetBackend:
         with torch.cuda.graph(g):
             outs = self._run(static_in, code, B, H, W)
         side = (self.mask_u8, self.bitmap)
+        gen = self.arena_generation()
 
         def replay():
+            # the graph holds the arena's addresses of capture time: a later, larger shape reallocates the arena
+            if self.arena_generation() != gen:
+                raise L.CtdError("this captured forward is stale: the engine's arena was reallocated for a larger "
+                                 "(B,H,W) after the capture; capture the largest shape first, or capture again")
             g.replay()
             self.mask_u8, self.bitmap = side
+            self._last_bhw = (B, H, W)
             return outs
 
+        replay.static_in = static_in        # the graph reads this buffer: it must live as long as the graph
         return static_in, replay
 
     # -- measurement helpers ------------------------------------------------------
@@ -189,6 +196,9 @@ class HipTextDetBackend:
         L.check(self._lib.ctd_engine_read_tensor(self._h, tid, out.ctypes.data_as(C.POINTER(C.c_float)), out.size),
                 "read_tensor")
         return out
+
+    def arena_generation(self) -> int:
+        return int(self._lib.ctd_engine_arena_generation(self._h))
 
     def workspace_bytes(self) -> int:
         return int(self._lib.ctd_engine_workspace_bytes(self._h))

@@ -68,6 +68,7 @@ struct ctd_engine {
   std::vector<void*> owned;  // device allocations to free
   char* arena = nullptr;
   size_t arena_bytes = 0;
+  int arena_gen = 0;           // bumped whenever the arena is reallocated: captured graphs hold the old addresses
   int pB = 0, pH = 0, pW = 0;  // current plan
   bool no_reuse = false;
   bool w_tiled = true;   // tile-major MFMA weight packing (CTD_W_TILED=0 disables)
@@ -351,7 +352,7 @@ int validate(ctd_engine* e) {
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 // ---- arena planning -----------------------------------------------------------
-int plan(ctd_engine* e, int B, int H, int W) {
+int plan(ctd_engine* e, int B, int H, int W, hipStream_t cap_stream = nullptr) {
   if (B < 1 || H < 64 || W < 64 || H % 64 || W % 64)
     return fail(CTD_ERR_INVALID, "H and W must be positive multiples of 64 and B >= 1");
   const int nT = (int)e->tensors.size(), nO = (int)e->ops.size();
@@ -428,7 +429,14 @@ int plan(ctd_engine* e, int B, int H, int W) {
       if (e->tensors[t].first_def >= 0 && e->tensors[t].last_use == i) release(e->tensors[t].offset, e->tensors[t].bytes);
   }
   if (top > e->arena_bytes) {
+    // growing the arena frees the old one: illegal inside a stream capture, and it invalidates every graph
+    // captured before (their kernels hold the old addresses; `ctd_engine_arena_generation` lets callers check)
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (cap_stream && hipStreamIsCapturing(cap_stream, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone)
+      return fail(CTD_ERR_INVALID, "the activation arena must grow for this (B,H,W), which cannot happen inside a stream "
+                                   "capture: run one eager forward of the largest shape first");
     HIP_TRY(hipDeviceSynchronize());
+    ++e->arena_gen;
     if (e->arena) HIP_TRY(hipFree(e->arena));
     e->arena = nullptr;
     e->arena_bytes = 0;
@@ -629,9 +637,9 @@ int launch_op(ctd_engine* e, int i, const Outs& x, hipStream_t st) {
   return CTD_OK;
 }
 
-int prepare(ctd_engine* e, int B, int H, int W) {
+int prepare(ctd_engine* e, int B, int H, int W, hipStream_t st = nullptr) {
   HIP_TRY(hipSetDevice(e->device));
-  if (B != e->pB || H != e->pH || W != e->pW) return plan(e, B, H, W);
+  if (B != e->pB || H != e->pH || W != e->pW) return plan(e, B, H, W, st);
   return CTD_OK;
 }
 
@@ -719,7 +727,7 @@ int ctd_engine_forward(ctd_engine* e, const void* input_dev, int32_t input_fmt, 
                        void* stream) {
   if (!e || !input_dev) return fail(CTD_ERR_INVALID, "null engine/input");
   if (input_fmt != CTD_IN_NCHW_F32 && input_fmt != CTD_IN_NHWC_U8) return fail(CTD_ERR_INVALID, "bad input format");
-  if (int rc = prepare(e, B, H, W)) return rc;
+  if (int rc = prepare(e, B, H, W, (hipStream_t)stream)) return rc;
   Outs x{input_dev, input_fmt, blks_dev, mask_dev, lines_dev, mask_u8_dev, bitmap_dev,
          e->det_rows_per_unit * (H / 64) * (W / 64)};
   for (int i = 0; i < (int)e->ops.size(); ++i)
@@ -780,6 +788,7 @@ int ctd_engine_read_tensor(ctd_engine* e, int32_t tensor_id, float* host_out, in
 }
 
 int64_t ctd_engine_workspace_bytes(const ctd_engine* e) { return e ? (int64_t)e->arena_bytes : 0; }
+int32_t ctd_engine_arena_generation(const ctd_engine* e) { return e ? e->arena_gen : -1; }
 
 // ---- post-processing entry points (kernels_post.hip) ------------------------------
 size_t ctd_nms_workspace_bytes(int32_t B, int32_t rows) { return nms_workspace_bytes(B, rows); }

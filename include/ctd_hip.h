@@ -160,6 +160,13 @@ int ctd_engine_read_tensor(ctd_engine* e, int32_t tensor_id, float* host_out, in
 
 /* Bytes of HBM held by the activation arena for the current plan. */
 int64_t ctd_engine_workspace_bytes(const ctd_engine* e);
+/* Counter that changes whenever the arena is reallocated (a forward with a (B,H,W) that needs more than the
+ * arena holds).  A hipGraph captured from ctd_engine_forward bakes the arena's addresses in: it may only be
+ * replayed while this value equals the one read at capture time.  Re-planning for a shape that fits does NOT
+ * change it (tensor offsets differ per shape, the allocation stays), so graphs of several shapes can coexist
+ * when the largest shape was run first.  A forward that would have to grow the arena inside a stream capture
+ * fails with CTD_ERR_INVALID. */
+int32_t ctd_engine_arena_generation(const ctd_engine* e);
 
 /* ---- post-processing kernels ------------------------------------------- */
 

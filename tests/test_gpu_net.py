@@ -211,3 +211,33 @@ def test_checkpoint_file_and_onnx_contract_entry(tmp_path):
     named = dnn.forward_named(x.numpy())
     assert sorted(named) == ["blk", "det", "seg"]
     np.testing.assert_array_equal(named["seg"], mask)
+
+
+def test_captured_forward_goes_stale_when_the_arena_grows():
+    """A hipGraph captured from the forward holds the arena's addresses.  Graphs of several shapes coexist
+    when the largest shape ran first; a later larger shape reallocates the arena and every older graph must
+    refuse to replay (it used to read freed memory silently)."""
+    p = pkg()
+    be = p.backend.HipTextDetBackend(checkpoint(0), device="cuda", precision="fp16")
+    x_big = torch.randint(0, 256, (2, 256, 256, 3), dtype=torch.uint8, device="cuda")
+    x_small = torch.randint(0, 256, (1, 128, 192, 3), dtype=torch.uint8, device="cuda")
+    in_big, replay_big = be.capture(2, 256, 256, "u8")            # largest first
+    in_small, replay_small = be.capture(1, 128, 192, "u8")
+    gen = be.arena_generation()
+    for static_in, replay, x in ((in_big, replay_big, x_big), (in_small, replay_small, x_small), (in_big, replay_big, x_big)):
+        static_in.copy_(x)
+        blks, mask, lines = replay()
+        torch.cuda.synchronize()
+        eb, em, el = be.forward_u8(x)
+        torch.cuda.synchronize()
+        assert torch.equal(mask, em) and torch.equal(lines, el) and torch.equal(blks, eb)
+        static_in.copy_(x)                      # the eager call re-planned; the graph must still be valid
+        blks, mask, lines = replay()
+        torch.cuda.synchronize()
+        assert torch.equal(mask, em)
+    assert be.arena_generation() == gen
+    be.forward_u8(torch.zeros((4, 512, 512, 3), dtype=torch.uint8, device="cuda"))   # needs a larger arena
+    torch.cuda.synchronize()
+    assert be.arena_generation() != gen
+    with pytest.raises(p._lib.CtdError):
+        replay_big()

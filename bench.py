@@ -369,8 +369,12 @@ def main() -> None:
                     "frac": round(ach_tf / peak_tf, 4)}
         # backbone (yolo.model.0-9) as its own line: the layers north_star's 60 % HBM target is about
         names = prof["names"]
-        bb = np.array([nm.startswith("yolo.model.") and nm.split(".")[2].isdigit() and int(nm.split(".")[2]) <= 9
-                       for nm in names])
+        def is_backbone(nm: str) -> bool:
+            parts = nm.split(".")
+            if parts[0] == "yolo":
+                parts = parts[1:]
+            return len(parts) > 1 and parts[0] == "model" and parts[1].isdigit() and int(parts[1]) <= 9
+        bb = np.array([is_backbone(nm) for nm in names])
         if bb.any():
             bb_ms, bb_bytes = float(ms[bb].sum()), float(by[bb].sum())
             roof["backbone"] = {"ms_per_step": round(bb_ms, 3), "alg_bytes_per_step": bb_bytes,

@@ -41,8 +41,10 @@ __global__ __launch_bounds__(NTHR, 4) void conv_halo_kernel(ConvArgs a) {   // 4
   constexpr int LDS_STAGE = 2 * A_BUF + 2 * W_BUF;
   constexpr int OP = BN + 8;
   constexpr int LDS_OUT = BMH * OP;
-  __shared__ __attribute__((aligned(16))) half_t lds[LDS_STAGE > LDS_OUT ? LDS_STAGE : LDS_OUT];
-  __shared__ __attribute__((aligned(16))) float bias_s[BN];   // this tile's biases, fetched under the K loop
+  constexpr int LDS_MAIN = LDS_STAGE > LDS_OUT ? LDS_STAGE : LDS_OUT;
+  // one LDS object (see kernels_igemm.hip): staging / output tile, then this tile's biases (fetched under the K loop)
+  __shared__ __attribute__((aligned(16))) half_t lds[LDS_MAIN + 2 * BN];
+  float* bias_s = (float*)(lds + LDS_MAIN);
   half_t* As = lds;               // [2][AROWS_PAD][32]
   half_t* Ws = lds + 2 * A_BUF;   // [2][BN][32]
 
@@ -304,6 +306,16 @@ void launch_halo_cfg(const ConvArgs& a, hipStream_t st) {
 
 }  // namespace
 
+// threshold of the dispatch below; CTD_HALO_MIN_PATCHES overrides it (read once: tests force the halo kernel
+// onto small maps by setting it before the library's first convolution)
+static long long halo_min_patches() {
+  static const long long v = [] {
+    const char* env = std::getenv("CTD_HALO_MIN_PATCHES");
+    return env ? std::atoll(env) : 1024ll;
+  }();
+  return v;
+}
+
 // Stride-1 KxK (K = 2 or 3) windows over non-upsampled fp16 sources whose M grid equals the input
 // grid; fp16 destination with 16-B aligned channel rows; weights packed for the 32-channel K step.
 bool conv_halo_supported(const ConvArgs& a, bool dst_f32) {
@@ -317,10 +329,7 @@ bool conv_halo_supported(const ConvArgs& a, bool dst_f32) {
   // small maps: too few 256-pixel patches to fill 256 CUs twice -> the 128-pixel kernel does better
   const long long patches = (long long)a.B * ((a.Mh + THP - 1) / THP) * ((a.Mw + TWP - 1) / TWP) * a.nphase *
                             (a.Npad / igemm_ntile(a.N));
-  // CTD_HALO_MIN_PATCHES overrides the threshold (tests force the halo kernel onto small maps)
-  const char* env = std::getenv("CTD_HALO_MIN_PATCHES");
-  const long long min_patches = env ? std::atoll(env) : 1024;
-  return patches >= min_patches;
+  return patches >= halo_min_patches();
 }
 
 void launch_conv_halo(const ConvArgs& a, hipStream_t st) {

@@ -32,7 +32,9 @@ int g_igemm_occ_lo = 0;  // tuning: 1 = register-staged loads instead of LDS-DMA
 namespace {
 
 // K step BK = 32 or 64 halves per LDS row (64 / 128 B), XOR-swizzled 16-B chunks.
-template <int BN, int BM, int WGN, int WGM, int BK, bool DST_F32, int MINW, int PF, bool PROF = false>
+// ABL: selftest-only instantiation that honours the ablation bits of a.k_rot; in the product
+// instantiations (ABL = false) every hook below is a compile-time zero.
+template <int BN, int BM, int WGN, int WGM, int BK, bool DST_F32, int MINW, int PF, bool PROF = false, bool ABL = false>
 __global__ __launch_bounds__(256, MINW) void conv_igemm_kernel(ConvArgs a) {
   constexpr int LP = BK;                            // LDS row pitch in halves (XOR swizzled, no pad)
   constexpr int SEGS = BK / 8;                      // 16-B chunks per row
@@ -45,10 +47,14 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_kernel(ConvArgs a) {
   static_assert(WGN * WGM == 4, "4 waves");
 
   constexpr int LDS_STAGE = 2 * (BM + BN) * LP, LDS_OUT = BM * (BN + 8);
-  __shared__ __attribute__((aligned(16))) half_t lds[LDS_STAGE > LDS_OUT ? LDS_STAGE : LDS_OUT];
-  // this tile's biases, fetched while the K loop runs: as global loads in the epilogue they cost a
-  // cold round trip right before the stores
-  __shared__ __attribute__((aligned(16))) float bias_s[BN];
+  constexpr int LDS_MAIN = LDS_STAGE > LDS_OUT ? LDS_STAGE : LDS_OUT;
+  // ONE LDS object: staging buffers / output tile, then this tile's biases (fetched while the K loop runs: as
+  // global loads in the epilogue they cost a cold round trip right before the stores).  A second __shared__
+  // array made the compiler's LDS-DMA alias tracking put `s_waitcnt vmcnt(0)` in front of the first ds_read of
+  // every K step (a block no longer overlapped its own DMAs with its MFMAs).
+  __shared__ __attribute__((aligned(16))) half_t lds[LDS_MAIN + 2 * BN];
+  float* bias_s = (float*)(lds + LDS_MAIN);
+  const int krot = ABL ? a.k_rot : 0;
   half_t* As = lds;                 // [2][BM][LP]  pixels
   half_t* Ws = lds + 2 * BM * LP;   // [2][BN][LP]  weights
 
@@ -76,7 +82,7 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_kernel(ConvArgs a) {
   const int bq = bid / ntn;
   int phase = a.nphase == 4 ? (bq & 3) : 0;
   int tile_m = a.nphase == 4 ? (bq >> 2) : bq;
-  if ((a.k_rot & 8) && a.nphase == 4) {   // selftest A/B: phase-major order
+  if ((krot & 8) && a.nphase == 4) {   // selftest A/B: phase-major order
     phase = bq / ntm;
     tile_m = bq % ntm;
   }
@@ -156,7 +162,7 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_kernel(ConvArgs a) {
     bool ok = true;
 #pragma unroll
     for (int i = 0; i < AROWS; ++i) ok = ok && vmask[i] == full;
-    interior = __builtin_amdgcn_ballot_w64(ok) == ~0ull && !(a.k_rot & 32);
+    interior = __builtin_amdgcn_ballot_w64(ok) == ~0ull && !(krot & 32);
   }
   // weights: tile-major [n_tile][k_step][BN][BK]; per-thread constant part of the address
   int woff[WROWS];
@@ -197,7 +203,7 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_kernel(ConvArgs a) {
     const int ch = first ? cc : cc - a.s0.c;
     const int tap = ty * a.KW + tx;
     rok = 0;
-    if ((a.k_rot & 128) && kp > 0) {
+    if ((krot & 128) && kp > 0) {
       // selftest ablation: no activation loads after the first K step
     } else if (GLDS && interior && !s.up) {
       // interior pixel tile: every tap of every row is inside the image.  One scalar base per
@@ -241,7 +247,7 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_kernel(ConvArgs a) {
     const char* wk = wtile + (size_t)kp * (BN * BK * 2);
 #pragma unroll
     for (int i = 0; i < WROWS; ++i)
-      if ((WCHUNKS >= 256 || t + 256 * i < WCHUNKS) && !((a.k_rot & 64) && kp > 0)) {
+      if ((WCHUNKS >= 256 || t + 256 * i < WCHUNKS) && !((krot & 64) && kp > 0)) {
         if (GLDS) dma(wk + woff[i], Wd, i);
         else rw[i] = *(const half8_t*)(wk + woff[i]);
       }
@@ -321,7 +327,7 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_kernel(ConvArgs a) {
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fw[i], fx[j], acc[i][j], 0, 0, 0);
     }
   };
-  const int abl = a.k_rot;   // selftest ablation bits: 1 = no loads in the K loop, 2 = no MFMAs, 4 = no stores
+  const int abl = krot;   // selftest ablation bits: 1 = no loads in the K loop, 2 = no MFMAs, 4 = no stores
   // One K step in flight: the LDS-DMAs (or loads) of step k+1 are issued before the MFMAs of step k.
   // (A 3-deep ring with two steps in flight and a counted vmcnt measured 3-6 % SLOWER on every
   // layer shape: the K loop is not short of bytes in flight, see DESIGN.md.)
@@ -469,7 +475,9 @@ void launch_cfg(const ConvArgs& a, bool dst_f32, hipStream_t st) {
   } else if (g_igemm_occ_lo == 1) {   // tuning variant: register-staged loads (global -> VGPR -> ds_write)
     hipLaunchKernelGGL((conv_igemm_kernel<BN, BM, WGN, WGM, BK, false, HI, 1>), grid, dim3(256), 0, st, a);
   } else if ((a.k_rot & 16) && a.dbg) {   // selftest: cycle-stamped instantiation
-    hipLaunchKernelGGL((conv_igemm_kernel<BN, BM, WGN, WGM, BK, false, HI, 2, true>), grid, dim3(256), 0, st, a);
+    hipLaunchKernelGGL((conv_igemm_kernel<BN, BM, WGN, WGM, BK, false, HI, 2, true, true>), grid, dim3(256), 0, st, a);
+  } else if (a.k_rot) {                   // selftest: ablation instantiation
+    hipLaunchKernelGGL((conv_igemm_kernel<BN, BM, WGN, WGM, BK, false, HI, 2, false, true>), grid, dim3(256), 0, st, a);
   } else {                            // default: LDS-DMA (global_load_lds, 16 B per lane), +5..10 % measured
     hipLaunchKernelGGL((conv_igemm_kernel<BN, BM, WGN, WGM, BK, false, HI, 2>), grid, dim3(256), 0, st, a);
   }

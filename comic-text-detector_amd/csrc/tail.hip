@@ -690,7 +690,14 @@ int ctd_tail_run(ctd_tail* t, int32_t B, int32_t Hn, int32_t Wn, const float* bl
   for (int b = 0; b < B; ++b)               // temporary first (one buffer: the stream runs the pages in order)
     if (pages[b].dw > 0) crop_px = std::max(crop_px, (size_t)(Hn - pages[b].dh) * (Wn - pages[b].dw));
   GET(t->d_crop, crop_px, uint8_t, tmp);
-  for (int b = 0; b < B; ++b) {
+  bool plain = true;                        // every page is the network input itself: one strided copy for the batch
+  for (int b = 0; b < B; ++b)
+    plain = plain && pages[b].im_h == Hn && pages[b].im_w == Wn && pages[b].dw == 0 && pages[b].dh == 0;
+  if (plain) {
+    const size_t stride = B > 1 ? t->poff[1] - t->poff[0] : hw;
+    T_TRY(hipMemcpy2DAsync(pmask, stride, mask_u8_dev, hw, hw, B, hipMemcpyDeviceToDevice, st));
+  }
+  for (int b = 0; b < B && !plain; ++b) {
     const ctd_tail_page& pg = pages[b];
     const int ch = Hn - pg.dh, cw = Wn - pg.dw;
     const uint8_t* src = mask_u8_dev + (size_t)b * hw;

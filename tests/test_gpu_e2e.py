@@ -248,3 +248,26 @@ def test_model2annotations_batch_driver_writes_the_reference_files(tmp_path):
     for path, content in expect.items():
         got = open(path, "rb").read()
         assert got == (content if isinstance(content, bytes) else content.encode("utf8")), path
+
+
+@pytest.mark.parametrize("keep", [0, 1])
+def test_tail_on_the_reference_example_page_matches_reference_code_golden(keep):
+    """The reference's real example page (1654x1170 spread, letterboxed to 1024) through the native tail,
+    against the results of the reference's OWN `TextDetector.__call__` for it (tests/golden/real_page.npz,
+    oracle/gen_golden_real.py): masks bit for bit, block records byte for byte."""
+    import json
+    from conftest import GOLDEN
+    from oracle.gen_golden_real import SIZE, load_fixture
+    p = pkg()
+    page, blks, mask_u8, prob, (dw, dh), g = load_fixture(os.path.join(GOLDEN, "real_page.npz"))
+    det = detector(SIZE)
+    im_h, im_w = page.shape[:2]
+    bitmap = (prob > 0.3).astype(np.uint8)
+    m, r, b = det.tail_batch([page], torch.from_numpy(blks).cuda(), torch.from_numpy(mask_u8)[None].cuda(),
+                             torch.from_numpy(prob)[None].cuda(), torch.from_numpy(bitmap)[None].cuda(), refine_mode=keep,
+                             keep_undetected_mask=bool(keep), metas=[(im_h, im_w, dw, dh)])[0]
+    assert m.shape == (1170, 1654)
+    np.testing.assert_array_equal(m, g[f"mask{keep}"])
+    np.testing.assert_array_equal(np.packbits(r > 0), g[f"refined{keep}"])
+    rec = p.annotations.blocks_json(b)
+    assert rec.encode("utf8") == g[f"records{keep}"].tobytes()

@@ -54,3 +54,26 @@ def test_oracle_detector_tail_equals_reference_call_golden(seed):
     np.testing.assert_array_equal(m, g["det_mask"])
     np.testing.assert_array_equal(np.packbits(r > 0), g["det_refined"])
     assert json.dumps([x.to_dict() for x in b], ensure_ascii=False, cls=A.NumpyEncoder) == bytes(g["det_records"]).decode("utf8")
+
+
+def test_oracle_tail_on_the_reference_example_page_matches_reference_code_golden():
+    """The reference's one real fixture (data/examples/AisazuNihaIrarenai-003.jpg + its published mask as the
+    source of the network outputs, oracle/gen_golden_real.py): the oracle tail against what the reference's own
+    `TextDetector.__call__` produced for it (masks bit for bit, block records byte for byte)."""
+    import json
+    import os
+    from conftest import GOLDEN
+    from oracle import annot_ref as A
+    from oracle.gen_golden_real import SIZE, load_fixture
+    page, blks, mask_u8, prob, (dw, dh), g = load_fixture(os.path.join(GOLDEN, "real_page.npz"))
+    assert page.shape[:2] == tuple(g["shape"]) == (1170, 1654)
+    mask_f = (mask_u8.astype(np.float32) / 255)[None, None]
+    lines_map = np.stack([prob, np.zeros_like(prob)])[None]
+    for keep in (0, 1):
+        m, r, b = R.detector_tail(page.copy(), blks.copy(), mask_f.copy(), lines_map.copy(), input_size=(SIZE, SIZE), dw=dw,
+                                  dh=dh, refine_mode=keep, keep_undetected_mask=bool(keep))
+        np.testing.assert_array_equal(m, g[f"mask{keep}"])
+        np.testing.assert_array_equal(np.packbits(r > 0), g[f"refined{keep}"])
+        rec = json.dumps([t.to_dict() for t in b], ensure_ascii=False, cls=A.NumpyEncoder)
+        assert rec.encode("utf8") == g[f"records{keep}"].tobytes()
+        assert len(b) == 16

@@ -167,3 +167,26 @@ def test_refine_mask_adversarial_windows_equal_reference_code(ref, seed):
                                       refine_mode=0)
     np.testing.assert_array_equal(a, b)
     np.testing.assert_array_equal(m1, m2)
+
+
+def test_reference_example_page_golden_is_what_the_reference_code_gives(ref):
+    """tests/golden/real_page.npz (the reference's real example page, network outputs from its published mask)
+    holds the results of the reference's own `TextDetector.__call__`: regenerate and compare."""
+    import json
+    import os
+    from conftest import GOLDEN
+    from oracle import annot_ref as A
+    from oracle import ref_post_import as RP
+    from oracle.gen_golden_real import SIZE, load_fixture
+    page, blks, mask_u8, prob, (dw, dh), g = load_fixture(os.path.join(GOLDEN, "real_page.npz"))
+    mask_f = (mask_u8.astype(np.float32) / 255)[None, None]
+    lines_map = np.stack([prob, np.zeros_like(prob)])[None]
+    det = RP.reference_detector(ref, (torch.from_numpy(blks.copy()), torch.from_numpy(mask_f.copy()),
+                                      torch.from_numpy(lines_map.copy())), input_size=(SIZE, SIZE))
+    m, r, b = det(page.copy(), refine_mode=1, keep_undetected_mask=True)
+    np.testing.assert_array_equal(m, g["mask1"])
+    np.testing.assert_array_equal(np.packbits(r > 0), g["refined1"])
+    rec = json.dumps([t.to_dict() for t in b], ensure_ascii=False, cls=A.NumpyEncoder)
+    assert rec.encode("utf8") == g["records1"].tobytes()
+    img_in, ratio, rdw, rdh = ref.INF.preprocess_img(page.copy(), input_size=(SIZE, SIZE), device="cpu")
+    assert (rdw, rdh) == (dw, dh)

@@ -141,8 +141,32 @@ def parity_sample(pkg, ckpt, be, page: torch.Tensor) -> dict:
             "mask_u8_max_level_diff": int((ou8.int() - gu8.int()).abs().max()),
             "mask_iou_at_127": iou(ou8 > 127, gu8 > 127),
             "line_bitmap_iou_at_0.3": iou(ob, gb),
-            "tail": "bit-exact vs the oracle tail on identical network outputs (tests/test_gpu_e2e.py); fp16-engine vs "
-                    "fp32-oracle end-to-end box / mask IoU: tests/test_gpu_accept.py"}
+            "tail": "bit-exact vs the oracle tail on identical network outputs (tests/test_gpu_e2e.py)",
+            "end_to_end": end_to_end_acceptance(pkg, be)}
+
+
+def end_to_end_acceptance(pkg, be) -> dict:
+    """north_star's acceptance metric on ONE 1024x1024 page, end to end: the benchmarked engine -> native tail
+    against the oracle (CPU fp32 network -> oracle tail = the reference's TextDetector.__call__ restated), with
+    a checkpoint whose maps have contours (`synth.make_blob_checkpoint`: still random weights; the blob
+    boundaries sit where the logits cross the threshold, so fp16-vs-fp32 differences move them).  The fp32
+    engine's result for the same page is alongside (tests/test_gpu_accept.py asserts it is identical)."""
+    from oracle import accept
+    from oracle import postproc_ref as R
+    from oracle.net_ref import OracleNet
+    DET = importlib.import_module("comic-text-detector_amd.detector")
+    ck = pkg.synth.make_blob_checkpoint(0)
+    S = 1024
+    page = pkg.synth.text_like_page((S, S), 3, n_blocks=8)
+    x = torch.from_numpy(np.ascontiguousarray(page.transpose(2, 0, 1)[None])).float() / 255
+    ob, om, ol = OracleNet(ck)(x)
+    ref = R.detector_tail(page, ob.numpy(), om.numpy(), ol.numpy(), input_size=(S, S), refine_mode=0, keep_undetected_mask=False)
+    out = {"page": "synth.text_like_page seed 3 at 1024x1024, synth.make_blob_checkpoint(0)"}
+    for name, half in ((be.precision, be.precision == "fp16"), ("fp32" if be.precision == "fp16" else "fp16", be.precision != "fp16")):
+        det = DET.TextDetector(ck, input_size=S, device=be.device, half=half)
+        out[name + "_engine"] = accept.compare(det(page, refine_mode=0, keep_undetected_mask=False), ref)
+        del det
+    return out
 
 
 def mixed_stream(args, pkg, D, BK, det, rank, world, dev) -> None:

@@ -21,6 +21,10 @@
 #include "kernels.h"
 
 int g_conv_halo = 1;   // selftest / tuning: 0 sends everything to the implicit-GEMM kernel
+int g_halo_tps = [] {   // taps per barrier of the halo kernel: 1 or 2 (CTD_HALO_TPS; A/B knob)
+  const char* e = std::getenv("CTD_HALO_TPS");
+  return e ? std::atoi(e) : 1;
+}();
 
 namespace {
 
@@ -31,13 +35,16 @@ constexpr int AROWS_PAD = 336;        // 18x18 = 324 haloed rows, rounded up to 
                                       // (LDS decides the blocks per CU: 336 rows let the 64-channel variant keep 3)
 constexpr int NTHR = 512;
 
-template <int BN, int WGN, int WGM, bool PROF>
+// TPS = taps per barrier: the weight tiles of TPS consecutive taps are staged together, so a chunk of a
+// ConvTranspose phase (4 taps) takes 2 barriers instead of 4 and a 3x3 chunk 5 instead of 9.
+template <int BN, int WGN, int WGM, bool PROF, int TPS = 1>
 __global__ __launch_bounds__(NTHR, 4) void conv_halo_kernel(ConvArgs a) {   // 4 waves / SIMD = 2 blocks / CU
   constexpr int TN = BN / (32 * WGN);
   constexpr int TM = BMH / (32 * WGM);
   static_assert(WGN * WGM == 8, "8 waves");
   constexpr int A_BUF = AROWS_PAD * BKH;          // halves
-  constexpr int W_BUF = BN * BKH;
+  constexpr int W_TILE = BN * BKH;                // one tap's weight tile
+  constexpr int W_BUF = TPS * W_TILE;
   constexpr int LDS_STAGE = 2 * A_BUF + 2 * W_BUF;
   constexpr int OP = BN + 8;
   constexpr int LDS_OUT = BMH * OP;
@@ -136,10 +143,10 @@ __global__ __launch_bounds__(NTHR, 4) void conv_halo_kernel(ConvArgs a) {   // 4
     if ((i * NTHR + wave_u * 64) / 4 < AROWS_PAD)   // pass 2: waves 0..4 cover rows 256..335
       __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)dst, 16, 0, 0);
   };
-  auto dma_w = [&](int chunk, int tap, int buf) {
+  auto dma_w = [&](int chunk, int tap, int buf, int slot = 0) {
     if (WCHUNKS >= NTHR || t < WCHUNKS) {
       const char* wk = wtile + (size_t)(tap * nkc + chunk) * (BN * BKH * 2);
-      half_t* dst = Ws + (size_t)buf * W_BUF + (size_t)(wave_u * 64) * 8;
+      half_t* dst = Ws + (size_t)buf * W_BUF + (size_t)slot * W_TILE + (size_t)(wave_u * 64) * 8;
       __builtin_amdgcn_global_load_lds((gptr_t)(wk + woff), (lptr_t)dst, 16, 0, 0);
     }
   };
@@ -167,6 +174,8 @@ __global__ __launch_bounds__(NTHR, 4) void conv_halo_kernel(ConvArgs a) {   // 4
   dma_a(0, 1);
   dma_a(0, 2);
   dma_w(0, 0, 0);
+  if (TPS > 1)
+    for (int j = 1; j < TPS && j < taps; ++j) dma_w(0, j, 0, j);
   __syncthreads();
   const long long T2 = stamp();
 
@@ -175,22 +184,37 @@ __global__ __launch_bounds__(NTHR, 4) void conv_halo_kernel(ConvArgs a) {   // 4
   // their third resident block, and the 128-channel variant gains nothing -- like the
   // implicit-GEMM kernel, the loop is not short of bytes in flight.)
   int step = 0;
+  const int nst = (taps + TPS - 1) / TPS;     // barriers per channel chunk
   for (int c = 0; c < nchunk; ++c) {
     const half_t* Ac = As + (size_t)(c & 1) * A_BUF;
-    int tap = 0;
-    for (int ty = 0; ty < a.KH; ++ty)
-      for (int tx = 0; tx < a.KW; ++tx, ++tap, ++step) {
-        // next step's weights, and a third of the next chunk's patch during the first three taps
-        const long long s0 = stamp();
-        const bool last_tap = tap + 1 == taps;
-        if (!(last_tap && c + 1 == nchunk)) dma_w(last_tap ? c + 1 : c, last_tap ? 0 : tap + 1, (step + 1) & 1);
-        if (c + 1 < nchunk) {   // static pass index: the row tables stay in registers
-          if (tap == 0) dma_a(c + 1, 0);
-          else if (tap == 1) dma_a(c + 1, 1);
-          else if (tap == 2) dma_a(c + 1, 2);
+    for (int sidx = 0; sidx < nst; ++sidx, ++step) {
+      const int tap0 = sidx * TPS;
+      // next step's weight tiles, and the next chunk's patch spread over this chunk's first steps
+      const long long s0 = stamp();
+      const bool last_st = sidx + 1 == nst;
+      if (!(last_st && c + 1 == nchunk)) {
+        const int nc = last_st ? c + 1 : c, nt0 = last_st ? 0 : tap0 + TPS;
+#pragma unroll
+        for (int j = 0; j < TPS; ++j)
+          if (nt0 + j < taps) dma_w(nc, nt0 + j, (step + 1) & 1, j);
+      }
+      if (c + 1 < nchunk) {   // static pass indices: the row tables stay in registers
+        if (TPS == 1) {
+          if (sidx == 0) dma_a(c + 1, 0);
+          else if (sidx == 1) dma_a(c + 1, 1);
+          else if (sidx == 2) dma_a(c + 1, 2);
+        } else {
+          if (sidx == 0) { dma_a(c + 1, 0); dma_a(c + 1, 1); }
+          else if (sidx == 1) dma_a(c + 1, 2);
         }
-        const long long s1 = stamp();
-        const half_t* Wb = Ws + (size_t)(step & 1) * W_BUF + (size_t)(wn * TN * 32 + l31) * BKH;
+      }
+      const long long s1 = stamp();
+#pragma unroll
+      for (int j = 0; j < TPS; ++j) {
+        const int tap = tap0 + j;
+        if (TPS > 1 && tap >= taps) break;
+        const int ty = tap / a.KW, tx = tap - ty * a.KW;
+        const half_t* Wb = Ws + (size_t)(step & 1) * W_BUF + (size_t)j * W_TILE + (size_t)(wn * TN * 32 + l31) * BKH;
         const int tapoff = ty * HW + tx;
 #pragma unroll
         for (int kk = 0; kk < BKH / 16; ++kk) {
@@ -198,21 +222,22 @@ __global__ __launch_bounds__(NTHR, 4) void conv_halo_kernel(ConvArgs a) {   // 4
 #pragma unroll
           for (int i = 0; i < TN; ++i) fw[i] = *(const half8_t*)(Wb + i * 32 * BKH + (((kk * 2 + khalf) ^ flw) * 8));
 #pragma unroll
-          for (int j = 0; j < TM; ++j) {
-            const int row = row0[j] + tapoff;
-            fx[j] = *(const half8_t*)(Ac + row * BKH + (((kk * 2 + khalf) ^ swz(row)) * 8));
+          for (int jj = 0; jj < TM; ++jj) {
+            const int row = row0[jj] + tapoff;
+            fx[jj] = *(const half8_t*)(Ac + row * BKH + (((kk * 2 + khalf) ^ swz(row)) * 8));
           }
 #pragma unroll
           for (int i = 0; i < TN; ++i)
 #pragma unroll
-            for (int j = 0; j < TM; ++j)
-              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fw[i], fx[j], acc[i][j], 0, 0, 0);
+            for (int jj = 0; jj < TM; ++jj)
+              acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fw[i], fx[jj], acc[i][jj], 0, 0, 0);
         }
-        const long long s2 = stamp();
-        __syncthreads();   // waits the DMAs (vmcnt 0) and fences the LDS buffers for reuse
-        const long long s3 = stamp();
-        t_issue += s1 - s0; t_comp += s2 - s1; t_wait += s3 - s2;
       }
+      const long long s2 = stamp();
+      __syncthreads();   // waits the DMAs (vmcnt 0) and fences the LDS buffers for reuse
+      const long long s3 = stamp();
+      t_issue += s1 - s0; t_comp += s2 - s1; t_wait += s3 - s2;
+    }
   }
   const long long T3 = stamp();
 
@@ -301,6 +326,7 @@ void launch_halo_cfg(const ConvArgs& a, hipStream_t st) {
   const int tilesX = (a.Mw + TWP - 1) / TWP, tilesY = (a.Mh + THP - 1) / THP;
   dim3 grid((unsigned)(ntn * a.nphase * tilesX * tilesY * a.B), 1, 1);
   if ((a.k_rot & 16) && a.dbg) hipLaunchKernelGGL((conv_halo_kernel<BN, WGN, WGM, true>), grid, dim3(NTHR), 0, st, a);
+  else if (g_halo_tps == 2) hipLaunchKernelGGL((conv_halo_kernel<BN, WGN, WGM, false, 2>), grid, dim3(NTHR), 0, st, a);
   else hipLaunchKernelGGL((conv_halo_kernel<BN, WGN, WGM, false>), grid, dim3(NTHR), 0, st, a);
 }
 

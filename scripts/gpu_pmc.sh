@@ -20,7 +20,7 @@ pass() {  # name, counters...
   [ -z "$have" ] && return
   echo "== case $ST_CASES pass $name:$have"
   timeout 300 rocprofv3 --pmc $have --kernel-trace --output-format csv -d $OUT/$name -o $name -- \
-      $ROOT/comic-text-detector_amd/ctd_selftest 8 > $OUT/$name.log 2>&1
+      $ROOT/comic-text-detector_amd/ctd_selftest ${ST_BATCH:-8} > $OUT/$name.log 2>&1
   echo "rc=$?"
 }
 
@@ -29,6 +29,7 @@ for CASE in $CASES; do
   export OUT=$OUTBASE/case$CASE
   mkdir -p $OUT
   pass sq1 SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_VALU_MFMA_BUSY_CYCLES
+  if [ -n "$PMC_ONLY_SQ1" ]; then python3 $ROOT/scripts/pmc_summary.py $OUT | head -40; continue; fi
   pass sq2 SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_VMEM SQ_INST_LEVEL_VMEM
   pass tcc1 TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum
   pass tcp1 TCP_TCC_READ_REQ_sum TCP_TCC_WRITE_REQ_sum TCP_PENDING_STALL_CYCLES_sum TCP_TOTAL_CACHE_ACCESSES_sum

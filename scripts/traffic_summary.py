@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Sum FETCH_SIZE / WRITE_SIZE of the conv_halo_kernel + conv_igemm_kernel dispatches of a bench.py run
-(--steps 1 --warmup 1 => 3 forwards incl. the profile pass) and write traffic.json."""
+(--mode net --steps 1 --warmup 1; the number of forwards in the run = the number of stem kernel dispatches)
+and write traffic.json."""
 import collections
 import csv
 import glob
@@ -9,13 +10,18 @@ import sys
 
 out = sys.argv[1]
 tot = collections.defaultdict(lambda: [0.0, 0])
+stems = collections.defaultdict(int)
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
     for f in glob.glob(f"{out}/{c}/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(f)):
-            if ("conv_igemm_kernel" in r["Kernel_Name"] or "conv_halo_kernel" in r["Kernel_Name"]) and r["Counter_Name"] == c:
+            if r["Counter_Name"] != c:
+                continue
+            if "conv_igemm_kernel" in r["Kernel_Name"] or "conv_halo_kernel" in r["Kernel_Name"]:
                 tot[c][0] += float(r["Counter_Value"])
                 tot[c][1] += 1
-n_fwd = 3
+            if "stem_mfma_kernel" in r["Kernel_Name"]:
+                stems[c] += 1
+n_fwd = max(stems["FETCH_SIZE"], 1)
 res = {
     "counter_unit": "KB",
     "forwards_in_run": n_fwd,

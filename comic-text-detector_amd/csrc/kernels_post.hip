@@ -294,10 +294,23 @@ __global__ __launch_bounds__(256) void ccl_border_h_kernel(int* __restrict__ par
   int* parent = parent_all + (size_t)blockIdx.z * H * W;
   const int p = y * W + x;
   if (parent[p] < 0) return;
-  if (parent[p - W] >= 0) uf_union(parent, p, p - W);
-  if (CONN == 8) {
-    if (x > 0 && parent[p - W - 1] >= 0) uf_union(parent, p, p - W - 1);
-    if (x + 1 < W && parent[p - W + 1] >= 0) uf_union(parent, p, p - W + 1);
+  // Only one link per pair of overlapping runs: horizontally adjacent foreground pixels are already one
+  // set (tile-local labelling, or the vertical-boundary kernel, whose pruning never relies on this one),
+  // so when the left neighbour is foreground it has made -- or inherited -- the links to the row above.
+  const bool q = x > 0 && parent[p - 1] >= 0;
+  const bool up = parent[p - W] >= 0;
+  if (CONN == 4) {
+    if (up && !(q && parent[p - W - 1] >= 0)) uf_union(parent, p, p - W);
+  } else {
+    const bool ur = x + 1 < W && parent[p - W + 1] >= 0;
+    if (q) {
+      if (ur && !up) uf_union(parent, p, p - W + 1);
+    } else if (up) {
+      uf_union(parent, p, p - W);
+    } else {
+      if (x > 0 && parent[p - W - 1] >= 0) uf_union(parent, p, p - W - 1);
+      if (ur) uf_union(parent, p, p - W + 1);
+    }
   }
 }
 
@@ -309,10 +322,24 @@ __global__ __launch_bounds__(256) void ccl_border_v_kernel(int* __restrict__ par
   int* parent = parent_all + (size_t)blockIdx.z * H * W;
   const int p = y * W + x;
   const bool me = parent[p] >= 0, left = parent[p - 1] >= 0;
-  if (me && left) uf_union(parent, p, p - 1);
-  if (CONN == 8 && y > 0) {
-    if (me && parent[p - W - 1] >= 0) uf_union(parent, p, p - W - 1);
-    if (left && parent[p - W] >= 0) uf_union(parent, p - 1, p - W);
+  if (!me && !left) return;
+  // Rows y-1 and y of one tile: vertical neighbours are already one set, so the 2x2 block needs a link only
+  // where the row above does not provide the connection.  On a horizontal tile boundary (y % CT == 0) nothing
+  // is assumed about the row above (that is the other kernel's job) and every adjacent pair is linked.
+  const bool ua = y > 0, same_tile = (y % CT) != 0;
+  const bool mu = ua && parent[p - W] >= 0, lu = ua && parent[p - W - 1] >= 0;
+  if (!same_tile) {
+    if (me && left) uf_union(parent, p, p - 1);
+    if (CONN == 8) {
+      if (me && lu) uf_union(parent, p, p - W - 1);
+      if (left && mu) uf_union(parent, p - 1, p - W);
+    }
+    return;
+  }
+  if (me && left && !(mu && lu)) uf_union(parent, p, p - 1);
+  if (CONN == 8) {
+    if (me && lu && !left && !mu) uf_union(parent, p, p - W - 1);
+    if (left && mu && !me && !lu) uf_union(parent, p - 1, p - W);
   }
 }
 
@@ -335,7 +362,7 @@ __global__ __launch_bounds__(256) void ccl_flatten_count_kernel(int* __restrict_
       const int v = parent[p];
       if (v >= 0) {
         const int r = uf_find(parent, p);
-        parent[p] = r;
+        if (r != v) parent[p] = r;              // most pixels already point at their root (tile-local labelling)
         local += r == p;
       }
     }
@@ -362,33 +389,41 @@ __device__ __forceinline__ int block_exclusive_scan(int v, int* sh, int* total) 
   return base + incl - v;
 }
 
-// pass 1 (mode 0): count roots per chunk.  pass 3 (mode 1): assign raster-order ids to roots.
+// pass 3: assign raster-order ids to the roots (pass 1, the per-chunk count, is fused into the flattening).
 __global__ __launch_bounds__(256) void ccl_rank_kernel(const int* __restrict__ parent_all, int hw, int nchunks,
-                                                       int* __restrict__ chunk_cnt, int* __restrict__ ids_all,
-                                                       int mode, int* __restrict__ first, int max_labels) {
+                                                       const int* __restrict__ chunk_cnt, int* __restrict__ ids_all,
+                                                       int* __restrict__ first, int max_labels) {
+  // A wave owns 1024 consecutive pixels of the chunk, 64 at a time (coalesced); the root masks of the 16
+  // groups stay in scalar registers between the counting and the numbering sweep.
+  static_assert(RK_CHUNK == 4 * 16 * 64, "4 waves x 16 groups x 64 lanes");
   __shared__ int sh[4];
   const int b = blockIdx.x / nchunks, ch = blockIdx.x % nchunks;
   const int* parent = parent_all + (size_t)b * hw;
-  const int p0 = ch * RK_CHUNK + threadIdx.x * RK_PER_T;
-  int local = 0;
-  for (int j = 0; j < RK_PER_T; ++j) {
-    const int p = p0 + j;
-    if (p < hw && parent[p] == p) ++local;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int base = ch * RK_CHUNK + w * 1024 + lane;
+  unsigned long long m[16];
+  int cnt = 0;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    const int p = base + 64 * j;
+    m[j] = __ballot(p < hw && parent[p] == p);
+    cnt += __popcll(m[j]);
   }
-  int total;
-  const int excl = block_exclusive_scan(local, sh, &total);
-  if (mode == 0) {
-    if (threadIdx.x == 0) chunk_cnt[blockIdx.x] = total;
-  } else {
-    int id = chunk_cnt[blockIdx.x] + excl;  // chunk_cnt now holds exclusive offsets
-    int* ids = ids_all + (size_t)b * hw;
-    for (int j = 0; j < RK_PER_T; ++j) {
-      const int p = p0 + j;
-      if (p < hw && parent[p] == p) {
-        ids[p] = ++id;
-        if (first && id <= max_labels) first[(size_t)b * max_labels + id - 1] = p;   // root = first pixel in raster order
-      }
+  if (lane == 0) sh[w] = cnt;
+  __syncthreads();
+  int id0 = chunk_cnt[blockIdx.x];   // exclusive offset of the chunk (after ccl_scan_chunks_kernel)
+  for (int i = 0; i < w; ++i) id0 += sh[i];
+  int* ids = ids_all + (size_t)b * hw;
+  const unsigned long long below = lane ? (~0ull >> (64 - lane)) : 0ull;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    if ((m[j] >> lane) & 1ull) {
+      const int p = base + 64 * j;
+      const int id = id0 + __popcll(m[j] & below) + 1;
+      ids[p] = id;
+      if (first && id <= max_labels) first[(size_t)b * max_labels + id - 1] = p;   // root = first pixel in raster order
     }
+    id0 += __popcll(m[j]);
   }
 }
 
@@ -410,10 +445,12 @@ __global__ __launch_bounds__(256) void ccl_scan_chunks_kernel(int* __restrict__ 
   if (threadIdx.x == 0) n_out[blockIdx.x] = carry;
 }
 
-__global__ void ccl_stats_init_kernel(int* __restrict__ stats, long long total, int H, int W) {
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
-       i += (long long)gridDim.x * blockDim.x) {
-    int* s = stats + i * 5;
+// rows of labels that exist (1..n, capped at max_labels) only: n is on the device by now
+__global__ void ccl_stats_init_kernel(int* __restrict__ stats, const int* __restrict__ n_out, int max_labels, int H, int W) {
+  const int b = blockIdx.y;
+  const int n = min(n_out[b], max_labels);
+  for (int l = blockIdx.x * blockDim.x + threadIdx.x; l < n; l += gridDim.x * blockDim.x) {
+    int* s = stats + ((size_t)b * max_labels + l) * 5;
     s[0] = W; s[1] = H; s[2] = -1; s[3] = -1; s[4] = 0;
   }
 }
@@ -495,18 +532,13 @@ __global__ __launch_bounds__(256) void ccl_label_kernel(int* __restrict__ labels
   }
 }
 
-__global__ void ccl_stats_final_kernel(int* __restrict__ stats, const int* __restrict__ n_out, int B, int max_labels) {
-  const long long total = (long long)B * max_labels;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
-       i += (long long)gridDim.x * blockDim.x) {
-    const int b = (int)(i / max_labels), l = (int)(i % max_labels);
-    int* s = stats + i * 5;
-    if (l < n_out[b]) {
-      s[2] = s[2] - s[0] + 1;
-      s[3] = s[3] - s[1] + 1;
-    } else {
-      s[0] = s[1] = s[2] = s[3] = s[4] = 0;
-    }
+__global__ void ccl_stats_final_kernel(int* __restrict__ stats, const int* __restrict__ n_out, int max_labels) {
+  const int b = blockIdx.y;
+  const int n = min(n_out[b], max_labels);
+  for (int l = blockIdx.x * blockDim.x + threadIdx.x; l < n; l += gridDim.x * blockDim.x) {
+    int* s = stats + ((size_t)b * max_labels + l) * 5;
+    s[2] = s[2] - s[0] + 1;
+    s[3] = s[3] - s[1] + 1;
   }
 }
 
@@ -565,14 +597,11 @@ void launch_ccl(const uint8_t* img, int B, int H, int W, int thresh, int conn, i
   }
   hipLaunchKernelGGL(ccl_flatten_count_kernel, dim3(B * nchunks), dim3(256), 0, st, labels, hw, nchunks, chunk_cnt);
   hipLaunchKernelGGL(ccl_scan_chunks_kernel, dim3(B), dim3(256), 0, st, chunk_cnt, nchunks, n_out);
-  hipLaunchKernelGGL(ccl_rank_kernel, dim3(B * nchunks), dim3(256), 0, st, labels, hw, nchunks, chunk_cnt, ids, 1,
-                     first, max_labels);
-  if (stats)
-    hipLaunchKernelGGL(ccl_stats_init_kernel, dim3(grid_for((long long)B * max_labels)), dim3(256), 0, st, stats,
-                       (long long)B * max_labels, H, W);
+  hipLaunchKernelGGL(ccl_rank_kernel, dim3(B * nchunks), dim3(256), 0, st, labels, hw, nchunks, chunk_cnt, ids, first,
+                     max_labels);
+  const int sgrid = std::max(1, std::min(64, (max_labels + 255) / 256));
+  if (stats) hipLaunchKernelGGL(ccl_stats_init_kernel, dim3(sgrid, B), dim3(256), 0, st, stats, n_out, max_labels, H, W);
   const int lchunks = (hw + LB_CHUNK - 1) / LB_CHUNK;
   hipLaunchKernelGGL(ccl_label_kernel, dim3(B * lchunks), dim3(256), 0, st, labels, ids, B, H, W, lchunks, stats, max_labels);
-  if (stats)
-    hipLaunchKernelGGL(ccl_stats_final_kernel, dim3(grid_for((long long)B * max_labels)), dim3(256), 0, st, stats,
-                       n_out, B, max_labels);
+  if (stats) hipLaunchKernelGGL(ccl_stats_final_kernel, dim3(sgrid, B), dim3(256), 0, st, stats, n_out, max_labels);
 }

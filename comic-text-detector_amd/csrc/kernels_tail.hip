@@ -97,16 +97,21 @@ __global__ void dbc_init_kernel(DbcTables t) {
 
 __global__ __launch_bounds__(256) void dbc_accum_kernel(DbcTables t) {
   const int hw = t.H * t.W;
-  const long long total = (long long)t.B * hw;
-  const long long span = (long long)gridDim.x * 256;
+  const int span = gridDim.x * 256;
   const int lane = threadIdx.x & 63;
-  for (long long i0 = (long long)blockIdx.x * 256; i0 < total; i0 += span) {
-    const long long i = i0 + threadIdx.x;
-    const bool live = i < total;
-    const int b = live ? (int)(i / hw) : 0, p = live ? (int)(i % hw) : 0;
+  const int b = blockIdx.y;                            // one page per grid row: 32-bit index arithmetic only
+  for (int p0 = blockIdx.x * 256; p0 < hw; p0 += span) {
+    const int p = min(p0 + (int)threadIdx.x, hw - 1);
+    const bool live = p0 + (int)threadIdx.x < hw;
+    const long long i = (long long)b * hw + p;
     const int x = p % t.W, y = p / t.W;
     const int lf = live ? t.lab_f[i] : 0, lb = live ? t.lab_b[i] : 0;
     const int key = lf > 0 ? lf : -lb;
+    // Most waves see only page background (a complement component that is no hole): nothing to add, and
+    // the f64 scan below (14 cross-lane moves) is what this kernel's time goes into.
+    const size_t cb = (size_t)b * t.cap, rb = (size_t)b * t.rcap;
+    const bool hole = live && lf <= 0 && lb > 0 && lb <= t.cap && t.par_b[cb + lb - 1] > 0;
+    if (!__ballot(live && (lf > 0 || hole))) continue;
     const double pr = live ? (double)t.prob[(long long)b * t.prob_stride + p] : 0.0;
     // horizontal runs of one label inside the wave: the first lane of a run acts for it
     const int prev = __shfl_up(key, 1);
@@ -123,7 +128,6 @@ __global__ __launch_bounds__(256) void dbc_accum_kernel(DbcTables t) {
     const double s_prev = __shfl_up(ps, 1);
     const double run = s_tail - (lane > 0 ? s_prev : 0.0);
     if (!live || t.hdr[b * 4 + 3]) continue;          // overflowed page: the host takes the label-image path
-    const size_t cb = (size_t)b * t.cap, rb = (size_t)b * t.rcap;
     if (lf > 0 && lf <= t.cap) {
       if (head) {
         unsafeAtomicAdd(t.sum_f + cb + lf - 1, run);
@@ -151,7 +155,7 @@ __global__ __launch_bounds__(256) void dbc_accum_kernel(DbcTables t) {
         atomicMin(t.row_lo + rb + row, x);
         atomicMax(t.row_hi + rb + row, x);
       }
-    } else if (head && lb > 0 && lb <= t.cap && t.par_b[cb + lb - 1] > 0) {
+    } else if (head && hole) {
       unsafeAtomicAdd(t.sum_b + cb + lb - 1, run);
     }
   }
@@ -165,18 +169,60 @@ __device__ __forceinline__ int gray_of(const uint8_t* p) {
   return ((int)p[0] * 3735 + (int)p[1] * 19235 + (int)p[2] * 9798 + 16384) >> 15;
 }
 
-__device__ __forceinline__ int erode_rect(const TWin& w, int x, int y) {
-  int m = 255;
-  for (int dy = -1; dy <= 1; ++dy) {
-    const int yy = y + dy;
-    if (yy < 0 || yy >= w.h) continue;
-    for (int dx = -1; dx <= 1; ++dx) {
-      const int xx = x + dx;
-      if (xx < 0 || xx >= w.w) continue;
-      m = min(m, (int)w.mask[(size_t)(w.y1 + yy) * w.mask_w + w.x1 + xx]);
+// One histogram increment per lane.  Page backgrounds are flat, so most of a wave hits ONE bin (a 64-way
+// LDS atomic conflict): the two most common values of the wave are added once by a leader lane, the rest
+// fall through to plain atomics.  Lanes that already left the caller's loop are simply absent from the ballots.
+__device__ __forceinline__ void hist_add(unsigned* h, int bin, bool on) {
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int round = 0; round < 2; ++round) {
+    const unsigned long long m = __ballot(on);
+    if (!m) return;
+    const int leader = __ffsll((long long)m) - 1;
+    const int v = __shfl(bin, leader);
+    const unsigned long long same = __ballot(on && bin == v);
+    if (lane == leader) atomicAdd(h + v, (unsigned)__popcll(same));
+    on = on && bin != v;
+  }
+  if (on) atomicAdd(h + bin, 1u);
+}
+
+// The window kernels walk a window in groups of four horizontally consecutive pixels per thread: one
+// 12-B load for the BGR bytes and one 4-/6-B load per mask row instead of a byte load each (the byte-load
+// version was bound by the number of vector-memory instructions, not by bytes: rocprofv3 0.11-0.19 ms per
+// kernel for ~29 Mpixel of windows per batch).  gfx950 global loads need no alignment, so the window origin
+// is free.  Groups cut by the window's right edge take the byte path.
+struct Grp {
+  int x, y, nv;   // first pixel, row, valid pixels (1..4)
+};
+__device__ __forceinline__ int win_groups(const TWin& w) { return ((w.w + 3) >> 2) * w.h; }
+__device__ __forceinline__ Grp win_group(const TWin& w, int g) {
+  const int ngx = (w.w + 3) >> 2;
+  Grp r;
+  r.y = g / ngx;
+  r.x = (g - r.y * ngx) * 4;
+  r.nv = min(4, w.w - r.x);
+  return r;
+}
+__device__ __forceinline__ void load_bgr4(const TWin& w, const Grp& g, uint8_t* px) {
+  const uint8_t* p = w.img + ((size_t)(w.y1 + g.y) * w.img_w + w.x1 + g.x) * 3;
+  if (g.nv == 4) {
+    __builtin_memcpy(px, p, 12);
+  } else {
+    for (int k = 0; k < 12; ++k) px[k] = k < g.nv * 3 ? p[k] : 0;
+  }
+}
+// six bytes of a row: columns x-1 .. x+4 of the window, `fill` outside the window
+__device__ __forceinline__ void load_row6(const uint8_t* row, int x, int ww, int fill, uint8_t* mv) {
+  if (x >= 1 && x + 5 <= ww) {
+    __builtin_memcpy(mv, row + x - 1, 6);
+  } else {
+#pragma unroll
+    for (int c = 0; c < 6; ++c) {
+      const int xx = x - 1 + c;
+      mv[c] = (xx >= 0 && xx < ww) ? row[xx] : (uint8_t)fill;
     }
   }
-  return m;
 }
 
 // grey over pixels whose 3x3-eroded mask > 127 (textmask.py:58-61) and B, G, R of the whole window (Otsu, :44-47)
@@ -185,14 +231,30 @@ __global__ __launch_bounds__(256) void tw_hist_kernel(const TWin* __restrict__ w
   const TWin w = wins[blockIdx.y];
   for (int i = threadIdx.x; i < 1024; i += 256) h[i] = 0;
   __syncthreads();
-  const int npix = w.w * w.h;
-  for (int i = blockIdx.x * 256 + threadIdx.x; i < npix; i += gridDim.x * 256) {
-    const int x = i % w.w, y = i / w.w;
-    const uint8_t* p = w.img + ((size_t)(w.y1 + y) * w.img_w + w.x1 + x) * 3;
-    atomicAdd(&h[256 + p[0]], 1u);
-    atomicAdd(&h[512 + p[1]], 1u);
-    atomicAdd(&h[768 + p[2]], 1u);
-    if (erode_rect(w, x, y) > 127) atomicAdd(&h[gray_of(p)], 1u);
+  const int ng = win_groups(w);
+  for (int gi = blockIdx.x * 256 + threadIdx.x; gi < ng; gi += gridDim.x * 256) {
+    const Grp g = win_group(w, gi);
+    uint8_t px[12];
+    load_bgr4(w, g, px);
+    int er[4] = {255, 255, 255, 255};               // 3x3 erosion, pixels outside the window ignored
+#pragma unroll
+    for (int dy = -1; dy <= 1; ++dy) {
+      const int yy = g.y + dy;
+      if (yy < 0 || yy >= w.h) continue;
+      uint8_t mv[6];
+      load_row6(w.mask + (size_t)(w.y1 + yy) * w.mask_w + w.x1, g.x, w.w, 255, mv);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) er[k] = min(er[k], min((int)mv[k], min((int)mv[k + 1], (int)mv[k + 2])));
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const bool on = k < g.nv;
+      const uint8_t* q = px + 3 * k;
+      hist_add(h + 256, q[0], on);
+      hist_add(h + 512, q[1], on);
+      hist_add(h + 768, q[2], on);
+      hist_add(h, gray_of(q), on && er[k] > 127);
+    }
   }
   __syncthreads();
   unsigned* out = hist + (size_t)blockIdx.y * 1024;
@@ -202,12 +264,9 @@ __global__ __launch_bounds__(256) void tw_hist_kernel(const TWin* __restrict__ w
 
 // kind 0: cv2.inRange(grey, lo, hi) with the integer bounds cv2 derives from the scalars (lo > hi: empty);
 // kind 1..3: threshold(channel B/G/R, lo, 255, THRESH_BINARY)
-__device__ __forceinline__ bool rule_on(int kind, int lo, int hi, const uint8_t* p) {
-  if (kind == 0) {
-    const int g = gray_of(p);
-    return g >= lo && g <= hi;
-  }
-  return (int)p[kind - 1] > lo;
+__device__ __forceinline__ bool rule_on(int kind, int lo, int hi, int b, int g, int r, int grey) {
+  if (kind == 0) return grey >= lo && grey <= hi;
+  return (kind == 1 ? b : (kind == 2 ? g : r)) > lo;   // selects, not an indexed read: the pixel stays in registers
 }
 
 // xor distance sum(cand ? 255 - m : m) of the 6 candidate rules of every window (textmask.py:36-37)
@@ -218,14 +277,26 @@ __global__ __launch_bounds__(256) void tw_xor_kernel(const TWin* __restrict__ wi
   TRule rs[6];
   for (int k = 0; k < 6; ++k) rs[k] = rules[(size_t)blockIdx.y * 6 + k];
   unsigned long long acc[6] = {0, 0, 0, 0, 0, 0};
-  const int npix = w.w * w.h;
-  for (int i = blockIdx.x * 256 + threadIdx.x; i < npix; i += gridDim.x * 256) {
-    const int x = i % w.w, y = i / w.w;
-    const uint8_t* p = w.img + ((size_t)(w.y1 + y) * w.img_w + w.x1 + x) * 3;
-    const int m = w.mask[(size_t)(w.y1 + y) * w.mask_w + w.x1 + x];
+  const int ng = win_groups(w);
+  for (int gi = blockIdx.x * 256 + threadIdx.x; gi < ng; gi += gridDim.x * 256) {
+    const Grp g = win_group(w, gi);
+    uint8_t px[12], mv[4];
+    load_bgr4(w, g, px);
+    const uint8_t* mrow = w.mask + (size_t)(w.y1 + g.y) * w.mask_w + w.x1 + g.x;
+    if (g.nv == 4) {
+      __builtin_memcpy(mv, mrow, 4);
+    } else {
+      for (int j = 0; j < 4; ++j) mv[j] = j < g.nv ? mrow[j] : 0;
+    }
 #pragma unroll
-    for (int k = 0; k < 6; ++k)
-      if (rs[k].kind >= 0) acc[k] += rule_on(rs[k].kind, rs[k].lo, rs[k].hi, p) ? (255 - m) : m;
+    for (int j = 0; j < 4; ++j) {
+      if (j >= g.nv) break;
+      const int m = mv[j];
+      const int cb = px[3 * j], cg = px[3 * j + 1], cr = px[3 * j + 2], grey = gray_of(px + 3 * j);
+#pragma unroll
+      for (int k = 0; k < 6; ++k)
+        if (rs[k].kind >= 0) acc[k] += rule_on(rs[k].kind, rs[k].lo, rs[k].hi, cb, cg, cr, grey) ? (255 - m) : m;
+    }
   }
   for (int k = 0; k < 6; ++k) {
     unsigned long long v = acc[k];
@@ -244,12 +315,20 @@ __global__ __launch_bounds__(256) void tw_render_kernel(const TWin* __restrict__
                                                         uint8_t* __restrict__ canvas, int canvas_w) {
   const TBand bd = bands[blockIdx.y];
   const TWin w = wins[bd.win];
-  const int npix = w.w * w.h;
-  for (int i = blockIdx.x * 256 + threadIdx.x; i < npix; i += gridDim.x * 256) {
-    const int x = i % w.w, y = i / w.w;
-    const uint8_t* p = w.img + ((size_t)(w.y1 + y) * w.img_w + w.x1 + x) * 3;
-    const bool on = rule_on(bd.kind, bd.lo, bd.hi, p) != (bd.invert != 0);
-    canvas[(size_t)(bd.cy + y) * canvas_w + bd.cx + x] = on ? 255 : 0;
+  const int ng = win_groups(w);
+  for (int gi = blockIdx.x * 256 + threadIdx.x; gi < ng; gi += gridDim.x * 256) {
+    const Grp g = win_group(w, gi);
+    uint8_t px[12], o[4];
+    load_bgr4(w, g, px);
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      o[j] = (rule_on(bd.kind, bd.lo, bd.hi, px[3 * j], px[3 * j + 1], px[3 * j + 2], gray_of(px + 3 * j)) != (bd.invert != 0)) ? 255 : 0;
+    uint8_t* dst = canvas + (size_t)(bd.cy + g.y) * canvas_w + bd.cx + g.x;
+    if (g.nv == 4) {
+      __builtin_memcpy(dst, o, 4);
+    } else {
+      for (int j = 0; j < g.nv; ++j) dst[j] = o[j];
+    }
   }
 }
 
@@ -263,9 +342,50 @@ __device__ __forceinline__ bool pred_on(const TWin& w, int x, int y) {
   return m > 60;
 }
 
+// four labels of a group (0 beyond the window's right edge)
+__device__ __forceinline__ void load_lab4(const int* row, const Grp& g, int* l) {
+  if (g.nv == 4) {
+    __builtin_memcpy(l, row, 16);
+  } else {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) l[k] = k < g.nv ? row[k] : 0;
+  }
+}
+
+// pred_on for the four pixels of a group: bit k set = predicted text
+__device__ __forceinline__ unsigned pred_on4(const TWin& w, const Grp& g) {
+  const uint8_t* base = w.mask + (size_t)(w.y1 + g.y) * w.mask_w + w.x1;
+  uint8_t c[6];
+  load_row6(base, g.x, w.w, 255, c);
+  int m[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) m[k] = min((int)c[k + 1], min((int)c[k], (int)c[k + 2]));
+#pragma unroll
+  for (int dy = -1; dy <= 1; dy += 2) {
+    const int yy = g.y + dy;
+    if (yy < 0 || yy >= w.h) continue;
+    const uint8_t* r = base + (long long)dy * w.mask_w + g.x;
+    uint8_t v[4];
+    if (g.nv == 4) {
+      __builtin_memcpy(v, r, 4);
+    } else {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) v[k] = k < g.nv ? r[k] : 255;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) m[k] = min(m[k], (int)v[k]);
+  }
+  unsigned bits = 0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) bits |= (m[k] > 60 ? 1u : 0u) << k;
+  return bits;
+}
+
 // counters[2l] / [2l+1]: pixels of component l not merged yet that are predicted text / background.
-// Consecutive lanes walk consecutive pixels of a window row: runs of one (label, prediction) inside a
-// wave are counted by their first lane (a candidate's big components would otherwise serialise on two words).
+// A thread owns four consecutive pixels, consecutive lanes consecutive groups.  Threads whose pixels all
+// carry one (label, prediction) key -- the inside of a component -- are merged into wave-level runs that
+// their first lane adds once (a candidate's big components would otherwise serialise on two words);
+// threads on a component's edge add their pixels one by one.
 __global__ __launch_bounds__(256) void tw_accept_count_kernel(const TWin* __restrict__ wins, const TBand* __restrict__ bands,
                                                               int round, const int* __restrict__ labels, int canvas_w,
                                                               int max_labels, const uint8_t* __restrict__ merged,
@@ -273,25 +393,59 @@ __global__ __launch_bounds__(256) void tw_accept_count_kernel(const TWin* __rest
   const TBand bd = bands[blockIdx.y];
   if (round >= 0 && bd.round != round) return;
   const TWin w = wins[bd.win];
-  const int npix = w.w * w.h;
+  const int ng = win_groups(w);
   const int lane = threadIdx.x & 63;
-  for (int i0 = blockIdx.x * 256; i0 < npix; i0 += gridDim.x * 256) {
-    const int i = i0 + threadIdx.x;
-    int key = 0;                                    // 0: nothing to count; else 2 * label + (pred ? 0 : 1)
-    if (i < npix) {
-      const int x = i % w.w, y = i / w.w;
-      const int l = labels[(size_t)(bd.cy + y) * canvas_w + bd.cx + x];
-      if (l > 0 && l <= max_labels && merged[(size_t)(w.my + y) * merged_w + w.mx + x] == 0)
-        key = 2 * l + (pred_on(w, x, y) ? 0 : 1);
+  for (int g0 = blockIdx.x * 256; g0 < ng; g0 += gridDim.x * 256) {
+    const int gi = g0 + threadIdx.x;
+    int ukey = 0, ulen = 0;                         // this thread's contribution to a wave-level run
+    if (gi < ng) {
+      const Grp g = win_group(w, gi);
+      int l[4];
+      load_lab4(labels + (size_t)(bd.cy + g.y) * canvas_w + bd.cx + g.x, g, l);
+      const uint8_t* mr = merged + (size_t)(w.my + g.y) * merged_w + w.mx + g.x;
+      uint8_t mg[4];
+      if (g.nv == 4) {
+        __builtin_memcpy(mg, mr, 4);
+      } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) mg[k] = k < g.nv ? mr[k] : 255;
+      }
+      bool any = false;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        if (!(k < g.nv && l[k] > 0 && l[k] <= max_labels && mg[k] == 0)) l[k] = 0;
+        any |= l[k] != 0;
+      }
+      if (any) {
+        const unsigned pred = pred_on4(w, g);
+        int key[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) key[k] = l[k] ? 2 * l[k] + (((pred >> k) & 1u) ? 0 : 1) : 0;
+        bool same = true;
+#pragma unroll
+        for (int k = 1; k < 4; ++k) same &= k >= g.nv || key[k] == key[0];
+        if (same) {
+          ukey = key[0], ulen = g.nv;
+        } else {
+#pragma unroll
+          for (int k = 0; k < 4; ++k)
+            if (key[k]) atomicAdd(counters + (size_t)key[k], 1u);
+        }
+      }
     }
-    const int prev = __shfl_up(key, 1);
-    const bool head = lane == 0 || prev != key;
+    if (!__ballot(ukey != 0)) continue;
+    const int prev = __shfl_up(ukey, 1);
+    const bool head = lane == 0 || prev != ukey;
     const unsigned long long heads = __ballot(head);
-    if (head && key) {
-      const unsigned long long later = lane == 63 ? 0ull : (heads >> (lane + 1));
-      const int len = later ? __ffsll((long long)later) : 64 - lane;
-      atomicAdd(counters + (size_t)key, (unsigned)len);
+    int ps = ulen;
+    for (int off = 1; off < 64; off <<= 1) {
+      const int u = __shfl_up(ps, off);
+      if (lane >= off) ps += u;
     }
+    const unsigned long long later = lane == 63 ? 0ull : (heads >> (lane + 1));
+    const int lanes = later ? __ffsll((long long)later) : 64 - lane;
+    const int tail = __shfl(ps, lane + lanes - 1);
+    if (head && ukey) atomicAdd(counters + (size_t)ukey, (unsigned)(tail - ps + ulen));
   }
 }
 
@@ -305,13 +459,19 @@ __global__ __launch_bounds__(256) void tw_accept_apply_kernel(const TWin* __rest
   const TBand bd = bands[blockIdx.y];
   if (round >= 0 && bd.round != round) return;
   const TWin w = wins[bd.win];
-  const int npix = w.w * w.h;
-  for (int i = blockIdx.x * 256 + threadIdx.x; i < npix; i += gridDim.x * 256) {
-    const int x = i % w.w, y = i / w.w;
-    const int l = labels[(size_t)(bd.cy + y) * canvas_w + bd.cx + x];
-    if (l <= 0 || l > max_labels) continue;
-    const bool ok = stats[(size_t)(l - 1) * 5 + 2] * stats[(size_t)(l - 1) * 5 + 3] >= min_box;
-    if (ok && counters[2 * (size_t)l] > counters[2 * (size_t)l + 1]) merged[(size_t)(w.my + y) * merged_w + w.mx + x] = 255;
+  const int ng = win_groups(w);
+  for (int gi = blockIdx.x * 256 + threadIdx.x; gi < ng; gi += gridDim.x * 256) {
+    const Grp g = win_group(w, gi);
+    int l[4];
+    load_lab4(labels + (size_t)(bd.cy + g.y) * canvas_w + bd.cx + g.x, g, l);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int lk = l[k];
+      if (lk <= 0 || lk > max_labels) continue;
+      const bool ok = stats[(size_t)(lk - 1) * 5 + 2] * stats[(size_t)(lk - 1) * 5 + 3] >= min_box;
+      if (ok && counters[2 * (size_t)lk] > counters[2 * (size_t)lk + 1])
+        merged[(size_t)(w.my + g.y) * merged_w + w.mx + g.x + k] = 255;
+    }
   }
 }
 
@@ -322,25 +482,36 @@ __global__ __launch_bounds__(256) void tw_dilate_kernel(const TWin* __restrict__
                                                         unsigned* __restrict__ count255, int dilate) {
   __shared__ unsigned red[4];
   const TWin w = wins[blockIdx.y];
-  const int npix = w.w * w.h;
   unsigned cnt = 0;
-  for (int i = blockIdx.x * 256 + threadIdx.x; i < npix; i += gridDim.x * 256) {
-    const int x = i % w.w, y = i / w.w;
-    int m = in[(size_t)(w.my + y) * merged_w + w.mx + x];
-    if (dilate) {
-      for (int dy = -1; dy <= 1; ++dy) {
-        const int yy = y + dy;
-        if (yy < 0 || yy >= w.h) continue;
-        for (int dx = -1; dx <= 1; ++dx) {
-          const int xx = x + dx;
-          if (xx < 0 || xx >= w.w) continue;
-          m = max(m, (int)in[(size_t)(w.my + yy) * merged_w + w.mx + xx]);
-        }
-      }
+  const int ng = win_groups(w);
+  for (int gi = blockIdx.x * 256 + threadIdx.x; gi < ng; gi += gridDim.x * 256) {
+    const Grp g = win_group(w, gi);
+    int m[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int dy = -1; dy <= 1; ++dy) {
+      if (dy != 0 && !dilate) continue;
+      const int yy = g.y + dy;
+      if (yy < 0 || yy >= w.h) continue;
+      uint8_t mv[6];
+      load_row6(in + (size_t)(w.my + yy) * merged_w + w.mx, g.x, w.w, 0, mv);
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        m[k] = max(m[k], dilate ? max((int)mv[k], max((int)mv[k + 1], (int)mv[k + 2])) : (int)mv[k + 1]);
     }
-    out[(size_t)(w.my + y) * merged_w + w.mx + x] = (uint8_t)m;
-    comp[(size_t)(w.my + y) * merged_w + w.mx + x] = (uint8_t)(255 - m);
-    cnt += m == 255;
+    uint8_t o[4], c[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      o[k] = (uint8_t)m[k];
+      c[k] = (uint8_t)(255 - m[k]);
+      cnt += k < g.nv && m[k] == 255;
+    }
+    const size_t at = (size_t)(w.my + g.y) * merged_w + w.mx + g.x;
+    if (g.nv == 4) {
+      __builtin_memcpy(out + at, o, 4);
+      __builtin_memcpy(comp + at, c, 4);
+    } else {
+      for (int k = 0; k < g.nv; ++k) out[at + k] = o[k], comp[at + k] = c[k];
+    }
   }
   for (int off = 32; off > 0; off >>= 1) cnt += __shfl_down(cnt, off);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = cnt;
@@ -363,7 +534,6 @@ __global__ __launch_bounds__(256) void tw_holes_kernel(const TWin* __restrict__ 
                                                        unsigned* __restrict__ counters2) {
   const TWin w = wins[blockIdx.y];
   int* tp = top2 + (size_t)blockIdx.y * 3;
-  const int npix = w.w * w.h;
   if (pass <= 1 && blockIdx.x == 0 && threadIdx.x == 0) {      // the background entry: pixels already set
     const int a = (int)count255[blockIdx.y];
     if (pass == 0) atomicMax(tp, a);
@@ -372,23 +542,30 @@ __global__ __launch_bounds__(256) void tw_holes_kernel(const TWin* __restrict__ 
   }
   const int m1 = pass >= 1 ? tp[0] : 0;
   const int thr = pass >= 2 ? (tp[1] >= 1 ? tp[0] : tp[2]) : 0;
-  for (int i = blockIdx.x * 256 + threadIdx.x; i < npix; i += gridDim.x * 256) {
-    const int x = i % w.w, y = i / w.w;
-    const size_t ci = (size_t)(w.my + y) * merged_w + w.mx + x;
-    const int l = labels2[ci];
-    if (l <= 0 || l > max_labels) continue;
-    const int area = stats2[(size_t)(l - 1) * 5 + 4];
-    if (pass <= 1) {
-      if (first2[l - 1] != (int)ci) continue;                  // one representative pixel per component
-      if (pass == 0) atomicMax(tp, area);
-      else if (area == m1) atomicAdd(tp + 1, 1);
-      else atomicMax(tp + 2, area);
-    } else if (pass == 2) {
-      // only components that may be filled are counted: the big ones (the window's real background) would
-      // serialise every pixel of the window on two counters
-      if (area < thr && merged[ci] == 0) atomicAdd(counters2 + 2 * (size_t)l + (pred_on(w, x, y) ? 0 : 1), 1u);
-    } else {
-      if (area < thr && counters2[2 * (size_t)l] > counters2[2 * (size_t)l + 1]) merged[ci] = 255;
+  const int ng = win_groups(w);
+  for (int gi = blockIdx.x * 256 + threadIdx.x; gi < ng; gi += gridDim.x * 256) {
+    const Grp g = win_group(w, gi);
+    const size_t c0 = (size_t)(w.my + g.y) * merged_w + w.mx + g.x;
+    int lab[4];
+    load_lab4(labels2 + c0, g, lab);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int l = lab[k];
+      if (l <= 0 || l > max_labels) continue;
+      const size_t ci = c0 + k;
+      const int area = stats2[(size_t)(l - 1) * 5 + 4];
+      if (pass <= 1) {
+        if (first2[l - 1] != (int)ci) continue;                  // one representative pixel per component
+        if (pass == 0) atomicMax(tp, area);
+        else if (area == m1) atomicAdd(tp + 1, 1);
+        else atomicMax(tp + 2, area);
+      } else if (pass == 2) {
+        // only components that may be filled are counted: the big ones (the window's real background) would
+        // serialise every pixel of the window on two counters
+        if (area < thr && merged[ci] == 0) atomicAdd(counters2 + 2 * (size_t)l + (pred_on(w, g.x + k, g.y) ? 0 : 1), 1u);
+      } else {
+        if (area < thr && counters2[2 * (size_t)l] > counters2[2 * (size_t)l + 1]) merged[ci] = 255;
+      }
     }
   }
 }
@@ -397,15 +574,23 @@ __global__ __launch_bounds__(256) void tw_holes_kernel(const TWin* __restrict__ 
 __global__ __launch_bounds__(256) void tw_commit_kernel(const TWin* __restrict__ wins, const uint8_t* __restrict__ merged,
                                                         int merged_w) {
   const TWin w = wins[blockIdx.y];
-  const int npix = w.w * w.h;
-  for (int i = blockIdx.x * 256 + threadIdx.x; i < npix; i += gridDim.x * 256) {
-    const int x = i % w.w, y = i / w.w;
-    const unsigned v = merged[(size_t)(w.my + y) * merged_w + w.mx + x];
+  const int ng = win_groups(w);
+  for (int gi = blockIdx.x * 256 + threadIdx.x; gi < ng; gi += gridDim.x * 256) {
+    const Grp g = win_group(w, gi);
+    const uint8_t* src = merged + (size_t)(w.my + g.y) * merged_w + w.mx + g.x;
+    unsigned v = 0;
+    if (g.nv == 4) {
+      __builtin_memcpy(&v, src, 4);
+    } else {
+      for (int k = 0; k < g.nv; ++k) v |= (unsigned)src[k] << (8 * k);
+    }
     if (!v) continue;
-    const size_t idx = (size_t)(w.y1 + y) * w.out_w + w.x1 + x;
-    uint8_t* a = w.out + (idx & ~(size_t)3);
-    // the page buffers are 4-byte aligned and padded to a multiple of 4 bytes
-    atomicOr((unsigned*)a, v << (8 * (idx & 3)));
+    const size_t idx = (size_t)(w.y1 + g.y) * w.out_w + w.x1 + g.x;
+    unsigned* a = (unsigned*)(w.out + (idx & ~(size_t)3));
+    // the page buffers are 4-byte aligned and padded to a multiple of 4 bytes: the group covers at most two words
+    const unsigned long long v2 = (unsigned long long)v << (8 * (idx & 3));
+    if ((unsigned)v2) atomicOr(a, (unsigned)v2);
+    if ((unsigned)(v2 >> 32)) atomicOr(a + 1, (unsigned)(v2 >> 32));
   }
 }
 
@@ -431,7 +616,8 @@ void launch_dbc(const DbcTables& t, hipStream_t st) {
   hipLaunchKernelGGL(dbc_prep_kernel, dim3((t.cap + 255) / 256, t.B), dim3(256), 0, st, t);
   hipLaunchKernelGGL(dbc_scan_kernel, dim3(t.B), dim3(256), 0, st, t);
   hipLaunchKernelGGL(dbc_init_kernel, dim3(grid_for((long long)t.B * t.rcap)), dim3(256), 0, st, t);
-  hipLaunchKernelGGL(dbc_accum_kernel, dim3(grid_for((long long)t.B * t.H * t.W)), dim3(256), 0, st, t);
+  const int per_page = std::max(1, std::min((t.H * t.W + 255) / 256, 8192 / std::max(1, t.B)));
+  hipLaunchKernelGGL(dbc_accum_kernel, dim3(per_page, t.B), dim3(256), 0, st, t);
 }
 
 void launch_tw_hist(const TWin* wins, int n, int max_pix, unsigned* hist, hipStream_t st) {

@@ -189,7 +189,8 @@ int ctd_nms(const float* blks_dev, int32_t B, int32_t rows, int32_t no, float co
  *                raster order of their first pixel
  *   n_dev      : (B) i32 number of components (excluding background)
  *   stats_dev  : (B, max_labels, 5) i32 [x, y, w, h, area] for labels 1..n at
- *                row label-1 (rows beyond max_labels are dropped, n still counts them) */
+ *                row label-1 (rows beyond max_labels are dropped, n still counts them;
+ *                rows of labels that do not exist are not written) */
 size_t ctd_ccl_workspace_bytes(int32_t B, int32_t H, int32_t W);
 int ctd_ccl(const uint8_t* img_dev, int32_t B, int32_t H, int32_t W, int32_t thresh,
             int32_t connectivity, int32_t* labels_dev, int32_t* n_dev, int32_t* stats_dev,

@@ -81,6 +81,24 @@ def test_ccl_matches_scipy(conn, shape):
         np.testing.assert_array_equal(stats[b, : nref - 1].cpu().numpy(), sref[1:])
 
 
+@pytest.mark.parametrize("conn", [4, 8])
+@pytest.mark.parametrize("shape", [(200, 333), (512, 512)])
+def test_ccl_dense_noise(conn, shape):
+    """Noise from sparse to nearly full: long runs across tile borders are where the border kernels link
+    only one pixel per pair of overlapping runs."""
+    rng = np.random.RandomState(shape[1] + conn)
+    imgs = np.stack([(rng.uniform(size=shape) < d).astype(np.uint8) * 255 for d in (0.3, 0.6, 0.75, 0.92, 0.99)])
+    imgs[4, ::32] = 0          # full tiles cut apart exactly on the tile rows / columns
+    imgs[3, :, 31::32] = 0
+    labels, n, stats = pkg().backend.connected_components(torch.from_numpy(imgs).cuda(), 0, conn, max_labels=1 << 17)
+    torch.cuda.synchronize()
+    for b in range(len(imgs)):
+        nref, lref, sref = R.connected_components_with_stats(imgs[b], conn)
+        assert int(n[b]) == nref - 1
+        np.testing.assert_array_equal(labels[b].cpu().numpy(), lref)
+        np.testing.assert_array_equal(stats[b, : nref - 1].cpu().numpy(), sref[1:])
+
+
 def test_ccl_threshold_semantics():
     """foreground = img > thresh (reference textmask.py:137: threshold(mask, 30, 255, BINARY) then CC)."""
     rng = np.random.RandomState(5)

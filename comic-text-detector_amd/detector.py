@@ -50,8 +50,10 @@ class TextDetector:
         self.half = half
         self.conf_thresh = conf_thresh
         self.nms_thresh = nms_thresh
-        self.net = BK.HipTextDetBackend(model_path, device=device, precision="fp16" if half else "fp32", act=act,
-                                        bitmap_thresh=0.3)
+        self._net_args = dict(model=model_path, device=device, precision="fp16" if half else "fp32", act=act,
+                              bitmap_thresh=0.3)
+        self.net = BK.HipTextDetBackend(**self._net_args)
+        self._lanes = [(self.net, None)]                      # (engine, stream) pairs of detect_stream, grown on demand
         self.backend = "hip"
         self.seg_rep = PP.SegRepresenter(thresh=0.3)          # inference.py:139
 
@@ -85,13 +87,28 @@ class TextDetector:
                              for g, m in zip(gpu, metas)])
         return x, gpu, metas
 
-    def _forward(self, pages: Sequence[Page]):
+    def _forward(self, pages: Sequence[Page], net=None):
+        net = net or self.net
         x, gpu, metas = self._prepare(pages)
-        blks, mask, lines_map = self.net.forward_u8(x)                      # the seam (inference.py:146)
+        blks, mask, lines_map = net.forward_u8(x)                           # the seam (inference.py:146)
         ev = torch.cuda.Event()
-        ev.record(torch.cuda.current_stream(self.net.device))
-        return dict(gpu=gpu, metas=metas, blks=blks, mask_u8=self.net.mask_u8, lines_map=lines_map,
-                    bitmap=self.net.bitmap, ev=ev, keep=(mask, x))
+        ev.record(torch.cuda.current_stream(net.device))
+        return dict(gpu=gpu, metas=metas, blks=blks, mask_u8=net.mask_u8, lines_map=lines_map,
+                    bitmap=net.bitmap, ev=ev, keep=(mask, x))
+
+    def _lane(self, i: int):
+        """Engine + stream number i of `detect_stream`.  Every lane is a whole engine (its own arena) on its own
+        HIP stream, so consecutive batches run concurrently: one batch's HBM-bound layers fill the gaps of the
+        other's MFMA-bound ones (scripts/gpu_dual.py: 10.86 -> 10.28 ms per 32 pages on the network alone).  End
+        to end the tail's kernels already fill those gaps and a second lane LOSES 10 % (bench.py --engines 2), so
+        `detect_stream` defaults to one lane; the option is for network-only serving."""
+        while len(self._lanes) <= i:
+            self._lanes.append((BK.HipTextDetBackend(**self._net_args), None))
+        net, st = self._lanes[i]
+        if st is None:
+            st = torch.cuda.Stream(net.device)
+            self._lanes[i] = (net, st)
+        return net, st
 
     def _tail(self, job, refine_mode, keep_undetected_mask):
         return thread_tail(self.net.device).run(job["gpu"], job["metas"], job["blks"], job["mask_u8"], job["lines_map"],
@@ -105,14 +122,23 @@ class TextDetector:
 
     @torch.no_grad()
     def detect_stream(self, batches: Iterable[Sequence[Page]], refine_mode=REFINEMASK_INPAINT,
-                      keep_undetected_mask=False, workers: int = 2, depth: int = 3) -> Iterator[list]:
+                      keep_undetected_mask=False, workers: int = 2, depth: int = 3, engines: int = 1) -> Iterator[list]:
         """Yields `detect_batch(batch)` for every batch, in order, with up to `depth` batches in flight:
-        the forward of the next batches is launched while `workers` threads run the tails of earlier ones."""
+        the forward of the next batches is launched while `workers` threads run the tails of earlier ones.
+        `engines` > 1 alternates the batches over that many engine copies on their own streams (`_lane`)."""
         pool = ThreadPoolExecutor(max_workers=max(1, workers), thread_name_prefix="ctd-tail")
         pending = deque()
+        engines = max(1, int(engines))
+        main = torch.cuda.current_stream(self.net.device)
         try:
-            for batch in batches:
-                job = self._forward(batch)
+            for i, batch in enumerate(batches):
+                if engines == 1:
+                    job = self._forward(batch)
+                else:
+                    net, st = self._lane(i % engines)
+                    st.wait_stream(main)                  # pages the caller produced on its stream
+                    with torch.cuda.stream(st):
+                        job = self._forward(batch, net)
                 pending.append(pool.submit(self._tail, job, refine_mode, keep_undetected_mask))
                 while len(pending) >= depth:
                     yield pending.popleft().result()

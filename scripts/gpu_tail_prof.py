@@ -45,5 +45,7 @@ if os.environ.get("PROFILE"):
         tail.run(pages, metas, blks, mask, prob, bitm, keep_undetected_mask=keep)
     pr.disable()
     pstats.Stats(pr).sort_stats("cumulative").print_stats(18)
-print(json.dumps({"tail_ms_per_batch": round(dt * 1e3, 3), "ms_per_page": round(dt * 1e3 / NP, 4), "stages": tail.timings(),
+area = sum(max(0, b.xyxy[2] - b.xyxy[0]) * max(0, b.xyxy[3] - b.xyxy[1]) for r in res for b in r[2])
+print(json.dumps({"block_area_over_page_area": round(float(area) / (NP * S * S), 3),
+                  "tail_ms_per_batch": round(dt * 1e3, 3), "ms_per_page": round(dt * 1e3 / NP, 4), "stages": tail.timings(),
                   "blocks": sum(len(r[2]) for r in res), "lines": sum(len(b.lines) for r in res for b in r[2])}))

@@ -213,13 +213,14 @@ def test_detect_stream_equals_detect_batch():
     det = detector(size)
     batches = [[p.synth.text_like_page((size, size), 30 + 3 * k + j, n_blocks=4) for j in range(3)] for k in range(4)]
     want = [det.detect_batch(b) for b in batches]
-    got = list(det.detect_stream(batches, workers=2, depth=3))
-    assert len(got) == len(want)
-    for gb, wb in zip(got, want):
-        for (m, r, bl), (m1, r1, bl1) in zip(gb, wb):
-            np.testing.assert_array_equal(m, m1)
-            np.testing.assert_array_equal(r, r1)
-            blocks_equal(bl, bl1)
+    for engines in (1, 2):                                 # 2: batches alternate over two engine copies / streams
+        got = list(det.detect_stream(batches, workers=2, depth=3, engines=engines))
+        assert len(got) == len(want)
+        for gb, wb in zip(got, want):
+            for (m, r, bl), (m1, r1, bl1) in zip(gb, wb):
+                np.testing.assert_array_equal(m, m1)
+                np.testing.assert_array_equal(r, r1)
+                blocks_equal(bl, bl1)
 
 
 def test_model2annotations_batch_driver_writes_the_reference_files(tmp_path):

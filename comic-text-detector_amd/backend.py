@@ -56,6 +56,7 @@ class HipTextDetBackend:
                                             self.device.index), "ctd_engine_create")
         self._h = h
         self.no = self.program.meta["no"]
+        self._offset_budget = 2 ** 31 - 1            # bytes addressable inside one activation tensor (see _run)
         self.mask_u8: Optional[torch.Tensor] = None      # fused (uint8)(mask*255), reference inference.py:96-99
         self.bitmap: Optional[torch.Tensor] = None       # fused lines_map[:,0] > 0.3, reference db_utils.py:71-72
 
@@ -83,25 +84,21 @@ class HipTextDetBackend:
         bitmap = torch.empty((B, H, W), dtype=torch.uint8, device=dev)
         return blks, mask, lines, mask_u8, bitmap
 
-    def _run(self, inp: torch.Tensor, fmt: int, B: int, H: int, W: int, profile: bool = False):
+    def _run(self, inp: torch.Tensor, fmt: int, B: int, H: int, W: int, profile: bool = False, outs=None):
         if H % 64 or W % 64:
             raise ValueError("H and W must be multiples of 64 (stride-32 backbone + AvgPool2d(2))")
-        # the MFMA kernel uses 32-bit byte offsets inside a tensor: the largest activation
-        # (64 fp16 channels at H/2 x W/2... up to 128 B per input pixel) must stay below 2 GiB,
-        # so larger batches run as consecutive sub-batches (pages are independent)
-        # (largest tensor of this network: 64 channels at half resolution = 32 B per input pixel)
-        max_b = max(1, (2 ** 31 - 1) // (H * W * 40)) if self.prec == L.PREC_F16 else B
+        # The MFMA kernels use 32-bit byte offsets inside a tensor: the largest activation (64 fp16 channels
+        # at half resolution = 32 B per input pixel, 40 with slack) must stay below 2 GiB, so larger batches
+        # run as consecutive sub-batches (pages are independent) that write into slices of ONE set of outputs.
+        max_b = max(1, self._offset_budget // (H * W * 40)) if self.prec == L.PREC_F16 else B
+        part = outs is not None                       # a sub-batch of the loop below: the caller finishes
+        if outs is None:
+            outs = self._outputs(B, H, W)
         if B > max_b and not profile:
-            parts, side = [], []
             for i in range(0, B, max_b):
-                parts.append(self._run(inp[i: i + max_b], fmt, min(max_b, B - i), H, W))
-                side.append((self.mask_u8, self.bitmap))
-            self.mask_u8 = torch.cat([s[0] for s in side])
-            self.bitmap = torch.cat([s[1] for s in side])
-            self._last_bhw = (B, H, W)
-            return tuple(torch.cat([p[k] for p in parts]) for k in range(3))
-        self._last_bhw = (B, H, W)
-        outs = self._outputs(B, H, W)
+                j = min(B, i + max_b)
+                self._run(inp[i:j], fmt, j - i, H, W, outs=tuple(t[i:j] for t in outs))
+            return self._finish(outs, B, H, W)
         stream = torch.cuda.current_stream(self.device).cuda_stream
         args = [self._h, inp.data_ptr(), fmt, B, H, W] + [t.data_ptr() for t in outs] + [stream]
         if profile:
@@ -111,8 +108,13 @@ class HipTextDetBackend:
             self.last_op_ms = np.array(ms[:], dtype=np.float64)
         else:
             L.check(self._lib.ctd_engine_forward(*args), "ctd_engine_forward")
+        return None if part else self._finish(outs, B, H, W)
+
+    def _finish(self, outs, B: int, H: int, W: int):
+        self._last_bhw = (B, H, W)
         self.mask_u8, self.bitmap = outs[3], outs[4]
         if self.step_eval:
+            stream = torch.cuda.current_stream(self.device).cuda_stream
             step = torch.empty((B, 1, H, W), dtype=torch.float32, device=self.device)
             L.check(self._lib.ctd_db_step(outs[2].data_ptr(), B, H, W, self.db_k, step.data_ptr(), outs[4].data_ptr(),
                                           self.bitmap_thresh, stream), "ctd_db_step")

@@ -119,6 +119,21 @@ def test_determinism_and_batch_independence(prec):
         assert torch.equal(u[1:2], v), "page result depends on its batch neighbours"
 
 
+def test_sub_batches_write_into_one_output_set():
+    """Batches whose largest activation would pass the 32-bit offset range run as consecutive sub-batches
+    (B > 51 at 1024x1024); here the budget is shrunk so that B=5 at 128x192 splits into 2+2+1."""
+    be = backend("fp16")
+    x = gen_golden.make_input(12, (5, 128, 192)).cuda()
+    want = [t.clone() for t in be(x)]
+    want_side = (be.mask_u8.clone(), be.bitmap.clone())
+    be._offset_budget = 2 * 128 * 192 * 40
+    got = be(x)
+    torch.cuda.synchronize()
+    for u, v in zip(want, got):
+        assert u.shape == v.shape and torch.equal(u, v)
+    assert torch.equal(be.mask_u8, want_side[0]) and torch.equal(be.bitmap, want_side[1])
+
+
 def test_fp16_vs_oracle_mid_size_statistics():
     """512x512, B=2: error statistics of the MFMA path against the fp32 oracle."""
     ck = checkpoint(0)

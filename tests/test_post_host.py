@@ -256,3 +256,23 @@ def test_db_boxes_geometric_invariants_on_random_blobs():
         tarea = 0.5 * abs(np.dot(t[:, 0], np.roll(t[:, 1], -1)) - np.dot(t[:, 1], np.roll(t[:, 0], -1)))
         if not clipped:
             assert abs(tarea - area) <= 0.15 * area + 8
+
+
+def test_oracle_resize_geometry_against_torch_bilinear():
+    """Independent check of `cv_ref.resize_linear_u8`'s sampling geometry (half-pixel centres, edge clamp, up- and
+    down-scaling without anti-aliasing): torch's float bilinear `interpolate(align_corners=False)` implements the
+    same `src = (dst + 0.5) * scale - 0.5` convention in floating point, so the fixed-point result must agree with
+    it to within one grey level (the 11-bit coefficient rounding), on every pixel."""
+    import torch
+    import torch.nn.functional as F
+    from oracle import cv_ref
+    rng = np.random.RandomState(7)
+    for (sh, sw), (dh, dw) in [((37, 53), (74, 106)), ((64, 48), (1024, 768)), ((413, 292), (1024, 724)),
+                               ((300, 200), (77, 51)), ((96, 128), (95, 127)), ((50, 50), (50, 131))]:
+        img = rng.randint(0, 256, (sh, sw, 3)).astype(np.uint8)
+        got = cv_ref.resize_linear_u8(img, (dw, dh)).astype(np.int64)
+        t = torch.from_numpy(img).permute(2, 0, 1)[None].double()
+        want = F.interpolate(t, size=(dh, dw), mode="bilinear", align_corners=False, antialias=False)[0].permute(1, 2, 0)
+        diff = np.abs(got - np.rint(want.numpy()).astype(np.int64))
+        assert diff.max() <= 1, ((sh, sw), (dh, dw), int(diff.max()))
+        assert (diff > 0).mean() < 0.2

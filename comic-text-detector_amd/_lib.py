@@ -81,6 +81,7 @@ SYMBOLS = {
     "ctd_db_step": (_i32, [_vp, _i32, _i32, _i32, _f, _vp, _vp, _f, _vp]),
     "ctd_ccl_workspace_bytes": (C.c_size_t, [_i32, _i32, _i32]),
     "ctd_ccl": (_i32, [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _i32, _vp, C.c_size_t, _vp]),
+    "ctd_ccl_dual": (_i32, [_vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, C.c_size_t, _vp]),
     "ctd_resize_linear_u8": (_i32, [_vp, _i32, _i32, _i32, _vp, _i32, _i32, _i32, _i32, _vp]),
     "ctd_db_boxes": (_i32, [_vp, _vp, _vp, _i32, _vp, _vp, _i32, _i32, _i32, _i32, C.c_double, _vp, _vp, C.POINTER(_i32)]),
     "ctd_tail_create": (_i32, [C.POINTER(_vp), _i32]),

@@ -310,6 +310,32 @@ def connected_components(img: torch.Tensor, thresh: int = 0, connectivity: int =
     return labels, n, stats
 
 
+def connected_components_dual(img: torch.Tensor, thresh: int = 0, max_labels: int = 4096):
+    """Foreground (8-connected) and background (4-connected) components of (img > thresh) in one pass -- the two
+    labellings behind `cv2.findContours(bitmap, RETR_LIST)` (reference utils/db_utils.py:136).
+    Returns labels (B,H,W) i32 signed (+id foreground / -id background), (n_f, n_b), (stats_f, stats_b),
+    (first_f, first_b)."""
+    lib = L.lib()
+    if not img.is_cuda or img.dtype != torch.uint8:
+        raise L.CtdError("connected_components_dual: img must be a uint8 GPU tensor")
+    if img.dim() == 2:
+        img = img[None]
+    img = img.contiguous()
+    B, H, W = img.shape
+    dev = img.device
+    labels = torch.empty((B, H, W), dtype=torch.int32, device=dev)
+    n = [torch.empty((B,), dtype=torch.int32, device=dev) for _ in range(2)]
+    stats = [torch.empty((B, max_labels, 5), dtype=torch.int32, device=dev) for _ in range(2)]
+    first = [torch.empty((B, max_labels), dtype=torch.int32, device=dev) for _ in range(2)]
+    nbytes = lib.ctd_ccl_workspace_bytes(B, H, W)
+    ws = torch.empty((nbytes,), dtype=torch.uint8, device=dev)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    L.check(lib.ctd_ccl_dual(img.data_ptr(), B, H, W, thresh, labels.data_ptr(), n[0].data_ptr(), n[1].data_ptr(),
+                             stats[0].data_ptr(), stats[1].data_ptr(), first[0].data_ptr(), first[1].data_ptr(),
+                             max_labels, ws.data_ptr(), nbytes, stream), "ctd_ccl_dual")
+    return labels, tuple(n), tuple(stats), tuple(first)
+
+
 def resize_linear_u8(src: torch.Tensor, dst_hw, canvas_hw=None) -> torch.Tensor:
     """HIP replacement of cv2.resize(INTER_LINEAR) for uint8 (H,W) or (H,W,3) GPU tensors
     (reference utils/imgproc_utils.py:113, inference.py:165); with `canvas_hw` larger than

@@ -831,6 +831,19 @@ int ctd_ccl(const uint8_t* img_dev, int32_t B, int32_t H, int32_t W, int32_t thr
   return CTD_OK;
 }
 
+int ctd_ccl_dual(const uint8_t* img_dev, int32_t B, int32_t H, int32_t W, int32_t thresh, int32_t* labels_dev,
+                 int32_t* n_f_dev, int32_t* n_b_dev, int32_t* stats_f_dev, int32_t* stats_b_dev, int32_t* first_f_dev,
+                 int32_t* first_b_dev, int32_t max_labels, void* ws_dev, size_t ws_bytes, void* stream) {
+  if (!img_dev || !labels_dev || !n_f_dev || !n_b_dev || !stats_f_dev || !stats_b_dev || !first_f_dev || !first_b_dev || !ws_dev)
+    return fail(CTD_ERR_INVALID, "null pointer");
+  if (B < 1 || H < 1 || W < 1 || (long long)H * W >= (1LL << 30) || max_labels < 1) return fail(CTD_ERR_INVALID, "bad sizes");
+  if (ws_bytes < ccl_workspace_bytes(B, H, W)) return fail(CTD_ERR_INVALID, "workspace too small");
+  launch_ccl_dual(img_dev, B, H, W, thresh, labels_dev, n_f_dev, n_b_dev, stats_f_dev, stats_b_dev, first_f_dev, first_b_dev,
+                  max_labels, ws_dev, (hipStream_t)stream);
+  HIP_TRY(hipGetLastError());
+  return CTD_OK;
+}
+
 int ctd_resize_linear_u8(const uint8_t* src_dev, int32_t sH, int32_t sW, int32_t C, uint8_t* dst_dev, int32_t dH,
                          int32_t dW, int32_t canvasH, int32_t canvasW, void* stream) {
   if (!src_dev || !dst_dev) return fail(CTD_ERR_INVALID, "null pointer");

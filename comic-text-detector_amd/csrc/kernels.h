@@ -74,6 +74,10 @@ size_t ccl_workspace_bytes(int B, int H, int W);
 // in raster order (= its union-find root), or null
 void launch_ccl(const uint8_t* img, int B, int H, int W, int thresh, int conn, int* labels, int* n_out,
                 int* stats, int max_labels, void* ws, hipStream_t st, int invert = 0, int* first = nullptr);
+// Foreground (img > thresh, 8-connected) and background (4-connected) components in one union-find:
+// labels (B,H,W) signed (+id / -id, per-class raster order), n / stats / first per class, same workspace.
+void launch_ccl_dual(const uint8_t* img, int B, int H, int W, int thresh, int* labels, int* n_f, int* n_b, int* st_f,
+                     int* st_b, int* first_f, int* first_b, int max_labels, void* ws, hipStream_t st);
 
 // ---- kernels_pre.hip ----------------------------------------------------------
 // cv2.resize(INTER_LINEAR) u8 (C = 1 or 3) into the top-left (dH,dW) of a zero-padded canvas

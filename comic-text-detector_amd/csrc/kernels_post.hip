@@ -542,6 +542,301 @@ __global__ void ccl_stats_final_kernel(int* __restrict__ stats, const int* __res
   }
 }
 
+// ======================================================================================================
+// Dual labelling: the 8-connected components of the FOREGROUND (img > thresh) and the 4-connected components
+// of the BACKGROUND of one image in ONE union-find.  The DB stage needs both (cv2.findContours(RETR_LIST)
+// yields a contour per foreground component and per enclosed background region); the two pixel sets are
+// disjoint, so one parent array, one border merge, one flattening, one ranking sweep and one label pass serve
+// both -- the two separate launches read and wrote every int32 plane twice.  Output: ONE signed label image
+// (+id foreground, -id background, ids per class in raster order of the first pixel) and per-class stats.
+// ======================================================================================================
+__global__ __launch_bounds__(256) void ccl2_local_kernel(const uint8_t* __restrict__ img, int* __restrict__ parent_all,
+                                                         int H, int W, int tiles_x, int tiles_y, int thresh) {
+  __shared__ int lp[CT * CT];
+  __shared__ unsigned mrow[2][CT];                 // row masks: [0] foreground, [1] background (pixels inside the image)
+  int bid = blockIdx.x;
+  const int tx = bid % tiles_x;
+  bid /= tiles_x;
+  const int ty = bid % tiles_y;
+  const int b = bid / tiles_y;
+  const size_t base = (size_t)b * H * W;
+  const int x0 = tx * CT, y0 = ty * CT;
+  const int lane = threadIdx.x & 63;
+  const int lx = threadIdx.x & 31;
+#pragma unroll
+  for (int k = 0; k < CT * CT / 256; ++k) {
+    const int li = threadIdx.x + 256 * k;
+    const int ly = li >> 5;
+    const int gx = x0 + lx, gy = y0 + ly;
+    const bool valid = gx < W && gy < H;
+    const bool fg = valid && (int)img[base + (size_t)gy * W + gx] > thresh;
+    const unsigned long long balf = __ballot(fg), balv = __ballot(valid);
+    const unsigned mf = (unsigned)(lane < 32 ? balf : balf >> 32);
+    const unsigned mv = (unsigned)(lane < 32 ? balv : balv >> 32);
+    const unsigned mb = mv & ~mf;
+    const unsigned mine = fg ? mf : mb;
+    const unsigned below = ~mine & ((1u << lx) - 1u);
+    const int start = below ? 32 - __clz(below) : 0;
+    lp[li] = valid ? (ly << 5) + start : -1;
+    if (lx == 0) mrow[0][ly] = mf, mrow[1][ly] = mb;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < CT * CT / 256; ++k) {
+    const int li = threadIdx.x + 256 * k;
+    const int ly = li >> 5;
+    if (ly == 0) continue;
+    const int cls = ((mrow[0][ly] >> lx) & 1u) ? 0 : 1;
+    const unsigned m = mrow[cls][ly], ma = mrow[cls][ly - 1];
+    if (!((m >> lx) & 1u) || (lx > 0 && ((m >> (lx - 1)) & 1u))) continue;   // heads of this class's runs only
+    const unsigned from = m >> lx;
+    const int len = (~from) ? __ffs(~from) - 1 : 32 - lx;
+    unsigned run = (len >= 32 ? 0xffffffffu : ((1u << len) - 1u)) << lx;
+    if (cls == 0) run |= (run << 1) | (run >> 1);                            // foreground: 8-connected
+    unsigned ov = ma & run;
+    while (ov) {
+      const int bpos = __ffs(ov) - 1;
+      const unsigned belowa = ~ma & ((1u << bpos) - 1u);
+      const int sa = belowa ? 32 - __clz(belowa) : 0;
+      lds_union(lp, li, ((ly - 1) << 5) + sa);
+      const unsigned froma = ma >> bpos;
+      const int lena = (~froma) ? __ffs(~froma) - 1 : 32 - bpos;
+      ov &= ~((lena >= 32 ? 0xffffffffu : ((1u << lena) - 1u)) << bpos);
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < CT * CT / 256; ++k) {
+    const int li = threadIdx.x + 256 * k;
+    const int gx = x0 + lx, gy = y0 + (li >> 5);
+    if (gx >= W || gy >= H) continue;
+    const int r = lds_find(lp, lp[li]);
+    parent_all[base + (size_t)gy * W + gx] = (y0 + (r >> 5)) * W + x0 + (r & 31);
+  }
+}
+
+// Border links of both classes (pruned to one link per pair of overlapping runs, see ccl_border_*_kernel):
+// foreground pixels follow the 8-connected rules, background pixels the 4-connected ones.
+__global__ __launch_bounds__(256) void ccl2_border_h_kernel(int* __restrict__ parent_all, const uint8_t* __restrict__ img_all,
+                                                            int thresh, int H, int W) {
+  const int x = blockIdx.x * 256 + threadIdx.x;
+  const int y = CT * (blockIdx.y + 1);
+  if (x >= W || y >= H) return;
+  int* parent = parent_all + (size_t)blockIdx.z * H * W;
+  const uint8_t* img = img_all + (size_t)blockIdx.z * H * W;
+  const int p = y * W + x;
+  const bool me = (int)img[p] > thresh;
+  auto same = [&](int q) { return ((int)img[q] > thresh) == me; };
+  const bool q = x > 0 && same(p - 1);
+  const bool up = same(p - W);
+  const bool ul = x > 0 && same(p - W - 1);
+  if (!me) {                                      // background: 4-connected
+    if (up && !(q && ul)) uf_union(parent, p, p - W);
+    return;
+  }
+  const bool ur = x + 1 < W && same(p - W + 1);
+  if (q) {
+    if (ur && !up) uf_union(parent, p, p - W + 1);
+  } else if (up) {
+    uf_union(parent, p, p - W);
+  } else {
+    if (ul) uf_union(parent, p, p - W - 1);
+    if (ur) uf_union(parent, p, p - W + 1);
+  }
+}
+
+__global__ __launch_bounds__(256) void ccl2_border_v_kernel(int* __restrict__ parent_all, const uint8_t* __restrict__ img_all,
+                                                            int thresh, int H, int W) {
+  const int y = blockIdx.x * 256 + threadIdx.x;
+  const int x = CT * (blockIdx.y + 1);
+  if (y >= H || x >= W) return;
+  int* parent = parent_all + (size_t)blockIdx.z * H * W;
+  const uint8_t* img = img_all + (size_t)blockIdx.z * H * W;
+  const int p = y * W + x;
+  const bool ua = y > 0, same_tile = (y % CT) != 0;
+  const bool fme = (int)img[p] > thresh, fleft = (int)img[p - 1] > thresh;
+  const bool fmu = ua && (int)img[p - W] > thresh, flu = ua && (int)img[p - W - 1] > thresh;
+  // background, 4-connected: only the horizontal pair
+  {
+    const bool me = !fme, left = !fleft, mu = ua && !fmu, lu = ua && !flu;
+    if (me && left && !(same_tile && mu && lu)) uf_union(parent, p, p - 1);
+  }
+  // foreground, 8-connected
+  {
+    const bool me = fme, left = fleft, mu = fmu, lu = flu;
+    if (!me && !left) return;
+    if (!same_tile) {
+      if (me && left) uf_union(parent, p, p - 1);
+      if (me && lu) uf_union(parent, p, p - W - 1);
+      if (left && mu) uf_union(parent, p - 1, p - W);
+      return;
+    }
+    if (me && left && !(mu && lu)) uf_union(parent, p, p - 1);
+    if (me && lu && !left && !mu) uf_union(parent, p, p - W - 1);
+    if (left && mu && !me && !lu) uf_union(parent, p - 1, p - W);
+  }
+}
+
+// chunk_cnt: (B, 2, nchunks) -- class 0 = foreground roots, 1 = background roots
+__global__ __launch_bounds__(256) void ccl2_flatten_count_kernel(int* __restrict__ parent_all, const uint8_t* __restrict__ img_all,
+                                                                 int thresh, int hw, int nchunks, int* __restrict__ chunk_cnt) {
+  __shared__ int sh[4];
+  const int b = blockIdx.x / nchunks, ch = blockIdx.x % nchunks;
+  int* parent = parent_all + (size_t)b * hw;
+  const uint8_t* img = img_all + (size_t)b * hw;
+  const int p0 = ch * RK_CHUNK + threadIdx.x;
+  int lf = 0, lb = 0;
+#pragma unroll 4
+  for (int j = 0; j < RK_PER_T; ++j) {
+    const int p = p0 + 256 * j;
+    if (p < hw) {
+      const int v = parent[p];
+      const int r = uf_find(parent, p);
+      if (r != v) parent[p] = r;
+      if (r == p) {
+        if ((int)img[p] > thresh) ++lf; else ++lb;
+      }
+    }
+  }
+  int tf, tb;
+  block_exclusive_scan(lf, sh, &tf);
+  block_exclusive_scan(lb, sh, &tb);
+  if (threadIdx.x == 0) {
+    chunk_cnt[((size_t)b * 2 + 0) * nchunks + ch] = tf;
+    chunk_cnt[((size_t)b * 2 + 1) * nchunks + ch] = tb;
+  }
+}
+
+// one block per (image, class): exclusive scan of that class's chunk counts; the totals go to n_f / n_b
+__global__ __launch_bounds__(256) void ccl2_scan_chunks_kernel(int* __restrict__ chunk_cnt, int nchunks, int* __restrict__ n_f,
+                                                               int* __restrict__ n_b) {
+  __shared__ int sh[4];
+  int* c = chunk_cnt + (size_t)blockIdx.x * nchunks;
+  int carry = 0;
+  for (int base = 0; base < nchunks; base += 256) {
+    const int i = base + threadIdx.x;
+    const int v = i < nchunks ? c[i] : 0;
+    int total;
+    const int excl = block_exclusive_scan(v, sh, &total);
+    if (i < nchunks) c[i] = carry + excl;
+    carry += total;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) ((blockIdx.x & 1) ? n_b : n_f)[blockIdx.x >> 1] = carry;
+}
+
+// ids: +rank for a foreground root, -rank for a background root (ranks per class, raster order)
+__global__ __launch_bounds__(256) void ccl2_rank_kernel(const int* __restrict__ parent_all, const uint8_t* __restrict__ img_all,
+                                                        int thresh, int hw, int nchunks, const int* __restrict__ chunk_cnt,
+                                                        int* __restrict__ ids_all, int* __restrict__ first_f,
+                                                        int* __restrict__ first_b, int max_labels) {
+  __shared__ int sh[2][4];
+  const int b = blockIdx.x / nchunks, ch = blockIdx.x % nchunks;
+  const int* parent = parent_all + (size_t)b * hw;
+  const uint8_t* img = img_all + (size_t)b * hw;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int base = ch * RK_CHUNK + w * 1024 + lane;
+  unsigned long long mf[16], mb[16];
+  int cf = 0, cb = 0;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    const int p = base + 64 * j;
+    const bool root = p < hw && parent[p] == p;
+    const bool fg = root && (int)img[p] > thresh;
+    mf[j] = __ballot(fg);
+    mb[j] = __ballot(root && !fg);
+    cf += __popcll(mf[j]);
+    cb += __popcll(mb[j]);
+  }
+  if (lane == 0) sh[0][w] = cf, sh[1][w] = cb;
+  __syncthreads();
+  int idf = chunk_cnt[((size_t)b * 2 + 0) * nchunks + ch], idb = chunk_cnt[((size_t)b * 2 + 1) * nchunks + ch];
+  for (int i = 0; i < w; ++i) idf += sh[0][i], idb += sh[1][i];
+  int* ids = ids_all + (size_t)b * hw;
+  const unsigned long long below = lane ? (~0ull >> (64 - lane)) : 0ull;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    const int p = base + 64 * j;
+    if ((mf[j] >> lane) & 1ull) {
+      const int id = idf + __popcll(mf[j] & below) + 1;
+      ids[p] = id;
+      if (id <= max_labels) first_f[(size_t)b * max_labels + id - 1] = p;
+    } else if ((mb[j] >> lane) & 1ull) {
+      const int id = idb + __popcll(mb[j] & below) + 1;
+      ids[p] = -id;
+      if (id <= max_labels) first_b[(size_t)b * max_labels + id - 1] = p;
+    }
+    idf += __popcll(mf[j]);
+    idb += __popcll(mb[j]);
+  }
+}
+
+// signed final labels + the statistics of both classes (aggregation as in ccl_label_kernel)
+__global__ __launch_bounds__(256) void ccl2_label_kernel(int* __restrict__ labels_all, const int* __restrict__ ids_all, int B, int H,
+                                                         int W, int chunks, int* __restrict__ st_f, int* __restrict__ st_b,
+                                                         int max_labels) {
+  constexpr int EMPTY = (int)0x80000000;
+  __shared__ int hkey[LB_SLOTS];
+  __shared__ int hst[LB_SLOTS * 5];
+  const int hw = H * W;
+  const int b = blockIdx.x / chunks, ch = blockIdx.x % chunks;
+  const int p_begin = ch * LB_CHUNK, p_end = min(hw, p_begin + LB_CHUNK);
+  const size_t base = (size_t)b * hw;
+  for (int s = threadIdx.x; s < LB_SLOTS; s += 256) {
+    hkey[s] = EMPTY;
+    hst[5 * s] = W, hst[5 * s + 1] = H, hst[5 * s + 2] = -1, hst[5 * s + 3] = -1, hst[5 * s + 4] = 0;
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  auto row_of = [&](int id) { return (id > 0 ? st_f : st_b) + ((size_t)b * max_labels + ((id > 0 ? id : -id) - 1)) * 5; };
+  for (int p0 = p_begin; p0 < p_end; p0 += 256) {
+    const int p = p0 + threadIdx.x;
+    const bool live = p < p_end;
+    int id = 0;                                             // 0 = dead lane (every pixel has a class, so no real id is 0)
+    if (live) {
+      id = ids_all[base + labels_all[base + p]];
+      labels_all[base + p] = id;
+    }
+    const int x = live ? p % W : 0, y = live ? p / W : 0;
+    const int prev = __shfl_up(id, 1);
+    const bool head = lane == 0 || prev != id || x == 0;
+    const unsigned long long heads = __ballot(head);
+    const int mag = id > 0 ? id : -id;
+    if (head && id != 0 && mag <= max_labels) {
+      const unsigned long long later = lane == 63 ? 0ull : (heads >> (lane + 1));
+      const int len = later ? __ffsll((long long)later) : 64 - lane;
+      int slot = -1;
+      const unsigned hsh = ((unsigned)id * 2654435761u) >> 25;    // 7 bits
+      for (int probe = 0; probe < 4; ++probe) {
+        const int sidx = (hsh + probe) & (LB_SLOTS - 1);
+        const int old = atomicCAS(&hkey[sidx], EMPTY, id);
+        if (old == EMPTY || old == id) {
+          slot = sidx;
+          break;
+        }
+      }
+      int* s = slot >= 0 ? hst + 5 * slot : row_of(id);
+      atomicMin(s + 0, x);
+      atomicMin(s + 1, y);
+      atomicMax(s + 2, x + len - 1);
+      atomicMax(s + 3, y);
+      atomicAdd(s + 4, len);
+    }
+  }
+  __syncthreads();
+  for (int sl = threadIdx.x; sl < LB_SLOTS; sl += 256) {
+    const int id = hkey[sl];
+    if (id == EMPTY) continue;
+    int* s = row_of(id);
+    atomicMin(s + 0, hst[5 * sl]);
+    atomicMin(s + 1, hst[5 * sl + 1]);
+    atomicMax(s + 2, hst[5 * sl + 2]);
+    atomicMax(s + 3, hst[5 * sl + 3]);
+    atomicAdd(s + 4, hst[5 * sl + 4]);
+  }
+}
+
+
 inline int grid_for(long long total, int block = 256) {
   long long g = (total + block - 1) / block;
   if (g > 256LL * 32) g = 256LL * 32;
@@ -575,7 +870,7 @@ void launch_nms(const float* blks, int B, int rows, int no, float conf, float io
 size_t ccl_workspace_bytes(int B, int H, int W) {
   const size_t hw = (size_t)H * W;
   const size_t nchunks = (hw + RK_CHUNK - 1) / RK_CHUNK;
-  return (size_t)B * hw * sizeof(int) + (size_t)B * nchunks * sizeof(int) + 512;
+  return (size_t)B * hw * sizeof(int) + 2 * (size_t)B * nchunks * sizeof(int) + 512;   // ids + chunk counts (two planes for launch_ccl_dual)
 }
 
 void launch_ccl(const uint8_t* img, int B, int H, int W, int thresh, int conn, int* labels, int* n_out, int* stats,
@@ -604,4 +899,31 @@ void launch_ccl(const uint8_t* img, int B, int H, int W, int thresh, int conn, i
   const int lchunks = (hw + LB_CHUNK - 1) / LB_CHUNK;
   hipLaunchKernelGGL(ccl_label_kernel, dim3(B * lchunks), dim3(256), 0, st, labels, ids, B, H, W, lchunks, stats, max_labels);
   if (stats) hipLaunchKernelGGL(ccl_stats_final_kernel, dim3(sgrid, B), dim3(256), 0, st, stats, n_out, max_labels);
+}
+
+void launch_ccl_dual(const uint8_t* img, int B, int H, int W, int thresh, int* labels, int* n_f, int* n_b, int* st_f,
+                     int* st_b, int* first_f, int* first_b, int max_labels, void* ws, hipStream_t st) {
+  const int hw = H * W;
+  const long long total = (long long)B * hw;
+  const int nchunks = (hw + RK_CHUNK - 1) / RK_CHUNK;
+  int* ids = (int*)ws;
+  int* chunk_cnt = (int*)((char*)ws + ((size_t)total * sizeof(int) + 255) / 256 * 256);   // (B, 2, nchunks)
+  const int tiles_x = (W + CT - 1) / CT, tiles_y = (H + CT - 1) / CT;
+  hipLaunchKernelGGL(ccl2_local_kernel, dim3(B * tiles_x * tiles_y), dim3(256), 0, st, img, labels, H, W, tiles_x, tiles_y,
+                     thresh);
+  const int nh = (H - 1) / CT, nv = (W - 1) / CT;
+  if (nh > 0) hipLaunchKernelGGL(ccl2_border_h_kernel, dim3((W + 255) / 256, nh, B), dim3(256), 0, st, labels, img, thresh, H, W);
+  if (nv > 0) hipLaunchKernelGGL(ccl2_border_v_kernel, dim3((H + 255) / 256, nv, B), dim3(256), 0, st, labels, img, thresh, H, W);
+  hipLaunchKernelGGL(ccl2_flatten_count_kernel, dim3(B * nchunks), dim3(256), 0, st, labels, img, thresh, hw, nchunks, chunk_cnt);
+  hipLaunchKernelGGL(ccl2_scan_chunks_kernel, dim3(2 * B), dim3(256), 0, st, chunk_cnt, nchunks, n_f, n_b);
+  hipLaunchKernelGGL(ccl2_rank_kernel, dim3(B * nchunks), dim3(256), 0, st, labels, img, thresh, hw, nchunks, chunk_cnt, ids,
+                     first_f, first_b, max_labels);
+  const int sgrid = std::max(1, std::min(64, (max_labels + 255) / 256));
+  hipLaunchKernelGGL(ccl_stats_init_kernel, dim3(sgrid, B), dim3(256), 0, st, st_f, n_f, max_labels, H, W);
+  hipLaunchKernelGGL(ccl_stats_init_kernel, dim3(sgrid, B), dim3(256), 0, st, st_b, n_b, max_labels, H, W);
+  const int lchunks = (hw + LB_CHUNK - 1) / LB_CHUNK;
+  hipLaunchKernelGGL(ccl2_label_kernel, dim3(B * lchunks), dim3(256), 0, st, labels, ids, B, H, W, lchunks, st_f, st_b,
+                     max_labels);
+  hipLaunchKernelGGL(ccl_stats_final_kernel, dim3(sgrid, B), dim3(256), 0, st, st_f, n_f, max_labels);
+  hipLaunchKernelGGL(ccl_stats_final_kernel, dim3(sgrid, B), dim3(256), 0, st, st_b, n_b, max_labels);
 }

@@ -35,13 +35,13 @@ __global__ __launch_bounds__(256) void dbc_prep_kernel(DbcTables t) {
   const size_t r = (size_t)b * t.cap + l;
   if (l < nf) {
     const int p = t.first_f[r];
-    t.par_f[r] = (p % t.W) > 0 ? t.lab_b[(size_t)b * hw + p - 1] : 0;
+    t.par_f[r] = (p % t.W) > 0 ? max(-t.lab[(size_t)b * hw + p - 1], 0) : 0;
     t.off_f[r] = t.st_f[r * 5 + 3];
   }
   if (l < nb) {
     const int* s = t.st_b + r * 5;
     const bool hole = s[0] > 0 && s[1] > 0 && s[0] + s[2] < t.W && s[1] + s[3] < t.H;   // does not touch the frame
-    t.par_b[r] = hole ? t.lab_f[(size_t)b * hw + t.first_b[r] - 1] : 0;
+    t.par_b[r] = hole ? max(t.lab[(size_t)b * hw + t.first_b[r] - 1], 0) : 0;
     t.off_b[r] = hole ? s[3] + 2 : 0;
   }
 }
@@ -105,8 +105,8 @@ __global__ __launch_bounds__(256) void dbc_accum_kernel(DbcTables t) {
     const bool live = p0 + (int)threadIdx.x < hw;
     const long long i = (long long)b * hw + p;
     const int x = p % t.W, y = p / t.W;
-    const int lf = live ? t.lab_f[i] : 0, lb = live ? t.lab_b[i] : 0;
-    const int key = lf > 0 ? lf : -lb;
+    const int key = live ? t.lab[i] : 0;                  // +foreground id / -background id
+    const int lf = max(key, 0), lb = max(-key, 0);
     // Most waves see only page background (a complement component that is no hole): nothing to add, and
     // the f64 scan below (14 cross-lane moves) is what this kernel's time goes into.
     const size_t cb = (size_t)b * t.cap, rb = (size_t)b * t.rcap;
@@ -143,7 +143,7 @@ __global__ __launch_bounds__(256) void dbc_accum_kernel(DbcTables t) {
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         if (!ok[k]) continue;
-        const int hb = t.lab_b[i + dq[k]];
+        const int hb = -t.lab[i + dq[k]];
         if (hb <= 0 || hb > t.cap || t.par_b[cb + hb - 1] != lf) continue;
         bool dup = false;
         for (int j = 0; j < ns; ++j) dup |= seen[j] == hb;

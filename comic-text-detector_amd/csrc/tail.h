@@ -4,15 +4,14 @@
 #include "ctd_common.h"
 
 // ---- DB text-line stage: per-contour tables compacted on the device ---------------------------------
-// Inputs: the two labelling passes of a page batch (8-connected foreground of the bitmap, 4-connected
-// background) with per-component stats and first pixels.  Outputs per page, fixed capacities `cap`
+// Inputs: the dual labelling of a page batch (8-connected foreground of the bitmap, 4-connected
+// background, one signed label image) with per-component stats and first pixels.  Outputs per page, fixed capacities `cap`
 // (components per polarity) and `rcap` (row-table entries):
 struct DbcTables {
   int B, H, W, cap, rcap;
   const float* prob;          // (B) planes of H*W f32, plane b at prob + b * prob_stride
   long long prob_stride;
-  const int* lab_f;           // (B,H,W) labels of the foreground pass
-  const int* lab_b;           // (B,H,W) labels of the background pass
+  const int* lab;             // (B,H,W) signed labels of launch_ccl_dual: +id foreground component, -id background region
   const int* n_f;             // (B)
   const int* n_b;             // (B)
   const int* st_f;            // (B,cap,5) [x,y,w,h,area]

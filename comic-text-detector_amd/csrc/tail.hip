@@ -135,7 +135,7 @@ struct ctd_tail {
   int device = 0;
   hipStream_t st = nullptr;
   // device
-  DevBuf d_dets, d_nms_ws, d_lab_f, d_lab_b, d_ccl_ws, d_ccl_small, d_dbc_i, d_dbc_d, d_rows, d_pmask, d_refined;
+  DevBuf d_dets, d_nms_ws, d_lab_f, d_ccl_ws, d_ccl_small, d_dbc_i, d_dbc_d, d_rows, d_pmask, d_refined;
   DevBuf d_wins, d_rules, d_bands, d_hist, d_sums, d_canvas, d_clab, d_cstats, d_cnt, d_merged, d_mlab, d_mstats, d_cnt2, d_small, d_crop;
   // pinned host
   PinBuf h_dets, h_hdr, h_tab, h_pmask, h_refined, h_hist, h_sums, h_wins, h_rules, h_bands, h_small, h_lab;
@@ -434,7 +434,7 @@ struct DbStage {
   int B = 0, Hn = 0, Wn = 0;
   const float* prob = nullptr;
   long long prob_stride = 0;
-  int *lab_f = nullptr, *lab_b = nullptr, *n_f = nullptr, *n_b = nullptr, *st_f = nullptr, *st_b = nullptr;
+  int *lab = nullptr, *n_f = nullptr, *n_b = nullptr, *st_f = nullptr, *st_b = nullptr;
   int *first_f = nullptr, *first_b = nullptr, *par_f = nullptr, *par_b = nullptr, *off_f = nullptr, *off_b = nullptr;
   int *hdr = nullptr, *ring_cnt = nullptr, *row_lo = nullptr, *row_hi = nullptr;
   double *sum_f = nullptr, *sum_b = nullptr, *ring_sum = nullptr;
@@ -447,13 +447,12 @@ int db_enqueue(ctd_tail* t, DbStage& d, int B, int Hn, int Wn, const float* prob
   const size_t hw = (size_t)Hn * Wn;
   const int cap = kCompCap, rcap = kRowCap;
   d.B = B, d.Hn = Hn, d.Wn = Wn, d.prob = prob_dev, d.prob_stride = prob_stride;
-  GET(t->d_lab_f, (size_t)B * hw * 4, int, lab_f);
-  GET(t->d_lab_b, (size_t)B * hw * 4, int, lab_b);
+  GET(t->d_lab_f, (size_t)B * hw * 4, int, lab);
   GET(t->d_ccl_ws, ccl_workspace_bytes(B, Hn, Wn), uint8_t, ccl_ws);
   // int tables: n_f, n_b (B each) | st_f, st_b (B,cap,5) | first, par, off x2 (B,cap) | hdr (B,4) | ring_cnt (B,cap)
   const size_t bc = (size_t)B * cap;
   GET(t->d_dbc_i, (2 * (size_t)B + 10 * bc + 6 * bc + 4 * (size_t)B + bc) * 4, int, ti);
-  d.lab_f = lab_f, d.lab_b = lab_b;
+  d.lab = lab;
   d.n_f = ti;
   d.n_b = d.n_f + B;
   d.st_f = d.n_b + B;
@@ -470,14 +469,14 @@ int db_enqueue(ctd_tail* t, DbStage& d, int B, int Hn, int Wn, const float* prob
   d.sum_f = td, d.sum_b = td + bc, d.ring_sum = td + 2 * bc;
   GET(t->d_rows, 2 * (size_t)B * rcap * 4, int, rows);
   d.row_lo = rows, d.row_hi = rows + (size_t)B * rcap;
-  launch_ccl(bitmap_dev, B, Hn, Wn, 0, 8, lab_f, d.n_f, d.st_f, cap, ccl_ws, st, 0, d.first_f);
-  launch_ccl(bitmap_dev, B, Hn, Wn, 0, 4, lab_b, d.n_b, d.st_b, cap, ccl_ws, st, 1, d.first_b);
+  // foreground 8-connected + background 4-connected components in one pass: signed label image
+  launch_ccl_dual(bitmap_dev, B, Hn, Wn, 0, lab, d.n_f, d.n_b, d.st_f, d.st_b, d.first_f, d.first_b, cap, ccl_ws, st);
   T_TRY(hipMemsetAsync(td, 0, 3 * bc * 8, st));
   T_TRY(hipMemsetAsync(d.ring_cnt, 0, bc * 4, st));
   DbcTables dt;
   dt.B = B, dt.H = Hn, dt.W = Wn, dt.cap = cap, dt.rcap = rcap;
   dt.prob = prob_dev, dt.prob_stride = prob_stride;
-  dt.lab_f = lab_f, dt.lab_b = lab_b, dt.n_f = d.n_f, dt.n_b = d.n_b, dt.st_f = d.st_f, dt.st_b = d.st_b;
+  dt.lab = lab, dt.n_f = d.n_f, dt.n_b = d.n_b, dt.st_f = d.st_f, dt.st_b = d.st_b;
   dt.first_f = d.first_f, dt.first_b = d.first_b, dt.par_f = d.par_f, dt.par_b = d.par_b, dt.off_f = d.off_f;
   dt.off_b = d.off_b, dt.hdr = d.hdr, dt.row_lo = d.row_lo, dt.row_hi = d.row_hi, dt.sum_f = d.sum_f, dt.sum_b = d.sum_b;
   dt.ring_sum = d.ring_sum, dt.ring_cnt = d.ring_cnt;
@@ -580,10 +579,14 @@ int db_collect(ctd_tail* t, const DbStage& d, const ctd_tail_params* prm) {
       int nfb[2];
       T_TRY(hipMemcpyAsync(nfb, d.n_f + b, 4, hipMemcpyDeviceToHost, st));
       T_TRY(hipMemcpyAsync(nfb + 1, d.n_b + b, 4, hipMemcpyDeviceToHost, st));
-      T_TRY(hipMemcpyAsync(lab_host_f.data(), d.lab_f + (size_t)b * hw, hw * 4, hipMemcpyDeviceToHost, st));
-      T_TRY(hipMemcpyAsync(lab_host_b.data(), d.lab_b + (size_t)b * hw, hw * 4, hipMemcpyDeviceToHost, st));
+      T_TRY(hipMemcpyAsync(lab_host_f.data(), d.lab + (size_t)b * hw, hw * 4, hipMemcpyDeviceToHost, st));
       T_TRY(hipMemcpyAsync(prob_h.data(), d.prob + (size_t)b * d.prob_stride, hw * 4, hipMemcpyDeviceToHost, st));
       T_TRY(hipStreamSynchronize(st));
+      for (size_t i = 0; i < hw; ++i) {            // split the signed image into the two label images ctd_db_boxes takes
+        const int32_t l = lab_host_f[i];
+        lab_host_f[i] = l > 0 ? l : 0;
+        lab_host_b[i] = l < 0 ? -l : 0;
+      }
       // stats beyond `cap` rows were dropped on the device: recompute them from the labels
       std::vector<int32_t> sf((size_t)nfb[0] * 5), sb((size_t)nfb[1] * 5);
       auto stats_of = [&](const std::vector<int32_t>& lab, std::vector<int32_t>& s, int n) {
@@ -641,7 +644,7 @@ void ctd_tail_destroy(ctd_tail* t) {
     (void)hipStreamSynchronize(t->st);
     (void)hipStreamDestroy(t->st);
   }
-  DevBuf* dv[] = {&t->d_dets, &t->d_nms_ws, &t->d_lab_f, &t->d_lab_b, &t->d_ccl_ws, &t->d_ccl_small, &t->d_dbc_i, &t->d_dbc_d,
+  DevBuf* dv[] = {&t->d_dets, &t->d_nms_ws, &t->d_lab_f, &t->d_ccl_ws, &t->d_ccl_small, &t->d_dbc_i, &t->d_dbc_d,
                   &t->d_rows, &t->d_pmask, &t->d_refined, &t->d_wins, &t->d_rules, &t->d_bands, &t->d_hist, &t->d_sums,
                   &t->d_canvas, &t->d_clab, &t->d_cstats, &t->d_cnt, &t->d_merged, &t->d_mlab, &t->d_mstats, &t->d_cnt2,
                   &t->d_small, &t->d_crop};

@@ -196,6 +196,18 @@ int ctd_ccl(const uint8_t* img_dev, int32_t B, int32_t H, int32_t W, int32_t thr
             int32_t connectivity, int32_t* labels_dev, int32_t* n_dev, int32_t* stats_dev,
             int32_t max_labels, void* ws_dev, size_t ws_bytes, void* stream);
 
+/* Both labellings `SegDetectorRepresenter.boxes_from_bitmap` needs (reference utils/db_utils.py:134-136:
+ * `cv2.findContours(bitmap, RETR_LIST)` = one contour per 8-connected foreground component and per enclosed
+ * 4-connected background region) in ONE union-find over the image:
+ *   labels_dev : (B, H, W) i32 signed: +id = foreground component (img > thresh, 8-connected),
+ *                -id = background region (4-connected); ids per class in raster order of the first pixel
+ *   n_f / n_b  : (B) counts; stats_f / stats_b : (B, max_labels, 5) as ctd_ccl; first_f / first_b :
+ *                (B, max_labels) linear index of each component's first pixel
+ * Label for label what ctd_ccl(img, connectivity 8) and ctd_ccl(complement of img, connectivity 4) give. */
+int ctd_ccl_dual(const uint8_t* img_dev, int32_t B, int32_t H, int32_t W, int32_t thresh, int32_t* labels_dev,
+                 int32_t* n_f_dev, int32_t* n_b_dev, int32_t* stats_f_dev, int32_t* stats_b_dev, int32_t* first_f_dev,
+                 int32_t* first_b_dev, int32_t max_labels, void* ws_dev, size_t ws_bytes, void* stream);
+
 /* `DBHead.step_function` (reference basemodel.py:159-160), the differentiable binarisation
  * 1 / (1 + exp(-k (P - T))) of the shrink map P and the threshold map T = the two planes of `lines_map`
  * (B,2,H,W); out (B,1,H,W) f32 is what `DBHead.forward(step_eval=True)` returns (basemodel.py:121-122);

@@ -99,6 +99,32 @@ def test_ccl_dense_noise(conn, shape):
         np.testing.assert_array_equal(stats[b, : nref - 1].cpu().numpy(), sref[1:])
 
 
+@pytest.mark.parametrize("shape", [(64, 64), (257, 131), (1024, 1024)])
+def test_ccl_dual_equals_the_two_separate_labellings(shape):
+    """`ctd_ccl_dual`: 8-connected foreground and 4-connected background components in one union-find, label for
+    label what scipy gives for the image and for its complement (ids, stats, first pixels, raster order)."""
+    rng = np.random.RandomState(shape[1])
+    noise = [(rng.uniform(size=shape) < d).astype(np.uint8) * 255 for d in (0.1, 0.45, 0.8)]
+    noise[2][::32] = 255
+    noise[1][:, 31::32] = 0
+    imgs = np.stack([blobs(rng, *shape, 60)] + noise + [np.zeros(shape, np.uint8), np.full(shape, 255, np.uint8)])
+    cap = 1 << 17
+    labels, (n_f, n_b), (st_f, st_b), (fi_f, fi_b) = pkg().backend.connected_components_dual(
+        torch.from_numpy(imgs).cuda(), 0, max_labels=cap)
+    torch.cuda.synchronize()
+    lab = labels.cpu().numpy()
+    for b in range(len(imgs)):
+        for sign, img, conn, n, st, fi in ((1, imgs[b], 8, n_f, st_f, fi_f), (-1, np.where(imgs[b] > 0, 0, 255).astype(np.uint8), 4, n_b, st_b, fi_b)):
+            nref, lref, sref = R.connected_components_with_stats(img, conn)
+            assert int(n[b]) == nref - 1
+            np.testing.assert_array_equal(np.maximum(sign * lab[b], 0), lref)
+            np.testing.assert_array_equal(st[b, : nref - 1].cpu().numpy(), sref[1:])
+            firsts = fi[b, : nref - 1].cpu().numpy()
+            flat = lref.ravel()
+            assert np.array_equal(flat[firsts], np.arange(1, nref))                     # a pixel of every component ...
+            assert all(not (flat[:f] == l + 1).any() for l, f in list(enumerate(firsts))[:50])   # ... and its first one
+
+
 def test_ccl_threshold_semantics():
     """foreground = img > thresh (reference textmask.py:137: threshold(mask, 30, 255, BINARY) then CC)."""
     rng = np.random.RandomState(5)

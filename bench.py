@@ -268,6 +268,10 @@ def main() -> None:
                          "hipGraph per size bucket (forward + NMS)")
     ap.add_argument("--workers", type=int, default=3, help="tail worker threads (e2e)")
     ap.add_argument("--depth", type=int, default=4, help="batches in flight (e2e)")
+    ap.add_argument("--host-input", action="store_true",
+                    help="e2e: the pages start in HOST memory (numpy, as the reference's callers hand them over): pinned "
+                         "staging + one async H2D per batch on loader threads; the PCIe-inclusive rate of DESIGN.md")
+    ap.add_argument("--loaders", type=int, default=2, help="loader threads of --host-input")
     ap.add_argument("--engines", type=int, default=1,
                     help="engine copies on their own streams that consecutive batches alternate over (e2e); "
                          "measured: 2 engines +5 %% on the network alone, -10 %% end to end (the tail's kernels already "
@@ -310,14 +314,18 @@ def main() -> None:
     pool = ThreadPoolExecutor(max_workers=max(1, args.workers), thread_name_prefix="ctd-tail")
     stats = {"blocks": 0, "lines": 0, "pages": 0}
 
-    def forward_job(i=0):
+    host_pages = [samples[i % NS][0] for i in range(nloc)] if args.host_input else None
+    lpool = ThreadPoolExecutor(max_workers=max(1, args.loaders), thread_name_prefix="ctd-load") if args.host_input else None
+
+    def forward_job(i=0, pg=None):
         # letterbox (a no-op at 1024x1024) + fused forward, async
+        pg = pages if pg is None else pg
         if args.engines > 1:
             net, st = det._lane(i % args.engines)
             with torch.cuda.stream(st):
-                job = det._forward(pages, net)
+                job = det._forward(pg, net)
         else:
-            job = det._forward(pages)
+            job = det._forward(pg)
         job.update(canned)                        # random weights -> noise maps: the tail gets the text-like outputs
         return job
 
@@ -330,14 +338,34 @@ def main() -> None:
         stats["blocks"] += sum(len(r[2]) for r in res)
         stats["lines"] += sum(len(b.lines) for r in res for b in r[2])
 
+    trace = {"stage_wait": 0.0, "forward_launch": 0.0, "tail_wait": 0.0} if os.environ.get("BENCH_TRACE") else None
+
     def run_steps_e2e(n):
-        pending = deque()
+        pending, ahead, issued = deque(), deque(), 0
+        main = torch.cuda.current_stream(dev)
         for i in range(n):
-            pending.append(pool.submit(det._tail, forward_job(i), 0, args.keep_undetected))
+            pg = None
+            ta = time.perf_counter()
+            if host_pages is not None:                  # loader threads stage up to `depth` batches ahead
+                while issued < n and len(ahead) < max(1, args.depth):
+                    ahead.append(lpool.submit(det._stage, host_pages))
+                    issued += 1
+                pg, ev = ahead.popleft().result()
+                main.wait_event(ev)
+            tb = time.perf_counter()
+            pending.append(pool.submit(det._tail, forward_job(i, pg), 0, args.keep_undetected))
+            tc = time.perf_counter()
             while len(pending) >= args.depth:
                 finish(pending.popleft().result())
+            if trace is not None:
+                td = time.perf_counter()
+                trace["stage_wait"] += tb - ta
+                trace["forward_launch"] += tc - tb
+                trace["tail_wait"] += td - tc
         while pending:
             finish(pending.popleft().result())
+        if trace is not None:
+            print("trace (s, cumulative over all calls):", {k: round(v, 4) for k, v in trace.items()}, file=sys.stderr)
 
     def run_steps_net(n):
         for _ in range(n):
@@ -452,7 +480,8 @@ def main() -> None:
             except Exception as e:                      # never lose the bench line to the extra check
                 parity = {"error": repr(e)}
         e2e = args.mode == "e2e"
-        workload = (f"BASELINE configs[2]: bs={B}/GPU {S}x{S} u8 pages resident in HBM; fused HIP forward (YOLOv5s+UNet+DB, "
+        where = "in HOST memory (H2D inside the timed region)" if (e2e and args.host_input) else "resident in HBM"
+        workload = (f"BASELINE configs[2]: bs={B}/GPU {S}x{S} u8 pages {where}; fused HIP forward (YOLOv5s+UNet+DB, "
                     f"seeded random weights, DB binarize + u8 mask fused)")
         if e2e:
             workload += (" + the WHOLE native tail per page: GPU NMS, DB boxes (2x GPU labelling + contour tables, host "
@@ -482,6 +511,8 @@ def main() -> None:
                        "input": "nhwc_u8", "precision": args.precision,
                        "tail_workers": args.workers if e2e else 0, "batches_in_flight": args.depth if e2e else 1,
                        "engines": args.engines if e2e else 1,
+                       "pages_start_in": "host memory (pinned staging + async H2D on %d loader threads)" % args.loaders
+                                         if (e2e and args.host_input) else "HBM",
                        "blocks_per_page": round(stats["blocks"] / max(stats["pages"], 1), 2) if e2e else None,
                        "lines_per_page": round(stats["lines"] / max(stats["pages"], 1), 2) if e2e else None,
                        "parallelism": f"dp{n_gpus} (pages sharded, no data-path collective except the final record "

@@ -102,6 +102,7 @@ SYMBOLS = {
     "ctd_inrange_bounds": (None, [C.c_double, C.c_double, C.POINTER(_i32), C.POINTER(_i32)]),
     "ctd_group_output": (_i32, [_vp, _vp, _i32, _vp, _i32, _i32, _i32, _vp, _i32, _vp, _i32, _vp, _i32, _vp, _i32,
                                 C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i32)]),
+    "ctd_host_gather": (_i32, [_vp, _vp, _vp, _i32, _i32]),
     "ctd_last_error": (C.c_char_p, []),
     "ctd_abi_version": (_i32, []),
     "ctd_device_info": (_i32, [_i32, C.c_char_p, C.POINTER(_i32), C.POINTER(_i64)]),

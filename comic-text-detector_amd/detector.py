@@ -22,9 +22,12 @@ from collections import deque
 from concurrent.futures import ThreadPoolExecutor
 from typing import Iterable, Iterator, List, Sequence, Tuple, Union
 
+import ctypes as C
+
 import numpy as np
 import torch
 
+from . import _lib as L
 from . import backend as BK
 from . import postproc as PP
 from .tail import thread_tail
@@ -89,12 +92,61 @@ class TextDetector:
 
     def _forward(self, pages: Sequence[Page], net=None):
         net = net or self.net
+        if not all(isinstance(p, torch.Tensor) and p.is_cuda for p in pages):     # host pages: one pinned copy
+            pages, ev = self._stage(pages)
+            torch.cuda.current_stream(net.device).wait_event(ev)
         x, gpu, metas = self._prepare(pages)
         blks, mask, lines_map = net.forward_u8(x)                           # the seam (inference.py:146)
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream(net.device))
         return dict(gpu=gpu, metas=metas, blks=blks, mask_u8=net.mask_u8, lines_map=lines_map,
                     bitmap=net.bitmap, ev=ev, keep=(mask, x))
+
+    # -- host pages -> HBM (the reference hands numpy images to `__call__`): one pinned staging buffer and ONE
+    #    async copy per batch, on a copy stream, from loader threads -- so that PCIe runs under the forward of
+    #    earlier batches instead of in front of every forward (per-page pageable copies: ~6 ms per 32 pages).
+    def _stage(self, pages: Sequence[Page]):
+        """Runs on a loader thread.  Returns (pages as device tensors, event to wait for) -- device tensors pass through."""
+        dev = self.net.device
+        if all(isinstance(p, torch.Tensor) and p.is_cuda for p in pages):
+            return list(pages), None
+        import threading
+        tl = self.__dict__.setdefault("_stage_tl", threading.local())
+        if not hasattr(tl, "ring"):
+            tl.ring, tl.k, tl.stream = [], 0, torch.cuda.Stream(dev)
+        arrs = []
+        for p in pages:
+            a = p.cpu().numpy() if isinstance(p, torch.Tensor) else np.asarray(p)
+            if a.dtype != np.uint8 or a.ndim != 3 or a.shape[2] != 3:
+                raise ValueError("pages must be uint8 BGR (H,W,3) arrays")
+            arrs.append(a)
+        total = sum(a.size for a in arrs)
+        if len(tl.ring) < 3:                                  # a loader's batches in flight: being filled, copying, in use
+            tl.ring.append(dict(buf=None, ev=None))
+        slot = tl.ring[tl.k % len(tl.ring)]
+        tl.k += 1
+        if slot["ev"] is not None:
+            slot["ev"].synchronize()                          # the copy that last read this buffer
+        if slot["buf"] is None or slot["buf"].numel() < total:
+            slot["buf"] = torch.empty((total,), dtype=torch.uint8).pin_memory()
+        # one C call gathers the pages into the pinned buffer: ctypes drops the interpreter lock for it (a numpy
+        # slice assignment held it: +5 ms per batch of 32 pages for every other thread of the pipeline; torch's
+        # copy_ fights over the intra-op thread pool: 10x worse)
+        arrs = [np.ascontiguousarray(a) for a in arrs]
+        n = len(arrs)
+        srcs = (C.c_void_p * n)(*[a.ctypes.data for a in arrs])
+        sizes = (C.c_size_t * n)(*[a.size for a in arrs])
+        L.check(L.lib().ctd_host_gather(slot["buf"].data_ptr(), srcs, sizes, n, 4), "ctd_host_gather")
+        off, views = 0, []
+        for a in arrs:
+            views.append((off, a.shape))
+            off += a.size
+        with torch.cuda.stream(tl.stream):
+            d = slot["buf"][:total].to(dev, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(tl.stream)
+        slot["ev"] = ev
+        return [d[o: o + h * w * 3].view(h, w, 3) for o, (h, w, _) in views], ev
 
     def _lane(self, i: int):
         """Engine + stream number i of `detect_stream`.  Every lane is a whole engine (its own arena) on its own
@@ -122,16 +174,31 @@ class TextDetector:
 
     @torch.no_grad()
     def detect_stream(self, batches: Iterable[Sequence[Page]], refine_mode=REFINEMASK_INPAINT,
-                      keep_undetected_mask=False, workers: int = 2, depth: int = 3, engines: int = 1) -> Iterator[list]:
+                      keep_undetected_mask=False, workers: int = 2, depth: int = 3, engines: int = 1,
+                      loaders: int = 2) -> Iterator[list]:
         """Yields `detect_batch(batch)` for every batch, in order, with up to `depth` batches in flight:
         the forward of the next batches is launched while `workers` threads run the tails of earlier ones.
+        Host (numpy) pages are staged to the GPU by `loaders` threads up to `depth` batches ahead (`_stage`).
         `engines` > 1 alternates the batches over that many engine copies on their own streams (`_lane`)."""
         pool = ThreadPoolExecutor(max_workers=max(1, workers), thread_name_prefix="ctd-tail")
+        lpool = ThreadPoolExecutor(max_workers=max(1, loaders), thread_name_prefix="ctd-load")
         pending = deque()
         engines = max(1, int(engines))
         main = torch.cuda.current_stream(self.net.device)
+
+        def staged():
+            ahead, it = deque(), iter(batches)
+            for batch in it:
+                ahead.append(lpool.submit(self._stage, batch))
+                if len(ahead) > max(1, depth):
+                    yield ahead.popleft().result()
+            while ahead:
+                yield ahead.popleft().result()
+
         try:
-            for i, batch in enumerate(batches):
+            for i, (batch, ev) in enumerate(staged()):
+                if ev is not None:
+                    main.wait_event(ev)
                 if engines == 1:
                     job = self._forward(batch)
                 else:
@@ -146,6 +213,7 @@ class TextDetector:
                 yield pending.popleft().result()
         finally:
             pool.shutdown(wait=True)
+            lpool.shutdown(wait=True)
 
     def tail_batch(self, pages: Sequence[Page], blks: torch.Tensor, mask_u8: torch.Tensor, prob: torch.Tensor,
                    bitmap: torch.Tensor, refine_mode=REFINEMASK_INPAINT, keep_undetected_mask=False, metas=None,

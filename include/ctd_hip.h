@@ -299,6 +299,13 @@ struct ctd_blk;
 int ctd_tail_page_fetch(const ctd_tail* t, int32_t page, struct ctd_blk* blocks, int32_t* lines, double* dist,
                         int16_t* db_boxes, float* db_scores, int32_t* yolo_xyxy, int32_t* yolo_cls, float* yolo_conf);
 
+/* ---- host-side input staging ---------------------------------------------------------------- */
+
+/* Copies `n` host buffers (the caller's page images, reference inference.py:141 `img`) back to back into
+ * `dst` (page-locked memory the caller then uploads with ONE asynchronous copy), on up to `threads` host
+ * threads.  Pure host code; called through an FFI it runs without the caller's interpreter lock. */
+int ctd_host_gather(void* dst, const void* const* srcs, const size_t* sizes, int32_t n, int32_t threads);
+
 /* ---- host-side contour geometry of the DB text-line stage -------------- */
 
 /* `SegDetectorRepresenter.boxes_from_bitmap` (reference utils/db_utils.py:134-211) downstream of

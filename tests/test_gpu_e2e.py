@@ -272,3 +272,22 @@ def test_tail_on_the_reference_example_page_matches_reference_code_golden(keep):
     np.testing.assert_array_equal(np.packbits(r > 0), g[f"refined{keep}"])
     rec = p.annotations.blocks_json(b)
     assert rec.encode("utf8") == g[f"records{keep}"].tobytes()
+
+
+def test_host_pages_are_staged_through_pinned_memory():
+    """numpy pages (what the reference's callers hand over) go through `_stage`: one pinned buffer and one async
+    copy per batch, from loader threads in `detect_stream`; results equal those of device-resident pages, mixed
+    page sizes included."""
+    p = pkg()
+    det = detector(256)
+    batches = [[p.synth.text_like_page((256, 256), 50 + 3 * k + j, n_blocks=4) for j in range(3)] for k in range(3)]
+    batches[1][1] = p.synth.text_like_page((200, 144), 77, n_blocks=3)
+    want = [det.detect_batch([torch.from_numpy(pg).cuda() for pg in b]) for b in batches]
+    got_batch = [det.detect_batch(b) for b in batches]
+    got_stream = list(det.detect_stream(batches, workers=2, depth=2, loaders=2))
+    for got in (got_batch, got_stream):
+        for gb, wb in zip(got, want):
+            for (m, r, bl), (m1, r1, bl1) in zip(gb, wb):
+                np.testing.assert_array_equal(m, m1)
+                np.testing.assert_array_equal(r, r1)
+                blocks_equal(bl, bl1)

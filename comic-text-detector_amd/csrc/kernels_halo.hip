@@ -178,7 +178,7 @@ __global__ __launch_bounds__(NTHR, 4) void conv_halo_kernel(ConvArgs a) {   // 4
   const long long T1 = stamp();
   dma_a(0, 0);
   dma_a(0, 1);
-  dma_a(0, 2);
+  if (HH * HW > 256) dma_a(0, 2);
   dma_w(0, 0, 0);
   if (TPS > 1)
     for (int j = 1; j < TPS && j < taps; ++j) dma_w(0, j, 0, j);
@@ -206,8 +206,10 @@ __global__ __launch_bounds__(NTHR, 4) void conv_halo_kernel(ConvArgs a) {   // 4
       }
       if (c + 1 < nchunk) {   // static pass indices: the row tables stay in registers
         if (TPS == 1) {
-          if (sidx == 0) dma_a(c + 1, 0);
-          else if (sidx == 1) dma_a(c + 1, 1);
+          if (sidx == 0) {
+            dma_a(c + 1, 0);
+            if (nst == 1) dma_a(c + 1, 1);      // 1x1: one step per chunk, the 256-row patch is two passes
+          } else if (sidx == 1) dma_a(c + 1, 1);
           else if (sidx == 2) dma_a(c + 1, 2);
         } else {
           if (sidx == 0) { dma_a(c + 1, 0); dma_a(c + 1, 1); }
@@ -353,7 +355,9 @@ static long long halo_min_patches() {
 bool conv_halo_supported(const ConvArgs& a, bool dst_f32) {
   if (!g_conv_halo || dst_f32) return false;
   if (a.stride != 1 || a.s0.up || (a.s1.c && a.s1.up)) return false;
-  if (!((a.KH == 3 && a.KW == 3) || (a.KH == 2 && a.KW == 2))) return false;
+  static const bool halo_1x1 = [] { const char* e = std::getenv("CTD_HALO_1X1"); return e && std::atoi(e) != 0; }();
+  if (!((a.KH == 3 && a.KW == 3) || (a.KH == 2 && a.KW == 2) || (halo_1x1 && a.KH == 1 && a.KW == 1 && a.nphase == 1)))
+    return false;
   if (a.Mh != a.Hin || a.Mw != a.Win) return false;
   if (a.s0.c % BKH || a.s1.c % BKH || a.bk != BKH || !a.w_tiled) return false;
   if (a.pitchD % 8 || a.N % 8) return false;

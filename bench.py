@@ -169,12 +169,11 @@ def end_to_end_acceptance(pkg, be) -> dict:
     return out
 
 
-def mixed_stream(args, pkg, D, BK, det, rank, world, dev) -> None:
+def mixed_stream(args, pkg, D, BK, be, rank, world, dev) -> None:
     """BASELINE configs[4]: a seeded stream of pages of three sizes, batched dynamically per size bucket under a
     fixed pixel budget, every bucket's forward captured ONCE into a hipGraph (largest bucket first, so the
     arena never moves) and replayed in steady state; GPU NMS after every replay.  A step = one pass over the
     whole stream shard of this rank.  Reported: pages/s, and what (re)planning + capturing a bucket costs."""
-    be = det.net
     sizes = (640, 1024, 1536)
     budget = 32 * 1024 * 1024                     # pixels per batch: 81 -> 64 @ 640, 32 @ 1024, 14 @ 1536
     cap = {s: max(1, min(64, budget // (s * s))) for s in sizes}
@@ -295,9 +294,13 @@ def main() -> None:
     ckpt = pkg.synth.make_checkpoint(0)
     B, S = args.batch, args.size
     det = DET.TextDetector(ckpt, input_size=S, device=dev, half=args.precision == "fp16")
-    be = det.net
+    # e2e: the detector's own engine (outputs="detector": what `TextDetector.__call__` consumes -- u8 mask, shrink
+    # map, blocks; the DB threshold branch and the f32 mask are not produced).  net / mixed: the seam's full
+    # contract (blks, mask f32, lines_map with both planes).
+    full = lambda: BK.HipTextDetBackend(ckpt, dev, precision=args.precision, outputs="all")   # noqa: E731
+    be = det.net if args.mode == "e2e" else full()
     if args.mode == "mixed":
-        return mixed_stream(args, pkg, D, BK, det, rank, world, dev)
+        return mixed_stream(args, pkg, D, BK, be, rank, world, dev)
     total_pages = B * n_gpus                      # weak scaling: fixed per-GPU work
     lo, hi = D.shard_range(total_pages, rank, world)
     nloc = hi - lo
@@ -476,7 +479,7 @@ def main() -> None:
         if not args.no_cpu_baseline and n_gpus == 1:
             cpu = cpu_baseline(pkg, ckpt, S, samples[0])
             try:
-                parity = parity_sample(pkg, ckpt, be, pages[0])
+                parity = parity_sample(pkg, ckpt, be if be.outputs == "all" else full(), pages[0])
             except Exception as e:                      # never lose the bench line to the extra check
                 parity = {"error": repr(e)}
         e2e = args.mode == "e2e"

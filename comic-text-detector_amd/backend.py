@@ -33,7 +33,7 @@ def _load_ckpt(model: Union[str, dict]) -> dict:
 class HipTextDetBackend:
     def __init__(self, model: Union[str, dict], device: Union[str, int, torch.device] = "cuda",
                  precision: str = "fp16", act: str = "leaky", bitmap_thresh: float = 0.3, step_eval: bool = False,
-                 db_k: float = 50.0):
+                 db_k: float = 50.0, outputs: str = "all"):
         if not torch.cuda.is_available():
             raise L.CtdError("HipTextDetBackend needs a ROCm GPU (MI355X); there is no CPU fallback")
         dev = torch.device(device)
@@ -46,8 +46,17 @@ class HipTextDetBackend:
         # `DBHead.forward(step_eval=True)` (reference basemodel.py:121-122): `lines_map` becomes the (B,1,H,W)
         # differentiable-binarisation map step_function(shrink, thresh) (:159-160, k = 50)
         self.step_eval, self.db_k, self.bitmap_thresh = bool(step_eval), float(db_k), float(bitmap_thresh)
+        # outputs="all": the seam's contract (blks, mask (B,1,H,W) f32, lines_map (B,2,H,W) f32).
+        # outputs="detector": what `TextDetector.__call__` consumes (reference inference.py:146-161 uses the u8
+        # mask and `lines_map[:, 0]` only): the DB threshold branch is not lowered, `lines_map` is (B,1,H,W) and
+        # the f32 mask is not written (`mask` is returned as None) -- same values, 0.2 ms and 270 MB less per 32 pages
+        if outputs not in ("all", "detector"):
+            raise ValueError("outputs must be 'all' or 'detector'")
+        if outputs == "detector" and step_eval:
+            raise ValueError("step_eval needs the threshold branch: outputs='all'")
+        self.outputs = outputs
         ckpt = _load_ckpt(model)
-        self.program = graph.lower(ckpt, self.prec, act=act, bitmap_thresh=bitmap_thresh)
+        self.program = graph.lower(ckpt, self.prec, act=act, bitmap_thresh=bitmap_thresh, db_thresh=outputs == "all")
         T, O, blob = graph.to_ctypes(self.program)
         self._blob = blob
         h = C.c_void_p()
@@ -78,8 +87,8 @@ class HipTextDetBackend:
     def _outputs(self, B: int, H: int, W: int):
         dev = self.device
         blks = torch.empty((B, self.blks_rows(H, W), self.no), dtype=torch.float32, device=dev)
-        mask = torch.empty((B, 1, H, W), dtype=torch.float32, device=dev)
-        lines = torch.empty((B, 2, H, W), dtype=torch.float32, device=dev)
+        mask = torch.empty((B, 1, H, W), dtype=torch.float32, device=dev) if self.outputs == "all" else None
+        lines = torch.empty((B, self.program.meta.get("line_planes", 2), H, W), dtype=torch.float32, device=dev)
         mask_u8 = torch.empty((B, H, W), dtype=torch.uint8, device=dev)
         bitmap = torch.empty((B, H, W), dtype=torch.uint8, device=dev)
         return blks, mask, lines, mask_u8, bitmap
@@ -97,10 +106,10 @@ class HipTextDetBackend:
         if B > max_b and not profile:
             for i in range(0, B, max_b):
                 j = min(B, i + max_b)
-                self._run(inp[i:j], fmt, j - i, H, W, outs=tuple(t[i:j] for t in outs))
+                self._run(inp[i:j], fmt, j - i, H, W, outs=tuple(None if t is None else t[i:j] for t in outs))
             return self._finish(outs, B, H, W)
         stream = torch.cuda.current_stream(self.device).cuda_stream
-        args = [self._h, inp.data_ptr(), fmt, B, H, W] + [t.data_ptr() for t in outs] + [stream]
+        args = [self._h, inp.data_ptr(), fmt, B, H, W] + [0 if t is None else t.data_ptr() for t in outs] + [stream]
         if profile:
             n = self._lib.ctd_engine_n_ops(self._h)
             ms = (C.c_float * n)()

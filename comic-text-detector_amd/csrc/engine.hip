@@ -269,13 +269,15 @@ int pack_op(ctd_engine* e, OpState& s, const float* P, int64_t nP) {
       if (!f16) return fail(CTD_ERR_UNSUPPORTED, "DB_UP op is fp16-path only");
       const int q = o.aux[1];
       if (q != 16) return fail(CTD_ERR_UNSUPPORTED, "fused db tail is q=16 only");
+      const int nbr = o.aux[2] > 0 ? o.aux[2] : 2;                 // branches lowered (1 = shrink map only)
+      if (nbr > 2) return fail(CTD_ERR_INVALID, "db-up: at most two branches");
       const int PB = q * q * 4 + q + q * 4 + 1;
-      if (!need(o.w_off, 2 * PB)) return fail(CTD_ERR_INVALID, "db-up params out of range");
+      if (!need(o.w_off, nbr * PB)) return fail(CTD_ERR_INVALID, "db-up params out of range");
       // blob per branch: W1 (c,o,py,px), b1 (o), W2 (o,0,qy,qx), b2  ->  device layout of
       // kernels_fused.hip DbUpLayout: W1p[pp][c][o], b1, W2p[qq][o], b2, padded to x4 floats
       const int SIZE = (4 * q * q + q + 4 * q + 1 + 3) / 4 * 4;
       std::vector<float> wp((size_t)2 * SIZE, 0.f);
-      for (int br = 0; br < 2; ++br) {
+      for (int br = 0; br < nbr; ++br) {
         const float* src = P + o.w_off + (size_t)br * PB;
         float* dst = wp.data() + (size_t)br * SIZE;
         for (int c = 0; c < q; ++c)
@@ -609,19 +611,19 @@ int launch_op(ctd_engine* e, int i, const Outs& x, hipStream_t st) {
     case CTD_OP_EXPORT: {
       const TensorState& ts = e->tensors[o.src0];
       float* out = o.aux[0] == CTD_OUT_MASK ? x.mask : x.lines;
-      if (!out) break;
-      const int nplanes = o.aux[0] == CTD_OUT_MASK ? 1 : 2;
+      const int nplanes = o.aux[0] == CTD_OUT_MASK ? 1 : (o.aux[2] > 0 ? o.aux[2] : 2);   // aux[2]: planes of lines_map
       uint8_t* u8 = nullptr;
       int mode = 0;
       if (o.aux[0] == CTD_OUT_MASK) { u8 = x.mask_u8; mode = 1; }
       else if (o.aux[1] == 0) { u8 = x.bitmap; mode = 2; }
+      if (!out && !u8) break;                      // the f32 plane may be skipped while its u8 side output is wanted
       launch_export_plane(tptr(o.src0, o.src0_coff), ts.t.channels, ts.esize == 2, out, nplanes, o.aux[1], u8, mode,
                           o.faux[0], B, ts.H, ts.W, st);
       break;
     }
     case CTD_OP_SEG_FINAL: {
       const TensorState& ts = e->tensors[o.src0];
-      if (!x.mask) break;
+      if (!x.mask && !x.mask_u8) break;
       launch_seg_final((const half_t*)tptr(o.src0, o.src0_coff), ts.t.channels, o.src0_c, B, ts.H, ts.W,
                        (const float*)s.w_dev, 0.f, x.mask, x.mask_u8, st);
       break;
@@ -629,7 +631,7 @@ int launch_op(ctd_engine* e, int i, const Outs& x, hipStream_t st) {
     case CTD_OP_DB_UP: {
       const TensorState& ts = e->tensors[o.src0];
       if (!x.lines) break;
-      launch_db_up((const half_t*)tptr(o.src0, o.src0_coff), ts.t.channels, o.aux[1], B, ts.H, ts.W,
+      launch_db_up((const half_t*)tptr(o.src0, o.src0_coff), ts.t.channels, o.aux[1], o.aux[2] > 0 ? o.aux[2] : 2, B, ts.H, ts.W,
                    (const float*)s.w_dev, x.lines, x.bitmap, o.faux[0], st);
       break;
     }

@@ -229,7 +229,7 @@ __global__ void export_plane_kernel(const T* __restrict__ src, int pitch, float*
        i += (long long)gridDim.x * blockDim.x) {
     const long long b = i / hw, p = i % hw;
     const float v = to_f(src[i * pitch]);
-    out[(b * nplanes + plane) * hw + p] = v;
+    if (out) out[(b * nplanes + plane) * hw + p] = v;
     if (u8_mode == 1) u8[i] = (uint8_t)(v * 255.0f);       // reference inference.py:96-99 (truncation)
     else if (u8_mode == 2) u8[i] = v > thresh ? 1 : 0;      // reference db_utils.py:71-72
   }

@@ -230,7 +230,7 @@ __global__ __launch_bounds__(256) void seg_final_kernel(const half_t* __restrict
     const float s0 = 1.0f / (1.0f + __expf(-o[py][0]));
     const float s1 = 1.0f / (1.0f + __expf(-o[py][1]));
     const long long off = (b * Ho + (2 * y + py)) * Wo + 2 * x;
-    *(float2*)(mask + off) = make_float2(s0, s1);
+    if (mask) *(float2*)(mask + off) = make_float2(s0, s1);
     if (mask_u8) {
       uchar2 q;
       q.x = (uint8_t)(s0 * 255.0f);
@@ -258,13 +258,13 @@ struct DbUpLayout {
 };
 
 template <int Q>
-__global__ __launch_bounds__(256) void db_up_kernel(const half_t* __restrict__ src, int pitch, int B, int H, int W,
+__global__ __launch_bounds__(256) void db_up_kernel(const half_t* __restrict__ src, int pitch, int nbr, int B, int H, int W,
                                                     const float* __restrict__ params, float* __restrict__ lines,
                                                     uint8_t* __restrict__ bitmap, float thresh) {
   using Lt = DbUpLayout<Q>;
   __shared__ __attribute__((aligned(16))) float P[2 * Lt::SIZE];
   __shared__ float xs[Q * 256];     // this thread's input channels, [c][tid]: lets the c loop stay rolled
-  for (int i = threadIdx.x; i < 2 * Lt::SIZE; i += 256) P[i] = params[i];
+  for (int i = threadIdx.x; i < nbr * Lt::SIZE; i += 256) P[i] = params[i];
   __syncthreads();
   const long long total = (long long)B * H * W;
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -278,7 +278,7 @@ __global__ __launch_bounds__(256) void db_up_kernel(const half_t* __restrict__ s
   // Loops are deliberately NOT unrolled (except the 16-wide output vector): full unrolling made
   // the compiler hoist every parameter load (1000+ registers -> scratch, 1 wave/SIMD).
 #pragma unroll 1
-  for (int br = 0; br < 2; ++br) {
+  for (int br = 0; br < nbr; ++br) {            // nbr = 1: shrink map only (the threshold branch is not lowered)
     const float* Pb = P + br * Lt::SIZE;
 #pragma unroll
     for (int c8 = 0; c8 < Q / 8; ++c8) {
@@ -328,7 +328,7 @@ __global__ __launch_bounds__(256) void db_up_kernel(const half_t* __restrict__ s
 #pragma unroll
       for (int qy = 0; qy < 2; ++qy) {
         const long long row = 4 * y + 2 * py + qy;
-        const long long off = ((b * 2 + br) * Ho + row) * Wo + 4 * x + 2 * px;
+        const long long off = ((b * nbr + br) * Ho + row) * Wo + 4 * x + 2 * px;
         *(float2*)(lines + off) = make_float2(r4[qy * 2], r4[qy * 2 + 1]);
         if (br == 0 && bitmap) {
           uchar2 q;
@@ -377,10 +377,10 @@ void launch_seg_final(const half_t* src, int pitch, int C, int B, int H, int W, 
   (void)C;
 }
 
-void launch_db_up(const half_t* src, int pitch, int q, int B, int H, int W, const float* params, float* lines,
+void launch_db_up(const half_t* src, int pitch, int q, int nbr, int B, int H, int W, const float* params, float* lines,
                   uint8_t* bitmap, float thresh, hipStream_t st) {
   const long long total = (long long)B * H * W;
   const int g = (int)((total + 255) / 256);
-  hipLaunchKernelGGL((db_up_kernel<16>), dim3(g), dim3(256), 0, st, src, pitch, B, H, W, params, lines, bitmap, thresh);
+  hipLaunchKernelGGL((db_up_kernel<16>), dim3(g), dim3(256), 0, st, src, pitch, nbr, B, H, W, params, lines, bitmap, thresh);
   (void)q;
 }

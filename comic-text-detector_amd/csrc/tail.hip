@@ -3,7 +3,7 @@
 //
 //   postprocess_yolo   (inference.py:101-114)   launch_nms                      + host unpack
 //   postprocess_mask   (:85-99)                 fused in the network epilogue (mask_u8)
-//   SegDetectorRepresenter (utils/db_utils.py)  launch_ccl x2 + launch_dbc       + host hull / calipers / unclip
+//   SegDetectorRepresenter (utils/db_utils.py)  launch_ccl_dual + launch_dbc      + host hull / calipers / unclip
 //   crop + resize of the mask (:164-165)        copy2d / resize_linear_u8
 //   group_output       (utils/textblock.py)     host (csrc/host_group.cpp)
 //   refine_mask        (utils/textmask.py)      tw_* kernels + launch_ccl x2     + host colour / threshold picks

@@ -54,7 +54,7 @@ class TextDetector:
         self.conf_thresh = conf_thresh
         self.nms_thresh = nms_thresh
         self._net_args = dict(model=model_path, device=device, precision="fp16" if half else "fp32", act=act,
-                              bitmap_thresh=0.3)
+                              bitmap_thresh=0.3, outputs="detector")
         self.net = BK.HipTextDetBackend(**self._net_args)
         self._lanes = [(self.net, None)]                      # (engine, stream) pairs of detect_stream, grown on demand
         self.backend = "hip"

@@ -191,7 +191,7 @@ class _Lower:
         return self.p.convt(y, w, b, ub.up.k, ub.up.s, ub.up.p, ub.up.act, name=ub.up.prefix)
 
 
-def lower(ckpt: dict, precision: int, act: str = "leaky", bitmap_thresh: float = 0.3) -> Program:
+def lower(ckpt: dict, precision: int, act: str = "leaky", bitmap_thresh: float = 0.3, db_thresh: bool = True) -> Program:
     """Checkpoint dict (reference format) -> Program."""
     fast = precision == L.PREC_F16
     prog = Program(precision)
@@ -292,26 +292,30 @@ def lower(ckpt: dict, precision: int, act: str = "leaky", bitmap_thresh: float =
     dx = dl.conv([dx], d.conv, name="db.conv.0")
     prog.taps["db.x"] = dx.tid
     q = d.binarize.conv3.c2
+    # `db_thresh=False`: the threshold branch (`lines_map[:, 1]`) is not lowered at all -- `TextDetector` only
+    # reads the shrink map (reference utils/db_utils.py:63 `pred[:, 0]`); `lines_map` then has ONE plane
+    branches = (d.binarize, d.thresh) if db_thresh else (d.binarize,)
+    nbr = len(branches)
+    prog.meta["line_planes"] = nbr
     if fast and q == 16:
-        wb, bb = fold(dl.sd, d.binarize.conv3)
-        wt, bt = fold(dl.sd, d.thresh.conv3)
-        y = prog.conv([dx], np.concatenate([wb, wt], 0), np.concatenate([bb, bt], 0), 3, 1, 1, "relu",
-                      name="db.binarize.0+thresh.0")
+        folded = [fold(dl.sd, br.conv3) for br in branches]
+        y = prog.conv([dx], np.concatenate([f[0] for f in folded], 0), np.concatenate([f[1] for f in folded], 0), 3, 1, 1,
+                      "relu", name="db.binarize.0+thresh.0" if db_thresh else "db.binarize.0")
         packed = []
-        for br in (d.binarize, d.thresh):
+        for br in branches:
             w1, b1 = fold(dl.sd, br.up1)        # (q, q, 2, 2), BN folded
             w2, b2 = fold(dl.sd, br.up2)        # (q, 1, 2, 2)
             packed += [w1.reshape(-1), b1.reshape(-1), w2.reshape(-1), b2.reshape(-1)]
-        prog.op(L.OP_DB_UP, src0=y.tid, src0_coff=0, src0_c=2 * q, w_off=prog.param(np.concatenate(packed)),
-                aux=[L.OUT_LINES, q] + [0] * 6, faux=[bitmap_thresh] + [0.0] * 7, name="db.up")
+        prog.op(L.OP_DB_UP, src0=y.tid, src0_coff=0, src0_c=nbr * q, w_off=prog.param(np.concatenate(packed)),
+                aux=[L.OUT_LINES, q, nbr] + [0] * 5, faux=[bitmap_thresh] + [0.0] * 7, name="db.up")
     else:
-        for plane, br in enumerate((d.binarize, d.thresh)):
+        for plane, br in enumerate(branches):
             t = dl.conv([dx], br.conv3)
             w1, b1 = fold(dl.sd, br.up1)
             t = prog.convt(t, w1, b1, 2, 2, 0, "relu", name=br.up1.prefix)
             w2, b2 = fold(dl.sd, br.up2)
             t = prog.convt(t, w2, b2, 2, 2, 0, "sigmoid", name=br.up2.prefix)
-            prog.op(L.OP_EXPORT, src0=t.tid, src0_coff=0, src0_c=1, aux=[L.OUT_LINES, plane] + [0] * 6,
+            prog.op(L.OP_EXPORT, src0=t.tid, src0_coff=0, src0_c=1, aux=[L.OUT_LINES, plane, nbr] + [0] * 5,
                     faux=[bitmap_thresh] + [0.0] * 7, name=f"db.export{plane}")
     return prog
 

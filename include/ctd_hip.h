@@ -100,10 +100,12 @@ typedef struct ctd_op {
   int32_t aux[8];
   /* DETECT   : aux[0]=level stride, aux[1]=row offset into blks PER 64x64 INPUT UNIT
                 (scaled by (H/64)*(W/64) at run time), aux[2]=na, aux[3]=no
-     EXPORT   : aux[0]=CTD_OUT_*, aux[1]=plane index
+     EXPORT   : aux[0]=CTD_OUT_*, aux[1]=plane index, aux[2]=planes of that output (0 = the default: 2 for
+                CTD_OUT_LINES) -- a program lowered without the DB threshold branch has ONE plane
      SEG_FINAL: aux[0]=CTD_OUT_MASK
-     DB_UP    : aux[0]=CTD_OUT_LINES, aux[1]=q (branch channels); parameter
-                layout at w_off: for branch in (binarize, thresh):
+     DB_UP    : aux[0]=CTD_OUT_LINES, aux[1]=q (branch channels), aux[2]=branches lowered (0 or 2: binarize and
+                thresh; 1: binarize only = the shrink map `SegDetectorRepresenter` reads); parameter
+                layout at w_off: for branch in (binarize, thresh)[:aux[2]]:
                   W1 (q,q,2,2), b1 (q), W2 (q,1,2,2), b2 (1)                          */
   float faux[8];
   /* DETECT   : faux[0..2*na) = anchors in pixels (anchor * stride)
@@ -131,8 +133,10 @@ int ctd_engine_blks_shape(const ctd_engine* e, int32_t H, int32_t W, int32_t* ro
 /* The fused forward: replaces `TextDetBase.forward` (reference basemodel.py:240-244).
  *   input_dev : B pages in `input_fmt`
  *   blks_dev  : (B, rows, no) f32           (`blk`, reference yolo.py:44)
- *   mask_dev  : (B, 1, H, W) f32            (`seg`, reference basemodel.py:74)
- *   lines_dev : (B, 2, H, W) f32            (`det`, reference basemodel.py:125)
+ *   mask_dev  : (B, 1, H, W) f32            (`seg`, reference basemodel.py:74); NULL: not written (the u8
+ *               side output below is what the detector consumes)
+ *   lines_dev : (B, P, H, W) f32            (`det`, reference basemodel.py:125); P = 2, or 1 for a program
+ *               lowered without the threshold branch
  *   mask_u8_dev / bitmap_dev : (B, H, W) u8 fused post-processing side outputs
  *               (reference inference.py:96-99 / utils/db_utils.py:71-72); may be NULL.
  * H and W must be multiples of 64 (reference SURVEY section 5).  Workspace is

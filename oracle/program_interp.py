@@ -50,7 +50,7 @@ def run_program(prog, x: torch.Tensor, bitmap_thresh: float = 0.3):
     unit = (H // 64) * (W // 64)
     rows = sum(d["na"] * (64 // d["stride"]) ** 2 for d in prog.det_levels) * unit
     no = prog.meta["no"]
-    out = dict(blks=torch.zeros(B, rows, no), mask=torch.zeros(B, 1, H, W), lines=torch.zeros(B, 2, H, W),
+    out = dict(blks=torch.zeros(B, rows, no), mask=torch.zeros(B, 1, H, W), lines=torch.zeros(B, prog.meta.get("line_planes", 2), H, W),
                mask_u8=torch.zeros(B, H, W, dtype=torch.uint8), bitmap=torch.zeros(B, H, W, dtype=torch.uint8))
 
     for o in prog.ops:
@@ -118,7 +118,7 @@ def run_program(prog, x: torch.Tensor, bitmap_thresh: float = 0.3):
             a = view(o, "src0")
             q = o["aux"][1]
             pb = q * q * 4 + q + q * 4 + 1
-            for br in range(2):
+            for br in range(o["aux"][2] or 2):
                 p = par(o["w_off"] + br * pb, pb)
                 w1 = p[: q * q * 4].view(q, q, 2, 2)
                 b1 = p[q * q * 4: q * q * 4 + q]

@@ -23,6 +23,26 @@ def detector(size):
     return _DET[size]
 
 
+_FULL = {}
+
+
+def full_outputs(det, x):
+    """The seam's full contract (blks, mask f32, lines_map with both planes) for the pages `x`, from a second engine
+    built with outputs="all" -- and the check that the detector's own engine (outputs="detector": no threshold
+    branch, no f32 mask) produces the very same blocks, u8 mask, shrink map and bitmap."""
+    if "net" not in _FULL:
+        _FULL["net"] = pkg().backend.HipTextDetBackend(checkpoint(0), device="cuda", precision=det.net.precision, outputs="all")
+    full = _FULL["net"]
+    blks, mask, lines_map = full.forward_u8(x)
+    side = (full.mask_u8.clone(), full.bitmap.clone())
+    b2, m2, l2 = det.net.forward_u8(x)
+    torch.cuda.synchronize()
+    assert m2 is None and l2.shape[1] == 1
+    assert torch.equal(b2, blks) and torch.equal(l2[:, 0], lines_map[:, 0])
+    assert torch.equal(det.net.mask_u8, side[0]) and torch.equal(det.net.bitmap, side[1])
+    return blks, mask, lines_map
+
+
 def blks_tensor(blks, rows=4096):
     """(blines, cls, confs) -> a fake Detect tensor (1,rows,7) whose NMS gives those blocks back."""
     blines, cls, confs = blks
@@ -62,8 +82,7 @@ def test_full_detector_on_network_outputs_matches_oracle():
     page = p.synth.text_like_page((size, size), 5, n_blocks=4)
     det = detector(size)
     m, refined, blk_list = det(page, refine_mode=0, keep_undetected_mask=True)
-    blks, mask, lines_map = det.net.forward_u8(torch.from_numpy(page)[None].cuda())
-    torch.cuda.synchronize()
+    blks, mask, lines_map = full_outputs(det, torch.from_numpy(page)[None].cuda())
     ref = R.detector_tail(page, blks.cpu().numpy(), mask.cpu().numpy(), lines_map.cpu().numpy(),
                           input_size=(size, size), refine_mode=0, keep_undetected_mask=True)
     np.testing.assert_array_equal(m, ref[0])
@@ -112,8 +131,7 @@ def test_detector_on_page_of_another_size_matches_oracle():
     m, refined, blk_list = det(page, refine_mode=1, keep_undetected_mask=True)
     lb, ratio, (dw, dh) = cv.letterbox(page, (size, size))
     x = torch.from_numpy(lb)[None].cuda()
-    blks, mask, lines_map = det.net.forward_u8(x)
-    torch.cuda.synchronize()
+    blks, mask, lines_map = full_outputs(det, x)
     ref = R.detector_tail(page, blks.cpu().numpy(), mask.cpu().numpy(), lines_map.cpu().numpy(),
                           input_size=(size, size), dw=dw, dh=dh, refine_mode=1, keep_undetected_mask=True)
     assert m.shape == page.shape[:2]

@@ -27,6 +27,26 @@ def test_program_semantics_match_oracle(prec):
     assert ((ol[:, 0] > 0.3).to(torch.uint8) != out["bitmap"]).float().mean() < 1e-3
 
 
+@pytest.mark.parametrize("prec", ["fp32", "fp16"])
+def test_detector_outputs_lowering_drops_only_the_threshold_branch(prec):
+    """`lower(db_thresh=False)` (what `TextDetector` builds): `lines_map` has the shrink map only and every other
+    output is what the full program gives -- `SegDetectorRepresenter` reads `pred[:, 0]` (reference db_utils.py:63)."""
+    p = pkg()
+    L = p._lib
+    ck = checkpoint(0)
+    pr = L.PREC_F16 if prec == "fp16" else L.PREC_F32
+    full, det = p.graph.lower(ck, pr), p.graph.lower(ck, pr, db_thresh=False)
+    assert full.meta["line_planes"] == 2 and det.meta["line_planes"] == 1
+    assert len(det.ops) < len(full.ops) or prec == "fp16"           # fp16: same op count, narrower fused ops
+    assert not any("thresh" in o["name"] for o in det.ops)
+    x = torch.rand(1, 3, 128, 128, generator=torch.Generator().manual_seed(2))
+    a, b = run_program(full, x), run_program(det, x)
+    assert b["lines"].shape[1] == 1
+    assert torch.equal(a["lines"][:, 0], b["lines"][:, 0])
+    for k in ("blks", "mask", "mask_u8", "bitmap"):
+        assert torch.equal(a[k], b[k]), k
+
+
 def test_program_structure():
     p = pkg()
     L = p._lib

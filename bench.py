@@ -294,11 +294,10 @@ def main() -> None:
     ckpt = pkg.synth.make_checkpoint(0)
     B, S = args.batch, args.size
     det = DET.TextDetector(ckpt, input_size=S, device=dev, half=args.precision == "fp16")
-    # e2e: the detector's own engine (outputs="detector": what `TextDetector.__call__` consumes -- u8 mask, shrink
-    # map, blocks; the DB threshold branch and the f32 mask are not produced).  net / mixed: the seam's full
-    # contract (blks, mask f32, lines_map with both planes).
+    # every mode times the WHOLE network (the seam's full contract: blks, mask f32, lines_map with both planes),
+    # as the reference's `TextDetBase.forward` computes it; `TextDetector(trim_outputs=True)` is not benchmarked
     full = lambda: BK.HipTextDetBackend(ckpt, dev, precision=args.precision, outputs="all")   # noqa: E731
-    be = det.net if args.mode == "e2e" else full()
+    be = det.net
     if args.mode == "mixed":
         return mixed_stream(args, pkg, D, BK, be, rank, world, dev)
     total_pages = B * n_gpus                      # weak scaling: fixed per-GPU work

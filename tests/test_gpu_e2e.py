@@ -27,19 +27,20 @@ _FULL = {}
 
 
 def full_outputs(det, x):
-    """The seam's full contract (blks, mask f32, lines_map with both planes) for the pages `x`, from a second engine
-    built with outputs="all" -- and the check that the detector's own engine (outputs="detector": no threshold
-    branch, no f32 mask) produces the very same blocks, u8 mask, shrink map and bitmap."""
+    """The seam's full contract (blks, mask f32, lines_map with both planes) for the pages `x` from the detector's
+    engine -- and the check that a trimmed engine (outputs="detector", `TextDetector(trim_outputs=True)`: no
+    threshold branch, no f32 mask) produces the very same blocks, u8 mask, shrink map and bitmap."""
     if "net" not in _FULL:
-        _FULL["net"] = pkg().backend.HipTextDetBackend(checkpoint(0), device="cuda", precision=det.net.precision, outputs="all")
-    full = _FULL["net"]
-    blks, mask, lines_map = full.forward_u8(x)
-    side = (full.mask_u8.clone(), full.bitmap.clone())
-    b2, m2, l2 = det.net.forward_u8(x)
+        _FULL["net"] = pkg().backend.HipTextDetBackend(checkpoint(0), device="cuda", precision=det.net.precision,
+                                                       outputs="detector")
+    trim = _FULL["net"]
+    blks, mask, lines_map = det.net.forward_u8(x)
+    side = (det.net.mask_u8.clone(), det.net.bitmap.clone())
+    b2, m2, l2 = trim.forward_u8(x)
     torch.cuda.synchronize()
-    assert m2 is None and l2.shape[1] == 1
+    assert m2 is None and l2.shape[1] == 1 and lines_map.shape[1] == 2
     assert torch.equal(b2, blks) and torch.equal(l2[:, 0], lines_map[:, 0])
-    assert torch.equal(det.net.mask_u8, side[0]) and torch.equal(det.net.bitmap, side[1])
+    assert torch.equal(trim.mask_u8, side[0]) and torch.equal(trim.bitmap, side[1])
     return blks, mask, lines_map
 
 
@@ -290,6 +291,18 @@ def test_tail_on_the_reference_example_page_matches_reference_code_golden(keep):
     np.testing.assert_array_equal(np.packbits(r > 0), g[f"refined{keep}"])
     rec = p.annotations.blocks_json(b)
     assert rec.encode("utf8") == g[f"records{keep}"].tobytes()
+
+
+def test_trimmed_detector_returns_the_same_results():
+    """`TextDetector(trim_outputs=True)`: same masks and blocks as the full-network detector."""
+    p = pkg()
+    page = p.synth.text_like_page((256, 256), 9, n_blocks=4)
+    a = detector(256)(page, refine_mode=0, keep_undetected_mask=True)
+    b = p.detector.TextDetector(checkpoint(0), input_size=256, device="cuda", half=True, trim_outputs=True)(
+        page, refine_mode=0, keep_undetected_mask=True)
+    np.testing.assert_array_equal(a[0], b[0])
+    np.testing.assert_array_equal(a[1], b[1])
+    blocks_equal(a[2], b[2])
 
 
 def test_host_pages_are_staged_through_pinned_memory():

@@ -222,7 +222,7 @@ def mixed_stream(args, pkg, D, BK, be, rank, world, dev) -> None:
         dist.barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device=dev if dist.get_backend() != "gloo" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     # eager comparison on this rank (re-plans on every size change)
@@ -288,7 +288,9 @@ def main() -> None:
     if world != args.gpus and rank == 0:
         print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
     n_gpus = world
-    dev = torch.device("cuda", local_rank)
+    # CTD_BENCH_ONE_DEVICE=1 (with CTD_DIST_BACKEND=gloo): every rank on GPU 0 -- a rehearsal of the N > 1 code
+    # path on a 1-GPU box, not a measurement
+    dev = torch.device("cuda", 0 if os.environ.get("CTD_BENCH_ONE_DEVICE") else local_rank)
     torch.cuda.set_device(dev)
 
     ckpt = pkg.synth.make_checkpoint(0)
@@ -396,7 +398,7 @@ def main() -> None:
         dist.barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device=dev if dist.get_backend() != "gloo" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 

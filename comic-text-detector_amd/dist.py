@@ -28,7 +28,8 @@ def init(backend: Optional[str] = None) -> Tuple[int, int, int]:
     rank, local_rank, world = env_world()
     if world > 1 and not dist.is_initialized():
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            # CTD_DIST_BACKEND=gloo: lets a 1-GPU box rehearse the N > 1 code path (all ranks on one device)
+            backend = os.environ.get("CTD_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         kw = {}
@@ -125,10 +126,14 @@ def gather_records(rec: torch.Tensor, n_total: int, rank: int, world: int) -> to
     if world == 1:
         return rec
     per = -(-n_total // world)
+    home = rec.device
+    if dist.get_backend() == "gloo" and rec.is_cuda:        # gloo gathers host tensors
+        rec = rec.cpu()
     pad = torch.zeros((per, rec.shape[1]), dtype=rec.dtype, device=rec.device)
     pad[: rec.shape[0]] = rec
     out = torch.empty((world * per, rec.shape[1]), dtype=rec.dtype, device=rec.device)
     dist.all_gather_into_tensor(out, pad)
+    out = out.to(home)
     parts = []
     for r in range(world):
         lo, hi = shard_range(n_total, r, world)

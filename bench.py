@@ -333,11 +333,16 @@ def main() -> None:
         job.update(canned)                        # random weights -> noise maps: the tail gets the text-like outputs
         return job
 
+    comm_stream = torch.cuda.Stream(dev) if world > 1 else None
+
     def finish(res):
         """Main-thread part of a step: (N>1) all-gather of the block records."""
         if world > 1:
-            rec = D.pack_results(res, device=dev)
-            D.gather_records(rec, total_pages, rank, world)
+            # on its own stream: the default stream holds the queued forwards of the next batches, and an upload or
+            # a collective enqueued behind them would stall this thread until they have run
+            with torch.cuda.stream(comm_stream):
+                rec = D.pack_results(res).pin_memory().to(dev, non_blocking=True)
+                D.gather_records(rec, total_pages, rank, world)
         stats["pages"] += len(res)
         stats["blocks"] += sum(len(r[2]) for r in res)
         stats["lines"] += sum(len(b.lines) for r in res for b in r[2])

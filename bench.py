@@ -504,7 +504,7 @@ def main() -> None:
         if n_gpus > 1:
             workload += " + RCCL all-gather of the per-page block records"
         out = {
-            "metric": "pages/sec at 1024x1024 bs=32" + (" (end-to-end detector)" if e2e else " (network + NMS)"),
+            "metric": f"pages/sec at {S}x{S} bs={B}" + (" (end-to-end detector)" if e2e else " (network + NMS)"),
             "value": round(total_pages * args.steps / dt, 2),
             "unit": "pages/s",
             "n_gpus": n_gpus,

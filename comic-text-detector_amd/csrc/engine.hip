@@ -253,10 +253,15 @@ int pack_op(ctd_engine* e, OpState& s, const float* P, int64_t nP) {
       return pack_bias(N);
     }
     case CTD_OP_SEG_FINAL: {
-      if (!f16) return fail(CTD_ERR_UNSUPPORTED, "SEG_FINAL op is fp16-path only");
       if (cin != 64 || N != 1) return fail(CTD_ERR_UNSUPPORTED, "fused seg-final is 64->1 only");
       if (!need(o.w_off, (int64_t)cin * 16)) return fail(CTD_ERR_INVALID, "seg-final weights out of range");
       const float* W = P + o.w_off;  // (cin, 1, 4, 4)
+      if (!f16) {                    // exact-fp32 engine: the checkpoint layout as it is
+        std::vector<float> wf(W, W + (size_t)cin * 16);
+        s.impl = IMPL_FUSED;
+        if (int rc = upload(e, wf, &s.w_dev)) return rc;
+        return pack_bias(1);
+      }
       // fp16, [cin/8][16 taps][8 channels]: one 8-channel group of all taps = 64 dwords of scalar loads
       std::vector<half_t> wp((size_t)16 * cin);
       for (int c = 0; c < cin; ++c)
@@ -266,7 +271,6 @@ int pack_op(ctd_engine* e, OpState& s, const float* P, int64_t nP) {
       return pack_bias(1);
     }
     case CTD_OP_DB_UP: {
-      if (!f16) return fail(CTD_ERR_UNSUPPORTED, "DB_UP op is fp16-path only");
       const int q = o.aux[1];
       if (q != 16) return fail(CTD_ERR_UNSUPPORTED, "fused db tail is q=16 only");
       const int nbr = o.aux[2] > 0 ? o.aux[2] : 2;                 // branches lowered (1 = shrink map only)
@@ -624,14 +628,18 @@ int launch_op(ctd_engine* e, int i, const Outs& x, hipStream_t st) {
     case CTD_OP_SEG_FINAL: {
       const TensorState& ts = e->tensors[o.src0];
       if (!x.mask && !x.mask_u8) break;
-      launch_seg_final((const half_t*)tptr(o.src0, o.src0_coff), ts.t.channels, o.src0_c, B, ts.H, ts.W,
-                       (const float*)s.w_dev, 0.f, x.mask, x.mask_u8, st);
+      if (ts.esize == 4)
+        launch_seg_final_f32((const float*)tptr(o.src0, o.src0_coff), ts.t.channels, o.src0_c, B, ts.H, ts.W,
+                             (const float*)s.w_dev, x.mask, x.mask_u8, st);
+      else
+        launch_seg_final((const half_t*)tptr(o.src0, o.src0_coff), ts.t.channels, o.src0_c, B, ts.H, ts.W,
+                         (const float*)s.w_dev, 0.f, x.mask, x.mask_u8, st);
       break;
     }
     case CTD_OP_DB_UP: {
       const TensorState& ts = e->tensors[o.src0];
       if (!x.lines) break;
-      launch_db_up((const half_t*)tptr(o.src0, o.src0_coff), ts.t.channels, o.aux[1], o.aux[2] > 0 ? o.aux[2] : 2, B, ts.H, ts.W,
+      launch_db_up(tptr(o.src0, o.src0_coff), ts.esize == 4, ts.t.channels, o.aux[1], o.aux[2] > 0 ? o.aux[2] : 2, B, ts.H, ts.W,
                    (const float*)s.w_dev, x.lines, x.bitmap, o.faux[0], st);
       break;
     }

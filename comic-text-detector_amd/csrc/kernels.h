@@ -62,7 +62,9 @@ void launch_seg_final(const half_t* src, int pitch, int C, int B, int H, int W, 
                       float* mask, uint8_t* mask_u8, hipStream_t st);
 // db tail: src (B,H,W, 2q) half [binarize q | thresh q] (already conv3x3+BN+ReLU)
 // params f32 per branch: W1[q][q][2][2] (cin,cout,ky,kx) b1[q] W2[q][1][2][2] b2[1]
-void launch_db_up(const half_t* src, int pitch, int q, int nbr, int B, int H, int W, const float* params, float* lines,
+void launch_seg_final_f32(const float* src, int pitch, int C, int B, int H, int W, const float* w, float* mask,
+                          uint8_t* mask_u8, hipStream_t st);
+void launch_db_up(const void* src, bool f32in, int pitch, int q, int nbr, int B, int H, int W, const float* params, float* lines,
                   uint8_t* bitmap, float thresh, hipStream_t st);
 
 // ---- kernels_post.hip -------------------------------------------------------

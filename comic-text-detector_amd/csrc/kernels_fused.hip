@@ -1,6 +1,7 @@
 // Fused head/tail kernels of the fp16 fast path.  These layers have a tiny
 // channel count on one side (3 in, or 1 out), so they are HBM/VALU work, not
 // GEMMs: no MFMA here (north_star: "MFMA only ... where it is a true GEMM").
+#include <type_traits>
 #include <vector>
 
 #include "kernels.h"
@@ -240,6 +241,90 @@ __global__ __launch_bounds__(256) void seg_final_kernel(const half_t* __restrict
   }
 }
 
+// The same layer for the exact-fp32 engine: f32 activations, f32 FMA, precise expf.  On the f32 MFMA kernel this
+// 64 -> 1 ConvT filled 1/32 of an N tile (1.9 ms at bs=8, 8 % of the fp32 forward).  16-channel chunks of the
+// 18x18 halo tile go through LDS (pixel pitch 20 floats: 16-B reads of consecutive pixels spread over the banks);
+// weights (cin,1,4,4) stay in their checkpoint layout and are read with wave-uniform indices (scalar loads).
+template <int C>
+__global__ __launch_bounds__(256) void seg_final_f32_kernel(const float* __restrict__ src, int pitch, int B, int H, int W,
+                                                            const float* __restrict__ w, float* __restrict__ mask,
+                                                            uint8_t* __restrict__ mask_u8) {
+  constexpr int TP = SF_T + 2, CC = 16, PP = CC + 4;
+  __shared__ __attribute__((aligned(16))) float tile[TP * TP * PP];
+  const int tiles_x = (W + SF_T - 1) / SF_T, tiles_y = (H + SF_T - 1) / SF_T;
+  int bid = blockIdx.x;
+  const int x0 = (bid % tiles_x) * SF_T;
+  bid /= tiles_x;
+  const int y0 = (bid % tiles_y) * SF_T;
+  const long long b = bid / tiles_y;
+  const int lx = threadIdx.x % SF_T, ly = threadIdx.x / SF_T;
+  float o[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
+  constexpr int NCH = TP * TP * (CC / 4), NIT = (NCH + 255) / 256;
+#pragma unroll 1
+  for (int cc = 0; cc < C / CC; ++cc) {
+    float4_t v[NIT];
+#pragma unroll
+    for (int k = 0; k < NIT; ++k) {
+      const int i = threadIdx.x + 256 * k;
+      const int c4 = i % (CC / 4), pp = i / (CC / 4);
+      const int ty = pp / TP, tx = pp % TP;
+      const int yy = y0 + ty - 1, xx = x0 + tx - 1;
+      const bool ok = i < NCH && yy >= 0 && yy < H && xx >= 0 && xx < W;
+      const float4_t z = {0.f, 0.f, 0.f, 0.f};
+      v[k] = ok ? *(const float4_t*)(src + ((b * H + yy) * W + xx) * pitch + cc * CC + c4 * 4) : z;
+    }
+    __syncthreads();                              // the previous chunk's reads are done
+#pragma unroll
+    for (int k = 0; k < NIT; ++k) {
+      const int i = threadIdx.x + 256 * k;
+      if (i < NCH) *(float4_t*)(tile + (i / (CC / 4)) * PP + (i % (CC / 4)) * 4) = v[k];
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int c4 = 0; c4 < CC / 4; ++c4) {
+      const float* wc = w + (size_t)(cc * CC + c4 * 4) * 16;        // [4 channels][ky*4+kx]
+#pragma unroll
+      for (int dy = -1; dy <= 1; ++dy) {
+#pragma unroll
+        for (int dx = -1; dx <= 1; ++dx) {
+          const float4_t xv = *(const float4_t*)(tile + ((ly + 1 + dy) * TP + (lx + 1 + dx)) * PP + c4 * 4);
+#pragma unroll
+          for (int py = 0; py < 2; ++py) {
+            const int ky = py + 1 - 2 * dy;
+            if (ky < 0 || ky > 3) continue;
+#pragma unroll
+            for (int px = 0; px < 2; ++px) {
+              const int kx = px + 1 - 2 * dx;
+              if (kx < 0 || kx > 3) continue;
+              float s = o[py][px];
+#pragma unroll
+              for (int e = 0; e < 4; ++e) s = fmaf(xv[e], wc[e * 16 + ky * 4 + kx], s);
+              o[py][px] = s;
+            }
+          }
+        }
+      }
+    }
+  }
+  const int x = x0 + lx, y = y0 + ly;
+  if (x >= W || y >= H) return;
+  const int Wo = 2 * W;
+  const long long Ho = 2LL * H;
+#pragma unroll
+  for (int py = 0; py < 2; ++py) {
+    const float s0 = 1.0f / (1.0f + expf(-o[py][0]));
+    const float s1 = 1.0f / (1.0f + expf(-o[py][1]));
+    const long long off = (b * Ho + (2 * y + py)) * Wo + 2 * x;
+    if (mask) *(float2*)(mask + off) = make_float2(s0, s1);
+    if (mask_u8) {
+      uchar2 q;
+      q.x = (uint8_t)(s0 * 255.0f);
+      q.y = (uint8_t)(s1 * 255.0f);
+      *(uchar2*)(mask_u8 + off) = q;
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------
 // DB tail: for each branch (binarize, thresh):
 //   ConvT 2x2/s2 (q->q) + BN + ReLU -> ConvT 2x2/s2 (q->1) -> sigmoid
@@ -257,8 +342,8 @@ struct DbUpLayout {
   static constexpr int W1 = 0, B1 = 4 * Q * Q, W2 = B1 + Q, B2 = W2 + 4 * Q, SIZE = (B2 + 1 + 3) / 4 * 4;
 };
 
-template <int Q>
-__global__ __launch_bounds__(256) void db_up_kernel(const half_t* __restrict__ src, int pitch, int nbr, int B, int H, int W,
+template <int Q, typename T>
+__global__ __launch_bounds__(256) void db_up_kernel(const T* __restrict__ src, int pitch, int nbr, int B, int H, int W,
                                                     const float* __restrict__ params, float* __restrict__ lines,
                                                     uint8_t* __restrict__ bitmap, float thresh) {
   using Lt = DbUpLayout<Q>;
@@ -272,7 +357,8 @@ __global__ __launch_bounds__(256) void db_up_kernel(const half_t* __restrict__ s
   const int tid = threadIdx.x;
   const int x = (int)(i % W), y = (int)((i / W) % H);
   const long long b = i / ((long long)W * H);
-  const half_t* p = src + i * pitch;
+  const T* p = src + i * pitch;
+  constexpr bool F32IN = std::is_same<T, float>::value;    // the exact-fp32 engine: f32 activations, precise expf
   const int Wo = 4 * W;
   const long long Ho = 4LL * H;
   // Loops are deliberately NOT unrolled (except the 16-wide output vector): full unrolling made
@@ -282,9 +368,15 @@ __global__ __launch_bounds__(256) void db_up_kernel(const half_t* __restrict__ s
     const float* Pb = P + br * Lt::SIZE;
 #pragma unroll
     for (int c8 = 0; c8 < Q / 8; ++c8) {
-      const half8_t v = *(const half8_t*)(p + br * Q + c8 * 8);
+      if constexpr (F32IN) {
+        const float4_t v0 = *(const float4_t*)(p + br * Q + c8 * 8), v1 = *(const float4_t*)(p + br * Q + c8 * 8 + 4);
 #pragma unroll
-      for (int e = 0; e < 8; ++e) xs[(c8 * 8 + e) * 256 + tid] = (float)v[e];
+        for (int e = 0; e < 4; ++e) xs[(c8 * 8 + e) * 256 + tid] = v0[e], xs[(c8 * 8 + 4 + e) * 256 + tid] = v1[e];
+      } else {
+        const half8_t v = *(const half8_t*)(p + br * Q + c8 * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) xs[(c8 * 8 + e) * 256 + tid] = (float)v[e];
+      }
     }
 #pragma unroll 1
     for (int pp = 0; pp < 4; ++pp) {
@@ -321,7 +413,7 @@ __global__ __launch_bounds__(256) void db_up_kernel(const half_t* __restrict__ s
           s = fmaf(h[o4 * 4 + 2], t.z, s);
           s = fmaf(h[o4 * 4 + 3], t.w, s);
         }
-        r4[qq] = 1.0f / (1.0f + __expf(-s));
+        r4[qq] = F32IN ? 1.0f / (1.0f + expf(-s)) : 1.0f / (1.0f + __expf(-s));
       }
       // sub-pixel (py,px) of the first ConvT owns output rows 4y+2py+{0,1}, columns 4x+2px+{0,1}
       const int py = pp >> 1, px = pp & 1;
@@ -377,10 +469,22 @@ void launch_seg_final(const half_t* src, int pitch, int C, int B, int H, int W, 
   (void)C;
 }
 
-void launch_db_up(const half_t* src, int pitch, int q, int nbr, int B, int H, int W, const float* params, float* lines,
+void launch_seg_final_f32(const float* src, int pitch, int C, int B, int H, int W, const float* w, float* mask,
+                          uint8_t* mask_u8, hipStream_t st) {
+  const int g = ((W + SF_T - 1) / SF_T) * ((H + SF_T - 1) / SF_T) * B;
+  hipLaunchKernelGGL((seg_final_f32_kernel<64>), dim3(g), dim3(256), 0, st, src, pitch, B, H, W, w, mask, mask_u8);
+  (void)C;
+}
+
+void launch_db_up(const void* src, bool f32in, int pitch, int q, int nbr, int B, int H, int W, const float* params, float* lines,
                   uint8_t* bitmap, float thresh, hipStream_t st) {
   const long long total = (long long)B * H * W;
   const int g = (int)((total + 255) / 256);
-  hipLaunchKernelGGL((db_up_kernel<16>), dim3(g), dim3(256), 0, st, src, pitch, nbr, B, H, W, params, lines, bitmap, thresh);
+  if (f32in)
+    hipLaunchKernelGGL((db_up_kernel<16, float>), dim3(g), dim3(256), 0, st, (const float*)src, pitch, nbr, B, H, W, params,
+                       lines, bitmap, thresh);
+  else
+    hipLaunchKernelGGL((db_up_kernel<16, half_t>), dim3(g), dim3(256), 0, st, (const half_t*)src, pitch, nbr, B, H, W, params,
+                       lines, bitmap, thresh);
   (void)q;
 }

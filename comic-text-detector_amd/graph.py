@@ -277,7 +277,7 @@ def lower(ckpt: dict, precision: int, act: str = "leaky", bitmap_thresh: float =
     prog.taps["u40"] = u40.tid
     prog.taps["u320"] = u320.tid
     w6, _ = fold(sl.sd, u.upconv6)
-    if fast and u.upconv6.c1 == 64:
+    if u.upconv6.c1 == 64:                     # fused 64 -> 1 ConvT + sigmoid + u8 mask (fp16 and fp32 engines)
         prog.op(L.OP_SEG_FINAL, src0=u320.tid, src0_coff=0, src0_c=u320.c, cout=1, k=4, stride=2, pad=1,
                 act=L.ACT["sigmoid"], w_off=prog.param(w6), aux=[L.OUT_MASK] + [0] * 7, name="seg.upconv6")
     else:
@@ -297,7 +297,7 @@ def lower(ckpt: dict, precision: int, act: str = "leaky", bitmap_thresh: float =
     branches = (d.binarize, d.thresh) if db_thresh else (d.binarize,)
     nbr = len(branches)
     prog.meta["line_planes"] = nbr
-    if fast and q == 16:
+    if q == 16:                                # fused DB tail (fp16 and fp32 engines)
         folded = [fold(dl.sd, br.conv3) for br in branches]
         y = prog.conv([dx], np.concatenate([f[0] for f in folded], 0), np.concatenate([f[1] for f in folded], 0), 3, 1, 1,
                       "relu", name="db.binarize.0+thresh.0" if db_thresh else "db.binarize.0")

@@ -37,7 +37,12 @@ constexpr int NTHR = 512;
 
 // TPS = taps per barrier: the weight tiles of TPS consecutive taps are staged together, so a chunk of a
 // ConvTranspose phase (4 taps) takes 2 barriers instead of 4 and a 3x3 chunk 5 instead of 9.
-template <int BN, int WGN, int WGM, bool PROF, int TPS = 1>
+// PAIR (ConvT 4x4/s2 with 64 output channels, BN = 128): a block computes the two sub-pixel phases (py, px = 0)
+// and (py, px = 1) of its patch -- N columns 0-63 are phase px = 0, 64-127 phase px = 1.  The two phases read the
+// same input rows and overlapping columns (dx in {-1,0} and {0,+1}), so ONE 17x18 patch serves both: half the
+// patch DMA per MFMA, and the wave tile is the 2x4-fragment tile of the 128-channel layers (6 LDS reads per 8
+// MFMAs) instead of 1x2 (3 reads per 2 MFMAs).
+template <int BN, int WGN, int WGM, bool PROF, int TPS = 1, bool PAIR = false>
 __global__ __launch_bounds__(NTHR, 4) void conv_halo_kernel(ConvArgs a) {   // 4 waves / SIMD = 2 blocks / CU
   constexpr int TN = BN / (32 * WGN);
   constexpr int TM = BMH / (32 * WGM);
@@ -67,9 +72,9 @@ __global__ __launch_bounds__(NTHR, 4) void conv_halo_kernel(ConvArgs a) {   // 4
 
   // ---- block -> (batch, patch, phase, N tile); XCD-aware: each XCD gets a contiguous run so
   // the N tiles / phases / neighbouring patches that share input pixels share an L2
-  const int ntn = a.Npad / BN;
+  const int ntn = PAIR ? 1 : a.Npad / BN;
   const int tilesX = (a.Mw + TWP - 1) / TWP, tilesY = (a.Mh + THP - 1) / THP;
-  const int nblk = ntn * a.nphase * tilesX * tilesY * a.B;
+  const int nblk = ntn * (PAIR ? 2 : a.nphase) * tilesX * tilesY * a.B;
   int v = blockIdx.x;
   {
     const int xcd = v & 7, within = v >> 3;
@@ -79,7 +84,10 @@ __global__ __launch_bounds__(NTHR, 4) void conv_halo_kernel(ConvArgs a) {   // 4
   const int tile_n = v % ntn;
   v /= ntn;
   int phase = 0;
-  if (a.nphase == 4) {
+  if (PAIR) {
+    phase = (v & 1) * 2;      // py; the block covers px = 0 and 1
+    v >>= 1;
+  } else if (a.nphase == 4) {
     phase = v & 3;
     v >>= 2;
   }
@@ -89,7 +97,7 @@ __global__ __launch_bounds__(NTHR, 4) void conv_halo_kernel(ConvArgs a) {   // 4
   const int b = v / tilesY;
   const int n0 = tile_n * BN;
   const int y0 = tpy * THP, x0 = tpx * TWP;
-  if (threadIdx.x < BN) bias_s[threadIdx.x] = a.bias[n0 + threadIdx.x];   // visible after the prologue barrier
+  if (threadIdx.x < BN) bias_s[threadIdx.x] = a.bias[PAIR ? (threadIdx.x & 63) : n0 + threadIdx.x];   // visible after the prologue barrier
 
   int dy0 = a.dy0, dx0 = a.dx0, ooy = a.ooy, oox = a.oox;
   const half_t* __restrict__ wbase = (const half_t*)a.w;
@@ -99,9 +107,10 @@ __global__ __launch_bounds__(NTHR, 4) void conv_halo_kernel(ConvArgs a) {   // 4
     dx0 = px ? 0 : -1;
     ooy = py;
     oox = px;
-    wbase += (size_t)phase * a.w_phase_stride;
+    if (!PAIR) wbase += (size_t)phase * a.w_phase_stride;
   }
-  const int HW = TWP + a.KW - 1, HH = THP + a.KH - 1;   // haloed patch
+  if (PAIR) dx0 = -1;                                    // the patch spans dx = -1 .. +1
+  const int HW = TWP + (PAIR ? 3 : a.KW) - 1, HH = THP + a.KH - 1;   // haloed patch
   const int taps = a.KH * a.KW;
   const int Ct = a.s0.c + a.s1.c;
   const int nchunk = Ct / BKH;
@@ -131,7 +140,12 @@ __global__ __launch_bounds__(NTHR, 4) void conv_halo_kernel(ConvArgs a) {   // 4
   constexpr int WCHUNKS = BN * 4;
   const int wr = t >> 2;
   const int woff = (wr * BKH + ((t & 3) ^ swz(wr)) * 8) * 2;
-  const char* wtile = (const char*)(wbase + (size_t)tile_n * (size_t)(a.K / BKH) * BN * BKH);
+  // PAIR: LDS weight rows 0-63 come from phase (py, 0)'s 64-row tiles, rows 64-127 from phase (py, 1)'s
+  const int wrow = PAIR ? (wr & 63) : wr;
+  const int woff_p = (wrow * BKH + ((t & 3) ^ swz(wr)) * 8) * 2;
+  const char* wtile = PAIR ? (const char*)(wbase + (size_t)(phase + (wr >> 6)) * a.w_phase_stride)
+                           : (const char*)(wbase + (size_t)tile_n * (size_t)(a.K / BKH) * BN * BKH);
+  constexpr int WPACK = PAIR ? 64 : BN;                  // rows of one packed weight tile
 
   auto dma_a = [&](int chunk, int i) {   // pass i (0..2) of the haloed patch of channel chunk `chunk`
     const int cc = chunk * BKH;
@@ -145,9 +159,9 @@ __global__ __launch_bounds__(NTHR, 4) void conv_halo_kernel(ConvArgs a) {   // 4
   };
   auto dma_w = [&](int chunk, int tap, int buf, int slot = 0) {
     if (WCHUNKS >= NTHR || t < WCHUNKS) {
-      const char* wk = wtile + (size_t)(tap * nkc + chunk) * (BN * BKH * 2);
+      const char* wk = wtile + (size_t)(tap * nkc + chunk) * (WPACK * BKH * 2);
       half_t* dst = Ws + (size_t)buf * W_BUF + (size_t)slot * W_TILE + (size_t)(wave_u * 64) * 8;
-      __builtin_amdgcn_global_load_lds((gptr_t)(wk + woff), (lptr_t)dst, 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)(wk + (PAIR ? woff_p : woff)), (lptr_t)dst, 16, 0, 0);
     }
   };
 
@@ -223,7 +237,7 @@ __global__ __launch_bounds__(NTHR, 4) void conv_halo_kernel(ConvArgs a) {   // 4
         if (TPS > 1 && tap >= taps) break;
         const int ty = tap / a.KW, tx = tap - ty * a.KW;
         const half_t* Wb = Ws + (size_t)(step & 1) * W_BUF + (size_t)j * W_TILE + (size_t)(wn * TN * 32 + l31) * BKH;
-        const int tapoff = ty * HW + tx;
+        const int tapoff = ty * HW + tx + (PAIR ? wn : 0);   // PAIR: phase px = 1 (wn = 1) reads one column further right
 #pragma unroll
         for (int kk = 0; kk < BKH / 16; ++kk) {
           half8_t fw[TN], fx[TM];
@@ -284,7 +298,8 @@ __global__ __launch_bounds__(NTHR, 4) void conv_halo_kernel(ConvArgs a) {   // 4
   constexpr int CPP = BN / 8;          // 16-B chunks per pixel row of the tile
   constexpr int PPI = NTHR / CPP;      // pixels covered by one pass of the block
   const int cch = t % CPP;
-  const int n = n0 + cch * 8;
+  const int n = PAIR ? (cch & 7) * 8 : n0 + cch * 8;     // PAIR: staged columns 64-127 are channels 0-63 of phase px = 1
+  if (PAIR) oox = cch >> 3;
   // The residual (C3 shortcut) joins here, on whole 16-B channel rows: coalesced loads, all of
   // them issued before the first use, and the sum is rounded like the reference's half-precision
   // `x + cv2(cv1(x))` (conv output rounded to fp16, then the add).  In the MFMA register layout
@@ -326,6 +341,12 @@ __global__ __launch_bounds__(NTHR, 4) void conv_halo_kernel(ConvArgs a) {   // 4
       d[0] = T1 - T0; d[1] = T2 - T1; d[2] = t_issue; d[3] = t_comp; d[4] = t_wait; d[5] = T4 - T3; d[6] = T5 - T4; d[7] = T5 - T0;
     }
   }
+}
+
+void launch_halo_pair(const ConvArgs& a, hipStream_t st) {
+  const int tilesX = (a.Mw + TWP - 1) / TWP, tilesY = (a.Mh + THP - 1) / THP;
+  dim3 grid((unsigned)(2 * tilesX * tilesY * a.B), 1, 1);
+  hipLaunchKernelGGL((conv_halo_kernel<128, 2, 4, false, 1, true>), grid, dim3(NTHR), 0, st, a);
 }
 
 template <int BN, int WGN, int WGM>
@@ -370,6 +391,9 @@ bool conv_halo_supported(const ConvArgs& a, bool dst_f32) {
 
 void launch_conv_halo(const ConvArgs& a, hipStream_t st) {
   const int bn = igemm_ntile(a.N);
+  static const bool pair = [] { const char* e = std::getenv("CTD_HALO_PAIR"); return !e || std::atoi(e) != 0; }();
+  if (pair && a.nphase == 4 && a.N == 64 && a.Npad == 64 && !a.res && !((a.k_rot & 16) && a.dbg) && g_halo_tps == 1)
+    return launch_halo_pair(a, st);
   if (bn == 128) launch_halo_cfg<128, 2, 4>(a, st);
   else if (bn == 64) launch_halo_cfg<64, 2, 4>(a, st);
   else launch_halo_cfg<32, 1, 8>(a, st);

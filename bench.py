@@ -15,9 +15,11 @@ over one batch of 32 synthetic pages already resident in HBM:
 The tail of step k runs on worker threads (own HIP streams) under the forward of step k+1
 (`TextDetector.detect_stream`'s pipeline).  Release weights are not available offline and random weights
 give noise maps, so the forward runs on the synthetic pages (its time is data independent) and the tail
-is fed the matching TEXT-LIKE network outputs of the same pages (`synth.text_like_outputs`: ~10 text
-blocks / ~40 lines per page) -- stated in `config.workload`.  `--mode net` times the old step (forward +
-NMS only) for comparison.
+is fed the matching TEXT-LIKE network outputs of the same pages (`synth.text_like_outputs`: ~15 text
+blocks / ~84 lines per page, block boxes = 35 % of the page) -- stated in `config.workload`.  Other lines:
+`--mode net` (forward + NMS only), `--mode mixed` (BASELINE configs[4]: 640/1024/1536 stream, one hipGraph
+per bucket), `--precision fp32 --batch 8` (configs[1], the exact-fp32 engine), `--host-input` (pages start in
+host memory: the PCIe-inclusive rate, never the headline), `--keep-undetected`.
 
     python bench.py --gpus 1 --steps 10 --warmup 3
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \

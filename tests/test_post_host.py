@@ -276,3 +276,47 @@ def test_oracle_resize_geometry_against_torch_bilinear():
         diff = np.abs(got - np.rint(want.numpy()).astype(np.int64))
         assert diff.max() <= 1, ((sh, sw), (dh, dw), int(diff.max()))
         assert (diff > 0).mean() < 0.2
+
+
+def test_oracle_round_offset_is_the_minkowski_sum_with_a_disc():
+    """Independent check of `cv_ref.clipper_offset_round` (the restated Clipper 6.4.2 JT_ROUND offset behind
+    `unclip`, reference db_utils.py:168-174): geometry, not Clipper's code.  For a convex polygon P and distance d
+    the exact result is the Minkowski sum P + disc(d): (1) every vertex of the ring lies at distance d from P, up to
+    the arc tolerance (chords sag inwards by <= 0.25) and the integer rounding (<= 0.5 * sqrt(2)); (2) its area is
+    Steiner's A + L*d + pi*d^2 up to the same two effects along its perimeter; (3) it contains P."""
+    from oracle import cv_ref
+    rng = np.random.RandomState(11)
+
+    def seg_dist(p, a, b):
+        ab, ap = b - a, p - a
+        t = np.clip(np.dot(ap, ab) / max(np.dot(ab, ab), 1e-12), 0.0, 1.0)
+        return float(np.linalg.norm(ap - t * ab))
+
+    for _ in range(60):
+        cx, cy = rng.uniform(100, 900, 2)
+        w, h = rng.uniform(6, 300), rng.uniform(4, 120)
+        th = rng.uniform(0, np.pi)
+        R = np.array([[np.cos(th), -np.sin(th)], [np.sin(th), np.cos(th)]])
+        quad = (np.array([[-w, -h], [w, -h], [w, h], [-w, h]]) / 2) @ R.T + [cx, cy]
+        ipts = np.trunc(quad).astype(np.int64)                       # pyclipper's cast
+        P = ipts.astype(np.float64)
+        A = abs(cv_ref.polygon_area(P.astype(np.float32)))
+        Lp = sum(np.linalg.norm(P[i] - P[(i + 1) % 4]) for i in range(4))
+        if A < 4:
+            continue
+        d = float(A * 1.5 / Lp)
+        ring = cv_ref.clipper_offset_round(ipts, d).astype(np.float64)
+        assert len(ring) >= 8
+        slack = 0.25 + 0.5 * 2 ** 0.5 + 1e-6
+        for v in ring:
+            dist = min(seg_dist(v, P[i], P[(i + 1) % 4]) for i in range(4))
+            assert d - slack <= dist <= d + 0.5 * 2 ** 0.5 + 1e-6, (d, dist)
+        x, y = ring[:, 0], ring[:, 1]
+        area = 0.5 * abs(np.dot(x, np.roll(y, -1)) - np.dot(y, np.roll(x, -1)))
+        steiner = A + Lp * d + np.pi * d * d
+        per = sum(np.linalg.norm(ring[i] - ring[(i + 1) % len(ring)]) for i in range(len(ring)))
+        assert abs(area - steiner) <= per * slack, (area, steiner)
+        # contains the polygon: every corner of P is on the inner side of every ring edge (ring is convex)
+        e, q = np.roll(ring, -1, 0) - ring, P[:, None, :] - ring[None, :, :]
+        s = np.sign(e[None, :, 0] * q[:, :, 1] - e[None, :, 1] * q[:, :, 0])
+        assert (s >= 0).all() or (s <= 0).all()

@@ -23,6 +23,7 @@ from concurrent.futures import ThreadPoolExecutor
 from typing import Iterable, Iterator, List, Sequence, Tuple, Union
 
 import ctypes as C
+import threading
 
 import numpy as np
 import torch
@@ -60,6 +61,7 @@ class TextDetector:
         # the benchmarked step is the whole network.
         self.net = BK.HipTextDetBackend(**self._net_args)
         self._lanes = [(self.net, None)]                      # (engine, stream) pairs of detect_stream, grown on demand
+        self._stage_tl = threading.local()
         self.backend = "hip"
         self.seg_rep = PP.SegRepresenter(thresh=0.3)          # inference.py:139
 
@@ -113,8 +115,7 @@ class TextDetector:
         dev = self.net.device
         if all(isinstance(p, torch.Tensor) and p.is_cuda for p in pages):
             return list(pages), None
-        import threading
-        tl = self.__dict__.setdefault("_stage_tl", threading.local())
+        tl = self._stage_tl                                   # per loader thread: pinned ring + copy stream
         if not hasattr(tl, "ring"):
             tl.ring, tl.k, tl.stream = [], 0, torch.cuda.Stream(dev)
         arrs = []

@@ -76,6 +76,7 @@ SYMBOLS = {
     "ctd_engine_read_tensor": (_i32, [_vp, _i32, C.POINTER(C.c_float), _i64]),
     "ctd_engine_workspace_bytes": (_i64, [_vp]),
     "ctd_engine_arena_generation": (_i32, [_vp]),
+    "ctd_tuning_set": (_i32, [C.c_char_p, C.c_int64]),
     "ctd_nms_workspace_bytes": (C.c_size_t, [_i32, _i32]),
     "ctd_nms": (_i32, [_vp, _i32, _i32, _i32, _f, _f, _i32, _i32, _f, _vp, _vp, _vp, C.c_size_t, _vp]),
     "ctd_db_step": (_i32, [_vp, _i32, _i32, _i32, _f, _vp, _vp, _f, _vp]),

@@ -800,6 +800,11 @@ int ctd_engine_read_tensor(ctd_engine* e, int32_t tensor_id, float* host_out, in
 int64_t ctd_engine_workspace_bytes(const ctd_engine* e) { return e ? (int64_t)e->arena_bytes : 0; }
 int32_t ctd_engine_arena_generation(const ctd_engine* e) { return e ? e->arena_gen : -1; }
 
+int ctd_tuning_set(const char* key, int64_t value) {
+  if (conv_tuning_set(key, (long long)value) != 0) return fail(CTD_ERR_INVALID, "unknown tuning key");
+  return CTD_OK;
+}
+
 // ---- post-processing entry points (kernels_post.hip) ------------------------------
 size_t ctd_nms_workspace_bytes(int32_t B, int32_t rows) { return nms_workspace_bytes(B, rows); }
 

@@ -49,6 +49,7 @@ void launch_conv_f32_mfma(const ConvArgs& a, hipStream_t st);
 // ---- kernels_halo.hip : halo-tile MFMA conv (stride-1 3x3, ConvTranspose phases) ----
 extern int g_conv_halo;   // 0 disables (selftest A/B)
 bool conv_halo_supported(const ConvArgs& a, bool dst_f32);
+int conv_tuning_set(const char* key, long long value);   // dispatch knobs of the MFMA conv kernels (kernels_halo.hip)
 void launch_conv_halo(const ConvArgs& a, hipStream_t st);
 
 // ---- kernels_fused.hip ----------------------------------------------------

@@ -18,6 +18,8 @@
 #include <cstdlib>
 #include <type_traits>
 
+#include <string>
+
 #include "kernels.h"
 
 int g_conv_halo = 1;   // selftest / tuning: 0 sends everything to the implicit-GEMM kernel
@@ -361,14 +363,25 @@ void launch_halo_cfg(const ConvArgs& a, hipStream_t st) {
 
 }  // namespace
 
-// threshold of the dispatch below; CTD_HALO_MIN_PATCHES overrides it (read once: tests force the halo kernel
-// onto small maps by setting it before the library's first convolution)
-static long long halo_min_patches() {
-  static const long long v = [] {
-    const char* env = std::getenv("CTD_HALO_MIN_PATCHES");
-    return env ? std::atoll(env) : 1024ll;
-  }();
-  return v;
+// Dispatch knobs of the halo kernel.  Initialised ONCE from the environment (A/B runs of the selftest and the
+// bench), changeable at run time through ctd_tuning_set (tests force the halo kernel onto small maps that way:
+// an environment variable read at the first convolution cannot be changed by a later test of the same process).
+static long long env_ll(const char* name, long long dflt) {
+  const char* e = std::getenv(name);
+  return e ? std::atoll(e) : dflt;
+}
+long long g_halo_min_patches = env_ll("CTD_HALO_MIN_PATCHES", 1024);   // fewer 256-pixel patches: implicit GEMM
+int g_halo_1x1 = (int)env_ll("CTD_HALO_1X1", 0);                       // 1x1 layers through the halo kernel
+int g_halo_pair = (int)env_ll("CTD_HALO_PAIR", 1);                     // 64-channel ConvT: both px phases per block
+
+int conv_tuning_set(const char* key, long long value) {
+  const std::string k(key ? key : "");
+  if (k == "halo_min_patches") g_halo_min_patches = value;
+  else if (k == "halo_1x1") g_halo_1x1 = (int)value;
+  else if (k == "halo_pair") g_halo_pair = (int)value;
+  else if (k == "halo") g_conv_halo = (int)value;
+  else return -1;
+  return 0;
 }
 
 // Stride-1 KxK (K = 2 or 3) windows over non-upsampled fp16 sources whose M grid equals the input
@@ -376,8 +389,7 @@ static long long halo_min_patches() {
 bool conv_halo_supported(const ConvArgs& a, bool dst_f32) {
   if (!g_conv_halo || dst_f32) return false;
   if (a.stride != 1 || a.s0.up || (a.s1.c && a.s1.up)) return false;
-  static const bool halo_1x1 = [] { const char* e = std::getenv("CTD_HALO_1X1"); return e && std::atoi(e) != 0; }();
-  if (!((a.KH == 3 && a.KW == 3) || (a.KH == 2 && a.KW == 2) || (halo_1x1 && a.KH == 1 && a.KW == 1 && a.nphase == 1)))
+  if (!((a.KH == 3 && a.KW == 3) || (a.KH == 2 && a.KW == 2) || (g_halo_1x1 && a.KH == 1 && a.KW == 1 && a.nphase == 1)))
     return false;
   if (a.Mh != a.Hin || a.Mw != a.Win) return false;
   if (a.s0.c % BKH || a.s1.c % BKH || a.bk != BKH || !a.w_tiled) return false;
@@ -386,13 +398,12 @@ bool conv_halo_supported(const ConvArgs& a, bool dst_f32) {
   // small maps: too few 256-pixel patches to fill 256 CUs twice -> the 128-pixel kernel does better
   const long long patches = (long long)a.B * ((a.Mh + THP - 1) / THP) * ((a.Mw + TWP - 1) / TWP) * a.nphase *
                             (a.Npad / igemm_ntile(a.N));
-  return patches >= halo_min_patches();
+  return patches >= g_halo_min_patches;
 }
 
 void launch_conv_halo(const ConvArgs& a, hipStream_t st) {
   const int bn = igemm_ntile(a.N);
-  static const bool pair = [] { const char* e = std::getenv("CTD_HALO_PAIR"); return !e || std::atoi(e) != 0; }();
-  if (pair && a.nphase == 4 && a.N == 64 && a.Npad == 64 && !a.res && !((a.k_rot & 16) && a.dbg) && g_halo_tps == 1)
+  if (g_halo_pair && a.nphase == 4 && a.N == 64 && a.Npad == 64 && !a.res && !((a.k_rot & 16) && a.dbg) && g_halo_tps == 1)
     return launch_halo_pair(a, st);
   if (bn == 128) launch_halo_cfg<128, 2, 4>(a, st);
   else if (bn == 64) launch_halo_cfg<64, 2, 4>(a, st);

@@ -172,6 +172,11 @@ int64_t ctd_engine_workspace_bytes(const ctd_engine* e);
  * fails with CTD_ERR_INVALID. */
 int32_t ctd_engine_arena_generation(const ctd_engine* e);
 
+/* Kernel-dispatch knobs (process-wide; no reference counterpart).  Keys: "halo_min_patches" (default 1024:
+ * maps with fewer 16x16 patches take the implicit-GEMM kernel), "halo" (0: never the halo kernel), "halo_pair",
+ * "halo_1x1".  The environment variables CTD_HALO_* give the initial values.  For tests and A/B measurements. */
+int ctd_tuning_set(const char* key, int64_t value);
+
 /* ---- post-processing kernels ------------------------------------------- */
 
 /* Class-aware greedy NMS on the decoded Detect rows; replaces

@@ -72,9 +72,9 @@ def test_network_sizes_against_oracle(shape):
 
 
 @pytest.mark.parametrize("shape", [(1, 64, 64), (3, 128, 64), (2, 320, 448)])
-def test_halo_kernel_forced_onto_small_maps_matches_oracle(shape, monkeypatch):
+def test_halo_kernel_forced_onto_small_maps_matches_oracle(shape):
     """The halo-tile conv kernel normally takes only maps with >= 1024 patches; forced onto tiny
-    ones (CTD_HALO_MIN_PATCHES=1) every 16x16 patch is partial: 2x2 ... 14x10 pixel maps, patches
+    ones (`ctd_tuning_set("halo_min_patches", 1)`) every 16x16 patch is partial: 2x2 ... 14x10 pixel maps, patches
     hanging over the right / bottom edge, ConvTranspose phases on 2x2 inputs."""
     ck = checkpoint(0)
     x = gen_golden.make_input(33, shape)
@@ -82,10 +82,14 @@ def test_halo_kernel_forced_onto_small_maps_matches_oracle(shape, monkeypatch):
     p = pkg()
     be = p.backend.HipTextDetBackend(ck, device="cuda", precision="fp16")
     ref = [t.clone() for t in be(x.cuda())]
-    monkeypatch.setenv("CTD_HALO_MIN_PATCHES", "1")
-    got = [t.clone() for t in be(x.cuda())]
-    torch.cuda.synchronize()
-    monkeypatch.delenv("CTD_HALO_MIN_PATCHES")
+    L = p._lib
+    L.check(L.lib().ctd_tuning_set(b"halo_min_patches", 1), "ctd_tuning_set")
+    try:
+        got = [t.clone() for t in be(x.cuda())]
+        torch.cuda.synchronize()
+    finally:
+        L.check(L.lib().ctd_tuning_set(b"halo_min_patches", 1024), "ctd_tuning_set")
+    assert not all(torch.equal(g, r) for g, r in zip(got, ref)), "the forced dispatch did not change any kernel"
     assert float((got[1].cpu() - om).abs().max()) < 3e-2
     assert float((got[2].cpu() - ol).abs().max()) < 3e-2
     assert float((got[0].cpu()[..., 4:] - ob[..., 4:]).abs().max()) < 3e-2

@@ -84,12 +84,25 @@ __global__ __launch_bounds__(256) void conv_f32_mfma_kernel(ConvArgs a) {
   }
 
   float4_t ra[AROWS], rw[WROWS];
+  // (tap, channel offset) of the NEXT tile to load, advanced incrementally: one 32-bit division per step and row
+  // was most of a K step's time on the narrow tiles (8 MFMAs per wave and step)
+  int nx_cc = 0, nx_ty = 0, nx_tx = 0;
   auto load_tile = [&](int ks) {
     const int k0 = ks * FBK;
     // Ct % 16 == 0: a K step stays inside one tap.  Ct == 4 (the stem's zero-padded image): one tap per 16-B chunk.
-    const int tap = Ct == 4 ? ks * 4 + seg : k0 / Ct;
-    const int cc = Ct == 4 ? 0 : k0 - tap * Ct;
-    const int ty = tap / a.KW, tx = tap - ty * a.KW;
+    int cc, ty, tx;
+    if (Ct == 4) {
+      const int tap = ks * 4 + seg;
+      cc = 0;
+      ty = tap / a.KW, tx = tap - ty * a.KW;
+    } else {
+      cc = nx_cc, ty = nx_ty, tx = nx_tx;
+      nx_cc += FBK;
+      if (nx_cc == Ct) {
+        nx_cc = 0;
+        if (++nx_tx == a.KW) nx_tx = 0, ++nx_ty;
+      }
+    }
     const bool first = cc < a.s0.c;
     const SrcView& s = first ? a.s0 : a.s1;
     const int ch = Ct == 4 ? 0 : (first ? cc : cc - a.s0.c) + seg * 4;
@@ -221,7 +234,15 @@ bool conv_f32_mfma_supported(const ConvArgs& a) {
 }
 
 void launch_conv_f32_mfma(const ConvArgs& a, hipStream_t st) {
-  const int bn = f32_mfma_ntile(a.N);
+  int bn = f32_mfma_ntile(a.N);
+  // Small maps (32x32 ... 128x128 at bs <= 8): a 128-channel tile leaves most of the 256 CUs idle while each
+  // wave walks a K loop of up to 288 steps x 32 MFMAs of 64 cycles (0.22 ms per layer whatever its size, measured
+  // at bs=1).  Narrower N tiles give 2-4x the blocks and a quarter of the MFMAs per wave and step; the weight
+  // rows are plain [n][K], so any tile width that divides Npad reads the same packing.  (Tried on top of this
+  // and measured slower: a second register set to prefetch two K steps ahead -- with 8 MFMAs per step the
+  // loop is bound by its address arithmetic, not by the memory round trip.)
+  const long long ntm = (a.M + FBM - 1) / FBM;
+  while (bn > 32 && (a.Npad / bn) * ntm * a.nphase < 256 && a.Npad % (bn / 2) == 0) bn >>= 1;
   if (bn == 128) launch_f32_cfg<128, 2, 2>(a, st);
   else if (bn == 64) launch_f32_cfg<64, 1, 4>(a, st);
   else launch_f32_cfg<32, 1, 4>(a, st);

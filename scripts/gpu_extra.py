@@ -2,7 +2,8 @@
 """Supplementary measurements for DESIGN.md / profiles (not the headline bench):
   1. bs=1 forward latency, eager launches vs hipGraph replay
   2. host+GPU time of the detector tail per 1024x1024 page on text-like outputs
-  3. config 2 (bs=8, exact-fp32 direct kernels) forward time"""
+  3. config 2 (bs=8, exact-fp32 engine) forward time
+  4. latency of one `TextDetector.__call__` on a host page (bs=1)"""
 import importlib
 import json
 import os
@@ -60,6 +61,21 @@ for keep in (False, True):
         res = det.tail_batch(pages, bt, mu, pr, bm, keep_undetected_mask=keep)
     out[f"tail_ms_per_page_textlike_1024_b{NP}_keep{int(keep)}"] = round((time.perf_counter() - t0) / 3 / NP * 1e3, 3)
 out["tail_blocks_per_page"] = [len(r[2]) for r in res][:8]
+
+# 4. latency mode: one numpy page in, `TextDetector.__call__` as the reference's callers use it (bs=1, host page,
+#    blob checkpoint so that the maps have contours -> the tail does real work)
+ckb = pkg.synth.make_blob_checkpoint(0)
+page1 = pkg.synth.text_like_page((1024, 1024), 3, n_blocks=8)
+import gc                                          # noqa: E402
+for half in (True, False):
+    d1 = pkg.detector.TextDetector(ckb, input_size=1024, device="cuda", half=half)
+    key = f"call_ms_b1_host_page_{'fp16' if half else 'fp32'}"
+    out[key + "_no_gc_freeze"] = round(timeit(lambda: d1(page1), n=10, warm=3), 3)
+    gc.collect()
+    gc.freeze()                                    # what a serving process does once after start-up
+    out[key] = round(timeit(lambda: d1(page1), n=10, warm=3), 3)
+    gc.unfreeze()
+    del d1
 
 be32 = pkg.backend.HipTextDetBackend(ck, precision="fp32")
 x = torch.rand(8, 3, 1024, 1024).cuda()

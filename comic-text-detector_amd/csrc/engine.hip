@@ -34,6 +34,8 @@ int fail(int code, const std::string& msg) {
       return fail(CTD_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e));                 \
   } while (0)
 
+int g_fuse_epoch = 0;   // bumped when a fusion threshold changes: cached plans are re-made
+
 enum Impl { IMPL_POINT = 0, IMPL_IGEMM = 1, IMPL_IGEMM_T = 2, IMPL_DIRECT = 3, IMPL_FUSED = 4 };
 
 struct OpState {
@@ -47,6 +49,12 @@ struct OpState {
   // filled by plan()
   ConvArgs args{};
   double flops = 0, bytes = 0;
+  bool c3_head = false;   // this op launches the fused C3 kernel for ops [i, i+3] ...
+  bool skip = false;      // ... and the other three launch nothing (also: pools 2, 3 of a fused SPPF)
+  bool sppf_head = false; // first of SPPF's three chained max pools: one launch does all three
+  bool stem2_head = false; // STEM op that also computes the following 3x3/s2 conv (which is `skip`)
+  Stem2Args st2{};
+  C3Args c3{};
 };
 
 struct TensorState {
@@ -70,6 +78,7 @@ struct ctd_engine {
   size_t arena_bytes = 0;
   int arena_gen = 0;           // bumped whenever the arena is reallocated: captured graphs hold the old addresses
   int pB = 0, pH = 0, pW = 0;  // current plan
+  int p_fuse = -1;             // value of g_fuse the current plan was made under
   bool no_reuse = false;
   bool w_tiled = true;   // tile-major MFMA weight packing (CTD_W_TILED=0 disables)
   bool f32_mfma = true;  // fp32 engine: f32-operand MFMA kernel (CTD_F32_MFMA=0: exact-order direct kernels only)
@@ -545,7 +554,94 @@ int plan(ctd_engine* e, int B, int H, int W, hipStream_t cap_stream = nullptr) {
                 (double)a.N * o.k * o.k * cin * es;
     }
     s.args = a;
+    s.c3_head = s.skip = s.sppf_head = s.stem2_head = false;
   }
+  // ---- stem + layer 1: the stem's output has one consumer, a 3x3/s2 conv 32 -> 64 -> one launch, never stored
+  for (int i = 0; f16 && (g_fuse & 4) && i + 1 < nO; ++i) {
+    OpState &S0 = e->ops[i], &S1 = e->ops[i + 1];
+    const ctd_op &o0 = S0.op, &o1 = S1.op;
+    if (o0.kind != CTD_OP_STEM || o1.kind != CTD_OP_CONV || S1.impl != IMPL_IGEMM || S1.bk != 32 || !e->w_tiled) continue;
+    const int T0 = o0.dst;
+    if (o0.cout != 32 || o0.dst_coff != 0 || e->tensors[T0].t.channels != 32) continue;
+    if (o1.k != 3 || o1.stride != 2 || o1.pad != 1 || o1.src0 != T0 || o1.src0_coff != 0 || o1.src0_c != 32 ||
+        o1.src0_up || o1.src1 >= 0 || o1.res >= 0 || o1.cout != 64 || o1.dst == T0)
+      continue;
+    if (e->tensors[T0].first_def != i || e->tensors[T0].last_use != i + 1 || e->tensors[o1.dst].esize != 2) continue;
+    Stem2Args f{};
+    f.B = B; f.H = H; f.W = W;
+    f.wfrag = (const half_t*)S0.w_dev; f.bias0 = S0.b_dev; f.act0 = o0.act;
+    f.w1 = (const half_t*)S1.w_dev; f.bias1 = S1.b_dev; f.act1 = o1.act;
+    f.dst = (half_t*)S1.args.dst; f.pitchD = S1.args.pitchD;
+    if (S1.args.oH != H / 4 || S1.args.oW != W / 4 || !stem_conv2_supported(f)) continue;
+    S0.stem2_head = true;
+    S0.st2 = f;
+    S1.skip = true;
+    S0.flops += S1.flops; S0.bytes += S1.bytes;
+    S1.flops = 0; S1.bytes = 0;
+  }
+  // ---- SPPF: three chained stride-1 max pools over the slots of one cat tensor -> one launch
+  for (int i = 0; f16 && (g_fuse & 2) && i + 2 < nO; ++i) {
+    const ctd_op &p0 = e->ops[i].op, &p1 = e->ops[i + 1].op, &p2 = e->ops[i + 2].op;
+    if (p0.kind != CTD_OP_MAXPOOL || p1.kind != CTD_OP_MAXPOOL || p2.kind != CTD_OP_MAXPOOL) continue;
+    const int c = p0.src0_c, P = p0.src0;
+    if (p0.dst != P || p1.src0 != P || p1.dst != P || p2.src0 != P || p2.dst != P) continue;
+    if (p1.src0_c != c || p2.src0_c != c || p1.k != p0.k || p2.k != p0.k) continue;
+    if (p0.dst_coff != p0.src0_coff + c || p1.src0_coff != p0.dst_coff || p1.dst_coff != p1.src0_coff + c ||
+        p2.src0_coff != p1.dst_coff || p2.dst_coff != p2.src0_coff + c)
+      continue;
+    const TensorState& tp = e->tensors[P];
+    if (tp.esize != 2 || !sppf_pool3_supported(tp.t.channels, c, c, tp.H, tp.W, p0.k, e->arena + tp.offset + (size_t)p0.src0_coff * 2))
+      continue;
+    e->ops[i].sppf_head = true;
+    e->ops[i + 1].skip = e->ops[i + 2].skip = true;
+    i += 2;
+  }
+  // ---- C3 blocks with 32 hidden channels and one bottleneck: ops [cv1+cv2, m.cv1, m.cv2 (+shortcut), cv3] whose
+  // intermediates nobody else reads become one launch of kernels_c3.hip (same packed weights, same arithmetic)
+  for (int i = 0; f16 && (g_fuse & 1) && i + 3 < nO; ++i) {
+    OpState &A = e->ops[i], &Bo = e->ops[i + 1], &C = e->ops[i + 2], &D = e->ops[i + 3];
+    const ctd_op &a = A.op, &b = Bo.op, &c = C.op, &d = D.op;
+    auto mfma16 = [&](const OpState& s) { return s.op.kind == CTD_OP_CONV && s.impl == IMPL_IGEMM && s.bk == 32 && e->w_tiled; };
+    if (!mfma16(A) || !mfma16(Bo) || !mfma16(C) || !mfma16(D)) continue;
+    const int Y = a.dst, T = b.dst;
+    if (a.k != 1 || a.stride != 1 || a.cout != 64 || a.res >= 0 || a.dst_coff != 0 || e->tensors[Y].t.channels != 64) continue;
+    if (b.k != 1 || b.stride != 1 || b.src0 != Y || b.src0_coff != 0 || b.src0_c != 32 || b.src1 >= 0 || b.cout != 32 ||
+        b.res >= 0 || b.dst_coff != 0 || e->tensors[T].t.channels != 32 || T == Y)
+      continue;
+    if (c.k != 3 || c.stride != 1 || c.pad != 1 || c.src0 != T || c.src0_coff != 0 || c.src0_c != 32 || c.src1 >= 0 ||
+        c.cout != 32 || c.dst != Y || c.dst_coff != 0 || c.res != Y || c.res_coff != 0)
+      continue;
+    if (d.k != 1 || d.stride != 1 || d.src0 != Y || d.src0_coff != 0 || d.src0_c != 64 || d.src1 >= 0 || d.cout != 64 ||
+        d.res >= 0 || d.dst == Y || d.dst == T)
+      continue;
+    if (a.act != b.act || a.act != c.act || a.act != d.act) continue;
+    if (b.src0_up || c.src0_up || d.src0_up) continue;
+    // the intermediates must be private to the block
+    if (e->tensors[Y].first_def != i || e->tensors[Y].last_use != i + 3 || e->tensors[T].first_def != i + 1 ||
+        e->tensors[T].last_use != i + 2)
+      continue;
+    if (e->tensors[d.dst].esize != 2 || e->tensors[Y].esize != 2 || e->tensors[T].esize != 2) continue;
+    C3Args f{};
+    f.s0 = A.args.s0;
+    f.s1 = A.args.s1;
+    f.B = B; f.H = A.args.Hin; f.W = A.args.Win;
+    f.w12 = (const half_t*)A.w_dev; f.wm1 = (const half_t*)Bo.w_dev; f.wm2 = (const half_t*)C.w_dev; f.wc3 = (const half_t*)D.w_dev;
+    f.b12 = A.b_dev; f.bm1 = Bo.b_dev; f.bm2 = C.b_dev; f.bc3 = D.b_dev;
+    f.dst = D.args.dst; f.pitchD = D.args.pitchD;
+    f.act = a.act;
+    f.zeros = e->zeros;
+    if (D.args.oH != f.H || D.args.oW != f.W || !c3_fused_supported(f)) continue;
+    A.c3_head = true;
+    A.c3 = f;
+    Bo.skip = C.skip = D.skip = true;
+    // the block's work is booked on its first op (the algorithmic bytes of the four layers stay the yardstick)
+    A.flops += Bo.flops + C.flops + D.flops;
+    A.bytes += Bo.bytes + C.bytes + D.bytes;
+    Bo.flops = C.flops = D.flops = 0;
+    Bo.bytes = C.bytes = D.bytes = 0;
+    i += 3;
+  }
+  e->p_fuse = g_fuse + 16 * g_fuse_epoch;
   e->pB = B; e->pH = H; e->pW = W;
   return CTD_OK;
 }
@@ -574,12 +670,21 @@ int launch_op(ctd_engine* e, int i, const Outs& x, hipStream_t st) {
       break;
     }
     case CTD_OP_STEM: {
+      if (s.stem2_head) {
+        Stem2Args f = s.st2;
+        f.in = x.input;
+        f.in_fmt = x.in_fmt;
+        launch_stem_conv2(f, st);
+        break;
+      }
       const TensorState& td = e->tensors[o.dst];
       launch_stem(x.input, x.in_fmt, (half_t*)tptr(o.dst, o.dst_coff), td.t.channels, B, H, W, o.cout,
                   (const half_t*)s.w_dev, s.b_dev, o.act, st);
       break;
     }
     case CTD_OP_CONV:
+      if (s.skip) break;
+      if (s.c3_head) { launch_c3_fused(s.c3, st); break; }
       if (s.impl == IMPL_IGEMM && !f16) launch_conv_f32_mfma(s.args, st);
       else if (s.impl == IMPL_IGEMM) launch_conv_igemm(s.args, e->tensors[o.dst].esize == 4, st);
       else launch_conv_direct(s.args, f16, st);
@@ -590,6 +695,12 @@ int launch_op(ctd_engine* e, int i, const Outs& x, hipStream_t st) {
       else launch_convt_direct(s.args, f16, st);
       break;
     case CTD_OP_MAXPOOL: {
+      if (s.skip) break;
+      if (s.sppf_head) {
+        const TensorState& tp = e->tensors[o.src0];
+        launch_sppf_pool3(tptr(o.src0, o.src0_coff), tp.t.channels, o.src0_c, o.src0_c, B, tp.H, tp.W, o.k, st);
+        break;
+      }
       const TensorState& ts = e->tensors[o.src0];
       const TensorState& td = e->tensors[o.dst];
       launch_maxpool(tptr(o.src0, o.src0_coff), ts.t.channels, tptr(o.dst, o.dst_coff), td.t.channels, o.src0_c, B,
@@ -649,7 +760,7 @@ int launch_op(ctd_engine* e, int i, const Outs& x, hipStream_t st) {
 
 int prepare(ctd_engine* e, int B, int H, int W, hipStream_t st = nullptr) {
   HIP_TRY(hipSetDevice(e->device));
-  if (B != e->pB || H != e->pH || W != e->pW) return plan(e, B, H, W, st);
+  if (B != e->pB || H != e->pH || W != e->pW || e->p_fuse != g_fuse + 16 * g_fuse_epoch) return plan(e, B, H, W, st);
   return CTD_OK;
 }
 
@@ -801,6 +912,8 @@ int64_t ctd_engine_workspace_bytes(const ctd_engine* e) { return e ? (int64_t)e-
 int32_t ctd_engine_arena_generation(const ctd_engine* e) { return e ? e->arena_gen : -1; }
 
 int ctd_tuning_set(const char* key, int64_t value) {
+  if (key && std::string(key) == "fuse") { g_fuse = (int)value; return CTD_OK; }
+  if (key && std::string(key) == "c3_min_patches") { g_c3_min_patches = value; g_fuse_epoch++; return CTD_OK; }
   if (conv_tuning_set(key, (long long)value) != 0) return fail(CTD_ERR_INVALID, "unknown tuning key");
   return CTD_OK;
 }

@@ -14,6 +14,9 @@ void launch_input_nchw(const float* in, void* dst, int pitch, int B, int H, int 
 void launch_input_u8(const uint8_t* in, void* dst, int pitch, int B, int H, int W, bool f16, hipStream_t st);
 void launch_maxpool(const void* src, int pitchS, void* dst, int pitchD, int C, int B, int H, int W, int k,
                     bool f16, hipStream_t st);
+// SPPF: the three chained stride-1 max pools of one cat tensor in one launch (fp16 engine)
+bool sppf_pool3_supported(int pitch, int slot, int C, int H, int W, int k, const void* cat);
+void launch_sppf_pool3(void* cat, int pitch, int slot, int C, int B, int H, int W, int k, hipStream_t st);
 void launch_avgpool2(const void* src, int pitchS, void* dst, int pitchD, int C, int B, int Ho, int Wo,
                      bool f16, hipStream_t st);
 // raw: (B,ny,nx,pitch) with na*no used channels -> blks rows [row_off, row_off+na*ny*nx)
@@ -51,6 +54,35 @@ extern int g_conv_halo;   // 0 disables (selftest A/B)
 bool conv_halo_supported(const ConvArgs& a, bool dst_f32);
 int conv_tuning_set(const char* key, long long value);   // dispatch knobs of the MFMA conv kernels (kernels_halo.hip)
 void launch_conv_halo(const ConvArgs& a, hipStream_t st);
+
+// ---- kernels_c3.hip : one-kernel C3 block (32 hidden channels, one bottleneck) -------------
+// Weights / biases are the packed arrays of the four unfused ops (tile-major, 32-channel K step):
+// w12 [Cin/32][64][32] (cv1 rows 0-31, cv2 rows 32-63), wm1 [32][32], wm2 [9 taps][32][32], wc3 [2][64][32].
+struct C3Args {
+  SrcView s0, s1;          // x = cat(s0, s1); s1.c == 0 when unused
+  int B, H, W;
+  const half_t *w12, *wm1, *wm2, *wc3;
+  const float *b12, *bm1, *bm2, *bc3;
+  void* dst;               // (B,H,W,pitchD) fp16, 64 channels written, already offset by the channel offset
+  int pitchD;
+  int act;
+  const void* zeros;       // >= 16 B of zeros in HBM (source of out-of-image rows)
+};
+extern int g_fuse;         // fusion bit mask (CTD_FUSE / ctd_tuning_set("fuse")): 1 C3 block, 2 SPPF pools, 4 stem + model.1
+extern long long g_c3_min_patches;
+bool c3_fused_supported(const C3Args& a);
+void launch_c3_fused(const C3Args& a, hipStream_t st);
+
+// ---- kernels_stem2.hip : stem (6x6/s2, 3 -> 32) + layer 1 (3x3/s2, 32 -> 64) in one kernel -----------
+struct Stem2Args {
+  const void* in; int in_fmt;          // network input (CTD_IN_NCHW_F32 / CTD_IN_NHWC_U8), filled per launch
+  int B, H, W;
+  const half_t* wfrag; const float* bias0; int act0;    // stem: stem_pack_weights fragments
+  const half_t* w1; const float* bias1; int act1;       // layer 1: implicit-GEMM packing [9 taps][64][32]
+  half_t* dst; int pitchD;             // (B, H/4, W/4, pitchD), 64 channels written
+};
+bool stem_conv2_supported(const Stem2Args& a);
+void launch_stem_conv2(const Stem2Args& a, hipStream_t st);
 
 // ---- kernels_fused.hip ----------------------------------------------------
 // stem: 6x6 s2 p2, 3 -> N (N <= 32... multiple of 8), reads the network input directly.

@@ -175,6 +175,50 @@ __global__ void maxpool_h8_kernel(const half_t* __restrict__ src, int pitchS, ha
   }
 }
 
+// SPPF's three chained MaxPool2d(5, 1, 2) (reference models/yolov5/common.py:190-196: y1 = m(x), y2 = m(y1),
+// y3 = m(y2), written into the channel slots 1..3 of the cat tensor) in ONE launch.  The maps are tiny
+// (H/32 x W/32) and the three dependent launches were latency, not bandwidth: 3 x 45 us for 17 MB each.
+// A block owns one channel group (V = 8 or 4 fp16 channels) of one page, keeps the whole map in LDS and applies
+// the pool as a row pass + a column pass, three times; every level is stored as it appears.  max is exact, so the
+// result equals the chained pools bit for bit (out-of-image taps are skipped = -inf padding, as nn.MaxPool2d).
+constexpr int SPPF_LDS_BYTES = 65536;
+template <typename V, int NV>
+__global__ __launch_bounds__(256) void sppf_pool3_kernel(half_t* __restrict__ cat, int pitch, int slot, int CG, int H, int W, int r) {
+  __shared__ __attribute__((aligned(16))) unsigned char sm_raw[SPPF_LDS_BYTES];
+  V* A = (V*)sm_raw;
+  V* Bf = A + H * W;
+  const int HW = H * W;
+  const int b = blockIdx.x / CG, cg = blockIdx.x - b * CG;
+  half_t* base = cat + (size_t)b * HW * pitch + cg * NV;
+  for (int p = threadIdx.x; p < HW; p += 256) A[p] = *(const V*)(base + (size_t)p * pitch);
+  __syncthreads();
+  auto vmax = [](V a, V b2) {
+    V o;
+#pragma unroll
+    for (int e = 0; e < NV; ++e) o[e] = b2[e] > a[e] ? b2[e] : a[e];
+    return o;
+  };
+  for (int lvl = 1; lvl <= 3; ++lvl) {
+    for (int p = threadIdx.x; p < HW; p += 256) {        // row pass: A -> Bf
+      const int y = p / W, x = p - y * W;
+      V m = A[p];
+      for (int dx = -r; dx <= r; ++dx)
+        if (dx && (unsigned)(x + dx) < (unsigned)W) m = vmax(m, A[p + dx]);
+      Bf[p] = m;
+    }
+    __syncthreads();
+    for (int p = threadIdx.x; p < HW; p += 256) {        // column pass: Bf -> A (+ this level's slot)
+      const int y = p / W;
+      V m = Bf[p];
+      for (int dy = -r; dy <= r; ++dy)
+        if (dy && (unsigned)(y + dy) < (unsigned)H) m = vmax(m, Bf[p + dy * W]);
+      A[p] = m;
+      *(V*)(base + (size_t)lvl * slot + (size_t)p * pitch) = m;
+    }
+    __syncthreads();
+  }
+}
+
 // nn.AvgPool2d(2, stride=2) (reference basemodel.py:38)
 template <typename T>
 __global__ void avgpool2_kernel(const T* __restrict__ src, int pitchS, T* __restrict__ dst, int pitchD, int C,
@@ -281,6 +325,19 @@ void launch_maxpool(const void* src, int pitchS, void* dst, int pitchD, int C, i
   else
     hipLaunchKernelGGL((maxpool_kernel<float>), dim3(g), dim3(256), 0, st, (const float*)src, pitchS, (float*)dst,
                        pitchD, C, B, H, W, k);
+}
+
+// cat: slot 0 of the SPPF cat tensor (already offset), slots `slot` channels apart; C channels per slot
+bool sppf_pool3_supported(int pitch, int slot, int C, int H, int W, int k, const void* cat) {
+  if (k != 5 && k != 3 && k != 7) return false;
+  if (C % 8 || pitch % 8 || slot % 8 || ((uintptr_t)cat & 15)) return false;
+  return (long long)H * W * 2 * 8 <= SPPF_LDS_BYTES;      // two planes of 4-channel (8-B) entries at least
+}
+void launch_sppf_pool3(void* cat, int pitch, int slot, int C, int B, int H, int W, int k, hipStream_t st) {
+  if ((long long)H * W * 2 * 16 <= SPPF_LDS_BYTES)
+    hipLaunchKernelGGL((sppf_pool3_kernel<half8_t, 8>), dim3(B * (C / 8)), dim3(256), 0, st, (half_t*)cat, pitch, slot, C / 8, H, W, k / 2);
+  else
+    hipLaunchKernelGGL((sppf_pool3_kernel<half4_t, 4>), dim3(B * (C / 4)), dim3(256), 0, st, (half_t*)cat, pitch, slot, C / 4, H, W, k / 2);
 }
 
 void launch_avgpool2(const void* src, int pitchS, void* dst, int pitchD, int C, int B, int Ho, int Wo, bool f16,

@@ -257,6 +257,234 @@ static void run_case(const Case& cs, int B, bool timing) {
   (void)hipFree(dBias); (void)hipFree(dWig); (void)hipFree(dWdr);
 }
 
+// ---- fused C3 block (kernels_c3.hip) against the four launches it replaces: must be bit-identical ----
+struct C3Case { const char* name; int c0, c1, H, act; };
+
+static void run_c3_case(const C3Case& cs, int B, int Hh, int Ww) {
+  const int H = Hh, W = Ww, cin = cs.c0 + cs.c1;
+  const size_t npx = (size_t)B * H * W;
+  std::vector<half_t> h0(npx * cs.c0), h1(cs.c1 ? npx * cs.c1 : 1);
+  for (auto& v : h0) v = (half_t)(frand() * 2.f);
+  for (auto& v : h1) v = (half_t)(frand() * 2.f);
+  half_t *d0 = dev_alloc<half_t>(h0.size()), *d1 = dev_alloc<half_t>(h1.size());
+  CK(hipMemcpy(d0, h0.data(), h0.size() * 2, hipMemcpyHostToDevice));
+  CK(hipMemcpy(d1, h1.data(), h1.size() * 2, hipMemcpyHostToDevice));
+  half_t *dY = dev_alloc<half_t>(npx * 64), *dT = dev_alloc<half_t>(npx * 32), *dZ = dev_alloc<half_t>(npx * 64),
+         *dF = dev_alloc<half_t>(npx * 64);
+  static void* zeros = nullptr;
+  if (!zeros) { CK(hipMalloc(&zeros, 256)); CK(hipMemset(zeros, 0, 256)); }
+
+  // the four convs: logical weights [N][K] (K index = tap * cin + c), packed exactly as engine.hip packs them
+  struct L { int N, cin, k; half_t* w; float* b; };
+  L ls[4] = {{64, cin, 1, nullptr, nullptr}, {32, 32, 1, nullptr, nullptr}, {32, 32, 3, nullptr, nullptr}, {64, 64, 1, nullptr, nullptr}};
+  for (L& l : ls) {
+    const int K = l.k * l.k * l.cin;
+    const float sc = 2.0f / std::sqrt((float)K);
+    std::vector<float> lg((size_t)l.N * K), bias(l.N);
+    for (auto& v : lg) v = frand() * 2.f * sc;
+    for (auto& v : bias) v = frand();
+    std::vector<half_t> wp;
+    igemm_pack_weights(lg.data(), 1, l.N, K, igemm_ntile(l.N), 32, true, wp);
+    l.w = dev_alloc<half_t>(wp.size());
+    l.b = dev_alloc<float>(l.N);
+    CK(hipMemcpy(l.w, wp.data(), wp.size() * 2, hipMemcpyHostToDevice));
+    CK(hipMemcpy(l.b, bias.data(), l.N * 4, hipMemcpyHostToDevice));
+  }
+  auto conv = [&](const L& l, SrcView s0, SrcView s1, half_t* dst, int pitchD, const half_t* res, int pitchR) {
+    ConvArgs a{};
+    a.s0 = s0; a.s1 = s1;
+    a.B = B; a.Hin = H; a.Win = W; a.Mh = H; a.Mw = W; a.KH = a.KW = l.k; a.stride = 1; a.dy0 = a.dx0 = -(l.k / 2);
+    a.w = l.w; a.bias = l.b; a.dst = dst; a.pitchD = pitchD; a.oH = H; a.oW = W; a.osy = a.osx = 1;
+    a.res = res; a.pitchR = pitchR; a.act = cs.act; a.N = l.N; a.Npad = l.N; a.K = l.k * l.k * l.cin; a.M = B * H * W;
+    a.nphase = 1; a.bk = 32; a.w_tiled = 1; a.zeros = zeros;
+    return a;
+  };
+  const SrcView x0{d0, cs.c0, cs.c0, 0, H, W}, x1{cs.c1 ? d1 : nullptr, cs.c1, cs.c1, 0, H, W}, none{};
+  const ConvArgs cA = conv(ls[0], x0, cs.c1 ? x1 : none, dY, 64, nullptr, 0);
+  const ConvArgs cB = conv(ls[1], SrcView{dY, 64, 32, 0, H, W}, none, dT, 32, nullptr, 0);
+  const ConvArgs cC = conv(ls[2], SrcView{dT, 32, 32, 0, H, W}, none, dY, 64, dY, 64);
+  const ConvArgs cD = conv(ls[3], SrcView{dY, 64, 64, 0, H, W}, none, dZ, 64, nullptr, 0);
+  g_igemm_force_bk = 32;
+  g_conv_halo = 1;
+  g_igemm_occ_lo = 0;
+  auto unfused = [&]() {
+    launch_conv_igemm(cA, false, 0);
+    launch_conv_igemm(cB, false, 0);
+    launch_conv_igemm(cC, false, 0);
+    launch_conv_igemm(cD, false, 0);
+  };
+  C3Args f{};
+  f.s0 = x0; if (cs.c1) f.s1 = x1;
+  f.B = B; f.H = H; f.W = W;
+  f.w12 = ls[0].w; f.wm1 = ls[1].w; f.wm2 = ls[2].w; f.wc3 = ls[3].w;
+  f.b12 = ls[0].b; f.bm1 = ls[1].b; f.bm2 = ls[2].b; f.bc3 = ls[3].b;
+  f.dst = dF; f.pitchD = 64; f.act = cs.act; f.zeros = zeros;
+  CK(hipMemset(dF, 0xff, npx * 64 * 2));
+  unfused();
+  launch_c3_fused(f, 0);
+  CK(hipDeviceSynchronize());
+  std::vector<half_t> z(npx * 64), zf(npx * 64);
+  CK(hipMemcpy(z.data(), dZ, z.size() * 2, hipMemcpyDeviceToHost));
+  CK(hipMemcpy(zf.data(), dF, zf.size() * 2, hipMemcpyDeviceToHost));
+  size_t diff = 0, bad = 0, first = (size_t)-1;
+  double maxerr = 0;
+  for (size_t i = 0; i < z.size(); ++i) {
+    if (std::memcmp(&z[i], &zf[i], 2)) { ++diff; if (first == (size_t)-1) first = i; }
+    const double e = std::fabs((double)z[i] - (double)zf[i]);
+    if (!(e <= 4e-3 * (1.0 + std::fabs((double)z[i])))) ++bad;
+    maxerr = std::fmax(maxerr, e);
+  }
+  if (bad) ++g_fail;
+  auto time_it = [&](auto&& fn) {
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    for (int i = 0; i < 3; ++i) fn();
+    CK(hipEventRecord(e0, 0));
+    const int it = 20;
+    for (int i = 0; i < it; ++i) fn();
+    CK(hipEventRecord(e1, 0));
+    CK(hipEventSynchronize(e1));
+    float tms;
+    CK(hipEventElapsedTime(&tms, e0, e1));
+    return (double)tms / it;
+  };
+  const double ms_u = time_it(unfused), ms_f = time_it([&]() { launch_c3_fused(f, 0); });
+  const double io = 2.0 * npx * (cin + 64);
+  std::printf("[c3] %-30s B=%d %dx%d cin=%d | %s: %zu of %zu values differ bitwise (max|d| %.3g, %zu out of tolerance",
+              cs.name, B, H, W, cin, bad ? "FAIL" : diff ? "ok(tol)" : "ok(bit-exact)", diff, z.size(), maxerr, bad);
+  if (diff) std::printf(", first at pixel %zu ch %zu", first / 64, first % 64);
+  std::printf(") | 4 launches %.3f ms, fused %.3f ms = %.0f GB/s of x+out\n", ms_u, ms_f, io / (ms_f * 1e-3) / 1e9);
+  g_igemm_force_bk = 0;
+  for (L& l : ls) { (void)hipFree(l.w); (void)hipFree(l.b); }
+  (void)hipFree(d0); (void)hipFree(d1); (void)hipFree(dY); (void)hipFree(dT); (void)hipFree(dZ); (void)hipFree(dF);
+}
+
+// ---- fused stem + layer 1 (kernels_stem2.hip) against the two launches it replaces: must be bit-identical ----
+static void run_stem2_case(const char* name, int B, int H, int W, int in_fmt, int act1) {
+  const size_t nin = (size_t)B * H * W * 3;
+  std::vector<uint8_t> h8(nin);
+  std::vector<float> hf(nin);
+  for (size_t i = 0; i < nin; ++i) {
+    g_seed = g_seed * 1664525u + 1013904223u;
+    h8[i] = (uint8_t)(g_seed >> 24);
+    hf[i] = frand() + 0.5f;
+  }
+  void* dIn = nullptr;
+  if (in_fmt == CTD_IN_NHWC_U8) { CK(hipMalloc(&dIn, nin + 64)); CK(hipMemcpy(dIn, h8.data(), nin, hipMemcpyHostToDevice)); }
+  else { CK(hipMalloc(&dIn, nin * 4 + 64)); CK(hipMemcpy(dIn, hf.data(), nin * 4, hipMemcpyHostToDevice)); }
+  const int Hs = H / 2, Ws = W / 2, Ho = H / 4, Wo = W / 4;
+  half_t* dS = dev_alloc<half_t>((size_t)B * Hs * Ws * 32);
+  half_t *dZ = dev_alloc<half_t>((size_t)B * Ho * Wo * 64), *dF = dev_alloc<half_t>((size_t)B * Ho * Wo * 64);
+  // stem weights (32,3,6,6) + bias
+  std::vector<float> W0(32 * 3 * 36), b0(32), lg((size_t)64 * 288), b1(64);
+  for (auto& v : W0) v = frand() * 0.4f;
+  for (auto& v : b0) v = frand();
+  for (auto& v : lg) v = frand() * 0.25f;
+  for (auto& v : b1) v = frand();
+  std::vector<half_t> wf, w1;
+  stem_pack_weights(W0.data(), wf);
+  igemm_pack_weights(lg.data(), 1, 64, 288, 64, 32, true, w1);
+  half_t *dWf = dev_alloc<half_t>(wf.size()), *dW1 = dev_alloc<half_t>(w1.size());
+  float *dB0 = dev_alloc<float>(32), *dB1 = dev_alloc<float>(64);
+  CK(hipMemcpy(dWf, wf.data(), wf.size() * 2, hipMemcpyHostToDevice));
+  CK(hipMemcpy(dW1, w1.data(), w1.size() * 2, hipMemcpyHostToDevice));
+  CK(hipMemcpy(dB0, b0.data(), 32 * 4, hipMemcpyHostToDevice));
+  CK(hipMemcpy(dB1, b1.data(), 64 * 4, hipMemcpyHostToDevice));
+  static void* zeros = nullptr;
+  if (!zeros) { CK(hipMalloc(&zeros, 256)); CK(hipMemset(zeros, 0, 256)); }
+  ConvArgs c{};
+  c.s0 = SrcView{dS, 32, 32, 0, Hs, Ws};
+  c.B = B; c.Hin = Hs; c.Win = Ws; c.Mh = Ho; c.Mw = Wo; c.KH = c.KW = 3; c.stride = 2; c.dy0 = c.dx0 = -1;
+  c.w = dW1; c.bias = dB1; c.dst = dZ; c.pitchD = 64; c.oH = Ho; c.oW = Wo; c.osy = c.osx = 1; c.act = act1; c.N = 64; c.Npad = 64;
+  c.K = 288; c.M = B * Ho * Wo; c.nphase = 1; c.bk = 32; c.w_tiled = 1; c.zeros = zeros;
+  g_igemm_force_bk = 32; g_conv_halo = 1; g_igemm_occ_lo = 0;
+  auto unfused = [&]() {
+    launch_stem(dIn, in_fmt, dS, 32, B, H, W, 32, dWf, dB0, CTD_ACT_SILU, 0);
+    launch_conv_igemm(c, false, 0);
+  };
+  Stem2Args f{};
+  f.in = dIn; f.in_fmt = in_fmt; f.B = B; f.H = H; f.W = W;
+  f.wfrag = dWf; f.bias0 = dB0; f.act0 = CTD_ACT_SILU; f.w1 = dW1; f.bias1 = dB1; f.act1 = act1; f.dst = dF; f.pitchD = 64;
+  const size_t nout = (size_t)B * Ho * Wo * 64;
+  CK(hipMemset(dF, 0xff, nout * 2));
+  unfused();
+  launch_stem_conv2(f, 0);
+  CK(hipDeviceSynchronize());
+  std::vector<half_t> z(nout), zf(nout);
+  CK(hipMemcpy(z.data(), dZ, nout * 2, hipMemcpyDeviceToHost));
+  CK(hipMemcpy(zf.data(), dF, nout * 2, hipMemcpyDeviceToHost));
+  size_t diff = 0, bad = 0, first = (size_t)-1;
+  double maxerr = 0;
+  for (size_t i = 0; i < nout; ++i) {
+    if (std::memcmp(&z[i], &zf[i], 2)) { ++diff; if (first == (size_t)-1) first = i; }
+    const double e = std::fabs((double)z[i] - (double)zf[i]);
+    if (!(e <= 4e-3 * (1.0 + std::fabs((double)z[i])))) ++bad;
+    maxerr = std::fmax(maxerr, e);
+  }
+  if (bad) ++g_fail;
+  auto time_it = [&](auto&& fn) {
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    for (int i = 0; i < 3; ++i) fn();
+    CK(hipEventRecord(e0, 0));
+    const int it = 20;
+    for (int i = 0; i < it; ++i) fn();
+    CK(hipEventRecord(e1, 0));
+    CK(hipEventSynchronize(e1));
+    float tms;
+    CK(hipEventElapsedTime(&tms, e0, e1));
+    return (double)tms / it;
+  };
+  const double ms_u = time_it(unfused), ms_f = time_it([&]() { launch_stem_conv2(f, 0); });
+  const double io = (double)nin * (in_fmt == CTD_IN_NHWC_U8 ? 1 : 4) + 2.0 * nout;
+  std::printf("[stem2] %-28s B=%d %dx%d %s | %s: %zu of %zu values differ bitwise (max|d| %.3g, %zu out of tolerance",
+              name, B, H, W, in_fmt == CTD_IN_NHWC_U8 ? "u8" : "f32", bad ? "FAIL" : diff ? "ok(tol)" : "ok(bit-exact)", diff,
+              nout, maxerr, bad);
+  if (diff) std::printf(", first at pixel %zu ch %zu", first / 64, first % 64);
+  std::printf(") | 2 launches %.3f ms, fused %.3f ms = %.0f GB/s of in+out\n", ms_u, ms_f, io / (ms_f * 1e-3) / 1e9);
+  g_igemm_force_bk = 0;
+  (void)hipFree(dIn); (void)hipFree(dS); (void)hipFree(dZ); (void)hipFree(dF); (void)hipFree(dWf); (void)hipFree(dW1);
+  (void)hipFree(dB0); (void)hipFree(dB1);
+}
+
+// ---- SPPF's three pools in one launch against three launch_maxpool calls ----
+static void run_sppf_case(int B, int H, int W, int C) {
+  const size_t npx = (size_t)B * H * W;
+  std::vector<half_t> h(npx * 4 * C);
+  for (auto& v : h) v = (half_t)frand();
+  half_t *dA = dev_alloc<half_t>(h.size()), *dB = dev_alloc<half_t>(h.size());
+  CK(hipMemcpy(dA, h.data(), h.size() * 2, hipMemcpyHostToDevice));
+  CK(hipMemcpy(dB, h.data(), h.size() * 2, hipMemcpyHostToDevice));
+  auto unfused = [&]() {
+    for (int j = 0; j < 3; ++j) launch_maxpool(dA + j * C, 4 * C, dA + (j + 1) * C, 4 * C, C, B, H, W, 5, true, 0);
+  };
+  const bool sup = sppf_pool3_supported(4 * C, C, C, H, W, 5, dB);
+  unfused();
+  if (sup) launch_sppf_pool3(dB, 4 * C, C, C, B, H, W, 5, 0);
+  CK(hipDeviceSynchronize());
+  std::vector<half_t> a(h.size()), b(h.size());
+  CK(hipMemcpy(a.data(), dA, h.size() * 2, hipMemcpyDeviceToHost));
+  CK(hipMemcpy(b.data(), dB, h.size() * 2, hipMemcpyDeviceToHost));
+  const size_t diff = sup ? (size_t)(std::memcmp(a.data(), b.data(), h.size() * 2) != 0) : 0;
+  if (diff) ++g_fail;
+  double ms_u = 0, ms_f = 0;
+  for (int which = 0; which < 2; ++which) {
+    if (which && !sup) break;
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    CK(hipEventRecord(e0, 0));
+    for (int i = 0; i < 20; ++i) { if (which) launch_sppf_pool3(dB, 4 * C, C, C, B, H, W, 5, 0); else unfused(); }
+    CK(hipEventRecord(e1, 0));
+    CK(hipEventSynchronize(e1));
+    float tms;
+    CK(hipEventElapsedTime(&tms, e0, e1));
+    (which ? ms_f : ms_u) = tms / 20;
+  }
+  std::printf("[sppf] B=%d %dx%d C=%d | %s | 3 launches %.3f ms, fused %.3f ms\n", B, H, W, C,
+              !sup ? "unsupported (falls back)" : diff ? "FAIL (differs)" : "ok(bit-exact)", ms_u, ms_f);
+  (void)hipFree(dA); (void)hipFree(dB);
+}
+
 int main(int argc, char** argv) {
   const int B = argc > 1 ? std::atoi(argv[1]) : 4;
   const bool quick = argc > 2;
@@ -290,6 +518,27 @@ int main(int argc, char** argv) {
       {"convT4 512->256 @16", 1, 512, 0, 0, 256, 4, 2, 16, 0},
   };
   const int ncase = sizeof(cases) / sizeof(cases[0]);
+  if (!std::getenv("ST_NO_C3")) {
+    // fused C3 block vs its four launches: the two network shapes, a partial-patch / odd-size map, every activation
+    const C3Case c3s[] = {{"model.2 (64 -> 64 @256)", 64, 0, 256, CTD_ACT_SILU},
+                          {"upconv5.conv.0 (64+32 -> 64 @512)", 64, 32, 512, CTD_ACT_LEAKY},
+                          {"two sources 32+32, relu @128", 32, 32, 128, CTD_ACT_RELU}};
+    for (const C3Case& c : c3s) run_c3_case(c, B, c.H, c.H);
+    run_c3_case(C3Case{"ragged 40x52 map (partial patches)", 64, 0, 0, CTD_ACT_SILU}, 3, 40, 52);
+    run_c3_case(C3Case{"ragged 9x17 map, one source 96", 96, 0, 0, CTD_ACT_LEAKY}, 2, 9, 17);
+    run_stem2_case("1024x1024 pages", B, 1024, 1024, CTD_IN_NHWC_U8, CTD_ACT_SILU);
+    run_stem2_case("1024x1024 pages (float in)", B > 2 ? 2 : B, 1024, 1024, CTD_IN_NCHW_F32, CTD_ACT_SILU);
+    run_stem2_case("192x320 (mostly border)", 3, 192, 320, CTD_IN_NHWC_U8, CTD_ACT_LEAKY);
+    run_stem2_case("64x64 (all border)", 2, 64, 64, CTD_IN_NCHW_F32, CTD_ACT_RELU);
+    run_sppf_case(B, 32, 32, 256);
+    run_sppf_case(3, 48, 48, 256);
+    run_sppf_case(2, 20, 36, 64);
+    run_sppf_case(1, 72, 72, 256);
+  }
+  if (std::getenv("ST_ONLY_C3")) {
+    std::printf("selftest: %s (%d failures)\n", g_fail ? "FAILED" : "PASSED", g_fail);
+    return g_fail ? 1 : 0;
+  }
   // ST_CASES="16,3": run only these case indices (PMC runs want few dispatches)
   const char* sel = std::getenv("ST_CASES");
   for (int i = 0; i < ncase; ++i) {

@@ -123,3 +123,41 @@ def test_large_batch_is_split_transparently():
     one = be.forward_u8(pages[B - 1: B].contiguous())
     torch.cuda.synchronize()
     assert torch.equal(one[1][0], mask[B - 1])
+
+
+def _tune(key, value):
+    L = pkg()._lib
+    L.check(L.lib().ctd_tuning_set(key, value), "ctd_tuning_set")
+
+
+@pytest.mark.parametrize("shape,u8", [((1, 64, 64), False), ((3, 128, 64), True), ((2, 320, 448), False),
+                                      ((2, 1024, 1024), True), ((1, 1536, 1536), True)])
+def test_fused_blocks_equal_the_layer_per_launch_program_bit_for_bit(shape, u8):
+    """The multi-layer kernels of the fp16 engine (stem + layer 1, the 32-channel C3 block, SPPF's three pools;
+    `ctd_tuning_set("fuse", mask)`) do the arithmetic of the launches they replace in the same order: every output
+    of the network must be IDENTICAL with and without them -- interior and border patches, float and uint8 input,
+    maps smaller than one patch (the C3 kernel is forced onto them with c3_min_patches = 1)."""
+    be = pkg().backend.HipTextDetBackend(checkpoint(0), device="cuda", precision="fp16")
+    if u8:
+        x = torch.randint(0, 256, (shape[0], shape[1], shape[2], 3), dtype=torch.uint8,
+                          generator=torch.Generator().manual_seed(5)).cuda()
+        run = lambda: [t.clone() for t in be.forward_u8(x)] + [be.mask_u8.clone(), be.bitmap.clone()]   # noqa: E731
+    else:
+        x = gen_golden.make_input(77, shape).cuda()
+        run = lambda: [t.clone() for t in be(x)] + [be.mask_u8.clone(), be.bitmap.clone()]              # noqa: E731
+    try:
+        _tune(b"fuse", 0)
+        ref = run()
+        _tune(b"c3_min_patches", 1)
+        outs = {}
+        for mask in (1, 2, 4, 7):
+            _tune(b"fuse", mask)
+            outs[mask] = run()
+        torch.cuda.synchronize()
+    finally:
+        _tune(b"fuse", 7)
+        _tune(b"c3_min_patches", 1024)
+    for mask, got in outs.items():
+        for i, (g, r) in enumerate(zip(got, ref)):
+            assert torch.equal(g, r), f"fuse mask {mask}: output {i} differs from the unfused program " \
+                                      f"(max |d| {float((g.float() - r.float()).abs().max()):.3g})"

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Sum FETCH_SIZE / WRITE_SIZE of the conv_halo_kernel + conv_igemm_kernel dispatches of a bench.py run
+"""Sum FETCH_SIZE / WRITE_SIZE of the conv_halo_kernel + conv_igemm_kernel (+ c3_fused_kernel) dispatches of a bench.py run
 (--mode net --steps 1 --warmup 1; the number of forwards in the run = the number of stem kernel dispatches)
 and write traffic.json."""
 import collections
@@ -16,10 +16,10 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
         for r in csv.DictReader(open(f)):
             if r["Counter_Name"] != c:
                 continue
-            if "conv_igemm_kernel" in r["Kernel_Name"] or "conv_halo_kernel" in r["Kernel_Name"]:
+            if any(k in r["Kernel_Name"] for k in ("conv_igemm_kernel", "conv_halo_kernel", "c3_fused_kernel")):
                 tot[c][0] += float(r["Counter_Value"])
                 tot[c][1] += 1
-            if "stem_mfma_kernel" in r["Kernel_Name"]:
+            if "stem_mfma_kernel" in r["Kernel_Name"] or "stem_conv2_kernel" in r["Kernel_Name"]:
                 stems[c] += 1
 n_fwd = max(stems["FETCH_SIZE"], 1)
 res = {

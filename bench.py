@@ -476,6 +476,17 @@ def main() -> None:
                      "alg_flops_per_step": fam_flops, "tflops": round(ach_tf, 1),
                      "mfma_frac": round(ach_tf / peak_tf, 4), "gbs": round(ach_gbs, 1),
                      "arith_intensity": round(ai, 1)})
+        # per-op roofline of the same family: every launch priced at max(its algorithmic bytes / HBM peak, its flops /
+        # MFMA peak) -- the time a perfect kernel would need for THAT layer -- summed, over the measured time.  (The
+        # family-level `frac` above prices the whole family against one roof; the big ConvT / 3x3 layers are MFMA-side,
+        # the 1x1s HBM-side, so the two numbers differ.)
+        try:
+            bound_ms = np.maximum(by[fam] / (HBM_PEAK_GBS * 1e9), fl[fam] / (peak_tf * 1e12)) * 1e3
+            roof["per_op"] = {"bound_ms_per_step": round(float(bound_ms.sum()), 3),
+                              "frac": round(float(bound_ms.sum()) / fam_ms, 4),
+                              "hbm_side_launches": int((by[fam] / (HBM_PEAK_GBS * 1e9) >= fl[fam] / (peak_tf * 1e12)).sum())}
+        except Exception as e:                          # never lose the bench line to a supplementary number
+            roof["per_op"] = {"error": repr(e)}
         if args.dump_ops:
             with open(args.dump_ops, "w") as f:
                 f.write("op\tclass\tms\tGFLOP\tMB\tTFLOP/s\tGB/s\n")

@@ -67,6 +67,7 @@ struct C3Args {
   int pitchD;
   int act;
   const void* zeros;       // >= 16 B of zeros in HBM (source of out-of-image rows)
+  half_t* dbg;             // selftest only: three (B,H,W,32) planes receiving y2, t, b of every patch pixel; null in the product
 };
 extern int g_fuse;         // fusion bit mask (CTD_FUSE / ctd_tuning_set("fuse")): 1 C3 block, 2 SPPF pools, 4 stem + model.1
 extern long long g_c3_min_patches;

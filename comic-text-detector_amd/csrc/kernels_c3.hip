@@ -53,7 +53,8 @@ constexpr int C3_WM1 = 9 * 32 * 32;                  // offset of wm1 behind the
 static_assert(C3_PX * C3_OP <= 2 * C3_XBUF, "output tile fits the x buffers");
 static_assert(C3_WM1 + 32 * 32 <= 2 * C3_XBUF, "tap tiles fit the x buffers");
 
-template <int ACT>
+// DBG: selftest-only instantiation that also dumps the block's intermediates (y2, t, b on the patch pixels) to a.dbg
+template <int ACT, bool DBG = false>
 __global__ __launch_bounds__(256, 2) void c3_fused_kernel(C3Args a) {
   __shared__ __attribute__((aligned(16))) half_t lds[C3_LDS + 2 * 192];
   float* bias_s = (float*)(lds + C3_LDS);   // [0,64) cv1|cv2, [64,96) m.cv1, [96,128) m.cv2, [128,192) cv3
@@ -253,6 +254,22 @@ __global__ __launch_bounds__(256, 2) void c3_fused_kernel(C3Args a) {
   }
   __syncthreads();
 
+  if (DBG) {   // three (B,H,W,32) planes: y2, t, b
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int idx = t + 256 * j, p = idx >> 2, ch = idx & 3;
+      const int pr = p >> 4, pc = p & 15, ri = (pr + 1) * C3_HW + pc + 1;
+      const int oy = y0 + pr, ox = x0 + pc;
+      if (oy < a.H && ox < a.W) {
+        const size_t plane = (size_t)a.B * a.H * a.W * 32;
+        half_t* d = a.dbg + (((size_t)b * a.H + oy) * a.W + ox) * 32 + ch * 8;
+        *(half8_t*)d = *(const half8_t*)(lds + C3_Y2 + p * 32 + ((ch ^ swz(p)) * 8));
+        *(half8_t*)(d + plane) = *(const half8_t*)(lds + C3_T + ri * 32 + ((ch ^ swz(ri)) * 8));
+        *(half8_t*)(d + 2 * plane) = *(const half8_t*)(lds + C3_Y1 + ri * 32 + ((ch ^ swz(ri)) * 8));
+      }
+    }
+  }
+
   // ================= S4: out = act(Wc3 [b ; y2]) ================================================================
   zero16(accA); zero16(accB);   // N fragments 0 / 1
 #pragma unroll
@@ -320,6 +337,14 @@ bool c3_fused_supported(const C3Args& a) {
 void launch_c3_fused(const C3Args& a, hipStream_t st) {
   const int tilesX = (a.W + C3_TW - 1) / C3_TW, tilesY = (a.H + C3_TH - 1) / C3_TH;
   const dim3 grid((unsigned)(tilesX * tilesY * a.B), 1, 1);
+  if (a.dbg) {   // selftest: intermediates dumped
+    switch (a.act) {
+      case CTD_ACT_SILU: hipLaunchKernelGGL((c3_fused_kernel<CTD_ACT_SILU, true>), grid, dim3(256), 0, st, a); break;
+      case CTD_ACT_LEAKY: hipLaunchKernelGGL((c3_fused_kernel<CTD_ACT_LEAKY, true>), grid, dim3(256), 0, st, a); break;
+      default: hipLaunchKernelGGL((c3_fused_kernel<CTD_ACT_RELU, true>), grid, dim3(256), 0, st, a); break;
+    }
+    return;
+  }
   switch (a.act) {
     case CTD_ACT_SILU: hipLaunchKernelGGL((c3_fused_kernel<CTD_ACT_SILU>), grid, dim3(256), 0, st, a); break;
     case CTD_ACT_LEAKY: hipLaunchKernelGGL((c3_fused_kernel<CTD_ACT_LEAKY>), grid, dim3(256), 0, st, a); break;

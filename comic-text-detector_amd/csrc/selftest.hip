@@ -335,6 +335,28 @@ static void run_c3_case(const C3Case& cs, int B, int Hh, int Ww) {
     maxerr = std::fmax(maxerr, e);
   }
   if (bad) ++g_fail;
+  if (std::getenv("ST_C3_DBG")) {
+    // which stage differs first?  intermediates of the fused kernel against the tensors the four launches leave behind:
+    // Y[32:64] = y2, T = t, Y[0:32] = b (after the in-place shortcut)
+    half_t* dD = dev_alloc<half_t>(npx * 32 * 3);
+    C3Args fd = f;
+    fd.dbg = dD;
+    launch_c3_fused(fd, 0);
+    CK(hipDeviceSynchronize());
+    std::vector<half_t> hd(npx * 32 * 3), hy(npx * 64), ht(npx * 32);
+    CK(hipMemcpy(hd.data(), dD, hd.size() * 2, hipMemcpyDeviceToHost));
+    CK(hipMemcpy(hy.data(), dY, hy.size() * 2, hipMemcpyDeviceToHost));
+    CK(hipMemcpy(ht.data(), dT, ht.size() * 2, hipMemcpyDeviceToHost));
+    size_t d_y2 = 0, d_t = 0, d_b = 0;
+    for (size_t px = 0; px < npx; ++px)
+      for (int c = 0; c < 32; ++c) {
+        d_y2 += std::memcmp(&hd[px * 32 + c], &hy[px * 64 + 32 + c], 2) != 0;
+        d_t += std::memcmp(&hd[npx * 32 + px * 32 + c], &ht[px * 32 + c], 2) != 0;
+        d_b += std::memcmp(&hd[2 * npx * 32 + px * 32 + c], &hy[px * 64 + c], 2) != 0;
+      }
+    std::printf("      [dbg] values differing from the unfused tensors: y2 %zu, t %zu, b %zu (of %zu each)\n", d_y2, d_t, d_b, npx * 32);
+    (void)hipFree(dD);
+  }
   auto time_it = [&](auto&& fn) {
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
@@ -526,6 +548,13 @@ int main(int argc, char** argv) {
     for (const C3Case& c : c3s) run_c3_case(c, B, c.H, c.H);
     run_c3_case(C3Case{"ragged 40x52 map (partial patches)", 64, 0, 0, CTD_ACT_SILU}, 3, 40, 52);
     run_c3_case(C3Case{"ragged 9x17 map, one source 96", 96, 0, 0, CTD_ACT_LEAKY}, 2, 9, 17);
+    if (std::getenv("ST_C3_DBG")) {   // act x source matrix on one shape
+      run_c3_case(C3Case{"64 leaky @128", 64, 0, 128, CTD_ACT_LEAKY}, B, 128, 128);
+      run_c3_case(C3Case{"64 relu @128", 64, 0, 128, CTD_ACT_RELU}, B, 128, 128);
+      run_c3_case(C3Case{"64 silu @128", 64, 0, 128, CTD_ACT_SILU}, B, 128, 128);
+      run_c3_case(C3Case{"64+32 silu @128", 64, 32, 128, CTD_ACT_SILU}, B, 128, 128);
+      run_c3_case(C3Case{"32 silu @128", 32, 0, 128, CTD_ACT_SILU}, B, 128, 128);
+    }
     run_stem2_case("1024x1024 pages", B, 1024, 1024, CTD_IN_NHWC_U8, CTD_ACT_SILU);
     run_stem2_case("1024x1024 pages (float in)", B > 2 ? 2 : B, 1024, 1024, CTD_IN_NCHW_F32, CTD_ACT_SILU);
     run_stem2_case("192x320 (mostly border)", 3, 192, 320, CTD_IN_NHWC_U8, CTD_ACT_LEAKY);

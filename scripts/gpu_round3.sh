@@ -15,7 +15,7 @@ T0=$(date +%s)
 el() { echo "[t+$(( $(date +%s) - T0 ))s] $*"; }
 FUSE_OK=1
 el "== 1 selftest (fused kernels, B=8)"
-ST_ONLY_C3=1 timeout 300 ./comic-text-detector_amd/ctd_selftest 8 > $O/selftest_fused_b8.txt 2>&1; echo rc=$?
+ST_C3_DBG=1 ST_ONLY_C3=1 timeout 300 ./comic-text-detector_amd/ctd_selftest 8 > $O/selftest_fused_b8.txt 2>&1; echo rc=$?
 cat $O/selftest_fused_b8.txt | cut -c1-260
 grep -q "selftest: PASSED" $O/selftest_fused_b8.txt || FUSE_OK=0
 el "== 2 pytest fused bit-identity"

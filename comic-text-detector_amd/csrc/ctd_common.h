@@ -64,8 +64,17 @@ __device__ __forceinline__ float ctd_act(float v, int act) {
   }
 }
 // compile-time activation for the MFMA epilogue: hardware rcp / exp2 (1 ulp, well inside fp16 rounding)
+// The fp32 result is handed back as an OPAQUE value: otherwise the compiler fuses SiLU's last multiply with the fp16
+// conversion of the store wherever its register pairing likes it (v_fma_mixlo_f16: the exact product rounded once to
+// fp16) and keeps v_mul_f32 + v_cvt (rounded to fp32, then to fp16) elsewhere -- the same layer then rounds 0.006 % of
+// its outputs differently from kernel to kernel (found by the fused-vs-unfused selftest).  Every fp16 activation is
+// RTNE(fp32 activation) now, in every kernel.
 template <int ACT> __device__ __forceinline__ float ctd_act_fast(float v) {
-  if (ACT == CTD_ACT_SILU) return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v));
+  if (ACT == CTD_ACT_SILU) {
+    float r = v * __builtin_amdgcn_rcpf(1.0f + __expf(-v));
+    asm("" : "+v"(r));
+    return r;
+  }
   if (ACT == CTD_ACT_LEAKY) return v > 0.f ? v : 0.1f * v;
   if (ACT == CTD_ACT_RELU) return v > 0.f ? v : 0.f;
   if (ACT == CTD_ACT_SIGMOID) return __builtin_amdgcn_rcpf(1.0f + __expf(-v));

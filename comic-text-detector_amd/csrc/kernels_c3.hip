@@ -14,7 +14,7 @@
 //
 // Arithmetic is the unfused path's, step for step (fp16 operands, fp32 MFMA accumulation over the same K order,
 // every intermediate rounded to fp16 where the unfused kernels store it, shortcut added to the ROUNDED conv
-// output), so the result is bit-identical to the four launches -- which is how the selftest checks it.
+// output), so the result is bit-identical to the four launches -- which is how the selftest and the GPU tests check it.
 //
 // Structure: 256 threads = 4 waves, 2 blocks per CU (65 KB of LDS each).  MFMA convention of kernels_igemm.hip:
 // weights = A operand (rows = output channels), pixels = B operand (columns), v_mfma_f32_32x32x16_f16; a lane
@@ -159,11 +159,17 @@ __global__ __launch_bounds__(256, 2) void c3_fused_kernel(C3Args a) {
   const int nch = (a.s0.c + a.s1.c) / 32;
   float16_t accA, accB, accC;
   zero16(accA); zero16(accB); zero16(accC);
+  // Both buffers are filled up front (one HBM round trip for a 64-channel x instead of two in a row: a block's
+  // time is latency, not bytes); a third / fourth chunk follows into the buffer the step before it has just released.
   dma_x(0, 0);
   dma_w12(0, 0);
+  if (nch > 1) {
+    dma_x(1, 1);
+    dma_w12(1, 1);
+  }
   __syncthreads();   // the compiler's barrier sequence waits for the LDS-DMAs (vmcnt 0) first
   for (int c = 0; c < nch; ++c) {
-    if (c + 1 < nch) {
+    if (c >= 1 && c + 1 < nch) {       // buffer (c + 1) & 1 was read by step c - 1, which every wave has left
       dma_x(c + 1, (c + 1) & 1);
       dma_w12(c + 1, (c + 1) & 1);
     }

@@ -40,7 +40,9 @@ constexpr int S2_LDS = S2_S + S2_SROWS * 32;
 constexpr int S2_OP = 72;
 static_assert(S2_TW * S2_TH * S2_OP <= S2_SROWS * 32, "output tile fits the stem patch");
 
-template <int ACT1>
+// ACT0 is a compile-time constant evaluated by the stem kernel's own `ctd_act` (same arithmetic, no per-element
+// switch on a run-time value)
+template <int ACT0, int ACT1>
 __global__ __launch_bounds__(256, 2) void stem_conv2_kernel(Stem2Args a) {
   __shared__ __attribute__((aligned(16))) half_t lds[S2_LDS + 2 * 96];
   float* bias_s = (float*)(lds + S2_LDS);     // [0,32) stem, [32,96) layer 1
@@ -188,7 +190,7 @@ __global__ __launch_bounds__(256, 2) void stem_conv2_kernel(Stem2Args a) {
       const float4_t bv = *(const float4_t*)(bias_s + 8 * g + 4 * khalf);
       half4_t o;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) o[e] = keep ? (half_t)ctd_act(acc[4 * g + e] * oscale + bv[e], a.act0) : (half_t)0.f;
+      for (int e = 0; e < 4; ++e) o[e] = keep ? (half_t)ctd_act(acc[4 * g + e] * oscale + bv[e], ACT0) : (half_t)0.f;
       *(half4_t*)(S + p * 32 + ((g ^ swz(p)) * 8) + 4 * khalf) = o;
     }
   }
@@ -255,6 +257,7 @@ __global__ __launch_bounds__(256, 2) void stem_conv2_kernel(Stem2Args a) {
 bool stem_conv2_supported(const Stem2Args& a) {
   if (!(g_fuse & 4)) return false;
   if (a.H % 4 || a.W % 4 || a.pitchD % 8) return false;
+  if (a.act0 != CTD_ACT_SILU) return false;       // the yolo stem; other activations take the two launches
   if (a.act1 != CTD_ACT_SILU && a.act1 != CTD_ACT_LEAKY && a.act1 != CTD_ACT_RELU) return false;
   return true;
 }
@@ -263,8 +266,8 @@ void launch_stem_conv2(const Stem2Args& a, hipStream_t st) {
   const int Ho = a.H / 4, Wo = a.W / 4;
   const dim3 grid((unsigned)(((Wo + S2_TW - 1) / S2_TW) * ((Ho + S2_TH - 1) / S2_TH) * a.B), 1, 1);
   switch (a.act1) {
-    case CTD_ACT_SILU: hipLaunchKernelGGL((stem_conv2_kernel<CTD_ACT_SILU>), grid, dim3(256), 0, st, a); break;
-    case CTD_ACT_LEAKY: hipLaunchKernelGGL((stem_conv2_kernel<CTD_ACT_LEAKY>), grid, dim3(256), 0, st, a); break;
-    default: hipLaunchKernelGGL((stem_conv2_kernel<CTD_ACT_RELU>), grid, dim3(256), 0, st, a); break;
+    case CTD_ACT_SILU: hipLaunchKernelGGL((stem_conv2_kernel<CTD_ACT_SILU, CTD_ACT_SILU>), grid, dim3(256), 0, st, a); break;
+    case CTD_ACT_LEAKY: hipLaunchKernelGGL((stem_conv2_kernel<CTD_ACT_SILU, CTD_ACT_LEAKY>), grid, dim3(256), 0, st, a); break;
+    default: hipLaunchKernelGGL((stem_conv2_kernel<CTD_ACT_SILU, CTD_ACT_RELU>), grid, dim3(256), 0, st, a); break;
   }
 }

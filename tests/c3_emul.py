@@ -134,8 +134,11 @@ class Block:
         # S1
         dma_x(0, 0)
         dma_w12(0, 0)
+        if nch > 1:
+            dma_x(1, 1)
+            dma_w12(1, 1)
         for c in range(nch):
-            if c + 1 < nch:
+            if c >= 1 and c + 1 < nch:
                 dma_x(c + 1, (c + 1) & 1)
                 dma_w12(c + 1, (c + 1) & 1)
             Xb, Wb = XR + (c & 1) * XBUF, WR + (c & 1) * WBUF

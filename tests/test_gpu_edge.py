@@ -132,14 +132,12 @@ def _tune(key, value):
 
 @pytest.mark.parametrize("shape,u8", [((1, 64, 64), False), ((3, 128, 64), True), ((2, 320, 448), False),
                                       ((2, 1024, 1024), True), ((1, 1536, 1536), True)])
-def test_fused_blocks_against_the_layer_per_launch_program(shape, u8):
+def test_fused_blocks_equal_the_layer_per_launch_program_bit_for_bit(shape, u8):
     """The multi-layer kernels of the fp16 engine (stem + layer 1, the 32-channel C3 block, SPPF's three pools;
-    `ctd_tuning_set("fuse", mask)`) do the arithmetic of the launches they replace in the same order -- interior and
-    border patches, float and uint8 input, maps smaller than one patch (the C3 kernel is forced onto them with
-    c3_min_patches = 1).  Stem + layer 1 and the pools reproduce the unfused program BIT FOR BIT.  The C3 kernel
-    does so for ReLU / LeakyReLU blocks; with SiLU (the yolo backbone's block) a fraction of a per cent of its
-    outputs land on the neighbouring fp16 value (measured by ctd_selftest: 0.13 % of the values, 1 ulp), so for it
-    the bar is the one of the other dispatch A/B test: the network's maps within 5e-3."""
+    `ctd_tuning_set("fuse", mask)`) do the arithmetic of the launches they replace in the same order: every output
+    of the network must be IDENTICAL with and without them -- interior and border patches, float and uint8 input,
+    maps smaller than one patch (the C3 kernel is forced onto them with c3_min_patches = 1).  (This test is what
+    found that the compiler rounded SiLU outputs once or twice depending on the kernel: ctd_common.h ctd_act_fast.)"""
     be = pkg().backend.HipTextDetBackend(checkpoint(0), device="cuda", precision="fp16")
     if u8:
         x = torch.randint(0, 256, (shape[0], shape[1], shape[2], 3), dtype=torch.uint8,
@@ -160,13 +158,7 @@ def test_fused_blocks_against_the_layer_per_launch_program(shape, u8):
     finally:
         _tune(b"fuse", 7)
         _tune(b"c3_min_patches", 1024)
-    for mask in (2, 4, 6):
-        for i, (g, r) in enumerate(zip(outs[mask], ref)):
+    for mask, got in outs.items():
+        for i, (g, r) in enumerate(zip(got, ref)):
             assert torch.equal(g, r), f"fuse mask {mask}: output {i} differs from the unfused program " \
                                       f"(max |d| {float((g.float() - r.float()).abs().max()):.3g})"
-    for mask in (1, 7):
-        blks, m, lines, m8, bm = outs[mask]
-        assert float((m - ref[1]).abs().max()) < 5e-3 and float((lines - ref[2]).abs().max()) < 5e-3
-        assert float(((blks - ref[0]).abs() / (1 + ref[0].abs())).max()) < 5e-3
-        assert int((m8.int() - ref[3].int()).abs().max()) <= 2 and float((m8 != ref[3]).float().mean()) < 0.05
-        assert float((bm != ref[4]).float().mean()) < 5e-3

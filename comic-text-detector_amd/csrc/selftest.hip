@@ -220,7 +220,7 @@ static void run_case(const Case& cs, int B, bool timing) {
       CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
       for (int i = 0; i < 3; ++i) launch_conv_igemm(ig, false, 0);
       CK(hipEventRecord(e0, 0));
-      const int it = 20;
+      static const int it = std::getenv("ST_ITERS") ? std::atoi(std::getenv("ST_ITERS")) : 20;   // long loops: power sampling
       for (int i = 0; i < it; ++i) launch_conv_igemm(ig, false, 0);
       CK(hipEventRecord(e1, 0));
       CK(hipEventSynchronize(e1));

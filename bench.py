@@ -278,6 +278,8 @@ def main() -> None:
                          "measured: 2 engines +5 %% on the network alone, -10 %% end to end (the tail's kernels already "
                          "fill the forward's gaps)")
     ap.add_argument("--keep-undetected", action="store_true", help="also run refine_undetected_mask in the tail")
+    ap.add_argument("--spinup", type=int, default=int(os.environ.get("BENCH_SPINUP", "100")),
+                    help="untimed steps before the warm-up steps (clock / host-side spin-up of a fresh process)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dump-ops", default="", help="write the per-op profile table to this file")
     args = ap.parse_args()
@@ -386,6 +388,14 @@ def main() -> None:
                 D.gather_records(D.pack_records(dets, counts), total_pages, rank, world)
 
     run_steps = run_steps_e2e if args.mode == "e2e" else run_steps_net
+    # Spin-up (untimed, before the W warm-up steps): a process that has just started measures transients, not the
+    # detector -- the board leaves its low-power state over roughly the first second of load (rocm-smi: sclk 94 MHz idle;
+    # profiles/r02_power_smi.json) and the host side (tail workers' buffers, pinned arenas, allocator, interpreter caches)
+    # settles over the first dozens of batches.  Measured on one box: 20 timed steps right after 5 warm-up steps 2362
+    # pages/s, 600 timed steps 2475.  A serving process is in the second state; `config.spinup_steps` records it and
+    # `--spinup 0` gives the cold number.
+    if args.spinup > 0:
+        run_steps(args.spinup)
     run_steps(args.warmup)
     # A serving process does this once after start-up: the interpreter's cyclic collector otherwise re-scans the
     # ~1M long-lived objects of torch / numpy whenever the per-page result objects (TextBlock records, line
@@ -533,6 +543,7 @@ def main() -> None:
                        "input": "nhwc_u8", "precision": args.precision,
                        "tail_workers": args.workers if e2e else 0, "batches_in_flight": args.depth if e2e else 1,
                        "engines": args.engines if e2e else 1,
+                       "spinup_steps": args.spinup,
                        "pages_start_in": "host memory (pinned staging + async H2D on %d loader threads)" % args.loaders
                                          if (e2e and args.host_input) else "HBM",
                        "blocks_per_page": round(stats["blocks"] / max(stats["pages"], 1), 2) if e2e else None,

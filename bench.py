@@ -269,6 +269,8 @@ def main() -> None:
                          "hipGraph per size bucket (forward + NMS)")
     ap.add_argument("--workers", type=int, default=3, help="tail worker threads (e2e)")
     ap.add_argument("--depth", type=int, default=4, help="batches in flight (e2e)")
+    ap.add_argument("--tail-split", type=int, default=int(os.environ.get("BENCH_TAIL_SPLIT", "1")),
+                    help="work items (page ranges) a batch's tail is cut into (e2e)")
     ap.add_argument("--host-input", action="store_true",
                     help="e2e: the pages start in HOST memory (numpy, as the reference's callers hand them over): pinned "
                          "staging + one async H2D per batch on loader threads; the PCIe-inclusive rate of DESIGN.md")
@@ -353,6 +355,9 @@ def main() -> None:
 
     trace = {"stage_wait": 0.0, "forward_launch": 0.0, "tail_wait": 0.0} if os.environ.get("BENCH_TRACE") else None
 
+    def collect(futs):
+        return [r for f in futs for r in f.result()]
+
     def run_steps_e2e(n):
         pending, ahead, issued = deque(), deque(), 0
         main = torch.cuda.current_stream(dev)
@@ -366,17 +371,19 @@ def main() -> None:
                 pg, ev = ahead.popleft().result()
                 main.wait_event(ev)
             tb = time.perf_counter()
-            pending.append(pool.submit(det._tail, forward_job(i, pg), 0, args.keep_undetected))
+            job = forward_job(i, pg)
+            pending.append([pool.submit(det._tail, job, 0, args.keep_undetected, lo, hi)
+                            for lo, hi in det._split(nloc, args.tail_split)])
             tc = time.perf_counter()
             while len(pending) >= args.depth:
-                finish(pending.popleft().result())
+                finish(collect(pending.popleft()))
             if trace is not None:
                 td = time.perf_counter()
                 trace["stage_wait"] += tb - ta
                 trace["forward_launch"] += tc - tb
                 trace["tail_wait"] += td - tc
         while pending:
-            finish(pending.popleft().result())
+            finish(collect(pending.popleft()))
         if trace is not None:
             print("trace (s, cumulative over all calls):", {k: round(v, 4) for k, v in trace.items()}, file=sys.stderr)
 
@@ -543,7 +550,7 @@ def main() -> None:
                        "input": "nhwc_u8", "precision": args.precision,
                        "tail_workers": args.workers if e2e else 0, "batches_in_flight": args.depth if e2e else 1,
                        "engines": args.engines if e2e else 1,
-                       "spinup_steps": args.spinup,
+                       "spinup_steps": args.spinup, "tail_split": args.tail_split if e2e else 1,
                        "pages_start_in": "host memory (pinned staging + async H2D on %d loader threads)" % args.loaders
                                          if (e2e and args.host_input) else "HBM",
                        "blocks_per_page": round(stats["blocks"] / max(stats["pages"], 1), 2) if e2e else None,

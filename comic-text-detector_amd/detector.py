@@ -166,10 +166,19 @@ class TextDetector:
             self._lanes[i] = (net, st)
         return net, st
 
-    def _tail(self, job, refine_mode, keep_undetected_mask):
-        return thread_tail(self.net.device).run(job["gpu"], job["metas"], job["blks"], job["mask_u8"], job["lines_map"],
-                                                job["bitmap"], self.conf_thresh, self.nms_thresh, 0.6, True, refine_mode,
-                                                keep_undetected_mask, job["ev"])
+    def _tail(self, job, refine_mode, keep_undetected_mask, lo=None, hi=None):
+        """The native tail of pages [lo, hi) of a forwarded batch (default: all of it) on the calling thread's `Tail`."""
+        sl = slice(lo, hi)
+        return thread_tail(self.net.device).run(job["gpu"][sl], job["metas"][sl], job["blks"][sl], job["mask_u8"][sl],
+                                                job["lines_map"][sl], job["bitmap"][sl], self.conf_thresh, self.nms_thresh,
+                                                0.6, True, refine_mode, keep_undetected_mask, job["ev"])
+
+    @staticmethod
+    def _split(n: int, parts: int):
+        """Page ranges of a batch's tail work items: `parts` near-equal contiguous pieces (pages are independent after
+        the forward, reference inference.py:148-178 is per page)."""
+        parts = max(1, min(int(parts), n))
+        return [(n * k // parts, n * (k + 1) // parts) for k in range(parts)]
 
     @torch.no_grad()
     def detect_batch(self, pages: Sequence[Page], refine_mode=REFINEMASK_INPAINT,
@@ -179,11 +188,13 @@ class TextDetector:
     @torch.no_grad()
     def detect_stream(self, batches: Iterable[Sequence[Page]], refine_mode=REFINEMASK_INPAINT,
                       keep_undetected_mask=False, workers: int = 2, depth: int = 3, engines: int = 1,
-                      loaders: int = 2) -> Iterator[list]:
+                      loaders: int = 2, tail_split: int = 1) -> Iterator[list]:
         """Yields `detect_batch(batch)` for every batch, in order, with up to `depth` batches in flight:
         the forward of the next batches is launched while `workers` threads run the tails of earlier ones.
         Host (numpy) pages are staged to the GPU by `loaders` threads up to `depth` batches ahead (`_stage`).
-        `engines` > 1 alternates the batches over that many engine copies on their own streams (`_lane`)."""
+        `engines` > 1 alternates the batches over that many engine copies on their own streams (`_lane`).
+        `tail_split` > 1 cuts every batch's tail into that many page ranges, each a work item of its own for the
+        workers: lower latency per batch (and a shorter drain when the stream ends) for more, smaller native calls."""
         pool = ThreadPoolExecutor(max_workers=max(1, workers), thread_name_prefix="ctd-tail")
         lpool = ThreadPoolExecutor(max_workers=max(1, loaders), thread_name_prefix="ctd-load")
         pending = deque()
@@ -210,11 +221,12 @@ class TextDetector:
                     st.wait_stream(main)                  # pages the caller produced on its stream
                     with torch.cuda.stream(st):
                         job = self._forward(batch, net)
-                pending.append(pool.submit(self._tail, job, refine_mode, keep_undetected_mask))
+                pending.append([pool.submit(self._tail, job, refine_mode, keep_undetected_mask, lo, hi)
+                                for lo, hi in self._split(len(job["metas"]), tail_split)])
                 while len(pending) >= depth:
-                    yield pending.popleft().result()
+                    yield [r for f in pending.popleft() for r in f.result()]
             while pending:
-                yield pending.popleft().result()
+                yield [r for f in pending.popleft() for r in f.result()]
         finally:
             pool.shutdown(wait=True)
             lpool.shutdown(wait=True)

@@ -232,8 +232,9 @@ def test_detect_stream_equals_detect_batch():
     det = detector(size)
     batches = [[p.synth.text_like_page((size, size), 30 + 3 * k + j, n_blocks=4) for j in range(3)] for k in range(4)]
     want = [det.detect_batch(b) for b in batches]
-    for engines in (1, 2):                                 # 2: batches alternate over two engine copies / streams
-        got = list(det.detect_stream(batches, workers=2, depth=3, engines=engines))
+    for engines, split in ((1, 1), (2, 1), (1, 2), (1, 8)):   # 2 engines: batches alternate over two engine copies /
+        # streams; split: a batch's tail as that many page-range work items (8 > pages per batch: one page each)
+        got = list(det.detect_stream(batches, workers=2, depth=3, engines=engines, tail_split=split))
         assert len(got) == len(want)
         for gb, wb in zip(got, want):
             for (m, r, bl), (m1, r1, bl1) in zip(gb, wb):

@@ -269,8 +269,8 @@ def main() -> None:
                          "hipGraph per size bucket (forward + NMS)")
     ap.add_argument("--workers", type=int, default=3, help="tail worker threads (e2e)")
     ap.add_argument("--depth", type=int, default=4, help="batches in flight (e2e)")
-    ap.add_argument("--tail-split", type=int, default=int(os.environ.get("BENCH_TAIL_SPLIT", "1")),
-                    help="work items (page ranges) a batch's tail is cut into (e2e)")
+    ap.add_argument("--tail-split", type=int, default=int(os.environ.get("BENCH_TAIL_SPLIT", "0")),
+                    help="work items (page ranges) a batch's tail is cut into (e2e); 0 = one per tail worker")
     ap.add_argument("--host-input", action="store_true",
                     help="e2e: the pages start in HOST memory (numpy, as the reference's callers hand them over): pinned "
                          "staging + one async H2D per batch on loader threads; the PCIe-inclusive rate of DESIGN.md")
@@ -285,6 +285,8 @@ def main() -> None:
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dump-ops", default="", help="write the per-op profile table to this file")
     args = ap.parse_args()
+    if args.tail_split <= 0:
+        args.tail_split = max(1, args.workers)
 
     pkg = importlib.import_module("comic-text-detector_amd")
     D = importlib.import_module("comic-text-detector_amd.dist")
@@ -487,7 +489,7 @@ def main() -> None:
         roof.update({"traffic": traffic, "traffic_note": tnote,
                      "kernel": ("conv_direct / convt_direct (exact-fp32 VALU kernels)" if not (cls[fam] != 3).any() else
                                 "conv_f32_mfma_kernel (f32-operand MFMA conv / convT family)" if args.precision == "fp32" else
-                                "conv_halo_kernel + conv_igemm_kernel (MFMA conv / convT family)"),
+                                "conv_halo_kernel + conv_igemm_kernel + c3_fused_kernel (MFMA conv / convT family)"),
                      "launches_per_step": int(fam.sum()), "family_ms_per_step": round(fam_ms, 3),
                      "net_ms_per_step": round(net_ms, 3), "alg_bytes_per_step": fam_bytes,
                      "alg_flops_per_step": fam_flops, "tflops": round(ach_tf, 1),
@@ -527,7 +529,8 @@ def main() -> None:
                          "geometry), mask crop, group_output, refine_mask"
                          + (", refine_undetected_mask" if args.keep_undetected else "")
                          + "; masks + TextBlock records delivered on the host; tail of step k on "
-                         f"{args.workers} worker threads under the forward of step k+1; the tail is fed text-like network "
+                         f"{args.workers} worker threads ({args.tail_split} page-range work items per batch) under the forward of step "
+                         "k+1; the tail is fed text-like network "
                          "outputs of the same pages (random weights give noise maps)")
         else:
             workload += " + GPU NMS (network-only mode)"

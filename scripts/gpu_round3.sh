@@ -26,10 +26,10 @@ if [ $FUSE_OK = 0 ]; then export CTD_FUSE=0; fi
 el "== 3 full GPU suite"
 timeout 1500 python -m pytest tests -m gpu -x -q > $O/pytest_gpu.txt 2>&1; echo rc=$?; tail -5 $O/pytest_gpu.txt | cut -c1-300
 el "== 4 bench e2e (headline)"
-timeout 600 python bench.py --steps 20 --warmup 3 --dump-ops $O/bench_per_op.tsv > $O/bench_n1.json 2> $O/bench_n1.err; echo rc=$?; cut -c1-220 $O/bench_n1.json
+timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 --dump-ops $O/bench_per_op.tsv > $O/bench_n1.json 2> $O/bench_n1.err; echo rc=$?; cut -c1-220 $O/bench_n1.json
 if [ $FUSE_OK = 1 ]; then
   el "== 5 bench e2e, CTD_FUSE=0 (A/B on the same box)"
-  CTD_FUSE=0 timeout 400 python bench.py --steps 20 --warmup 3 --no-cpu-baseline --dump-ops $O/bench_per_op_fuse0.tsv > $O/bench_n1_fuse0.json 2>/dev/null; cut -c1-220 $O/bench_n1_fuse0.json
+  CTD_FUSE=0 timeout 400 python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --dump-ops $O/bench_per_op_fuse0.tsv > $O/bench_n1_fuse0.json 2>/dev/null; cut -c1-220 $O/bench_n1_fuse0.json
 fi
 cd /tmp
 el "== 6 rocprofv3 e2e"
@@ -45,7 +45,7 @@ python3 $ROOT/scripts/traffic_summary.py $O/traffic > $O/traffic_summary.txt 2>&
 rm -f $O/traffic/*/*kernel_trace.csv $O/traffic/*/*/*kernel_trace.csv
 cd $ROOT
 el "== 8 bench net + rocprofv3 net"
-timeout 300 python bench.py --mode net --steps 20 --warmup 3 --no-cpu-baseline > $O/bench_net.json 2>/dev/null; cut -c1-160 $O/bench_net.json
+timeout 300 python bench.py --mode net --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_net.json 2>/dev/null; cut -c1-160 $O/bench_net.json
 cd /tmp
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_net -o net -- python $ROOT/bench.py --mode net --steps 10 --warmup 2 --no-cpu-baseline > $O/rocprof_net.log 2>&1; echo rc=$?
 rm -f $O/prof_*/*kernel_trace.csv $O/prof_*/*/*kernel_trace.csv
@@ -55,4 +55,8 @@ ST_ONLY_C3=1 timeout 200 ./comic-text-detector_amd/ctd_selftest 32 > $O/selftest
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.txt 2>&1; echo smoke rc=$?; tail -3 $O/smoke.txt | cut -c1-200
 timeout 300 python bench.py --mode mixed --steps 5 --warmup 2 > $O/bench_mixed.json 2>/dev/null; cut -c1-160 $O/bench_mixed.json
 timeout 300 python bench.py --precision fp32 --batch 8 --mode net --steps 10 --warmup 2 --no-cpu-baseline > $O/bench_fp32_bs8_net.json 2>/dev/null; cut -c1-160 $O/bench_fp32_bs8_net.json
+timeout 300 python bench.py --precision fp32 --batch 8 --steps 10 --warmup 2 --no-cpu-baseline > $O/bench_fp32_bs8_e2e.json 2>/dev/null; cut -c1-160 $O/bench_fp32_bs8_e2e.json
+timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --keep-undetected > $O/bench_e2e_keep.json 2>/dev/null; cut -c1-160 $O/bench_e2e_keep.json
+timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --host-input > $O/bench_e2e_host.json 2>/dev/null; cut -c1-160 $O/bench_e2e_host.json
+timeout 300 python bench.py --steps 300 --warmup 5 --no-cpu-baseline > $O/bench_e2e_long.json 2>/dev/null; cut -c1-160 $O/bench_e2e_long.json
 el "done"; ls $O

@@ -38,7 +38,7 @@ rm -f $O/prof_*/*kernel_trace.csv $O/prof_*/*/*kernel_trace.csv
 el "== 7 HBM traffic (PMC, separate passes)"
 for C in FETCH_SIZE WRITE_SIZE; do
   timeout 400 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $O/traffic/$C -o $C -- \
-     python $ROOT/bench.py --mode net --steps 1 --warmup 1 --no-cpu-baseline > $O/traffic_$C.log 2>&1
+     python $ROOT/bench.py --mode net --steps 1 --warmup 1 --spinup 0 --no-cpu-baseline > $O/traffic_$C.log 2>&1
   echo "$C rc=$?"
 done
 python3 $ROOT/scripts/traffic_summary.py $O/traffic > $O/traffic_summary.txt 2>&1; tail -3 $O/traffic_summary.txt

@@ -8,7 +8,7 @@ mkdir -p $OUT
 cd /tmp
 for C in FETCH_SIZE WRITE_SIZE; do
   timeout 600 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/$C -o $C -- \
-     python $ROOT/bench.py --mode net --steps 1 --warmup 1 --no-cpu-baseline > $OUT/$C.log 2>&1
+     python $ROOT/bench.py --mode net --steps 1 --warmup 1 --spinup 0 --no-cpu-baseline > $OUT/$C.log 2>&1
   echo "$C rc=$?"
 done
 python3 $ROOT/scripts/traffic_summary.py $OUT

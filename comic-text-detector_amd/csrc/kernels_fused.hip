@@ -1,6 +1,8 @@
 // Fused head/tail kernels of the fp16 fast path.  These layers have a tiny
 // channel count on one side (3 in, or 1 out), so they are HBM/VALU work, not
 // GEMMs: no MFMA here (north_star: "MFMA only ... where it is a true GEMM").
+#include <algorithm>
+#include <cstdlib>
 #include <type_traits>
 #include <vector>
 
@@ -433,6 +435,110 @@ __global__ __launch_bounds__(256) void db_up_kernel(const T* __restrict__ src, i
   }
 }
 
+// ---------------------------------------------------------------------------
+// DB tail on the matrix cores (fp16 engine).  db_up_kernel above is VALU work: 2560 fp32 FMAs per input pixel with
+// broadcast LDS reads of the weights, 0.29 ms per 32 pages against a 0.08 ms byte floor.  Its first stage -- ConvT
+// 2x2/s2, 16 -> 16 channels, four sub-pixel positions -- is a GEMM with K = 16: D[n = pp * 16 + o][pixel] =
+// sum_c W1[pp][c][o] x[pixel][c], i.e. ONE v_mfma_f32_32x32x16_f16 per 32 pixels and 32 rows of n (two per branch).
+// The B operand of a lane is 16 contiguous bytes of its pixel's channel row, loaded straight from HBM.  A lane ends
+// with 8 of the 16 hidden channels of one pixel for two positions per fragment; it applies bias + ReLU, takes its
+// half of the second ConvT's dot products (16 -> 1, four output positions each) and swaps halves with lane ^ 32,
+// so that lane (pixel, hi) finishes output rows 4y + 2hi + {0, 1}: 4 contiguous floats per row = one 16-B store
+// (the VALU kernel stored 8 B pieces).  W1 is rounded to fp16 like every other MFMA layer of this engine; the
+// accumulation, the hidden activations and the second stage stay fp32.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void db_up_mfma_kernel(const half_t* __restrict__ src, int pitch, int nbr, int B, int H, int W,
+                                                         const float* __restrict__ params, float* __restrict__ lines,
+                                                         uint8_t* __restrict__ bitmap, float thresh, int ngroups) {
+  using Lt = DbUpLayout<16>;
+  constexpr int Q = 16;
+  __shared__ __attribute__((aligned(16))) float P[2 * Lt::SIZE];
+  for (int i = threadIdx.x; i < nbr * Lt::SIZE; i += 256) P[i] = params[i];
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int l31 = lane & 31, hi = lane >> 5;
+  const long long total = (long long)B * H * W;
+  const int Wo = 4 * W;
+  const long long Ho = 4LL * H;
+#pragma unroll 1
+  for (int br = 0; br < nbr; ++br) {
+    const float* Pb = P + br * Lt::SIZE;
+    // A fragments: row n = f * 32 + l31 = pp * 16 + o, k = c = 8 * hi + e
+    half8_t wa[2];
+#pragma unroll
+    for (int f = 0; f < 2; ++f) {
+      const int n = f * 32 + l31, pp = n >> 4, o = n & 15;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) wa[f][e] = (half_t)Pb[Lt::W1 + (pp * Q + 8 * hi + e) * Q + o];
+    }
+    // this lane's 8 hidden channels (accumulator register j of either half: o = (j & 3) + 8 * ((j >> 2) & 1) + 4 * hi)
+    float b1r[8], w2r[4][8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int o = (j & 3) + 8 * ((j >> 2) & 1) + 4 * hi;
+      b1r[j] = Pb[Lt::B1 + o];
+#pragma unroll
+      for (int qq = 0; qq < 4; ++qq) w2r[qq][j] = Pb[Lt::W2 + qq * Q + o];
+    }
+    const float b2 = Pb[Lt::B2];
+    for (int g = blockIdx.x * 4 + wave; g < ngroups; g += gridDim.x * 4) {
+      const long long i = (long long)g * 32 + l31;
+      const bool valid = i < total;
+      const long long ic = valid ? i : 0;
+      const int x = (int)(ic % W), y = (int)((ic / W) % H);
+      const long long b = ic / ((long long)W * H);
+      const half8_t xv = *(const half8_t*)(src + ic * pitch + br * Q + 8 * hi);
+      float part[4][4];   // [pp][qq]: this lane's half of the sum over the hidden channels
+#pragma unroll
+      for (int f = 0; f < 2; ++f) {
+        float16_t acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa[f], xv, acc, 0, 0, 0);
+        // register r = 8 ph + j: position pp = 2f + ph, hidden channel o(j)
+#pragma unroll
+        for (int ph = 0; ph < 2; ++ph) {
+          float s4[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const float hv = fmaxf(acc[ph * 8 + j] + b1r[j], 0.f);
+#pragma unroll
+            for (int qq = 0; qq < 4; ++qq) s4[qq] = fmaf(hv, w2r[qq][j], s4[qq]);
+          }
+#pragma unroll
+          for (int qq = 0; qq < 4; ++qq) part[2 * f + ph][qq] = s4[qq];
+        }
+      }
+      // lane hi finishes positions pp = 2 hi + {0, 1} (py = hi): it keeps its halves of those and receives the partner's
+      float r8[2][4];
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int qq = 0; qq < 4; ++qq) {
+          const float send = hi ? part[j][qq] : part[2 + j][qq];
+          const float mine = hi ? part[2 + j][qq] : part[j][qq];
+          const float tot = mine + __shfl_xor(send, 32) + b2;
+          r8[j][qq] = 1.0f / (1.0f + __expf(-tot));
+        }
+      if (valid) {
+        // position (py = hi, px = j) owns output rows 4y + 2hi + qy, columns 4x + 2j + qx (qq = qy * 2 + qx)
+#pragma unroll
+        for (int qy = 0; qy < 2; ++qy) {
+          const long long row = 4LL * y + 2 * hi + qy;
+          const long long off = ((b * nbr + br) * Ho + row) * Wo + 4 * x;
+          float4_t o = {r8[0][qy * 2], r8[0][qy * 2 + 1], r8[1][qy * 2], r8[1][qy * 2 + 1]};
+          *(float4_t*)(lines + off) = o;
+          if (br == 0 && bitmap) {
+            uchar4 q;
+            q.x = o[0] > thresh; q.y = o[1] > thresh; q.z = o[2] > thresh; q.w = o[3] > thresh;
+            *(uchar4*)(bitmap + (b * Ho + row) * Wo + 4 * x) = q;
+          }
+        }
+      }
+    }
+  }
+}
+
 }  // namespace
 
 void launch_stem(const void* in, int in_fmt, half_t* dst, int pitchD, int B, int H, int W, int N, const half_t* wfrag,
@@ -476,6 +582,11 @@ void launch_seg_final_f32(const float* src, int pitch, int C, int B, int H, int 
   (void)C;
 }
 
+int g_db_up_mfma = [] {   // CTD_DBUP_MFMA=0: the VALU kernel (A/B knob; ctd_tuning_set("db_up_mfma"))
+  const char* e = std::getenv("CTD_DBUP_MFMA");
+  return e ? std::atoi(e) : 1;
+}();
+
 void launch_db_up(const void* src, bool f32in, int pitch, int q, int nbr, int B, int H, int W, const float* params, float* lines,
                   uint8_t* bitmap, float thresh, hipStream_t st) {
   const long long total = (long long)B * H * W;
@@ -483,7 +594,12 @@ void launch_db_up(const void* src, bool f32in, int pitch, int q, int nbr, int B,
   if (f32in)
     hipLaunchKernelGGL((db_up_kernel<16, float>), dim3(g), dim3(256), 0, st, (const float*)src, pitch, nbr, B, H, W, params,
                        lines, bitmap, thresh);
-  else
+  else if (g_db_up_mfma && pitch % 8 == 0 && (((uintptr_t)src | (uintptr_t)lines) & 15) == 0) {
+    const int ngroups = (int)((total + 31) / 32);
+    const int blocks = (int)std::min<long long>((ngroups + 3) / 4, 256 * 16);
+    hipLaunchKernelGGL(db_up_mfma_kernel, dim3(blocks), dim3(256), 0, st, (const half_t*)src, pitch, nbr, B, H, W, params, lines,
+                       bitmap, thresh, ngroups);
+  } else
     hipLaunchKernelGGL((db_up_kernel<16, half_t>), dim3(g), dim3(256), 0, st, (const half_t*)src, pitch, nbr, B, H, W, params,
                        lines, bitmap, thresh);
   (void)q;

@@ -507,6 +507,74 @@ static void run_sppf_case(int B, int H, int W, int C) {
   (void)hipFree(dA); (void)hipFree(dB);
 }
 
+// ---- DB tail: the MFMA kernel against the VALU kernel (same math; W1 rounded to fp16, another summation order) ----
+static void run_dbup_case(int B, int H, int W, int nbr) {
+  const int Q = 16, pitch = 2 * Q;
+  const size_t npx = (size_t)B * H * W;
+  std::vector<half_t> hx(npx * pitch);
+  for (auto& v : hx) v = (half_t)(frand() * 2.f + 0.5f);          // post-ReLU-like activations
+  const int PB = 4 * Q * Q + Q + 4 * Q + 1, SIZE = (PB + 3) / 4 * 4;
+  std::vector<float> prm((size_t)2 * SIZE, 0.f);
+  for (int br = 0; br < 2; ++br) {
+    float* d = prm.data() + (size_t)br * SIZE;
+    for (int i = 0; i < 4 * Q * Q; ++i) d[i] = frand() * 0.5f;     // W1p[pp][c][o]
+    for (int i = 0; i < Q; ++i) d[4 * Q * Q + i] = frand() * 0.2f; // b1
+    for (int i = 0; i < 4 * Q; ++i) d[4 * Q * Q + Q + i] = frand();  // W2p[qq][o]
+    d[4 * Q * Q + Q + 4 * Q] = frand();
+  }
+  half_t* dX = dev_alloc<half_t>(hx.size());
+  float* dP = dev_alloc<float>(prm.size());
+  CK(hipMemcpy(dX, hx.data(), hx.size() * 2, hipMemcpyHostToDevice));
+  CK(hipMemcpy(dP, prm.data(), prm.size() * 4, hipMemcpyHostToDevice));
+  const size_t nout = npx * 16 * nbr, nbm = npx * 16;
+  float *dL0 = dev_alloc<float>(nout), *dL1 = dev_alloc<float>(nout);
+  uint8_t *dB0 = dev_alloc<uint8_t>(nbm), *dB1 = dev_alloc<uint8_t>(nbm);
+  CK(hipMemset(dL1, 0xff, nout * 4));
+  CK(hipMemset(dB1, 0xff, nbm));
+  auto run = [&](int mfma, float* L, uint8_t* Bm) {
+    g_db_up_mfma = mfma;
+    launch_db_up(dX, false, pitch, Q, nbr, B, H, W, dP, L, Bm, 0.3f, 0);
+  };
+  run(0, dL0, dB0);
+  run(1, dL1, dB1);
+  CK(hipDeviceSynchronize());
+  std::vector<float> l0(nout), l1(nout);
+  std::vector<uint8_t> b0(nbm), b1(nbm);
+  CK(hipMemcpy(l0.data(), dL0, nout * 4, hipMemcpyDeviceToHost));
+  CK(hipMemcpy(l1.data(), dL1, nout * 4, hipMemcpyDeviceToHost));
+  CK(hipMemcpy(b0.data(), dB0, nbm, hipMemcpyDeviceToHost));
+  CK(hipMemcpy(b1.data(), dB1, nbm, hipMemcpyDeviceToHost));
+  double maxerr = 0, sumerr = 0;
+  size_t bad = 0, bmdiff = 0;
+  for (size_t i = 0; i < nout; ++i) {
+    const double e = std::fabs((double)l0[i] - (double)l1[i]);
+    if (!(e <= 3e-3)) ++bad;          // also catches NaN / unwritten
+    maxerr = std::fmax(maxerr, e);
+    sumerr += e;
+  }
+  for (size_t i = 0; i < nbm; ++i) bmdiff += b0[i] != b1[i];
+  if (bad || bmdiff > nbm / 200) ++g_fail;
+  double ms[2];
+  for (int m = 0; m < 2; ++m) {
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    for (int i = 0; i < 3; ++i) run(m, m ? dL1 : dL0, m ? dB1 : dB0);
+    CK(hipEventRecord(e0, 0));
+    for (int i = 0; i < 20; ++i) run(m, m ? dL1 : dL0, m ? dB1 : dB0);
+    CK(hipEventRecord(e1, 0));
+    CK(hipEventSynchronize(e1));
+    float tms;
+    CK(hipEventElapsedTime(&tms, e0, e1));
+    ms[m] = tms / 20;
+  }
+  g_db_up_mfma = 1;
+  const double io = (double)hx.size() * 2 * nbr / 2 + (double)nout * 4 + nbm;
+  std::printf("[dbup] B=%d %dx%d branches=%d | %s: max|d| %.3g mean|d| %.3g, %zu values > 3e-3, bitmap differs on %zu of %zu | VALU %.3f ms, MFMA %.3f ms = %.0f GB/s\n",
+              B, H, W, nbr, (bad || bmdiff > nbm / 200) ? "FAIL" : "ok", maxerr, sumerr / nout, bad, bmdiff, nbm, ms[0], ms[1],
+              io / (ms[1] * 1e-3) / 1e9);
+  (void)hipFree(dX); (void)hipFree(dP); (void)hipFree(dL0); (void)hipFree(dL1); (void)hipFree(dB0); (void)hipFree(dB1);
+}
+
 int main(int argc, char** argv) {
   const int B = argc > 1 ? std::atoi(argv[1]) : 4;
   const bool quick = argc > 2;
@@ -563,6 +631,9 @@ int main(int argc, char** argv) {
     run_sppf_case(3, 48, 48, 256);
     run_sppf_case(2, 20, 36, 64);
     run_sppf_case(1, 72, 72, 256);
+    run_dbup_case(B, 256, 256, 2);
+    run_dbup_case(3, 40, 52, 1);
+    run_dbup_case(1, 7, 9, 2);          // 63 pixels: a partial group of 32
   }
   if (std::getenv("ST_ONLY_C3")) {
     std::printf("selftest: %s (%d failures)\n", g_fail ? "FAILED" : "PASSED", g_fail);

@@ -914,6 +914,7 @@ int32_t ctd_engine_arena_generation(const ctd_engine* e) { return e ? e->arena_g
 int ctd_tuning_set(const char* key, int64_t value) {
   if (key && std::string(key) == "fuse") { g_fuse = (int)value; return CTD_OK; }
   if (key && std::string(key) == "db_up_mfma") { g_db_up_mfma = (int)value; return CTD_OK; }
+  if (key && std::string(key) == "seg_final_mfma") { g_seg_final_mfma = (int)value; return CTD_OK; }
   if (key && std::string(key) == "c3_min_patches") { g_c3_min_patches = value; g_fuse_epoch++; return CTD_OK; }
   if (conv_tuning_set(key, (long long)value) != 0) return fail(CTD_ERR_INVALID, "unknown tuning key");
   return CTD_OK;

@@ -98,6 +98,7 @@ void launch_seg_final(const half_t* src, int pitch, int C, int B, int H, int W, 
 // params f32 per branch: W1[q][q][2][2] (cin,cout,ky,kx) b1[q] W2[q][1][2][2] b2[1]
 void launch_seg_final_f32(const float* src, int pitch, int C, int B, int H, int W, const float* w, float* mask,
                           uint8_t* mask_u8, hipStream_t st);
+extern int g_seg_final_mfma;   // fp16 engine: seg-final's channel reduction on the MFMA (CTD_SEGFINAL_MFMA / "seg_final_mfma")
 extern int g_db_up_mfma;   // fp16 engine: DB tail's first stage on the MFMA (CTD_DBUP_MFMA / ctd_tuning_set("db_up_mfma"))
 void launch_db_up(const void* src, bool f32in, int pitch, int q, int nbr, int B, int H, int W, const float* params, float* lines,
                   uint8_t* bitmap, float thresh, hipStream_t st);

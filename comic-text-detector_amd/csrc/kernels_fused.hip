@@ -539,6 +539,96 @@ __global__ __launch_bounds__(256) void db_up_mfma_kernel(const half_t* __restric
   }
 }
 
+// ---------------------------------------------------------------------------
+// Seg final on the matrix cores (fp16 engine).  seg_final_kernel above spends 1024 FMAs per input pixel on a
+// 64 -> 1 transposed convolution (0.36 ms per 32 pages against 0.23 ms of bytes).  Per input pixel the layer is a
+// 16 x 64 matrix-vector product -- P[pixel][tap = ky * 4 + kx] = sum_c x[pixel][c] w[c][tap] -- followed by a
+// col2im: out(2y + py, 2x + px) = sum over the 2x2 neighbours (dy, dx) of P[(y + dy, x + dx)][py + 1 - 2dy][px + 1 - 2dx].
+// So: the P of the 18x18 haloed tile by MFMA (rows n = tap, 16 of the 32 used; B operand = 16 contiguous bytes of a
+// pixel's channel row straight from HBM, the tile of x is never staged), P through LDS (22 KB instead of 47 KB), and
+// 16 LDS reads + 16 adds per pixel for the gather.  Weights are the fp16 pairs the VALU kernel already uses.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void seg_final_mfma_kernel(const half_t* __restrict__ src, int pitch, int B, int H, int W,
+                                                             const half_t* __restrict__ w, float bias,
+                                                             float* __restrict__ mask, uint8_t* __restrict__ mask_u8) {
+  constexpr int C = 64, TP = SF_T + 2, NPX = TP * TP, NFRAG = (NPX + 31) / 32;   // 324 haloed pixels, 11 fragments
+  __shared__ __attribute__((aligned(16))) float Ps[NFRAG * 32 * 16];
+  const int tiles_x = (W + SF_T - 1) / SF_T, tiles_y = (H + SF_T - 1) / SF_T;
+  int bid = blockIdx.x;
+  const int x0 = (bid % tiles_x) * SF_T;
+  bid /= tiles_x;
+  const int y0 = (bid % tiles_y) * SF_T;
+  const long long b = bid / tiles_y;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int l31 = lane & 31, hi = lane >> 5;
+  // A fragments: row n = tap (l31 < 16), k = channel 16 ks + 8 hi + e: one 16-B piece of w [C/8][16 taps][8]
+  half8_t wa[C / 16];
+#pragma unroll
+  for (int ks = 0; ks < C / 16; ++ks) {
+    const half8_t z = {0, 0, 0, 0, 0, 0, 0, 0};
+    wa[ks] = l31 < 16 ? *(const half8_t*)(w + ((size_t)(2 * ks + hi) * 16 + l31) * 8) : z;
+  }
+  for (int f = wave; f < NFRAG; f += 4) {
+    const int p = 32 * f + l31;
+    const int ty = p / TP, tx = p - ty * TP;
+    const int yy = y0 + ty - 1, xx = x0 + tx - 1;
+    const bool ok = p < NPX && yy >= 0 && yy < H && xx >= 0 && xx < W;
+    const half_t* px = src + (ok ? ((b * H + yy) * W + xx) * pitch : 0) + 8 * hi;
+    half8_t xv[C / 16];
+#pragma unroll
+    for (int ks = 0; ks < C / 16; ++ks) xv[ks] = *(const half8_t*)(px + 16 * ks);     // all loads before the first use
+    float16_t acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < C / 16; ++ks) {
+      const half8_t z = {0, 0, 0, 0, 0, 0, 0, 0};
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa[ks], ok ? xv[ks] : z, acc, 0, 0, 0);
+    }
+    // rows n = (r & 3) + 8 (r >> 2) + 4 hi: r = 0..3 -> taps 4hi .. 4hi+3, r = 4..7 -> taps 8 + 4hi .. (r >= 8: the unused rows)
+    const float4_t lo = {acc[0], acc[1], acc[2], acc[3]}, hi4 = {acc[4], acc[5], acc[6], acc[7]};
+    *(float4_t*)(Ps + p * 16 + 4 * hi) = lo;
+    *(float4_t*)(Ps + p * 16 + 8 + 4 * hi) = hi4;
+  }
+  __syncthreads();
+  const int lx = threadIdx.x % SF_T, ly = threadIdx.x / SF_T;
+  const int x = x0 + lx, y = y0 + ly;
+  if (x >= W || y >= H) return;
+  float o[2][2] = {{bias, bias}, {bias, bias}};
+#pragma unroll
+  for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+    for (int dx = -1; dx <= 1; ++dx) {
+      const float* Pn = Ps + ((ly + 1 + dy) * TP + (lx + 1 + dx)) * 16;
+#pragma unroll
+      for (int py = 0; py < 2; ++py) {
+        const int ky = py + 1 - 2 * dy;
+        if (ky < 0 || ky > 3) continue;
+#pragma unroll
+        for (int px2 = 0; px2 < 2; ++px2) {
+          const int kx = px2 + 1 - 2 * dx;
+          if (kx < 0 || kx > 3) continue;
+          o[py][px2] += Pn[ky * 4 + kx];
+        }
+      }
+    }
+  const int Wo = 2 * W;
+  const long long Ho = 2LL * H;
+#pragma unroll
+  for (int py = 0; py < 2; ++py) {
+    const float s0 = 1.0f / (1.0f + expf(-o[py][0]));
+    const float s1 = 1.0f / (1.0f + expf(-o[py][1]));
+    const long long off = (b * Ho + (2 * y + py)) * Wo + 2 * x;
+    if (mask) *(float2*)(mask + off) = make_float2(s0, s1);
+    if (mask_u8) {
+      uchar2 q;
+      q.x = (uint8_t)(s0 * 255.0f);
+      q.y = (uint8_t)(s1 * 255.0f);
+      *(uchar2*)(mask_u8 + off) = q;
+    }
+  }
+}
+
 }  // namespace
 
 void launch_stem(const void* in, int in_fmt, half_t* dst, int pitchD, int B, int H, int W, int N, const half_t* wfrag,
@@ -571,7 +661,10 @@ void stem_pack_weights(const float* W /* (32, 3, 6, 6) */, std::vector<half_t>& 
 void launch_seg_final(const half_t* src, int pitch, int C, int B, int H, int W, const float* w, float bias,
                       float* mask, uint8_t* mask_u8, hipStream_t st) {
   const int g = ((W + SF_T - 1) / SF_T) * ((H + SF_T - 1) / SF_T) * B;
-  hipLaunchKernelGGL((seg_final_kernel<64>), dim3(g), dim3(256), 0, st, src, pitch, B, H, W, w, bias, mask, mask_u8);
+  if (g_seg_final_mfma && C == 64 && pitch % 8 == 0 && (((uintptr_t)src | (uintptr_t)w) & 15) == 0)
+    hipLaunchKernelGGL(seg_final_mfma_kernel, dim3(g), dim3(256), 0, st, src, pitch, B, H, W, (const half_t*)w, bias, mask, mask_u8);
+  else
+    hipLaunchKernelGGL((seg_final_kernel<64>), dim3(g), dim3(256), 0, st, src, pitch, B, H, W, w, bias, mask, mask_u8);
   (void)C;
 }
 
@@ -582,6 +675,10 @@ void launch_seg_final_f32(const float* src, int pitch, int C, int B, int H, int 
   (void)C;
 }
 
+int g_seg_final_mfma = [] {   // CTD_SEGFINAL_MFMA=0: the VALU kernel (A/B knob; ctd_tuning_set("seg_final_mfma"))
+  const char* e = std::getenv("CTD_SEGFINAL_MFMA");
+  return e ? std::atoi(e) : 1;
+}();
 int g_db_up_mfma = [] {   // CTD_DBUP_MFMA=0: the VALU kernel (A/B knob; ctd_tuning_set("db_up_mfma"))
   const char* e = std::getenv("CTD_DBUP_MFMA");
   return e ? std::atoi(e) : 1;

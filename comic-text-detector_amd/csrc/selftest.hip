@@ -575,6 +575,63 @@ static void run_dbup_case(int B, int H, int W, int nbr) {
   (void)hipFree(dX); (void)hipFree(dP); (void)hipFree(dL0); (void)hipFree(dL1); (void)hipFree(dB0); (void)hipFree(dB1);
 }
 
+// ---- seg final: the MFMA kernel against the VALU kernel (same fp16 weights, another summation order) ----
+static void run_segfinal_case(int B, int H, int W) {
+  const int C = 64;
+  const size_t npx = (size_t)B * H * W, nout = npx * 4;
+  std::vector<half_t> hx(npx * C), hw((size_t)C * 16);
+  for (auto& v : hx) v = (half_t)(frand() * 2.f + 0.3f);
+  for (auto& v : hw) v = (half_t)(frand() * 0.25f);
+  half_t *dX = dev_alloc<half_t>(hx.size()), *dW = dev_alloc<half_t>(hw.size());
+  CK(hipMemcpy(dX, hx.data(), hx.size() * 2, hipMemcpyHostToDevice));
+  CK(hipMemcpy(dW, hw.data(), hw.size() * 2, hipMemcpyHostToDevice));
+  float *dM0 = dev_alloc<float>(nout), *dM1 = dev_alloc<float>(nout);
+  uint8_t *dU0 = dev_alloc<uint8_t>(nout), *dU1 = dev_alloc<uint8_t>(nout);
+  CK(hipMemset(dM1, 0xff, nout * 4));
+  auto run = [&](int mfma, float* M, uint8_t* U) {
+    g_seg_final_mfma = mfma;
+    launch_seg_final(dX, C, C, B, H, W, (const float*)dW, 0.f, M, U, 0);
+  };
+  run(0, dM0, dU0);
+  run(1, dM1, dU1);
+  CK(hipDeviceSynchronize());
+  std::vector<float> m0(nout), m1(nout);
+  std::vector<uint8_t> u0(nout), u1(nout);
+  CK(hipMemcpy(m0.data(), dM0, nout * 4, hipMemcpyDeviceToHost));
+  CK(hipMemcpy(m1.data(), dM1, nout * 4, hipMemcpyDeviceToHost));
+  CK(hipMemcpy(u0.data(), dU0, nout, hipMemcpyDeviceToHost));
+  CK(hipMemcpy(u1.data(), dU1, nout, hipMemcpyDeviceToHost));
+  double maxerr = 0;
+  size_t bad = 0, udiff = 0, ubig = 0;
+  for (size_t i = 0; i < nout; ++i) {
+    const double e = std::fabs((double)m0[i] - (double)m1[i]);
+    if (!(e <= 2e-5)) ++bad;
+    maxerr = std::fmax(maxerr, e);
+    udiff += u0[i] != u1[i];
+    ubig += std::abs((int)u0[i] - (int)u1[i]) > 1;
+  }
+  const bool fail = bad || ubig || udiff > nout / 1000;
+  if (fail) ++g_fail;
+  double ms[2];
+  for (int m = 0; m < 2; ++m) {
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    for (int i = 0; i < 3; ++i) run(m, m ? dM1 : dM0, m ? dU1 : dU0);
+    CK(hipEventRecord(e0, 0));
+    for (int i = 0; i < 20; ++i) run(m, m ? dM1 : dM0, m ? dU1 : dU0);
+    CK(hipEventRecord(e1, 0));
+    CK(hipEventSynchronize(e1));
+    float tms;
+    CK(hipEventElapsedTime(&tms, e0, e1));
+    ms[m] = tms / 20;
+  }
+  g_seg_final_mfma = 1;
+  const double io = (double)hx.size() * 2 + (double)nout * 5;
+  std::printf("[segfinal] B=%d %dx%d | %s: max|d| %.3g, %zu values > 2e-5, u8 differs on %zu of %zu (%zu by more than one level) | VALU %.3f ms, MFMA %.3f ms = %.0f GB/s\n",
+              B, H, W, fail ? "FAIL" : "ok", maxerr, bad, udiff, nout, ubig, ms[0], ms[1], io / (ms[1] * 1e-3) / 1e9);
+  (void)hipFree(dX); (void)hipFree(dW); (void)hipFree(dM0); (void)hipFree(dM1); (void)hipFree(dU0); (void)hipFree(dU1);
+}
+
 int main(int argc, char** argv) {
   const int B = argc > 1 ? std::atoi(argv[1]) : 4;
   const bool quick = argc > 2;
@@ -634,6 +691,9 @@ int main(int argc, char** argv) {
     run_dbup_case(B, 256, 256, 2);
     run_dbup_case(3, 40, 52, 1);
     run_dbup_case(1, 7, 9, 2);          // 63 pixels: a partial group of 32
+    run_segfinal_case(B, 512, 512);
+    run_segfinal_case(3, 40, 52);       // partial 16x16 tiles
+    run_segfinal_case(2, 9, 17);
   }
   if (std::getenv("ST_ONLY_C3")) {
     std::printf("selftest: %s (%d failures)\n", g_fail ? "FAILED" : "PASSED", g_fail);

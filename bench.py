@@ -490,7 +490,8 @@ def main() -> None:
                      "kernel": ("conv_direct / convt_direct (exact-fp32 VALU kernels)" if not (cls[fam] != 3).any() else
                                 "conv_f32_mfma_kernel (f32-operand MFMA conv / convT family)" if args.precision == "fp32" else
                                 "conv_halo_kernel + conv_igemm_kernel + c3_fused_kernel (MFMA conv / convT family)"),
-                     "launches_per_step": int((fam & (by > 0)).sum()),   # ops folded into a multi-layer kernel launch nothing (no bytes booked) "family_ms_per_step": round(fam_ms, 3),
+                     # ops folded into a multi-layer kernel launch nothing (no bytes booked on them)
+                     "launches_per_step": int((fam & (by > 0)).sum()), "family_ms_per_step": round(fam_ms, 3),
                      "net_ms_per_step": round(net_ms, 3), "alg_bytes_per_step": fam_bytes,
                      "alg_flops_per_step": fam_flops, "tflops": round(ach_tf, 1),
                      "mfma_frac": round(ach_tf / peak_tf, 4), "gbs": round(ach_gbs, 1),

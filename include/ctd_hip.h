@@ -176,8 +176,10 @@ int32_t ctd_engine_arena_generation(const ctd_engine* e);
  * maps with fewer 16x16 patches take the implicit-GEMM kernel), "halo" (0: never the halo kernel), "halo_pair",
  * "halo_1x1"; "fuse" = bit mask of the fp16 engine's multi-layer kernels (1: C3 block with 32 hidden channels,
  * 2: SPPF's three pools, 4: stem + layer 1; default 7; 0 = one launch per layer; results are bit-identical either
- * way), "c3_min_patches" (default 1024: smaller grids take the per-layer kernels).  The environment variables
- * CTD_HALO_* / CTD_FUSE give the initial values.  Engines re-plan on their next forward.  For tests and A/B
+ * way), "c3_min_patches" (default 1024: smaller grids take the per-layer kernels); "db_up_mfma" / "seg_final_mfma"
+ * (default 1: the DB tail / the seg-final layer with their channel reductions on the MFMA, 0: the VALU kernels; same
+ * results within 2e-4 / 1e-6).  The environment variables CTD_HALO_* / CTD_FUSE / CTD_DBUP_MFMA / CTD_SEGFINAL_MFMA give
+ * the initial values.  Engines re-plan on their next forward.  For tests and A/B
  * measurements. */
 int ctd_tuning_set(const char* key, int64_t value);
 

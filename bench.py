@@ -316,13 +316,14 @@ def main() -> None:
     # ---- inputs resident in HBM: the pages, and the text-like network outputs of the same pages
     NS = 8
     samples = [pkg.synth.text_like_outputs(100 * rank + s, S) for s in range(NS)]
-    pages = [torch.from_numpy(samples[i % NS][0]).to(dev) for i in range(nloc)]
+    # the batch lives in HBM as ONE (B,H,W,3) tensor, the pages are its slices (the detector then needs no torch.stack)
+    x_net = torch.from_numpy(np.stack([samples[i % NS][0] for i in range(nloc)])).to(dev)
+    pages = [x_net[i] for i in range(nloc)]
     canned = dict(
         blks=torch.from_numpy(np.concatenate([samples[i % NS][1] for i in range(nloc)])).to(dev),
         mask_u8=torch.from_numpy(np.stack([samples[i % NS][2] for i in range(nloc)])).to(dev),
         lines_map=torch.from_numpy(np.stack([samples[i % NS][3] for i in range(nloc)])).to(dev),
         bitmap=torch.from_numpy(np.stack([samples[i % NS][4] for i in range(nloc)])).to(dev))
-    x_net = torch.stack(pages)
     pool = ThreadPoolExecutor(max_workers=max(1, args.workers), thread_name_prefix="ctd-tail")
     stats = {"blocks": 0, "lines": 0, "pages": 0}
 
@@ -523,7 +524,8 @@ def main() -> None:
                 parity = {"error": repr(e)}
         e2e = args.mode == "e2e"
         where = "in HOST memory (H2D inside the timed region)" if (e2e and args.host_input) else "resident in HBM"
-        workload = (f"BASELINE configs[2]: bs={B}/GPU {S}x{S} u8 pages {where}; fused HIP forward (YOLOv5s+UNet+DB, "
+        workload = (f"BASELINE configs[2]: bs={B}/GPU {S}x{S} u8 pages {where}"
+                    + ("" if (e2e and args.host_input) else " (slices of one batch tensor)") + "; fused HIP forward (YOLOv5s+UNet+DB, "
                     f"seeded random weights, DB binarize + u8 mask fused)")
         if e2e:
             workload += (" + the WHOLE native tail per page: GPU NMS, DB boxes (2x GPU labelling + contour tables, host "

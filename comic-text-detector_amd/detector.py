@@ -89,11 +89,28 @@ class TextDetector:
             gpu.append(src)
             metas.append((im_h, im_w, int(Wn - nw), int(Hn - nh)))
         if all(m == (Hn, Wn, 0, 0) for m in metas):             # nothing to resize (letterbox: shape == new_unpad)
-            x = torch.stack(gpu)
+            x = self._as_batch(gpu)
         else:
             x = torch.stack([g if m == (Hn, Wn, 0, 0) else BK.resize_linear_u8(g, (Hn - m[3], Wn - m[2]), (Hn, Wn))
                              for g, m in zip(gpu, metas)])
         return x, gpu, metas
+
+    @staticmethod
+    def _as_batch(pages: Sequence[torch.Tensor]) -> torch.Tensor:
+        """Equal-size pages as ONE (B,H,W,3) tensor -- WITHOUT a copy when they already lie back to back in one
+        allocation (pages uploaded by `_stage`, slices of a caller's batch tensor): `torch.stack` of 32 1024x1024 pages
+        is a 200 MB round trip through HBM per batch (0.12 ms of GPU time, rocprofv3 `CatArrayBatchedCopy`)."""
+        p0 = pages[0]
+        n = p0.numel()
+        try:
+            same = all(g.shape == p0.shape and g.dtype == p0.dtype and g.is_contiguous() and
+                       g.untyped_storage().data_ptr() == p0.untyped_storage().data_ptr() and
+                       g.storage_offset() == p0.storage_offset() + i * n for i, g in enumerate(pages))
+        except (RuntimeError, AttributeError):
+            same = False
+        if same and p0.is_contiguous():
+            return torch.as_strided(p0, (len(pages),) + tuple(p0.shape), (n,) + tuple(p0.stride()), p0.storage_offset())
+        return torch.stack(list(pages))
 
     def _forward(self, pages: Sequence[Page], net=None):
         net = net or self.net

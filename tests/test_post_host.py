@@ -320,3 +320,23 @@ def test_oracle_round_offset_is_the_minkowski_sum_with_a_disc():
         e, q = np.roll(ring, -1, 0) - ring, P[:, None, :] - ring[None, :, :]
         s = np.sign(e[None, :, 0] * q[:, :, 1] - e[None, :, 1] * q[:, :, 0])
         assert (s >= 0).all() or (s <= 0).all()
+
+
+def test_pages_lying_back_to_back_become_a_batch_without_a_copy():
+    """`TextDetector._as_batch`: slices of one allocation (the pages `_stage` uploads) are viewed, anything else is stacked."""
+    import importlib
+    import torch
+    det = importlib.import_module("comic-text-detector_amd.detector")
+    buf = torch.arange(5 * 4 * 6 * 3, dtype=torch.uint8)            # wraps at 256, content irrelevant
+    pages = [buf[i * 72:(i + 1) * 72].view(4, 6, 3) for i in range(1, 5)]      # a run that does not start at the allocation
+    x = det.TextDetector._as_batch(pages)
+    assert x.shape == (4, 4, 6, 3) and x.data_ptr() == pages[0].data_ptr()      # a view: no copy
+    assert all(torch.equal(x[i], p) for i, p in enumerate(pages))
+    shuffled = [pages[1], pages[0], pages[2]]
+    y = det.TextDetector._as_batch(shuffled)
+    assert y.data_ptr() != shuffled[0].data_ptr() and all(torch.equal(y[i], p) for i, p in enumerate(shuffled))
+    separate = [p.clone() for p in pages]
+    z = det.TextDetector._as_batch(separate)
+    assert z.data_ptr() != separate[0].data_ptr() and torch.equal(z, x)
+    gap = [pages[0], pages[2]]                                         # same allocation, not adjacent
+    assert torch.equal(det.TextDetector._as_batch(gap), torch.stack(gap))

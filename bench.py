@@ -350,8 +350,7 @@ def main() -> None:
             # on its own stream: the default stream holds the queued forwards of the next batches, and an upload or
             # a collective enqueued behind them would stall this thread until they have run
             with torch.cuda.stream(comm_stream):
-                rec = D.pack_results(res).pin_memory().to(dev, non_blocking=True)
-                D.gather_records(rec, total_pages, rank, world)
+                D.gather_results(res, total_pages, rank, world, device=dev, pin=True)
         stats["pages"] += len(res)
         stats["blocks"] += sum(len(r[2]) for r in res)
         stats["lines"] += sum(len(b.lines) for r in res for b in r[2])

@@ -76,14 +76,21 @@ MAX_BLK = MAX_DET + MAX_LINES      # group_output yields at most one block per y
 BLK_F = 12                          # xyxy(4), language, vertical, angle, font_size, n_lines, norm, vec(2)
 
 
-def pack_results(results, device=None) -> torch.Tensor:
+HDR = 4                             # n_blk, n_lines (true counts), cap_blk, cap_line
+CAP_BLK, CAP_LINE = 128, 512        # the compact record: 45 KB per page instead of 208 KB at the worst-case capacities
+
+
+def pack_results(results, device=None, cap_blk: int = MAX_BLK, cap_line: int = MAX_BLK) -> torch.Tensor:
     """`detect_batch` results [(mask, mask_refined, blk_list), ...] -> one fixed-size f64 record per page:
-    [n_blk, n_lines, blocks MAX_BLK x 12, lines MAX_BLK x 8 (4 points, in block order)].  float64 holds
-    every field exactly (coordinates and angles are integers, font sizes / norms are doubles).  Masks stay
-    on the rank that produced them."""
+    [n_blk, n_lines, cap_blk, cap_line, blocks cap_blk x 12, lines cap_line x 8 (4 points, in block order)].
+    float64 holds every field exactly (coordinates and angles are integers, font sizes / norms are doubles).
+    The counts are the TRUE counts: a page with more blocks / lines than the capacities is stored truncated and is
+    recognisable as such (`gather_results` then repeats the gather at the worst-case capacities).  Masks stay on
+    the rank that produced them."""
     import numpy as np
     from .textblock import LANGCLS2IDX
-    rec = np.zeros((len(results), 2 + MAX_BLK * (BLK_F + 8)), np.float64)
+    rec = np.zeros((len(results), HDR + cap_blk * BLK_F + cap_line * 8), np.float64)
+    rec[:, 2], rec[:, 3] = cap_blk, cap_line
     for p, r in enumerate(results):
         blks = r[2]
         if not blks:
@@ -93,8 +100,9 @@ def pack_results(results, device=None) -> torch.Tensor:
         lines = [np.asarray(b.lines, np.float64).reshape(-1, 8) for b in blks if len(b.lines)]
         lines = np.concatenate(lines) if lines else np.zeros((0, 8))
         rec[p, 0], rec[p, 1] = len(blks), len(lines)
-        rec[p, 2: 2 + head.size] = head.ravel()
-        lb = 2 + MAX_BLK * BLK_F
+        head, lines = head[:cap_blk], lines[:cap_line]
+        rec[p, HDR: HDR + head.size] = head.ravel()
+        lb = HDR + cap_blk * BLK_F
         rec[p, lb: lb + lines.size] = lines.ravel()
     out = torch.from_numpy(rec)
     return out.to(device) if device is not None else out
@@ -106,17 +114,35 @@ def unpack_results(rec: torch.Tensor):
     rec = rec.cpu()
     out = []
     for p in range(rec.shape[0]):
-        nb = int(rec[p, 0])
+        nb, cap_blk, cap_line = int(rec[p, 0]), int(rec[p, 2]), int(rec[p, 3])
+        if nb > cap_blk or int(rec[p, 1]) > cap_line:
+            raise ValueError("truncated page record: gather at the worst-case capacities (gather_results does)")
         blks, nl = [], 0
         for i in range(nb):
-            f = rec[p, 2 + i * BLK_F: 2 + (i + 1) * BLK_F].tolist()
+            f = rec[p, HDR + i * BLK_F: HDR + (i + 1) * BLK_F].tolist()
             n = int(f[8])
-            lb = 2 + MAX_BLK * BLK_F + nl * 8
+            lb = HDR + cap_blk * BLK_F + nl * 8
             lines = rec[p, lb: lb + 8 * n].reshape(n, 4, 2).to(torch.int64).tolist()
             nl += n
             blks.append(dict(xyxy=[int(v) for v in f[:4]], language=LANG_LIST[int(f[4])], vertical=bool(f[5]),
                              angle=int(f[6]), font_size=f[7], norm=f[9], vec=[f[10], f[11]], lines=lines))
         out.append(blks)
+    return out
+
+
+def gather_results(results, n_total: int, rank: int, world: int, device=None, pin: bool = False) -> torch.Tensor:
+    """The data path's collective: all-gather of this rank's page records at the COMPACT capacities (CAP_BLK blocks,
+    CAP_LINE lines: 4.6x fewer bytes than the worst case, host packing included).  Every rank sees every page's true
+    counts in the gathered tensor, so all ranks agree without further communication on whether some page did not fit
+    -- only then the gather is repeated at the worst-case capacities (MAX_BLK)."""
+    def one(cb, cl):
+        rec = pack_results(results, None, cb, cl)
+        if device is not None:
+            rec = (rec.pin_memory() if pin else rec).to(device, non_blocking=pin)
+        return gather_records(rec, n_total, rank, world)
+    out = one(CAP_BLK, CAP_LINE)
+    if out.shape[0] and bool(((out[:, 0] > CAP_BLK) | (out[:, 1] > CAP_LINE)).any()):
+        out = one(MAX_BLK, MAX_BLK)
     return out
 
 

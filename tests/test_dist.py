@@ -80,15 +80,19 @@ def test_shard_range_partitions_everything():
 # ---- the whole N>1 data path on CPU: shard -> per-page grouping (native host code) -> gather of the block records
 
 
-def _page_blocks(i):
-    """The grouped block list of global page i (native `ctd_group_output`, host only)."""
+def _page_blocks(i, crowded=False):
+    """The grouped block list of global page i (native `ctd_group_output`, host only).  crowded: the LAST page gets more
+    blocks than the compact record holds (copies of its blocks), which must send every rank to the full-capacity gather."""
     from test_group_native import random_page
     p = pkg()
     blks, lines, im_w, im_h, mask = random_page(500 + i)
-    return p.textblock.group_output(blks, lines, im_w, im_h, mask)
+    out = p.textblock.group_output(blks, lines, im_w, im_h, mask)
+    if crowded and i == crowded - 1 and out:
+        out = (out * (p.dist.CAP_BLK // len(out) + 2))[: p.dist.CAP_BLK + 7]
+    return out
 
 
-def _worker_blocks(rank, world, port, n_total, q):
+def _worker_blocks(rank, world, port, n_total, q, crowded=0):
     import sys
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -97,12 +101,13 @@ def _worker_blocks(rank, world, port, n_total, q):
     D = pkg().dist
     r, lr, w = D.init("gloo")
     lo, hi = D.shard_range(n_total, r, w)
-    results = [(None, None, _page_blocks(i)) for i in range(lo, hi)]          # this rank's pages
-    allrec = D.gather_records(D.pack_results(results), n_total, r, w)
+    results = [(None, None, _page_blocks(i, crowded)) for i in range(lo, hi)]          # this rank's pages
+    allrec = D.gather_results(results, n_total, r, w)
     got = D.unpack_results(allrec)
-    ok = len(got) == n_total
+    ok_caps = int(allrec[0, 2]) == (D.MAX_BLK if crowded else D.CAP_BLK)         # compact unless a page did not fit
+    ok = len(got) == n_total and ok_caps
     for i in range(n_total):
-        ref = _page_blocks(i)
+        ref = _page_blocks(i, crowded)
         ok &= len(got[i]) == len(ref)
         for a, b in zip(got[i], ref):
             ok &= a["xyxy"] == [int(v) for v in b.xyxy] and a["lines"] == [[[int(x) for x in pt] for pt in ln] for ln in b.lines]
@@ -113,14 +118,15 @@ def _worker_blocks(rank, world, port, n_total, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("n_total", [6, 5])
-def test_gloo_world2_grouped_blocks_gathered_equal_single_process(n_total):
+@pytest.mark.parametrize("n_total,crowded", [(6, 0), (5, 0), (5, 5)])
+def test_gloo_world2_grouped_blocks_gathered_equal_single_process(n_total, crowded):
     """Every rank ends up with the final block list of EVERY page (SURVEY 8(e) record: blocks + their
-    lines), identical to what one process computes -- also with an uneven split."""
+    lines), identical to what one process computes -- also with an uneven split, and also when one page (on the last
+    rank) holds more blocks than the compact record: all ranks then repeat the gather at the worst-case capacities."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker_blocks, args=(r, 2, port, n_total, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker_blocks, args=(r, 2, port, n_total, q, crowded)) for r in range(2)]
     for p in procs:
         p.start()
     res = [q.get(timeout=180) for _ in procs]

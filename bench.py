@@ -12,8 +12,10 @@ over one batch of 32 synthetic pages already resident in HBM:
        hole filling), masks and TextBlock records back on the host
     -> (N>1) RCCL all-gather of the fixed-capacity per-page block records.
 
-The tail of step k runs on worker threads (own HIP streams) under the forward of step k+1
-(`TextDetector.detect_stream`'s pipeline).  Release weights are not available offline and random weights
+The tail of step k runs on worker threads (own HIP streams; one page-range work item per worker, `--tail-split`)
+under the forward of step k+1 (`TextDetector.detect_stream`'s pipeline).  Before the W warm-up steps the process
+runs `--spinup` (default 100) untimed steps -- board out of its low-power state, host buffers settled -- recorded in
+`config.spinup_steps`; the timed region is exactly K steps between barriers + synchronisations.  Release weights are not available offline and random weights
 give noise maps, so the forward runs on the synthetic pages (its time is data independent) and the tail
 is fed the matching TEXT-LIKE network outputs of the same pages (`synth.text_like_outputs`: ~15 text
 blocks / ~84 lines per page, block boxes = 35 % of the page) -- stated in `config.workload`.  Other lines:

@@ -6,11 +6,11 @@
 //     b  = y1 + act(m.cv2 t)                     3x3, 32 -> 32, zero padding, shortcut
 //     out = act(cv3 [b ; y2])                    1x1, 64 -> 64
 //
-// Why: as four launches the block moves 14 channel rows per pixel through HBM (x in, y out/in three times,
-// t out/in, residual in, cat in, out) for ~340 flop per byte; `model.2` (256x256x64 maps) and the UNet head's
-// `upconv5.conv.0` (512x512) run at 45-50 % of what their bytes allow and are 1.37 ms of the 10.9 ms forward.
-// Here a block owns a 16x8 pixel patch, reads the 18x10 haloed patch of x once, keeps y1 / y2 / t / b in LDS and
-// writes `out` once: 2 (+ halo overlap, served by L2) channel rows per pixel.
+// Why: as four launches the block moves 14 channel rows per pixel through HBM (x in, y out / in three times, t out / in,
+// residual in, cat in, out) for ~340 flop per byte; `model.2` (256x256x64 maps at 1024x1024, the only C3 of this network
+// with 32 hidden channels and its most byte-bound chain) ran at 45 % of what its bytes allow: 0.437 ms per 32 pages.
+// Here a block owns a 16x8 pixel patch, reads the 18x10 haloed patch of x once, keeps y1 / y2 / t / b in LDS and writes
+// `out` once: 2 (+ halo overlap, served by L2) channel rows per pixel; 0.321 ms (latency-bound now).
 //
 // Arithmetic is the unfused path's, step for step (fp16 operands, fp32 MFMA accumulation over the same K order,
 // every intermediate rounded to fp16 where the unfused kernels store it, shortcut added to the ROUNDED conv

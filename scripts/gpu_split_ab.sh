@@ -1,7 +1,6 @@
 #!/bin/bash
 # e2e bench: a batch's tail as 1 / 2 / 3 / 4 work items (page ranges) on 3 workers, driver-length runs (x3) and long
-# runs, one box.  (4 workers: 1611-1985 pages/s against 2324-2464 with 3 -- a fourth tail thread fights the launcher
-# thread for the interpreter lock.)
+# runs, one box.  (4 workers: 1611-1985 pages/s against 2324-2464 with 3 -- measured, cause not traced.)
 export TMPDIR=/tmp
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$ROOT/gpurun_out/split

@@ -82,3 +82,50 @@ def test_unsupported_module_raises():
     cfg["backbone"][2] = [-1, 3, "BottleneckCSP", [128]]
     with pytest.raises(NotImplementedError):
         a.parse_yolo_cfg(cfg)
+
+
+def test_program_contains_the_patterns_the_engine_fuses():
+    """engine.hip replaces three op patterns of the fp16 program by multi-layer kernels at plan time (stem + 3x3/s2 conv
+    on a private stem output; a C3 block with 32 hidden channels and one bottleneck whose intermediates are private; three
+    chained stride-1 max pools over the slots of one tensor).  A lowering change that breaks a pattern would silently
+    fall back to one launch per layer -- this pins that the yolov5s program still contains exactly one of each."""
+    import importlib
+    p = importlib.import_module("comic-text-detector_amd")
+    G = importlib.import_module("comic-text-detector_amd.graph")
+    L = importlib.import_module("comic-text-detector_amd._lib")
+    prog = G.lower(p.synth.make_checkpoint(0), L.PREC_F16)
+    ops, T = prog.ops, prog.tensors
+    first, last = {}, {}
+    for i, o in enumerate(ops):
+        reads = [o["src0"], o["src1"], o["res"]] if o["kind"] in (L.OP_CONV, L.OP_CONVT) else [o["src0"]]
+        writes = [o["dst"]] if o["kind"] in (L.OP_INPUT, L.OP_STEM, L.OP_CONV, L.OP_CONVT, L.OP_MAXPOOL, L.OP_AVGPOOL2) else []
+        for t in reads + writes:
+            if t >= 0:
+                last[t] = i
+        for t in writes:
+            first.setdefault(t, i)
+    private = lambda t, a, b: first[t] == a and last[t] == b       # noqa: E731
+    stem2 = [i for i in range(len(ops) - 1)
+             if ops[i]["kind"] == L.OP_STEM and ops[i]["cout"] == 32 and ops[i + 1]["kind"] == L.OP_CONV
+             and (ops[i + 1]["k"], ops[i + 1]["stride"], ops[i + 1]["pad"], ops[i + 1]["cout"]) == (3, 2, 1, 64)
+             and ops[i + 1]["src0"] == ops[i]["dst"] and ops[i + 1]["src1"] < 0 and private(ops[i]["dst"], i, i + 1)]
+    c3 = []
+    for i in range(len(ops) - 3):
+        a, b, c, d = ops[i:i + 4]
+        if not all(x["kind"] == L.OP_CONV for x in (a, b, c, d)):
+            continue
+        Y, Tt = a["dst"], b["dst"]
+        if (a["k"] == 1 and a["cout"] == 64 and a["res"] < 0 and T[Y][0] == 64 and b["k"] == 1 and b["src0"] == Y
+                and b["src0_c"] == 32 and b["cout"] == 32 and T[Tt][0] == 32 and c["k"] == 3 and c["stride"] == 1
+                and c["src0"] == Tt and c["dst"] == Y and c["res"] == Y and c["cout"] == 32 and d["k"] == 1
+                and d["src0"] == Y and d["src0_c"] == 64 and d["cout"] == 64 and len({x["act"] for x in (a, b, c, d)}) == 1
+                and private(Y, i, i + 3) and private(Tt, i + 1, i + 2)):
+            c3.append(a["name"])
+    pools = [i for i in range(len(ops) - 2)
+             if all(ops[i + j]["kind"] == L.OP_MAXPOOL and ops[i + j]["src0"] == ops[i]["src0"] == ops[i + j]["dst"]
+                    and ops[i + j]["k"] == ops[i]["k"] and ops[i + j]["dst_coff"] == ops[i + j]["src0_coff"] + ops[i]["src0_c"]
+                    for j in range(3))
+             and ops[i + 1]["src0_coff"] == ops[i]["dst_coff"] and ops[i + 2]["src0_coff"] == ops[i + 1]["dst_coff"]]
+    assert stem2 == [0]
+    assert c3 == ["model.2.cv1+cv2"]
+    assert len(pools) == 1 and ops[pools[0]]["name"].endswith("model.9.m0")

@@ -264,7 +264,7 @@ def main() -> None:
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=32, help="pages per GPU per step")
     ap.add_argument("--size", type=int, default=1024)
-    ap.add_argument("--precision", default="fp16", choices=["fp16", "fp32"])
+    ap.add_argument("--precision", default="fp16", choices=["fp16", "fp32", "fp32s"])
     ap.add_argument("--mode", default="e2e", choices=["e2e", "net", "mixed"],
                     help="e2e: forward + the whole native tail (default); net: forward + GPU NMS only; mixed: BASELINE "
                          "configs[4], a seeded stream of 640 / 1024 / 1536 pages, dynamic batches, one captured "
@@ -305,7 +305,7 @@ def main() -> None:
 
     ckpt = pkg.synth.make_checkpoint(0)
     B, S = args.batch, args.size
-    det = DET.TextDetector(ckpt, input_size=S, device=dev, half=args.precision == "fp16")
+    det = DET.TextDetector(ckpt, input_size=S, device=dev, precision=args.precision)
     # every mode times the WHOLE network (the seam's full contract: blks, mask f32, lines_map with both planes),
     # as the reference's `TextDetBase.forward` computes it; `TextDetector(trim_outputs=True)` is not benchmarked
     full = lambda: BK.HipTextDetBackend(ckpt, dev, precision=args.precision, outputs="all")   # noqa: E731
@@ -453,7 +453,8 @@ def main() -> None:
         ach_gbs = fam_bytes / (fam_ms * 1e-3) / 1e9
         ach_tf = fam_flops / (fam_ms * 1e-3) / 1e12
         ai = fam_flops / fam_bytes
-        peak_tf = MFMA_F16_PEAK_TFLOPS if args.precision == "fp16" else MFMA_F32_PEAK_TFLOPS
+        # fp32s: every product costs three fp16 MFMAs -> a third of the fp16 peak for the ALGORITHMIC flops
+        peak_tf = {"fp16": MFMA_F16_PEAK_TFLOPS, "fp32": MFMA_F32_PEAK_TFLOPS, "fp32s": MFMA_F16_PEAK_TFLOPS / 3}[args.precision]
         ridge = peak_tf * 1e12 / (HBM_PEAK_GBS * 1e9)
         if ai < ridge:
             roof = {"bound": "hbm", "achieved": round(ach_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -491,6 +492,7 @@ def main() -> None:
         roof.update({"traffic": traffic, "traffic_note": tnote,
                      "kernel": ("conv_direct / convt_direct (exact-fp32 VALU kernels)" if not (cls[fam] != 3).any() else
                                 "conv_f32_mfma_kernel (f32-operand MFMA conv / convT family)" if args.precision == "fp32" else
+                                "conv_split_kernel (split-operand conv / convT family: 3 fp16 MFMAs per product on fp32 tensors)" if args.precision == "fp32s" else
                                 "conv_halo_kernel + conv_igemm_kernel + c3_fused_kernel (MFMA conv / convT family)"),
                      # ops folded into a multi-layer kernel launch nothing (no bytes booked on them)
                      "launches_per_step": int((fam & (by > 0)).sum()), "family_ms_per_step": round(fam_ms, 3),

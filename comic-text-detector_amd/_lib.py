@@ -16,7 +16,7 @@ SELFTEST_PATH = os.path.join(_HERE, "ctd_selftest")
 # ---- constants mirrored from include/ctd_hip.h -------------------------------
 ABI_VERSION = 2
 OK = 0
-PREC_F32, PREC_F16 = 0, 1
+PREC_F32, PREC_F16, PREC_F32S = 0, 1, 2
 ACT = {"none": 0, "silu": 1, "leaky": 2, "relu": 3, "sigmoid": 4}
 IN_NCHW_F32, IN_NHWC_U8 = 0, 1
 (OP_INPUT, OP_CONV, OP_CONVT, OP_MAXPOOL, OP_AVGPOOL2, OP_DETECT, OP_EXPORT, OP_STEM, OP_SEG_FINAL,

@@ -40,7 +40,7 @@ class HipTextDetBackend:
         if dev.type != "cuda":
             raise L.CtdError(f"device must be a cuda/hip device, got {device!r}")
         self.device = torch.device("cuda", dev.index if dev.index is not None else torch.cuda.current_device())
-        self.prec = {"fp16": L.PREC_F16, "fp32": L.PREC_F32}[precision]
+        self.prec = {"fp16": L.PREC_F16, "fp32": L.PREC_F32, "fp32s": L.PREC_F32S}[precision]
         self.precision = precision
         self._lib = L.lib()
         # `DBHead.forward(step_eval=True)` (reference basemodel.py:121-122): `lines_map` becomes the (B,1,H,W)

@@ -52,6 +52,8 @@ struct ConvArgs {
   unsigned mw_mul, mw_sh;  // igemm: n / Mw == (uint64(n) * mw_mul) >> mw_sh for n < 2^31 (filled by the launcher)
   unsigned mh_mul, mh_sh;  //        same for Mh
   int k_rot;               // igemm: selftest ablation bits (0 in the product): 1 no K-loop loads, 2 no MFMAs, 4 no stores
+  const void* w2;          // split kernel (kernels_split.hip): the lo plane of the weights (`w` is the hi plane)
+  const float* oscale;     // split kernel: per output channel 1 / (power of two its weights were scaled by), padded to Npad
 };
 
 __device__ __forceinline__ float ctd_act(float v, int act) {

@@ -46,6 +46,8 @@ struct OpState {
   float* aux_dev = nullptr;   // anchors etc.
   int npad = 0;
   int bk = 0;
+  bool split = false;         // fp32s engine: split-operand kernel (kernels_split.hip); w_dev = hi plane | lo plane
+  float* oscale_dev = nullptr;
   // filled by plan()
   ConvArgs args{};
   double flops = 0, bytes = 0;
@@ -163,12 +165,22 @@ int pack_op(ctd_engine* e, OpState& s, const float* P, int64_t nP) {
         const int bn = f32_mfma_ntile(N);
         s.npad = (N + bn - 1) / bn * bn;
         const int K = k * k * cin;
-        std::vector<float> wp((size_t)s.npad * K, 0.f);
+        // fp32s engine: split operands on the fp16 MFMA wherever a 32-channel K step never crosses a tap / source
+        s.split = e->prec == CTD_PREC_F32S && o.src0_c % 32 == 0 && (o.src1 < 0 || o.src1_c % 32 == 0);
+        std::vector<float> wp((size_t)(s.split ? N : s.npad) * K, 0.f);
         for (int n = 0; n < N; ++n)
           for (int c = 0; c < cin; ++c)
             for (int ky = 0; ky < k; ++ky)
               for (int kx = 0; kx < k; ++kx)
                 wp[(size_t)n * K + (size_t)(ky * k + kx) * cin + c] = W[(((size_t)n * cin + c) * k + ky) * k + kx];
+        if (s.split) {
+          std::vector<half_t> ws;
+          std::vector<float> osc;
+          split_pack_weights(wp.data(), 1, N, K, s.npad, ws, osc);
+          if (int rc = upload(e, ws, &s.w_dev)) return rc;
+          if (int rc = upload(e, osc, (void**)&s.oscale_dev)) return rc;
+          return pack_bias(s.npad);
+        }
         if (int rc = upload(e, wp, &s.w_dev)) return rc;
         return pack_bias(s.npad);
       }
@@ -222,7 +234,9 @@ int pack_op(ctd_engine* e, OpState& s, const float* P, int64_t nP) {
         const int bn = f32_mfma_ntile(N);
         s.npad = (N + bn - 1) / bn * bn;
         const int K = 4 * cin;
-        std::vector<float> wp((size_t)4 * s.npad * K, 0.f);
+        s.split = e->prec == CTD_PREC_F32S && cin % 32 == 0;
+        const int rows = s.split ? N : s.npad;          // the split packer pads by itself
+        std::vector<float> wp((size_t)4 * rows * K, 0.f);
         for (int ph = 0; ph < 4; ++ph) {
           const int py = ph >> 1, px = ph & 1;
           for (int ty = 0; ty < 2; ++ty)
@@ -231,9 +245,17 @@ int pack_op(ctd_engine* e, OpState& s, const float* P, int64_t nP) {
               const int ky = py + 1 - 2 * dy, kx = px + 1 - 2 * dx;
               for (int n = 0; n < N; ++n)
                 for (int c = 0; c < cin; ++c)
-                  wp[((size_t)ph * s.npad + n) * K + (size_t)(ty * 2 + tx) * cin + c] =
+                  wp[((size_t)ph * rows + n) * K + (size_t)(ty * 2 + tx) * cin + c] =
                       W[(((size_t)c * N + n) * 4 + ky) * 4 + kx];
             }
+        }
+        if (s.split) {
+          std::vector<half_t> ws;
+          std::vector<float> osc;
+          split_pack_weights(wp.data(), 4, N, K, s.npad, ws, osc);
+          if (int rc = upload(e, ws, &s.w_dev)) return rc;
+          if (int rc = upload(e, osc, (void**)&s.oscale_dev)) return rc;
+          return pack_bias(s.npad);
         }
         if (int rc = upload(e, wp, &s.w_dev)) return rc;
         return pack_bias(s.npad);
@@ -372,7 +394,7 @@ int plan(ctd_engine* e, int B, int H, int W, hipStream_t cap_stream = nullptr) {
     return fail(CTD_ERR_INVALID, "H and W must be positive multiples of 64 and B >= 1");
   const int nT = (int)e->tensors.size(), nO = (int)e->ops.size();
   for (auto& t : e->tensors) {
-    t.esize = (e->prec == CTD_PREC_F32 || t.t.dtype == 1) ? 4 : 2;
+    t.esize = (e->prec != CTD_PREC_F16 || t.t.dtype == 1) ? 4 : 2;
     t.H = H >> t.t.log2_down;
     t.W = W >> t.t.log2_down;
     t.bytes = align_up((size_t)B * t.H * t.W * t.t.channels * t.esize, 256);
@@ -546,7 +568,12 @@ int plan(ctd_engine* e, int B, int H, int W, hipStream_t cap_stream = nullptr) {
         // every input pixel meets k*k taps
         s.flops = 2.0 * (double)B * a.Hin * a.Win * o.k * o.k * cin * a.N;
       }
-      if ((s.impl == IMPL_IGEMM || s.impl == IMPL_IGEMM_T) && !(f16 ? igemm_supported(a) : conv_f32_mfma_supported(a)))
+      if (s.split) {
+        a.w2 = (const half_t*)s.w_dev + (size_t)a.nphase * s.npad * a.K;
+        a.oscale = s.oscale_dev;
+      }
+      if ((s.impl == IMPL_IGEMM || s.impl == IMPL_IGEMM_T) &&
+          !(f16 ? igemm_supported(a) : s.split ? conv_split_supported(a) : conv_f32_mfma_supported(a)))
         return fail(CTD_ERR_UNSUPPORTED, "op " + std::to_string(i) + ": shape rejected by the MFMA kernel");
       const double es = f16 ? 2 : 4;
       s.bytes = ((double)B * a.s0.H * a.s0.W * a.s0.c + (o.src1 >= 0 ? (double)B * a.s1.H * a.s1.W * a.s1.c : 0)) * es +
@@ -685,12 +712,14 @@ int launch_op(ctd_engine* e, int i, const Outs& x, hipStream_t st) {
     case CTD_OP_CONV:
       if (s.skip) break;
       if (s.c3_head) { launch_c3_fused(s.c3, st); break; }
-      if (s.impl == IMPL_IGEMM && !f16) launch_conv_f32_mfma(s.args, st);
+      if (s.impl == IMPL_IGEMM && s.split) launch_conv_split(s.args, st);
+      else if (s.impl == IMPL_IGEMM && !f16) launch_conv_f32_mfma(s.args, st);
       else if (s.impl == IMPL_IGEMM) launch_conv_igemm(s.args, e->tensors[o.dst].esize == 4, st);
       else launch_conv_direct(s.args, f16, st);
       break;
     case CTD_OP_CONVT:
-      if (s.impl == IMPL_IGEMM_T && !f16) launch_conv_f32_mfma(s.args, st);
+      if (s.impl == IMPL_IGEMM_T && s.split) launch_conv_split(s.args, st);
+      else if (s.impl == IMPL_IGEMM_T && !f16) launch_conv_f32_mfma(s.args, st);
       else if (s.impl == IMPL_IGEMM_T) launch_conv_igemm(s.args, false, st);
       else launch_convt_direct(s.args, f16, st);
       break;
@@ -789,7 +818,8 @@ int ctd_engine_create(ctd_engine** out, const ctd_tensor* tensors, int32_t n_ten
                       int32_t n_ops, const float* params, int64_t n_params, int32_t precision, int32_t device) {
   if (!out || !tensors || !ops || !params || n_tensors < 1 || n_ops < 1)
     return fail(CTD_ERR_INVALID, "null/empty program");
-  if (precision != CTD_PREC_F32 && precision != CTD_PREC_F16) return fail(CTD_ERR_INVALID, "bad precision");
+  if (precision != CTD_PREC_F32 && precision != CTD_PREC_F16 && precision != CTD_PREC_F32S)
+    return fail(CTD_ERR_INVALID, "bad precision");
   HIP_TRY(hipSetDevice(device));
   ctd_engine* e = new ctd_engine();
   e->device = device;
@@ -913,6 +943,7 @@ int32_t ctd_engine_arena_generation(const ctd_engine* e) { return e ? e->arena_g
 
 int ctd_tuning_set(const char* key, int64_t value) {
   if (key && std::string(key) == "fuse") { g_fuse = (int)value; return CTD_OK; }
+  if (key && std::string(key) == "split_wdma") { g_split_wdma = (int)value; return CTD_OK; }
   if (key && std::string(key) == "db_up_mfma") { g_db_up_mfma = (int)value; return CTD_OK; }
   if (key && std::string(key) == "seg_final_mfma") { g_seg_final_mfma = (int)value; return CTD_OK; }
   if (key && std::string(key) == "c3_min_patches") { g_c3_min_patches = value; g_fuse_epoch++; return CTD_OK; }

@@ -49,6 +49,14 @@ int f32_mfma_ntile(int N);
 bool conv_f32_mfma_supported(const ConvArgs& a);
 void launch_conv_f32_mfma(const ConvArgs& a, hipStream_t st);
 
+// ---- kernels_split.hip : split-operand (fp16 hi + lo, 3 MFMAs per product) conv on f32 tensors: the "fp32s" engine ----
+extern int g_split_wdma;   // 1: weight tiles by LDS-DMA, 0: through registers (ctd_tuning_set("split_wdma"))
+bool conv_split_supported(const ConvArgs& a);
+void launch_conv_split(const ConvArgs& a, hipStream_t st);
+// logical f32 [nphase][N][K] -> hi plane + lo plane (halves, [nphase][npad/32][K/32][32][32] each) + oscale[npad]
+void split_pack_weights(const float* logical, int nphase, int N, int K, int npad, std::vector<half_t>& out,
+                        std::vector<float>& oscale);
+
 // ---- kernels_halo.hip : halo-tile MFMA conv (stride-1 3x3, ConvTranspose phases) ----
 extern int g_conv_halo;   // 0 disables (selftest A/B)
 bool conv_halo_supported(const ConvArgs& a, bool dst_f32);

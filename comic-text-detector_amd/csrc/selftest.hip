@@ -632,6 +632,193 @@ static void run_segfinal_case(int B, int H, int W) {
   (void)hipFree(dX); (void)hipFree(dW); (void)hipFree(dM0); (void)hipFree(dM1); (void)hipFree(dU0); (void)hipFree(dU1);
 }
 
+// ---- fp16 denormals on the matrix cores: the split engine's low halves of small values are fp16 subnormals ----
+static void probe_denorm() {
+  std::vector<half_t> A(32 * 16, (half_t)9.5367431640625e-07f /* 2^-20: subnormal in fp16 */), B(16 * 32, (half_t)1.0f);
+  half_t *dA = dev_alloc<half_t>(A.size()), *dB = dev_alloc<half_t>(B.size());
+  float* dD = dev_alloc<float>(32 * 32);
+  CK(hipMemcpy(dA, A.data(), A.size() * 2, hipMemcpyHostToDevice));
+  CK(hipMemcpy(dB, B.data(), B.size() * 2, hipMemcpyHostToDevice));
+  launch_mfma_probe(dA, dB, dD, 0);
+  std::vector<float> D(32 * 32);
+  CK(hipMemcpy(D.data(), dD, D.size() * 4, hipMemcpyDeviceToHost));
+  const double want = 16.0 * 9.5367431640625e-07;
+  std::printf("[probe] fp16 subnormal operands on the MFMA: 16 x 2^-20 x 1 = %.6g (exact %.6g)  %s\n", (double)D[0], want,
+              std::fabs(D[0] - want) < 1e-12 ? "PRESERVED" : "FLUSHED / changed");
+  (void)hipFree(dA); (void)hipFree(dB); (void)hipFree(dD);
+}
+
+// ---- split-operand kernel (kernels_split.hip) against the f32-operand MFMA kernel (kernels_f32.hip) on the same f32
+// tensors, both against a float64 host reference on sampled outputs ----
+static void run_split_case(const Case& cs, int B, bool timing) {
+  const int Hin = cs.H, Win = cs.H, cin = cs.c0 + cs.c1;
+  const int k = cs.k, s = cs.s, pad = cs.kind ? 1 : k / 2;
+  const int Ho = cs.kind ? 2 * Hin : (Hin + 2 * pad - k) / s + 1, Wo = Ho;
+  const int H0 = cs.up0 ? Hin / 2 : Hin;
+  const size_t n0 = (size_t)B * H0 * H0 * cs.c0, n1 = (size_t)B * Hin * Win * cs.c1;
+  std::vector<float> h0(n0), h1(n1 ? n1 : 1);
+  // activations like the network's: mostly O(1), some small, a few large
+  auto arand = [&]() { const float u = frand(); return u * u * u * 40.f + frand() * 0.5f; };
+  for (auto& v : h0) v = arand();
+  for (auto& v : h1) v = arand();
+  float *d0 = dev_alloc<float>(n0), *d1 = dev_alloc<float>(n1 ? n1 : 1);
+  CK(hipMemcpy(d0, h0.data(), n0 * 4, hipMemcpyHostToDevice));
+  if (n1) CK(hipMemcpy(d1, h1.data(), n1 * 4, hipMemcpyHostToDevice));
+  const int pitchD = (cs.N + 3) / 4 * 4;
+  const size_t nout = (size_t)B * Ho * Wo * pitchD;
+  float *dOut = dev_alloc<float>(nout), *dRef = dev_alloc<float>(nout), *dRes = nullptr;
+  std::vector<float> hres;
+  if (cs.res) {
+    hres.resize(nout);
+    for (auto& v : hres) v = frand();
+    dRes = dev_alloc<float>(nout);
+    CK(hipMemcpy(dRes, hres.data(), nout * 4, hipMemcpyHostToDevice));
+  }
+  const int bn = f32_mfma_ntile(cs.N);
+  const int Npad = (cs.N + bn - 1) / bn * bn;
+  const int nphase = cs.kind ? 4 : 1;
+  const int K = cs.kind ? 4 * cin : k * k * cin;
+  const float wscale = 1.0f / std::sqrt((float)(cin * (cs.kind ? 4 : k * k)));
+  // logical weights [nphase][N][K]; per-channel magnitudes spread over 2^-6 .. 2^2 like BN-folded layers
+  std::vector<float> lg((size_t)nphase * cs.N * K), bias(Npad, 0.f);
+  for (int n = 0; n < cs.N; ++n) {
+    const float ch = std::ldexp(1.f, (int)(frand() * 8.f) - 2);
+    for (int ph = 0; ph < nphase; ++ph)
+      for (int kk = 0; kk < K; ++kk) lg[((size_t)ph * cs.N + n) * K + kk] = frand() * 2.f * wscale * ch;
+    bias[n] = frand();
+  }
+  std::vector<float> wf((size_t)nphase * Npad * K, 0.f);
+  for (int ph = 0; ph < nphase; ++ph)
+    for (int n = 0; n < cs.N; ++n)
+      std::memcpy(&wf[((size_t)ph * Npad + n) * K], &lg[((size_t)ph * cs.N + n) * K], (size_t)K * 4);
+  std::vector<half_t> ws;
+  std::vector<float> osc;
+  split_pack_weights(lg.data(), nphase, cs.N, K, Npad, ws, osc);
+  float *dWf = dev_alloc<float>(wf.size()), *dBias = dev_alloc<float>(Npad), *dOsc = dev_alloc<float>(Npad);
+  half_t* dWs = dev_alloc<half_t>(ws.size());
+  CK(hipMemcpy(dWf, wf.data(), wf.size() * 4, hipMemcpyHostToDevice));
+  CK(hipMemcpy(dWs, ws.data(), ws.size() * 2, hipMemcpyHostToDevice));
+  CK(hipMemcpy(dBias, bias.data(), Npad * 4, hipMemcpyHostToDevice));
+  CK(hipMemcpy(dOsc, osc.data(), Npad * 4, hipMemcpyHostToDevice));
+
+  ConvArgs a{};
+  a.s0 = SrcView{d0, cs.c0, cs.c0, cs.up0, H0, H0};
+  if (cs.c1) a.s1 = SrcView{d1, cs.c1, cs.c1, 0, Hin, Win};
+  a.B = B; a.Hin = Hin; a.Win = Win;
+  a.bias = dBias; a.pitchD = pitchD; a.oH = Ho; a.oW = Wo;
+  a.res = dRes; a.pitchR = pitchD; a.act = CTD_ACT_SILU; a.N = cs.N; a.Npad = Npad; a.K = K;
+  if (cs.kind == 0) {
+    a.Mh = Ho; a.Mw = Wo; a.KH = a.KW = k; a.stride = s; a.dy0 = a.dx0 = -pad; a.M = B * Ho * Wo;
+    a.nphase = 1; a.osy = a.osx = 1;
+  } else {
+    a.Mh = Hin; a.Mw = Win; a.KH = a.KW = 2; a.stride = 1; a.M = B * Hin * Win;
+    a.nphase = 4; a.osy = a.osx = 2; a.w_phase_stride = (long long)Npad * K;
+  }
+  ConvArgs af = a, as = a;
+  af.w = dWf; af.dst = dRef;
+  as.w = dWs; as.w2 = dWs + (size_t)nphase * Npad * K; as.oscale = dOsc; as.dst = dOut;
+  std::printf("[split] %-32s B=%d out %dx%dx%d |", cs.name, B, Ho, Wo, cs.N);
+  if (!conv_f32_mfma_supported(af) || !conv_split_supported(as)) {
+    std::printf(" unsupported  FAIL\n");
+    ++g_fail;
+    return;
+  }
+  launch_conv_f32_mfma(af, 0);
+  CK(hipDeviceSynchronize());
+  std::vector<float> r(nout), o(nout);
+  CK(hipMemcpy(r.data(), dRef, nout * 4, hipMemcpyDeviceToHost));
+  // float64 reference on sampled outputs
+  const int NS = 4000;
+  std::vector<size_t> sidx(NS);
+  std::vector<double> sref(NS);
+  for (int q = 0; q < NS; ++q) {
+    g_seed = g_seed * 1664525u + 1013904223u;
+    const size_t pix = (size_t)(g_seed >> 4) % ((size_t)B * Ho * Wo);
+    g_seed = g_seed * 1664525u + 1013904223u;
+    const int n = (int)((g_seed >> 8) % (unsigned)cs.N);
+    const int ox = (int)(pix % Wo), oy = (int)((pix / Wo) % Ho), b = (int)(pix / ((size_t)Wo * Ho));
+    int ph = 0, gy = oy, gx = ox, dy0 = -pad, dx0 = -pad, st = s, KH = k;
+    if (cs.kind) {
+      const int py = oy & 1, px = ox & 1;
+      ph = py * 2 + px; gy = oy >> 1; gx = ox >> 1; dy0 = py ? 0 : -1; dx0 = px ? 0 : -1; st = 1; KH = 2;
+    }
+    double acc = 0;
+    for (int ty = 0; ty < KH; ++ty)
+      for (int tx = 0; tx < KH; ++tx) {
+        const int iy = gy * st + dy0 + ty, ix = gx * st + dx0 + tx;
+        if (iy < 0 || iy >= Hin || ix < 0 || ix >= Win) continue;
+        const float* wr = &lg[((size_t)ph * cs.N + n) * K + (size_t)(ty * KH + tx) * cin];
+        const int sy = cs.up0 ? iy >> 1 : iy, sx = cs.up0 ? ix >> 1 : ix;
+        const float* x0 = &h0[(((size_t)b * H0 + sy) * H0 + sx) * cs.c0];
+        for (int c = 0; c < cs.c0; ++c) acc += (double)wr[c] * (double)x0[c];
+        if (cs.c1) {
+          const float* x1 = &h1[(((size_t)b * Hin + iy) * Win + ix) * cs.c1];
+          for (int c = 0; c < cs.c1; ++c) acc += (double)wr[cs.c0 + c] * (double)x1[c];
+        }
+      }
+    double v = acc + bias[n];
+    v = v / (1.0 + std::exp(-v));
+    const size_t oi = pix * pitchD + n;
+    if (cs.res) v += hres[oi];
+    sidx[q] = oi;
+    sref[q] = v;
+  }
+  auto err64 = [&](const std::vector<float>& got, double& rms, double& mx) {
+    double se = 0; mx = 0;
+    for (int q = 0; q < NS; ++q) {
+      const double e = std::fabs((double)got[sidx[q]] - sref[q]) / (1.0 + std::fabs(sref[q]));
+      se += e * e; mx = std::fmax(mx, e);
+    }
+    rms = std::sqrt(se / NS);
+  };
+  double rms_f, mx_f;
+  err64(r, rms_f, mx_f);
+  const double flops = cs.kind ? 2.0 * B * Hin * Win * 16.0 * cin * cs.N : 2.0 * (double)a.M * cs.N * K;
+  const double bytes = 4.0 * ((double)n0 + n1 + (double)B * Ho * Wo * cs.N * (cs.res ? 2 : 1) + (double)cs.N * cin * k * k);
+  auto time_it = [&](auto&& fn) {
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    for (int i = 0; i < 3; ++i) fn();
+    CK(hipEventRecord(e0, 0));
+    static const int it = std::getenv("ST_ITERS") ? std::atoi(std::getenv("ST_ITERS")) : 20;
+    for (int i = 0; i < it; ++i) fn();
+    CK(hipEventRecord(e1, 0));
+    CK(hipEventSynchronize(e1));
+    float t;
+    CK(hipEventElapsedTime(&t, e0, e1));
+    return (double)t / it;
+  };
+  const double ms_f = timing ? time_it([&]() { launch_conv_f32_mfma(af, 0); }) : 0;
+  std::printf(" f32-MFMA: err vs f64 rms %.2e max %.2e, %.3f ms %.0f TF |", rms_f, mx_f, ms_f, flops / (ms_f * 1e-3) / 1e12);
+  for (int wdma = 1; wdma >= 0; --wdma) {
+    g_split_wdma = wdma;
+    CK(hipMemset(dOut, 0xff, nout * 4));
+    launch_conv_split(as, 0);
+    CK(hipDeviceSynchronize());
+    CK(hipMemcpy(o.data(), dOut, nout * 4, hipMemcpyDeviceToHost));
+    double maxd = 0;
+    size_t bad = 0;
+    for (size_t i = 0; i < nout; ++i) {
+      if ((int)(i % pitchD) >= cs.N) continue;
+      const double e = std::fabs((double)o[i] - (double)r[i]);
+      maxd = std::fmax(maxd, e / (1.0 + std::fabs((double)r[i])));
+      if (!(e <= 2e-5 * (1.0 + std::fabs((double)r[i])))) ++bad;     // also catches NaN / unwritten
+    }
+    double rms_s, mx_s;
+    err64(o, rms_s, mx_s);
+    const bool fail = bad || !(rms_s <= 3.0 * rms_f + 1e-7);
+    if (fail) ++g_fail;
+    const double ms_s = timing ? time_it([&]() { launch_conv_split(as, 0); }) : 0;
+    std::printf(" split(%s): %s err vs f64 rms %.2e max %.2e, max|d| vs f32-MFMA %.2e (%zu > 2e-5), %.3f ms %.0f TF %.0f GB/s |",
+                wdma ? "dma" : "reg", fail ? "FAIL" : "ok", rms_s, mx_s, maxd, bad, ms_s, flops / (ms_s * 1e-3) / 1e12,
+                bytes / (ms_s * 1e-3) / 1e9);
+  }
+  g_split_wdma = 1;
+  std::printf("\n");
+  (void)hipFree(d0); (void)hipFree(d1); (void)hipFree(dOut); (void)hipFree(dRef); if (dRes) (void)hipFree(dRes);
+  (void)hipFree(dWf); (void)hipFree(dWs); (void)hipFree(dBias); (void)hipFree(dOsc);
+}
+
 int main(int argc, char** argv) {
   const int B = argc > 1 ? std::atoi(argv[1]) : 4;
   const bool quick = argc > 2;
@@ -665,6 +852,29 @@ int main(int argc, char** argv) {
       {"convT4 512->256 @16", 1, 512, 0, 0, 256, 4, 2, 16, 0},
   };
   const int ncase = sizeof(cases) / sizeof(cases[0]);
+  if (std::getenv("ST_SPLIT")) {     // the fp32s engine's kernel only: ST_SPLIT=1 ctd_selftest [batch]
+    probe_denorm();
+    const Case ragged[] = {{"3x3 32->64 @20 ragged (s2)", 0, 32, 0, 0, 64, 3, 2, 20, 0},
+                           {"1x1 cat(32up,64)->21 @12", 0, 32, 64, 1, 21, 1, 1, 12, 0},
+                           {"convT4 64->32 @9", 1, 64, 0, 0, 32, 4, 2, 9, 0},
+                           {"3x3 64->16 @24 (db branch)", 0, 64, 0, 0, 16, 3, 1, 24, 0}};
+    for (const Case& c : ragged) run_split_case(c, 3, false);
+    const char* sel = std::getenv("ST_CASES");
+    for (int i = 0; i < ncase; ++i) {
+      if (sel) {
+        bool on = false;
+        for (const char* p = sel; *p;) {
+          if (std::atoi(p) == i) on = true;
+          while (*p && *p != ',') ++p;
+          if (*p == ',') ++p;
+        }
+        if (!on) continue;
+      }
+      run_split_case(cases[i], B, true);
+    }
+    std::printf("selftest: %s (%d failures)\n", g_fail ? "FAILED" : "PASSED", g_fail);
+    return g_fail ? 1 : 0;
+  }
   if (!std::getenv("ST_NO_C3")) {
     // fused C3 block vs its four launches: the two network shapes, a partial-patch / odd-size map, every activation
     const C3Case c3s[] = {{"model.2 (64 -> 64 @256)", 64, 0, 256, CTD_ACT_SILU},

@@ -46,7 +46,8 @@ class TextDetector:
     langcls2idx = {"eng": 0, "ja": 1, "unknown": 2}
 
     def __init__(self, model_path: Union[str, dict], input_size=1024, device="cuda", half=False,
-                 nms_thresh=0.35, conf_thresh=0.4, mask_thresh=0.3, act="leaky", trim_outputs=False):
+                 nms_thresh=0.35, conf_thresh=0.4, mask_thresh=0.3, act="leaky", trim_outputs=False,
+                 precision: str = None):
         if isinstance(input_size, int):
             input_size = (input_size, input_size)
         self.input_size = input_size
@@ -54,7 +55,16 @@ class TextDetector:
         self.half = half
         self.conf_thresh = conf_thresh
         self.nms_thresh = nms_thresh
-        self._net_args = dict(model=model_path, device=device, precision="fp16" if half else "fp32", act=act,
+        # `precision` (an addition to the reference's keywords) names the engine directly and overrides `half`:
+        #   "fp32"  f32-operand MFMA (an fmaf chain's arithmetic)        = half=False, the default
+        #   "fp32s" fp32 tensors, split-operand products on the fp16 MFMA (same results to ~1e-6, several x faster)
+        #   "fp16"  fp16 tensors and operands, fp32 accumulate           = half=True
+        if precision is None:
+            precision = "fp16" if half else "fp32"
+        if precision not in ("fp32", "fp32s", "fp16"):
+            raise ValueError("precision must be 'fp32', 'fp32s' or 'fp16'")
+        self.precision = precision
+        self._net_args = dict(model=model_path, device=device, precision=precision, act=act,
                               bitmap_thresh=0.3, outputs="detector" if trim_outputs else "all")
         # trim_outputs=True: the engine computes only what this class consumes (no DB threshold branch, no f32 mask
         # plane; same results, ~1.5 % less GPU time).  Off by default -- the reference's network computes both, and

@@ -38,6 +38,9 @@ extern "C" {
 /* ---- arithmetic modes -------------------------------------------------- */
 #define CTD_PREC_F32 0 /* fp32 activations, exact fmaf chains (parity / config 2)   */
 #define CTD_PREC_F16 1 /* fp16 activations+weights, fp32 accumulate on MFMA (config 3) */
+#define CTD_PREC_F32S 2 /* fp32 activations and weights, every product computed on the fp16 MFMA from
+                           split operands (x = hi + lo: 3 MFMAs per product, ~22 mantissa bits,
+                           fp32 accumulate): the fp32 engine's results at several times its rate */
 
 /* ---- activations (reference models/yolov5/common.py:36-44, basemodel.py) -- */
 #define CTD_ACT_NONE 0

@@ -37,17 +37,19 @@ def oracle_result(ck, page, size):
                            refine_mode=0, keep_undetected_mask=False)
 
 
-@pytest.mark.parametrize("half,size,shape", [(False, 512, (512, 512)), (True, 512, (512, 512)), (True, 1024, (1024, 1024)),
-                                             (True, 512, (700, 495))])
-def test_detector_end_to_end_vs_oracle(half, size, shape):
+@pytest.mark.parametrize("prec,size,shape", [("fp32", 512, (512, 512)), ("fp32s", 512, (512, 512)), ("fp32s", 1024, (1024, 1024)),
+                                             ("fp32s", 512, (700, 495)), ("fp16", 512, (512, 512)),
+                                             ("fp16", 1024, (1024, 1024)), ("fp16", 512, (700, 495))])
+def test_detector_end_to_end_vs_oracle(prec, size, shape):
     p = pkg()
     ck = blob_ckpt()
+    half = prec == "fp16"
     page = p.synth.text_like_page(shape, 3, n_blocks=8)
-    det = p.detector.TextDetector(ck, input_size=size, device="cuda", half=half)
+    det = p.detector.TextDetector(ck, input_size=size, device="cuda", precision=prec)
     got = det(page, refine_mode=0, keep_undetected_mask=False)
     ref = oracle_result(ck, page, size)
     rep = accept.compare(got, ref)
-    print(f"\nacceptance half={half} size={size} page={shape}: {rep}")
+    print(f"\nacceptance engine={prec} size={size} page={shape}: {rep}")
     assert rep["lines"]["ref"] >= 5 and rep["blocks"]["ref"] >= 3            # the pages have something to compare
     if not half:
         # the reference's precision: single-level mask flips only, geometry identical

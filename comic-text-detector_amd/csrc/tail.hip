@@ -657,10 +657,18 @@ void ctd_tail_destroy(ctd_tail* t) {
 
 void* ctd_tail_stream(ctd_tail* t) { return t ? (void*)t->st : nullptr; }
 
-int ctd_tail_run(ctd_tail* t, int32_t B, int32_t Hn, int32_t Wn, const float* blks_dev, int32_t rows, int32_t no,
-                 const uint8_t* mask_u8_dev, const float* prob_dev, int64_t prob_stride, const uint8_t* bitmap_dev,
-                 const ctd_tail_page* pages, const ctd_tail_params* prm, uint8_t* const* mask_out,
-                 uint8_t* const* refined_out, void* ready_event) {
+// Every failure exit of the three entry points that enqueue work drains the tail's stream first: kernels and copies
+// already enqueued still use the caller's tensors and page-locked result arrays, which the caller frees (and its
+// caching allocators hand out again) as soon as the error is raised.
+static int drained(ctd_tail* t, int rc) {
+  if (rc != CTD_OK && t && t->st) (void)hipStreamSynchronize(t->st);
+  return rc;
+}
+
+static int tail_run_impl(ctd_tail* t, int32_t B, int32_t Hn, int32_t Wn, const float* blks_dev, int32_t rows, int32_t no,
+                         const uint8_t* mask_u8_dev, const float* prob_dev, int64_t prob_stride, const uint8_t* bitmap_dev,
+                         const ctd_tail_page* pages, const ctd_tail_params* prm, uint8_t* const* mask_out,
+                         uint8_t* const* refined_out, void* ready_event) {
   if (!t || !blks_dev || !mask_u8_dev || !prob_dev || !bitmap_dev || !pages || !prm || B < 1 || Hn < 1 || Wn < 1 ||
       rows < 1 || no < 6)
     return ctd_fail_msg(CTD_ERR_INVALID, "ctd_tail_run: bad arguments");
@@ -803,6 +811,14 @@ int ctd_tail_run(ctd_tail* t, int32_t B, int32_t Hn, int32_t Wn, const float* bl
   return rc;
 }
 
+int ctd_tail_run(ctd_tail* t, int32_t B, int32_t Hn, int32_t Wn, const float* blks_dev, int32_t rows, int32_t no,
+                 const uint8_t* mask_u8_dev, const float* prob_dev, int64_t prob_stride, const uint8_t* bitmap_dev,
+                 const ctd_tail_page* pages, const ctd_tail_params* prm, uint8_t* const* mask_out,
+                 uint8_t* const* refined_out, void* ready_event) {
+  return drained(t, tail_run_impl(t, B, Hn, Wn, blks_dev, rows, no, mask_u8_dev, prob_dev, prob_stride, bitmap_dev, pages, prm,
+                                  mask_out, refined_out, ready_event));
+}
+
 int ctd_tail_timings(const ctd_tail* t, double* ms10) {   // 11 entries
   if (!t || !ms10) return ctd_fail_msg(CTD_ERR_INVALID, "null argument");
   std::memcpy(ms10, t->ms_stage, sizeof(t->ms_stage));
@@ -810,8 +826,8 @@ int ctd_tail_timings(const ctd_tail* t, double* ms10) {   // 11 entries
   return CTD_OK;
 }
 
-int ctd_tail_db_boxes(ctd_tail* t, int32_t B, int32_t Hn, int32_t Wn, const float* prob_dev, int64_t prob_stride,
-                      const uint8_t* bitmap_dev, int32_t max_candidates, double unclip_ratio) {
+static int tail_db_boxes_impl(ctd_tail* t, int32_t B, int32_t Hn, int32_t Wn, const float* prob_dev, int64_t prob_stride,
+                             const uint8_t* bitmap_dev, int32_t max_candidates, double unclip_ratio) {
   if (!t || !prob_dev || !bitmap_dev || B < 1 || Hn < 1 || Wn < 1) return ctd_fail_msg(CTD_ERR_INVALID, "bad arguments");
   T_TRY(hipSetDevice(t->device));
   t->B = B;
@@ -826,9 +842,14 @@ int ctd_tail_db_boxes(ctd_tail* t, int32_t B, int32_t Hn, int32_t Wn, const floa
   return db_collect(t, db, &prm);
 }
 
-int ctd_tail_refine(ctd_tail* t, int32_t n_pages, const ctd_tail_page* pages, const uint8_t* const* masks_host,
-                    const int32_t* blk_xyxy, const int32_t* blk_counts, int32_t refine_mode, int32_t keep_undetected_mask,
-                    uint8_t* const* mask_out, uint8_t* const* refined_out) {
+int ctd_tail_db_boxes(ctd_tail* t, int32_t B, int32_t Hn, int32_t Wn, const float* prob_dev, int64_t prob_stride,
+                      const uint8_t* bitmap_dev, int32_t max_candidates, double unclip_ratio) {
+  return drained(t, tail_db_boxes_impl(t, B, Hn, Wn, prob_dev, prob_stride, bitmap_dev, max_candidates, unclip_ratio));
+}
+
+static int tail_refine_impl(ctd_tail* t, int32_t n_pages, const ctd_tail_page* pages, const uint8_t* const* masks_host,
+                            const int32_t* blk_xyxy, const int32_t* blk_counts, int32_t refine_mode,
+                            int32_t keep_undetected_mask, uint8_t* const* mask_out, uint8_t* const* refined_out) {
   if (!t || n_pages < 1 || !pages || !masks_host || !blk_counts || !refined_out)
     return ctd_fail_msg(CTD_ERR_INVALID, "ctd_tail_refine: bad arguments");
   T_TRY(hipSetDevice(t->device));
@@ -859,6 +880,13 @@ int ctd_tail_refine(ctd_tail* t, int32_t n_pages, const ctd_tail_page* pages, co
   return download_pages(t, keep_undetected_mask != 0, mask_out, refined_out);
 }
 
+int ctd_tail_refine(ctd_tail* t, int32_t n_pages, const ctd_tail_page* pages, const uint8_t* const* masks_host,
+                    const int32_t* blk_xyxy, const int32_t* blk_counts, int32_t refine_mode, int32_t keep_undetected_mask,
+                    uint8_t* const* mask_out, uint8_t* const* refined_out) {
+  return drained(t, tail_refine_impl(t, n_pages, pages, masks_host, blk_xyxy, blk_counts, refine_mode, keep_undetected_mask,
+                                     mask_out, refined_out));
+}
+
 int ctd_tail_page_counts(const ctd_tail* t, int32_t page, int32_t* n_blocks, int32_t* n_lines, int32_t* n_dist,
                          int32_t* n_db_boxes, int32_t* n_yolo) {
   if (!t || page < 0 || page >= (int)t->out.size()) return ctd_fail_msg(CTD_ERR_INVALID, "bad page index");
@@ -868,6 +896,41 @@ int ctd_tail_page_counts(const ctd_tail* t, int32_t page, int32_t* n_blocks, int
   if (n_dist) *n_dist = (int32_t)(po.dist.size() / 3);
   if (n_db_boxes) *n_db_boxes = (int32_t)po.db_scores.size();
   if (n_yolo) *n_yolo = (int32_t)po.yolo_cls.size();
+  return CTD_OK;
+}
+
+int ctd_tail_pack_records(const ctd_tail* t, int32_t cap_blk, int32_t cap_line, double* out) {
+  if (!t || !out || cap_blk < 0 || cap_line < 0) return ctd_fail_msg(CTD_ERR_INVALID, "ctd_tail_pack_records: bad arguments");
+  const size_t R = 4 + (size_t)cap_blk * 12 + (size_t)cap_line * 8;
+  std::memset(out, 0, t->out.size() * R * sizeof(double));
+  for (size_t b = 0; b < t->out.size(); ++b) {
+    const PageOut& po = t->out[b];
+    double* r = out + b * R;
+    double* rl = r + 4 + (size_t)cap_blk * 12;
+    long long nl = 0;
+    for (size_t i = 0; i < po.blks.size(); ++i) {
+      const ctd_blk& k = po.blks[i];
+      if ((int)i < cap_blk) {
+        double* q = r + 4 + i * 12;
+        q[0] = k.xyxy[0], q[1] = k.xyxy[1], q[2] = k.xyxy[2], q[3] = k.xyxy[3];
+        q[4] = k.language, q[5] = k.vertical ? 1 : 0, q[6] = k.angle;
+        q[7] = k.font_is_float ? k.font_size : (double)(long long)k.font_size;
+        q[8] = k.n_lines, q[9] = k.norm, q[10] = k.vec[0], q[11] = k.vec[1];
+      }
+      for (int j = 0; j < k.n_lines; ++j, ++nl) {
+        if (nl >= cap_line) continue;
+        const int32_t* src = po.lines.data() + ((size_t)k.line_off + j) * 8;
+        for (int e = 0; e < 8; ++e) rl[nl * 8 + e] = src[e];
+      }
+    }
+    r[0] = (double)po.blks.size(), r[1] = (double)nl, r[2] = cap_blk, r[3] = cap_line;
+  }
+  return CTD_OK;
+}
+
+int ctd_tail_set_threads(ctd_tail* t, int32_t n) {
+  if (!t || n < 1) return ctd_fail_msg(CTD_ERR_INVALID, "ctd_tail_set_threads: n >= 1");
+  t->host_threads = n;
   return CTD_OK;
 }
 

@@ -193,12 +193,13 @@ class TextDetector:
             self._lanes[i] = (net, st)
         return net, st
 
-    def _tail(self, job, refine_mode, keep_undetected_mask, lo=None, hi=None):
-        """The native tail of pages [lo, hi) of a forwarded batch (default: all of it) on the calling thread's `Tail`."""
+    def _tail(self, job, refine_mode, keep_undetected_mask, lo=None, hi=None, records=None):
+        """The native tail of pages [lo, hi) of a forwarded batch (default: all of it) on the calling thread's `Tail`.
+        records=(cap_blk, cap_line): the pages come back as `PageResult`s carrying their multi-GPU gather records."""
         sl = slice(lo, hi)
         return thread_tail(self.net.device).run(job["gpu"][sl], job["metas"][sl], job["blks"][sl], job["mask_u8"][sl],
                                                 job["lines_map"][sl], job["bitmap"][sl], self.conf_thresh, self.nms_thresh,
-                                                0.6, True, refine_mode, keep_undetected_mask, job["ev"])
+                                                0.6, True, refine_mode, keep_undetected_mask, job["ev"], records=records)
 
     @staticmethod
     def _split(n: int, parts: int):

@@ -89,7 +89,13 @@ def pack_results(results, device=None, cap_blk: int = MAX_BLK, cap_line: int = M
     the rank that produced them."""
     import numpy as np
     from .textblock import LANGCLS2IDX
-    rec = np.zeros((len(results), HDR + cap_blk * BLK_F + cap_line * 8), np.float64)
+    width = HDR + cap_blk * BLK_F + cap_line * 8
+    # records the native tail already built (`Tail.run(records=...)` -> `PageResult.record`): no Python loop
+    pre = [getattr(r, "record", None) for r in results]
+    if results and all(p is not None and p.shape == (width,) and p[2] == cap_blk and p[3] == cap_line for p in pre):
+        out = torch.from_numpy(np.stack(pre))
+        return out.to(device) if device is not None else out
+    rec = np.zeros((len(results), width), np.float64)
     rec[:, 2], rec[:, 3] = cap_blk, cap_line
     for p, r in enumerate(results):
         blks = r[2]

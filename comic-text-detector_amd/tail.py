@@ -34,6 +34,22 @@ def _pinned_pages(shapes) -> List[np.ndarray]:
     return out
 
 
+class PageResult(tuple):
+    """(mask, mask_refined, blk_list) of one page -- the reference's return triple -- that may also carry `.record`, the
+    page's fixed-capacity f64 block record for the multi-GPU gather (dist.pack_results), built natively."""
+    record = None
+
+
+_host_threads = None            # native threads per Tail for its per-page / per-window host loops (None: library default)
+
+
+def set_host_threads(n: int) -> None:
+    """Host threads every `Tail` created from now on may use inside a native call (`ctd_tail_set_threads`).  One process
+    per GPU on a shared host: usable cores / ranks / tail workers."""
+    global _host_threads
+    _host_threads = max(1, int(n))
+
+
 class Tail:
     def __init__(self, device: torch.device):
         self._lib = L.lib()
@@ -41,6 +57,8 @@ class Tail:
         h = C.c_void_p()
         L.check(self._lib.ctd_tail_create(C.byref(h), self.device.index or 0), "ctd_tail_create")
         self._h = h
+        if _host_threads is not None:
+            L.check(self._lib.ctd_tail_set_threads(h, _host_threads), "ctd_tail_set_threads")
 
     def __del__(self):
         h = getattr(self, "_h", None)
@@ -92,20 +110,28 @@ class Tail:
     def run(self, pages_gpu: Sequence[torch.Tensor], metas, blks: torch.Tensor, mask_u8: torch.Tensor,
             lines_map: torch.Tensor, bitmap: torch.Tensor, conf_thresh=0.4, nms_thresh=0.35, box_thresh=0.6,
             refine: bool = True, refine_mode: int = 0, keep_undetected_mask: bool = False,
-            ready_event: Optional[torch.cuda.Event] = None, want_extras: bool = False):
+            ready_event: Optional[torch.cuda.Event] = None, want_extras: bool = False, records=None):
         """metas[b] = (im_h, im_w, dw, dh); blks (B,rows,no) f32, mask_u8 (B,Hn,Wn) u8, lines_map (B,2,Hn,Wn) f32
         or its plane 0 (B,Hn,Wn), bitmap (B,Hn,Wn) u8 -- all on the GPU.  Returns per page
-        (mask, mask_refined, blk_list[, extras]) as the reference's `TextDetector.__call__` does."""
+        (mask, mask_refined, blk_list[, extras]) as the reference's `TextDetector.__call__` does.
+        records=(cap_blk, cap_line): every page's tuple is a `PageResult` whose `.record` is its gather record."""
         B = len(metas)
         for tns in (blks, mask_u8, lines_map, bitmap):
             if not tns.is_cuda:
                 raise L.CtdError("Tail.run: the network outputs must live on the GPU")
+        Hn, Wn = mask_u8.shape[-2:]
+        # The native tail reads these buffers on ITS stream and waits for `ready_event` only.  A layout / dtype
+        # conversion here runs on torch's current stream AFTER that event: order the tail behind it with a fresh event.
+        converted = not (blks.is_contiguous() and mask_u8.is_contiguous() and bitmap.is_contiguous())
         blks = blks.contiguous()
         mask_u8 = mask_u8.contiguous()
         bitmap = bitmap.contiguous()
-        Hn, Wn = mask_u8.shape[-2:]
         if lines_map.dtype != torch.float32 or lines_map.stride(-1) != 1 or lines_map.stride(-2) != Wn:
             lines_map = lines_map.float().contiguous()
+            converted = True
+        if converted:
+            ready_event = torch.cuda.Event()
+            ready_event.record(torch.cuda.current_stream(self.device))
         prob_stride = lines_map.stride(0)
         tab = self._page_table(pages_gpu, metas)
         prm = L.CtdTailParams(conf_thresh, nms_thresh, box_thresh, 1000, 1.5, int(bool(refine)), int(refine_mode),
@@ -119,10 +145,19 @@ class Tail:
         L.check(self._lib.ctd_tail_run(self._h, B, Hn, Wn, blks.data_ptr(), blks.shape[1], blks.shape[2],
                                        mask_u8.data_ptr(), lines_map.data_ptr(), prob_stride, bitmap.data_ptr(), tab,
                                        C.byref(prm), mptr, rptr, ev), "ctd_tail_run")
+        rec = None
+        if records is not None:
+            cb, cl = int(records[0]), int(records[1])
+            rec = np.empty((B, 4 + 12 * cb + 8 * cl), np.float64)
+            L.check(self._lib.ctd_tail_pack_records(self._h, cb, cl, rec.ctypes.data), "ctd_tail_pack_records")
         out = []
         for b in range(B):
             blk_list, extras = self._blocks(b, want_extras)
-            out.append((masks[b], refined[b], blk_list, extras) if want_extras else (masks[b], refined[b], blk_list))
+            r = (masks[b], refined[b], blk_list, extras) if want_extras else (masks[b], refined[b], blk_list)
+            if rec is not None:
+                r = PageResult(r)
+                r.record = rec[b]
+            out.append(r)
         return out
 
     def timings(self) -> dict:

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define CTD_ABI_VERSION 2
+#define CTD_ABI_VERSION 3
 
 /* ---- error codes ------------------------------------------------------ */
 #define CTD_OK 0
@@ -316,6 +316,19 @@ int ctd_tail_page_counts(const ctd_tail* t, int32_t page, int32_t* n_blocks, int
 struct ctd_blk;
 int ctd_tail_page_fetch(const ctd_tail* t, int32_t page, struct ctd_blk* blocks, int32_t* lines, double* dist,
                         int16_t* db_boxes, float* db_scores, int32_t* yolo_xyxy, int32_t* yolo_cls, float* yolo_conf);
+
+/* The grouped blocks of EVERY page of the last ctd_tail_run as fixed-capacity f64 records, the unit of the multi-GPU
+ * record gather (comic-text-detector_amd/dist.py): per page
+ *   [n_blocks, n_lines (true counts), cap_blk, cap_line,
+ *    cap_blk x 12: x1, y1, x2, y2, language, vertical, angle, font_size, n_lines, norm, vec_x, vec_y,
+ *    cap_line x 8: the line quads in block order]
+ * truncated (counts stay true) when a page has more blocks / lines than the capacities.  `out` holds
+ * B * (4 + 12 cap_blk + 8 cap_line) doubles, zero filled where unused.  Pure host code. */
+int ctd_tail_pack_records(const ctd_tail* t, int32_t cap_blk, int32_t cap_line, double* out);
+
+/* Host threads the per-page / per-window host loops of this tail object may use (default 8; >= 1).  A node running one
+ * process per GPU divides its cores between the ranks' tail workers. */
+int ctd_tail_set_threads(ctd_tail* t, int32_t n);
 
 /* ---- host-side input staging ---------------------------------------------------------------- */
 

@@ -76,3 +76,84 @@ def compare(result, ref_result) -> dict:
         "lines": {"ours": ln, "ref": ln0, "identical": lex, "mean_iou": round(lm, 6), "min_iou": round(lmin, 6)},
         "blocks": {"ours": bn, "ref": bn0, "identical": bex, "mean_iou": round(bm, 6), "min_iou": round(bmin, 6)},
     }
+
+
+def band_report(prob_ref: np.ndarray, mask_ref: np.ndarray, bitmap: np.ndarray, mask_u8: np.ndarray, eps: float,
+                prob: np.ndarray = None, mask: np.ndarray = None, bitmap_thresh: float = 0.3) -> dict:
+    """Bounds a reduced-precision engine's deviation at the PIXEL level: every pixel whose thresholded value differs
+    from the oracle's must lie within `eps` of the threshold in the ORACLE's map.
+
+    prob_ref / mask_ref : the oracle's shrink map `lines_map[0, 0]` and mask `mask[0, 0]` (f32, HxW)
+    bitmap / mask_u8    : the product's fused side outputs (`prob > 0.3`; `(uint8)(mask * 255)`)
+    prob / mask         : the product's f32 maps (optional; gives max |delta|)
+    Thresholds: the DB bitmap at `bitmap_thresh` (reference utils/db_utils.py:71-72) and the u8 mask at 127
+    (BASELINE's "mask bit-exact after uint8 threshold"; u8 > 127 <=> mask * 255 >= 128)."""
+    bm_ref = prob_ref > bitmap_thresh
+    flips = bm_ref != bitmap.astype(bool)
+    d_bm = np.abs(prob_ref.astype(np.float64) - bitmap_thresh)
+    u8_ref = (mask_ref * 255).astype(np.uint8)                       # postprocess_mask: truncation
+    flips_m = (u8_ref > 127) != (mask_u8 > 127)
+    d_m = np.abs(mask_ref.astype(np.float64) * 255 - 128) / 255
+    rep = {
+        "eps": eps,
+        "bitmap_flips": int(flips.sum()),
+        "bitmap_flips_max_dist_to_thresh": float(d_bm[flips].max()) if flips.any() else 0.0,
+        "bitmap_flips_out_of_band": int((d_bm[flips] >= eps).sum()),
+        "bitmap_in_band_frac": round(float((d_bm < eps).mean()), 6),
+        "mask127_flips": int(flips_m.sum()),
+        "mask127_flips_max_dist_to_thresh": float(d_m[flips_m].max()) if flips_m.any() else 0.0,
+        "mask127_flips_out_of_band": int((d_m[flips_m] >= eps).sum()),
+        "mask127_in_band_frac": round(float((d_m < eps).mean()), 6),
+    }
+    if prob is not None:
+        rep["prob_max_abs_delta"] = float(np.abs(prob.astype(np.float64) - prob_ref).max())
+    if mask is not None:
+        rep["mask_max_abs_delta"] = float(np.abs(mask.astype(np.float64) - mask_ref).max())
+    rep["_flips"] = flips                                            # for explain_geometry; callers drop it before printing
+    return rep
+
+
+def explain_geometry(result, ref_result, flips: np.ndarray, ratio_xy=(1.0, 1.0), margin: int = 3) -> dict:
+    """Every text line / block of the product that is not IDENTICAL to one of the oracle's (and vice versa) must touch a
+    pixel whose DB bitmap value flipped (`flips`, network resolution; `ratio_xy` maps page to network coordinates):
+    its bounding box, grown by `margin` px, contains one.  A block also counts as explained when one of its lines
+    differs.  Returns counts; `unexplained_*` must be 0 for the claim "all differences come from threshold pixels"."""
+    def boxes_of(res):
+        lines = [np.asarray(ln).reshape(-1, 2) for b in res[2] for ln in b.lines]
+        blks = [(tuple(int(v) for v in b.xyxy), [np.asarray(ln).reshape(-1, 2) for ln in b.lines]) for b in res[2]]
+        return lines, blks
+
+    H, W = flips.shape
+    ii = np.zeros((H + 1, W + 1), np.int64)
+    ii[1:, 1:] = flips.astype(np.int64).cumsum(0).cumsum(1)
+
+    def touched(x1, y1, x2, y2):
+        x1, x2 = int(np.floor(x1 * ratio_xy[0])) - margin, int(np.ceil(x2 * ratio_xy[0])) + margin + 1
+        y1, y2 = int(np.floor(y1 * ratio_xy[1])) - margin, int(np.ceil(y2 * ratio_xy[1])) + margin + 1
+        x1, y1, x2, y2 = max(x1, 0), max(y1, 0), min(x2, W), min(y2, H)
+        if x2 <= x1 or y2 <= y1:
+            return False
+        return (ii[y2, x2] - ii[y1, x2] - ii[y2, x1] + ii[y1, x1]) > 0
+
+    la, ba = boxes_of(result)
+    lb, bb = boxes_of(ref_result)
+    out = {}
+    keyl = lambda q: q.astype(np.int64).tobytes()
+    sa, sb = {keyl(q) for q in la}, {keyl(q) for q in lb}
+    diff_lines = [q for q in la if keyl(q) not in sb] + [q for q in lb if keyl(q) not in sa]
+    bad = [q for q in diff_lines if not touched(q[:, 0].min(), q[:, 1].min(), q[:, 0].max(), q[:, 1].max())]
+    out["lines_differing"] = len(diff_lines)
+    out["lines_unexplained"] = len(bad)
+    keyb = lambda t: (t[0], tuple(sorted(keyl(q) for q in t[1])))
+    ka, kb = {keyb(t) for t in ba}, {keyb(t) for t in bb}
+    diff_blks = [t for t in ba if keyb(t) not in kb] + [t for t in bb if keyb(t) not in ka]
+    both = sa & sb
+    unexpl = 0
+    for xyxy, lns in diff_blks:
+        if any(keyl(q) not in both for q in lns):
+            continue                                                  # one of its lines differs (explained above)
+        if not touched(xyxy[0], xyxy[1], xyxy[2], xyxy[3]):
+            unexpl += 1
+    out["blocks_differing"] = len(diff_blks)
+    out["blocks_unexplained"] = unexpl
+    return out

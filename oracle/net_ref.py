@@ -96,7 +96,7 @@ def detect_decode(raw: Sequence[torch.Tensor], anchors: torch.Tensor, strides: S
     for i, x in enumerate(raw):
         bs, _, ny, nx = x.shape
         x = x.view(bs, na, no, ny, nx).permute(0, 1, 3, 4, 2).contiguous()
-        yv, xv = torch.meshgrid([torch.arange(ny), torch.arange(nx)], indexing="ij")
+        yv, xv = torch.meshgrid([torch.arange(ny, device=x.device), torch.arange(nx, device=x.device)], indexing="ij")
         grid = torch.stack((xv, yv), 2).expand((1, na, ny, nx, 2)).float()
         anchor_grid = (anchors[i].clone() * strides[i]).view((1, na, 1, 1, 2)).expand((1, na, ny, nx, 2)).float()
         y = x.sigmoid()

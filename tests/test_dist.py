@@ -136,3 +136,57 @@ def test_gloo_world2_grouped_blocks_gathered_equal_single_process(n_total, crowd
     for rank, ok, shape in res:
         assert ok, f"rank {rank}: gathered block lists differ from the single-process result"
         assert shape[0] == n_total
+
+
+# ---- -m gpu: the record gather's inputs built natively, and the N > 1 bench path rehearsed on one device ------------
+
+
+@pytest.mark.gpu
+def test_native_page_records_equal_the_python_packing():
+    """`Tail.run(records=...)` -> `ctd_tail_pack_records`: the per-page gather record the native tail builds is the array
+    `dist.pack_results` builds from the Python `TextBlock` objects, field for field, at the compact AND at tiny
+    (truncating) capacities -- so the N > 1 step needs no Python loop over blocks."""
+    import numpy as np
+    p = pkg()
+    D = p.dist
+    ck = p.synth.make_blob_checkpoint(0)
+    det = p.detector.TextDetector(ck, input_size=512, device="cuda", precision="fp16")
+    pages = [p.synth.text_like_page((512, 512), s, n_blocks=6) for s in (3, 4, 5)]
+    for caps in ((D.CAP_BLK, D.CAP_LINE), (4, 6)):
+        job = det._forward(pages)
+        res = det._tail(job, 0, False, records=caps)
+        assert all(r.record is not None and len(r) == 3 for r in res)
+        assert sum(len(r[2]) for r in res) > 10                                  # the pages have blocks to pack
+        native = np.stack([r.record for r in res])
+        plain = [(r[0], r[1], r[2]) for r in res]                                # no .record: the Python loop packs
+        ref = D.pack_results(plain, None, *caps).numpy()
+        np.testing.assert_array_equal(native, ref)
+        assert D.pack_results(res, None, *caps).numpy().tobytes() == ref.tobytes()     # the fast path returns the same
+    got = D.unpack_results(D.pack_results(res, None, D.CAP_BLK, D.CAP_LINE))
+    assert [len(g) for g in got] == [len(r[2]) for r in res]
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_on_one_device():
+    """`python bench.py --gpus 2` with no torchrun environment re-executes itself under torch.distributed.run; on a box
+    with one GPU both ranks share it over gloo (flagged in the line as a rehearsal).  Covers rank start-up, sharding,
+    the native page records, the all-gather inside the pipelined step, the barrier / max-over-ranks timing."""
+    import json
+    import subprocess
+    import sys
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    if torch.cuda.device_count() >= 2:
+        env["CTD_BENCH_ONE_DEVICE"] = "1"
+        env["CTD_DIST_BACKEND"] = "gloo"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--spinup", "2", "--batch", "4", "--size", "512", "--batches", "2", "--no-cpu-baseline", "--no-extras"],
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 8
+    assert "ranks=2" in out["config"]["parallelism"] and out["config"]["one_device_rehearsal"] is True
+    assert out["value"] > 0 and out["config"]["blocks_per_page"] > 0

@@ -113,7 +113,7 @@ def make_workload(pkg, args, rank: int, nloc: int, dev):
             lines_map=torch.from_numpy(np.stack([samples[i % NS][3] for i in range(nloc)])).to(dev),
             bitmap=torch.from_numpy(np.stack([samples[i % NS][4] for i in range(nloc)])).to(dev))
         return ckpt, [x], canned, samples[0]
-    ckpt = pkg.synth.make_blob_checkpoint(0)
+    ckpt = pkg.synth.make_blob_checkpoint(0, sparse_det=not args.dense_blocks)
     nb = max(1, args.batches)
     batches = []
     for k in range(nb):
@@ -485,8 +485,8 @@ def mixed_stream(pkg, D, BK, det, rank, world, dev, steps, warmup, with_tail=Tru
                 if g["busy"] is not None:                 # the tail that last read this instance's outputs
                     drain(g["busy"])
                     g["busy"] = None
-                c = cursor[s]
-                cursor[s] = (c + n) % (pool_pages[s].shape[0] - n + 1)
+                c = cursor[s] % (pool_pages[s].shape[0] - n + 1)      # a rotating window of n pages of this size's pool
+                cursor[s] += n
                 x = pool_pages[s][c: c + n]
                 g["static_in"].copy_(x)
                 blks, _, lines = g["replay"]()
@@ -659,6 +659,9 @@ def main() -> None:
                     help="forward: the tail consumes the timed forward's own outputs (blob checkpoint, text-like pages); "
                          "canned: round 2's workload (random checkpoint, the tail fed text-like maps of the same pages)")
     ap.add_argument("--batches", type=int, default=4, help="distinct batches rotated through the steps (HBM resident)")
+    ap.add_argument("--dense-blocks", action="store_true",
+                    help="blob checkpoint without `sparse_det`: ~65 text blocks of ~160 px per page (1.5 page areas of block "
+                         "windows) instead of the reference fixture's density (~15 blocks); also a sub-run of the default line")
     ap.add_argument("--workers", type=int, default=0, help="tail worker threads (e2e); 0 = from the host-thread budget")
     ap.add_argument("--depth", type=int, default=4, help="batches in flight (e2e)")
     ap.add_argument("--tail-split", type=int, default=int(os.environ.get("BENCH_TAIL_SPLIT", "0")),
@@ -711,7 +714,7 @@ def main() -> None:
     nloc = hi - lo
 
     if args.mode == "mixed":
-        ckpt = pkg.synth.make_blob_checkpoint(0)
+        ckpt = pkg.synth.make_blob_checkpoint(0, sparse_det=not args.dense_blocks)
         det = DET.TextDetector(ckpt, input_size=1024, device=dev, precision=args.precision)
         out = mixed_stream(pkg, D, BK, det, rank, world, dev, args.steps, args.warmup, with_tail=True)
         if rank == 0:
@@ -806,11 +809,27 @@ def main() -> None:
             except Exception as e:
                 extra["fp32_bs8_e2e"] = {"error": repr(e)[:400]}
             try:                                         # BASELINE configs[4]
-                d4 = DET.TextDetector(pkg.synth.make_blob_checkpoint(0), input_size=1024, device=dev, precision=args.precision)
+                d4 = DET.TextDetector(ckpt, input_size=1024, device=dev, precision=args.precision)
                 extra["mixed_e2e"] = mixed_stream(pkg, D, BK, d4, 0, 1, dev, steps=2, warmup=1, with_tail=True, n_per_gpu=256)
                 del d4
             except Exception as e:
                 extra["mixed_e2e"] = {"error": repr(e)[:400]}
+            if canned is None and not args.dense_blocks:
+                try:                                     # the same chain on the DENSE blob checkpoint (~65 blocks per page)
+                    ck5 = pkg.synth.make_blob_checkpoint(0)
+                    d5 = DET.TextDetector(ck5, input_size=S, device=dev, precision=args.precision)
+                    p5 = Pipeline(d5, batches, None, dev, 1, 0, B, D, args.workers, args.depth, args.tail_split)
+                    dt5 = timed(p5.run, 8, 2, 6, 1, dev, p5.stats)
+                    extra["dense_blocks_e2e"] = {
+                        "config": "the headline's pages and pipeline on synth.make_blob_checkpoint(0) WITHOUT sparse_det: every "
+                                  "cell of one Detect anchor fires (random weights), NMS packs the page with boxes",
+                        "value": round(B * 8 / dt5, 2), "unit": "pages/s", "ms_per_step": round(dt5 / 8 * 1e3, 3), "steps": 8,
+                        "blocks_per_page": round(p5.stats["blocks"] / max(p5.stats["pages"], 1), 2),
+                        "lines_per_page": round(p5.stats["lines"] / max(p5.stats["pages"], 1), 2)}
+                    p5.close()
+                    del p5, d5
+                except Exception as e:
+                    extra["dense_blocks_e2e"] = {"error": repr(e)[:400]}
             if args.rocm_timeout > 0:
                 torch.cuda.synchronize()
                 rocm = rocm_baseline_subprocess(args, args.rocm_timeout)
@@ -828,7 +847,8 @@ def main() -> None:
         real = canned is None
         workload = (f"BASELINE configs[2]: bs={B}/GPU {S}x{S} u8 pages {where}, {len(batches)} distinct batches rotated; "
                     f"fused HIP forward (YOLOv5s+UNet+DB, "
-                    + ("synth.make_blob_checkpoint: random weights whose maps have contours, text-like pages" if real else
+                    + ("synth.make_blob_checkpoint(" + ("dense" if args.dense_blocks else "sparse_det: block density of the "
+                       "reference's fixture page") + "): random weights whose maps have contours, text-like pages" if real else
                        "seeded random weights") + ", DB binarize + u8 mask fused)")
         if e2e:
             workload += (" + the WHOLE native tail per page: GPU NMS, DB boxes (2x GPU labelling + contour tables, host "

@@ -47,6 +47,7 @@ struct OpState {
   int npad = 0;
   int bk = 0;
   bool split = false;         // fp32s engine: split-operand kernel (kernels_split.hip); w_dev = hi plane | lo plane
+  int kpad = 0;               // ... and its K (the stem's taps x 4 padded to a multiple of 32)
   float* oscale_dev = nullptr;
   // filled by plan()
   ConvArgs args{};
@@ -166,17 +167,21 @@ int pack_op(ctd_engine* e, OpState& s, const float* P, int64_t nP) {
         s.npad = (N + bn - 1) / bn * bn;
         const int K = k * k * cin;
         // fp32s engine: split operands on the fp16 MFMA wherever a 32-channel K step never crosses a tap / source
-        s.split = e->prec == CTD_PREC_F32S && o.src0_c % 32 == 0 && (o.src1 < 0 || o.src1_c % 32 == 0);
-        std::vector<float> wp((size_t)(s.split ? N : s.npad) * K, 0.f);
+        const bool stem4 = o.src0_c == 4 && o.src1 < 0;          // zero-padded image: K = taps x 4
+        s.split = e->prec == CTD_PREC_F32S && (stem4 || (o.src0_c % 32 == 0 && (o.src1 < 0 || o.src1_c % 32 == 0)));
+        // the split kernel walks K in steps of 32: the stem's K = 144 is padded with zero taps
+        const int Kp = s.split ? (K + 31) / 32 * 32 : K;
+        s.kpad = Kp;
+        std::vector<float> wp((size_t)(s.split ? N : s.npad) * Kp, 0.f);
         for (int n = 0; n < N; ++n)
           for (int c = 0; c < cin; ++c)
             for (int ky = 0; ky < k; ++ky)
               for (int kx = 0; kx < k; ++kx)
-                wp[(size_t)n * K + (size_t)(ky * k + kx) * cin + c] = W[(((size_t)n * cin + c) * k + ky) * k + kx];
+                wp[(size_t)n * Kp + (size_t)(ky * k + kx) * cin + c] = W[(((size_t)n * cin + c) * k + ky) * k + kx];
         if (s.split) {
           std::vector<half_t> ws;
           std::vector<float> osc;
-          split_pack_weights(wp.data(), 1, N, K, s.npad, ws, osc);
+          split_pack_weights(wp.data(), 1, N, Kp, s.npad, ws, osc);
           if (int rc = upload(e, ws, &s.w_dev)) return rc;
           if (int rc = upload(e, osc, (void**)&s.oscale_dev)) return rc;
           return pack_bias(s.npad);
@@ -569,6 +574,7 @@ int plan(ctd_engine* e, int B, int H, int W, hipStream_t cap_stream = nullptr) {
         s.flops = 2.0 * (double)B * a.Hin * a.Win * o.k * o.k * cin * a.N;
       }
       if (s.split) {
+        if (o.kind == CTD_OP_CONV) a.K = s.kpad;
         a.w2 = (const half_t*)s.w_dev + (size_t)a.nphase * s.npad * a.K;
         a.oscale = s.oscale_dev;
       }
@@ -607,7 +613,7 @@ int plan(ctd_engine* e, int B, int H, int W, hipStream_t cap_stream = nullptr) {
     S1.flops = 0; S1.bytes = 0;
   }
   // ---- SPPF: three chained stride-1 max pools over the slots of one cat tensor -> one launch
-  for (int i = 0; f16 && (g_fuse & 2) && i + 2 < nO; ++i) {
+  for (int i = 0; (g_fuse & 2) && i + 2 < nO; ++i) {   // every engine: max is exact in any precision
     const ctd_op &p0 = e->ops[i].op, &p1 = e->ops[i + 1].op, &p2 = e->ops[i + 2].op;
     if (p0.kind != CTD_OP_MAXPOOL || p1.kind != CTD_OP_MAXPOOL || p2.kind != CTD_OP_MAXPOOL) continue;
     const int c = p0.src0_c, P = p0.src0;
@@ -617,7 +623,7 @@ int plan(ctd_engine* e, int B, int H, int W, hipStream_t cap_stream = nullptr) {
         p2.src0_coff != p1.dst_coff || p2.dst_coff != p2.src0_coff + c)
       continue;
     const TensorState& tp = e->tensors[P];
-    if (tp.esize != 2 || !sppf_pool3_supported(tp.t.channels, c, c, tp.H, tp.W, p0.k, e->arena + tp.offset + (size_t)p0.src0_coff * 2))
+    if (!sppf_pool3_supported(tp.t.channels, c, c, tp.H, tp.W, p0.k, e->arena + tp.offset + (size_t)p0.src0_coff * tp.esize, tp.esize))
       continue;
     e->ops[i].sppf_head = true;
     e->ops[i + 1].skip = e->ops[i + 2].skip = true;
@@ -727,7 +733,7 @@ int launch_op(ctd_engine* e, int i, const Outs& x, hipStream_t st) {
       if (s.skip) break;
       if (s.sppf_head) {
         const TensorState& tp = e->tensors[o.src0];
-        launch_sppf_pool3(tptr(o.src0, o.src0_coff), tp.t.channels, o.src0_c, o.src0_c, B, tp.H, tp.W, o.k, st);
+        launch_sppf_pool3(tptr(o.src0, o.src0_coff), tp.t.channels, o.src0_c, o.src0_c, B, tp.H, tp.W, o.k, st, tp.esize);
         break;
       }
       const TensorState& ts = e->tensors[o.src0];

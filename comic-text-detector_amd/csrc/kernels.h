@@ -14,9 +14,9 @@ void launch_input_nchw(const float* in, void* dst, int pitch, int B, int H, int 
 void launch_input_u8(const uint8_t* in, void* dst, int pitch, int B, int H, int W, bool f16, hipStream_t st);
 void launch_maxpool(const void* src, int pitchS, void* dst, int pitchD, int C, int B, int H, int W, int k,
                     bool f16, hipStream_t st);
-// SPPF: the three chained stride-1 max pools of one cat tensor in one launch (fp16 engine)
-bool sppf_pool3_supported(int pitch, int slot, int C, int H, int W, int k, const void* cat);
-void launch_sppf_pool3(void* cat, int pitch, int slot, int C, int B, int H, int W, int k, hipStream_t st);
+// SPPF: the three chained stride-1 max pools of one cat tensor in one launch (esize 2: fp16 tensors, 4: fp32)
+bool sppf_pool3_supported(int pitch, int slot, int C, int H, int W, int k, const void* cat, int esize = 2);
+void launch_sppf_pool3(void* cat, int pitch, int slot, int C, int B, int H, int W, int k, hipStream_t st, int esize = 2);
 void launch_avgpool2(const void* src, int pitchS, void* dst, int pitchD, int C, int B, int Ho, int Wo,
                      bool f16, hipStream_t st);
 // raw: (B,ny,nx,pitch) with na*no used channels -> blks rows [row_off, row_off+na*ny*nx)

@@ -182,14 +182,14 @@ __global__ void maxpool_h8_kernel(const half_t* __restrict__ src, int pitchS, ha
 // the pool as a row pass + a column pass, three times; every level is stored as it appears.  max is exact, so the
 // result equals the chained pools bit for bit (out-of-image taps are skipped = -inf padding, as nn.MaxPool2d).
 constexpr int SPPF_LDS_BYTES = 65536;
-template <typename V, int NV>
-__global__ __launch_bounds__(256) void sppf_pool3_kernel(half_t* __restrict__ cat, int pitch, int slot, int CG, int H, int W, int r) {
+template <typename T, typename V, int NV>
+__global__ __launch_bounds__(256) void sppf_pool3_kernel(T* __restrict__ cat, int pitch, int slot, int CG, int H, int W, int r) {
   __shared__ __attribute__((aligned(16))) unsigned char sm_raw[SPPF_LDS_BYTES];
   V* A = (V*)sm_raw;
   V* Bf = A + H * W;
   const int HW = H * W;
   const int b = blockIdx.x / CG, cg = blockIdx.x - b * CG;
-  half_t* base = cat + (size_t)b * HW * pitch + cg * NV;
+  T* base = cat + (size_t)b * HW * pitch + cg * NV;
   for (int p = threadIdx.x; p < HW; p += 256) A[p] = *(const V*)(base + (size_t)p * pitch);
   __syncthreads();
   auto vmax = [](V a, V b2) {
@@ -328,16 +328,25 @@ void launch_maxpool(const void* src, int pitchS, void* dst, int pitchD, int C, i
 }
 
 // cat: slot 0 of the SPPF cat tensor (already offset), slots `slot` channels apart; C channels per slot
-bool sppf_pool3_supported(int pitch, int slot, int C, int H, int W, int k, const void* cat) {
+bool sppf_pool3_supported(int pitch, int slot, int C, int H, int W, int k, const void* cat, int esize) {
   if (k != 5 && k != 3 && k != 7) return false;
-  if (C % 8 || pitch % 8 || slot % 8 || ((uintptr_t)cat & 15)) return false;
-  return (long long)H * W * 2 * 8 <= SPPF_LDS_BYTES;      // two planes of 4-channel (8-B) entries at least
+  const int v = 16 / esize;                                // elements of a 16-B entry
+  if (C % v || pitch % v || slot % v || ((uintptr_t)cat & 15)) return false;
+  return (long long)H * W * 2 * 8 <= SPPF_LDS_BYTES;      // two planes of 8-B entries at least
 }
-void launch_sppf_pool3(void* cat, int pitch, int slot, int C, int B, int H, int W, int k, hipStream_t st) {
-  if ((long long)H * W * 2 * 16 <= SPPF_LDS_BYTES)
-    hipLaunchKernelGGL((sppf_pool3_kernel<half8_t, 8>), dim3(B * (C / 8)), dim3(256), 0, st, (half_t*)cat, pitch, slot, C / 8, H, W, k / 2);
-  else
-    hipLaunchKernelGGL((sppf_pool3_kernel<half4_t, 4>), dim3(B * (C / 4)), dim3(256), 0, st, (half_t*)cat, pitch, slot, C / 4, H, W, k / 2);
+void launch_sppf_pool3(void* cat, int pitch, int slot, int C, int B, int H, int W, int k, hipStream_t st, int esize) {
+  typedef float float2_t __attribute__((ext_vector_type(2)));
+  const bool wide = (long long)H * W * 2 * 16 <= SPPF_LDS_BYTES;
+  if (esize == 4) {
+    if (wide)
+      hipLaunchKernelGGL((sppf_pool3_kernel<float, float4_t, 4>), dim3(B * (C / 4)), dim3(256), 0, st, (float*)cat, pitch, slot, C / 4, H, W, k / 2);
+    else
+      hipLaunchKernelGGL((sppf_pool3_kernel<float, float2_t, 2>), dim3(B * (C / 2)), dim3(256), 0, st, (float*)cat, pitch, slot, C / 2, H, W, k / 2);
+  } else if (wide) {
+    hipLaunchKernelGGL((sppf_pool3_kernel<half_t, half8_t, 8>), dim3(B * (C / 8)), dim3(256), 0, st, (half_t*)cat, pitch, slot, C / 8, H, W, k / 2);
+  } else {
+    hipLaunchKernelGGL((sppf_pool3_kernel<half_t, half4_t, 4>), dim3(B * (C / 4)), dim3(256), 0, st, (half_t*)cat, pitch, slot, C / 4, H, W, k / 2);
+  }
 }
 
 void launch_avgpool2(const void* src, int pitchS, void* dst, int pitchD, int C, int B, int Ho, int Wo, bool f16,

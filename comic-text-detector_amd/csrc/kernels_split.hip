@@ -147,6 +147,23 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(ConvArgs a) {
   half8_t rwh[WROWS], rwl[WROWS];
   int nx_cc = 0, nx_ty = 0, nx_tx = 0;   // (channel offset, tap) of the NEXT tile to load
   auto load_tile = [&](int ks, int dbuf) {
+    if (Ct == 4) {
+      // the stem: the image is stored with a zero 4th channel, so one tap = one 16-B chunk and a K step = 8 taps
+      // (this thread's two chunks are taps 8 ks + 2 seg, + 1); taps beyond KH * KW pad K to a multiple of 32 (zero weights)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int tap = ks * 8 + seg * 2 + h;
+        const int ty = tap / a.KW, tx = tap - ty * a.KW;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const int iy = poy[i] * a.stride + dy0 + ty, ix = pox[i] * a.stride + dx0 + tx;
+          const bool ok = pv[i] && ty < a.KH && (unsigned)iy < (unsigned)a.Hin && (unsigned)ix < (unsigned)a.Win;
+          float4_t v = {0.f, 0.f, 0.f, 0.f};
+          if (ok) v = *(const float4_t*)((const float*)a.s0.ptr + ((size_t)((size_t)pb[i] * a.s0.H + iy) * a.s0.W + ix) * a.s0.pitch);
+          ra[i][h] = v;
+        }
+      }
+    } else {
     const int cc = nx_cc, ty = nx_ty, tx = nx_tx;
     nx_cc += SBK;
     if (nx_cc == Ct) {
@@ -169,6 +186,7 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(ConvArgs a) {
       }
       ra[i][0] = v0;
       ra[i][1] = v1;
+    }
     }
     const int kofs = ks * (32 * SBK);
 #pragma unroll
@@ -306,7 +324,8 @@ int g_split_wdma = 1;   // weight tiles by LDS-DMA (ctd_tuning_set("split_wdma",
 
 // f32 sources / destination with 16-B aligned channel rows, source channel counts multiples of 32
 bool conv_split_supported(const ConvArgs& a) {
-  if (a.s0.c % SBK || a.s1.c % SBK || a.s0.c == 0) return false;
+  const bool stem = a.s0.c == 4 && a.s1.c == 0 && !a.s0.up && a.nphase == 1;   // K = taps x 4, padded to 32 by the packer
+  if (!stem && (a.s0.c % SBK || a.s1.c % SBK || a.s0.c == 0)) return false;
   if (a.s0.pitch % 4 || (a.s1.c && a.s1.pitch % 4) || (a.N >= 4 && a.pitchD % 4)) return false;
   if (a.res && a.pitchR % 4) return false;
   if (a.K % SBK || a.Npad % 32) return false;

@@ -610,7 +610,59 @@ __global__ void copy2d_u8_kernel(const uint8_t* __restrict__ src, int spitch, ui
 
 inline int win_gx(int max_pix) { return max(1, min(64, (max_pix + 4095) / 4096)); }
 
+// ---- one launch for many copies / fills -----------------------------------------------------------------------------
+// The tail moves dozens of small tables per batch (counts, contour tables, window / rule / band tables, histograms,
+// page masks) and zeroes a dozen scratch buffers.  As hipMemcpyAsync / hipMemsetAsync each of them is a blit-kernel
+// launch of its own (rocprofv3, round 2: 64 copyBuffer + 52 fillBuffer launches per step, 2.3 ms of kernel time per
+// 12.8 ms step).  Here a stage's copies and fills are segments of ONE kernel: device <-> device, device -> page-locked
+// host and page-locked host -> device alike (hipHostMalloc'ed memory is device accessible), linear or 2-D.
+template <typename V>
+__device__ __forceinline__ void mseg_run(const MSeg& g, long long first, long long step) {
+  const long long rowv = (long long)(g.row_bytes / sizeof(V));
+  const long long total = rowv * g.rows;
+  V fillv;
+  if (!g.src) __builtin_memset(&fillv, g.fill, sizeof(V));
+  for (long long i = first; i < total; i += step) {
+    long long r = 0, c = i;
+    if (g.rows > 1) r = i / rowv, c = i - r * rowv;
+    V* d = (V*)((char*)g.dst + r * g.dpitch) + c;
+    if (g.src) *d = *((const V*)((const char*)g.src + r * g.spitch) + c);
+    else *d = fillv;
+  }
+}
+
+__global__ __launch_bounds__(256) void multi_copy_kernel(MSegs m) {
+  int s = 0;
+  while (s + 1 < m.n && (int)blockIdx.x >= m.blk_off[s + 1]) ++s;     // <= 24 segments: a scalar loop
+  const MSeg& g = m.s[s];
+  const int nb = m.blk_off[s + 1] - m.blk_off[s];
+  const long long first = (long long)(blockIdx.x - m.blk_off[s]) * 256 + threadIdx.x, step = (long long)nb * 256;
+  if (g.vec == 16) mseg_run<uint4>(g, first, step);
+  else if (g.vec == 4) mseg_run<unsigned>(g, first, step);
+  else mseg_run<uint8_t>(g, first, step);
+}
+
 }  // namespace
+
+void launch_multi_copy(MSegs& m, hipStream_t st) {
+  if (m.n <= 0) return;
+  int off = 0;
+  for (int i = 0; i < m.n; ++i) {
+    MSeg& g = m.s[i];
+    const unsigned long long a = (unsigned long long)(uintptr_t)g.dst | (unsigned long long)(uintptr_t)g.src | g.row_bytes |
+                                 (g.rows > 1 ? (unsigned long long)g.dpitch | (unsigned long long)g.spitch : 0ull);
+    g.vec = (a & 15) == 0 ? 16 : ((a & 3) == 0 ? 4 : 1);
+    const unsigned long long elems = g.row_bytes / g.vec * (unsigned long long)g.rows;
+    // 8 elements per thread, at most 128 blocks per segment: a PCIe-bound segment needs few waves in flight, and the
+    // forward running next to the tail should keep its CUs
+    const int nb = (int)std::min<unsigned long long>(128, std::max<unsigned long long>(1, (elems + 2047) / 2048));
+    m.blk_off[i] = off;
+    off += nb;
+  }
+  m.blk_off[m.n] = off;
+  hipLaunchKernelGGL(multi_copy_kernel, dim3(off), dim3(256), 0, st, m);
+  m.n = 0;
+}
 
 void launch_dbc(const DbcTables& t, hipStream_t st) {
   hipLaunchKernelGGL(dbc_prep_kernel, dim3((t.cap + 255) / 256, t.B), dim3(256), 0, st, t);

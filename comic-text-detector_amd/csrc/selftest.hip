@@ -693,7 +693,14 @@ static void run_split_case(const Case& cs, int B, bool timing) {
       std::memcpy(&wf[((size_t)ph * Npad + n) * K], &lg[((size_t)ph * cs.N + n) * K], (size_t)K * 4);
   std::vector<half_t> ws;
   std::vector<float> osc;
-  split_pack_weights(lg.data(), nphase, cs.N, K, Npad, ws, osc);
+  const int Ks = (K + 31) / 32 * 32;                 // the split kernel's K (the 4-channel stem: 144 -> 160, zero taps)
+  if (Ks != K) {
+    std::vector<float> lgp((size_t)nphase * cs.N * Ks, 0.f);
+    for (size_t r = 0; r < (size_t)nphase * cs.N; ++r) std::memcpy(&lgp[r * Ks], &lg[r * K], (size_t)K * 4);
+    split_pack_weights(lgp.data(), nphase, cs.N, Ks, Npad, ws, osc);
+  } else {
+    split_pack_weights(lg.data(), nphase, cs.N, K, Npad, ws, osc);
+  }
   float *dWf = dev_alloc<float>(wf.size()), *dBias = dev_alloc<float>(Npad), *dOsc = dev_alloc<float>(Npad);
   half_t* dWs = dev_alloc<half_t>(ws.size());
   CK(hipMemcpy(dWf, wf.data(), wf.size() * 4, hipMemcpyHostToDevice));
@@ -716,7 +723,8 @@ static void run_split_case(const Case& cs, int B, bool timing) {
   }
   ConvArgs af = a, as = a;
   af.w = dWf; af.dst = dRef;
-  as.w = dWs; as.w2 = dWs + (size_t)nphase * Npad * K; as.oscale = dOsc; as.dst = dOut;
+  as.K = Ks; as.w_phase_stride = (long long)Npad * Ks;
+  as.w = dWs; as.w2 = dWs + (size_t)nphase * Npad * Ks; as.oscale = dOsc; as.dst = dOut;
   std::printf("[split] %-32s B=%d out %dx%dx%d |", cs.name, B, Ho, Wo, cs.N);
   if (!conv_f32_mfma_supported(af) || !conv_split_supported(as)) {
     std::printf(" unsupported  FAIL\n");
@@ -857,8 +865,10 @@ int main(int argc, char** argv) {
     const Case ragged[] = {{"3x3 32->64 @20 ragged (s2)", 0, 32, 0, 0, 64, 3, 2, 20, 0},
                            {"1x1 cat(32up,64)->21 @12", 0, 32, 64, 1, 21, 1, 1, 12, 0},
                            {"convT4 64->32 @9", 1, 64, 0, 0, 32, 4, 2, 9, 0},
-                           {"3x3 64->16 @24 (db branch)", 0, 64, 0, 0, 16, 3, 1, 24, 0}};
+                           {"3x3 64->16 @24 (db branch)", 0, 64, 0, 0, 16, 3, 1, 24, 0},
+                           {"stem 6x6s2 4->32 @44 ragged", 0, 4, 0, 0, 32, 6, 2, 44, 0}};
     for (const Case& c : ragged) run_split_case(c, 3, false);
+    run_split_case(Case{"stem 6x6s2 4->32 @1024", 0, 4, 0, 0, 32, 6, 2, 1024, 0}, B, true);
     const char* sel = std::getenv("ST_CASES");
     for (int i = 0; i < ncase; ++i) {
       if (sel) {

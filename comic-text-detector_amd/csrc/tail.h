@@ -73,3 +73,24 @@ void launch_tw_commit(const TWin* wins, int n, int max_pix, const uint8_t* merge
 void launch_mask_clear_where(uint8_t* mask, const uint8_t* refined, long long n, int thr, hipStream_t st);
 // dst (rows x cols, pitch dpitch) = src (pitch spitch): the crop of inference.py:164
 void launch_copy2d_u8(const uint8_t* src, int spitch, uint8_t* dst, int dpitch, int rows, int cols, hipStream_t st);
+
+// ---- many copies / fills in one launch (kernels_tail.hip) ------------------------------------------------------------
+struct MSeg {
+  void* dst;
+  const void* src;                 // null: fill with the byte `fill`
+  unsigned long long row_bytes;    // bytes per row (the whole segment when rows == 1)
+  long long dpitch, spitch;        // bytes between rows
+  int rows;
+  int fill;
+  int vec;                         // set by the launcher: 16 / 4 / 1 bytes per element
+  int pad_;
+};
+constexpr int kMSegMax = 24;
+struct MSegs {
+  int n = 0;
+  int blk_off[kMSegMax + 1];
+  MSeg s[kMSegMax];
+};
+// launches one kernel for the segments of `m` (no-op when empty) and empties it; dst / src: device memory or
+// device-accessible (hipHostMalloc / hipHostRegister) host memory
+void launch_multi_copy(MSegs& m, hipStream_t st);

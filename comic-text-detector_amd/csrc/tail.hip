@@ -69,6 +69,13 @@ struct PinBuf {
       const size_t want = bytes + bytes / 4 + 4096;
       hipError_t e = hipHostMalloc(&p, want, hipHostMallocDefault);
       if (e != hipSuccess) return ctd_fail_msg(CTD_ERR_NOMEM, std::string("hipHostMalloc: ") + hipGetErrorString(e));
+      // the copy kernel (launch_multi_copy) addresses these buffers from the device by their host pointer
+      void* dv = nullptr;
+      if (hipHostGetDevicePointer(&dv, p, 0) != hipSuccess || dv != p) {
+        (void)hipHostFree(p);
+        p = nullptr;
+        return ctd_fail_msg(CTD_ERR_HIP, "page-locked host memory is not device accessible at its host address");
+      }
       cap = want;
     }
     *out = p;
@@ -123,6 +130,38 @@ void parallel_for(int n, int max_threads, F f) {
   for (int k = 1; k < nt; ++k) th.emplace_back(work);
   work();
   for (auto& x : th) x.join();
+}
+
+// A stage's copies and fills as segments of one kernel launch (launch_multi_copy, kernels_tail.hip).
+struct Batch {
+  MSegs m;
+  hipStream_t st;
+  explicit Batch(hipStream_t s) : st(s) {}
+  void seg(void* dst, const void* src, size_t row_bytes, int rows, long long dp, long long sp, int fill) {
+    if (!row_bytes || rows < 1) return;
+    if (m.n == kMSegMax) launch_multi_copy(m, st);
+    MSeg& g = m.s[m.n++];
+    g.dst = dst, g.src = src, g.row_bytes = row_bytes, g.rows = rows, g.dpitch = dp, g.spitch = sp, g.fill = fill, g.vec = 1, g.pad_ = 0;
+  }
+  void copy(void* dst, const void* src, size_t bytes) { seg(dst, src, bytes, 1, 0, 0, 0); }
+  void copy2d(void* dst, size_t dpitch, const void* src, size_t spitch, size_t width, int rows) {
+    if (rows == 1 || (dpitch == width && spitch == width)) seg(dst, src, width * (size_t)rows, 1, 0, 0, 0);
+    else seg(dst, src, width, rows, (long long)dpitch, (long long)spitch, 0);
+  }
+  void fill(void* dst, int byte, size_t bytes) { seg(dst, nullptr, bytes, 1, 0, 0, byte); }
+  void flush() { launch_multi_copy(m, st); }
+};
+
+// Device-visible address of a caller's host array when it is page-locked (hipHostMalloc / hipHostRegister), else null:
+// the result arrays of ctd_tail_run are written by the copy kernel directly when they are, by hipMemcpyAsync otherwise.
+inline void* device_view(const void* host) {
+  hipPointerAttribute_t a;
+  if (hipPointerGetAttributes(&a, host) != hipSuccess) {
+    (void)hipGetLastError();
+    return nullptr;
+  }
+  if (a.type == hipMemoryTypeHost && a.devicePointer) return a.devicePointer;
+  return nullptr;
 }
 
 inline double now_ms() {
@@ -229,13 +268,39 @@ int refine_windows(ctd_tail* t, const std::vector<WinReq>& reqs, int refine_mode
     w.mx = pm.x[i], w.my = pm.y[i];
   }
   GET(t->d_wins, sizeof(TWin) * n, TWin, dw);
-  T_TRY(hipMemcpyAsync(dw, hw, sizeof(TWin) * n, hipMemcpyHostToDevice, st));
-  // ---- histograms -> rules
+  // ---- everything whose size depends on the windows only: one launch uploads the window table and zeroes the
+  // histograms, the xor sums, the merged canvases and the hole-filling counters
   GET(t->d_hist, (size_t)n * 1024 * 4, unsigned, dhist);
   GET(t->h_hist, (size_t)n * 1024 * 4, uint32_t, hhist);
-  T_TRY(hipMemsetAsync(dhist, 0, (size_t)n * 1024 * 4, st));
+  GET(t->d_sums, (size_t)n * 6 * 8, unsigned long long, dsums);
+  GET(t->h_sums, (size_t)n * 6 * 8, uint64_t, hsums);
+  long long bound2 = 1;                                  // 8-connected components: at most one per 2x2 cell
+  for (int i = 0; i < n; ++i) bound2 += (long long)((ww[i] + 1) / 2) * ((wh[i] + 1) / 2);
+  if ((long long)pm.W * pm.H >= (1LL << 30) || bound2 >= (1LL << 28))
+    return ctd_fail_msg(CTD_ERR_UNSUPPORTED, "refine: too many window pixels in one batch");
+  const int cap2 = (int)bound2;
+  const size_t mpx = (size_t)pm.W * pm.H;
+  GET(t->d_merged, mpx * 3, uint8_t, merged_a);
+  uint8_t* merged_b = merged_a + mpx;
+  uint8_t* comp = merged_a + 2 * mpx;
+  GET(t->d_small, (size_t)n * 16 + 64, int, small);       // [n2 (1) | pad | count255 (n) | top2 (n,3)]
+  int* n_dev = small;
+  unsigned* count255 = (unsigned*)(small + 16);
+  int* top2 = small + 16 + n;
+  GET(t->d_cnt2, ((size_t)cap2 + 1) * 8, unsigned, counters2);
+  Batch bt(st);
+  bt.copy(dw, hw, sizeof(TWin) * n);
+  bt.fill(dhist, 0, (size_t)n * 1024 * 4);
+  bt.fill(dsums, 0, (size_t)n * 6 * 8);
+  bt.fill(merged_a, 0, mpx * 3);
+  bt.fill(count255, 0, (size_t)n * 4);
+  bt.fill(top2, 0xFF, (size_t)n * 12);
+  bt.fill(counters2, 0, ((size_t)cap2 + 1) * 8);
+  bt.flush();
+  // ---- histograms -> rules
   launch_tw_hist(dw, n, max_pix, dhist, st);
-  T_TRY(hipMemcpyAsync(hhist, dhist, (size_t)n * 1024 * 4, hipMemcpyDeviceToHost, st));
+  bt.copy(hhist, dhist, (size_t)n * 1024 * 4);
+  bt.flush();
   const double tr0 = now_ms();
   T_TRY(hipStreamSynchronize(st));
   const double tr1 = now_ms();
@@ -243,13 +308,12 @@ int refine_windows(ctd_tail* t, const std::vector<WinReq>& reqs, int refine_mode
   parallel_for(n, t->host_threads, [&](int i) { refine_rules(hhist + (size_t)i * 1024, hrules + (size_t)i * 6); });
   static_assert(sizeof(RRule) == sizeof(TRule), "rule layouts must agree");
   GET(t->d_rules, sizeof(TRule) * 6 * n, TRule, drules);
-  T_TRY(hipMemcpyAsync(drules, hrules, sizeof(TRule) * 6 * n, hipMemcpyHostToDevice, st));
+  bt.copy(drules, hrules, sizeof(TRule) * 6 * n);
+  bt.flush();
   // ---- xor distances -> polarity and merge order
-  GET(t->d_sums, (size_t)n * 6 * 8, unsigned long long, dsums);
-  GET(t->h_sums, (size_t)n * 6 * 8, uint64_t, hsums);
-  T_TRY(hipMemsetAsync(dsums, 0, (size_t)n * 6 * 8, st));
   launch_tw_xor(dw, drules, n, max_pix, dsums, st);
-  T_TRY(hipMemcpyAsync(hsums, dsums, (size_t)n * 6 * 8, hipMemcpyDeviceToHost, st));
+  bt.copy(hsums, dsums, (size_t)n * 6 * 8);
+  bt.flush();
   const double tr2 = now_ms();
   T_TRY(hipStreamSynchronize(st));
   const double tr3 = now_ms();
@@ -272,38 +336,28 @@ int refine_windows(ctd_tail* t, const std::vector<WinReq>& reqs, int refine_mode
   const int nbands = (int)bands.size();
   Packed pc;
   shelf_pack(bw, bh, 2048, pc);
-  long long bound1 = 1, bound2 = 1;                      // 8-connected components: at most one per 2x2 cell
+  long long bound1 = 1;
   for (int j = 0; j < nbands; ++j) {
     bands[j].cx = pc.x[j], bands[j].cy = pc.y[j];
     bound1 += (long long)((bw[j] + 1) / 2) * ((bh[j] + 1) / 2);
   }
-  for (int i = 0; i < n; ++i) bound2 += (long long)((ww[i] + 1) / 2) * ((wh[i] + 1) / 2);
-  if ((long long)pc.W * pc.H >= (1LL << 30) || (long long)pm.W * pm.H >= (1LL << 30) || bound1 >= (1LL << 28))
+  if ((long long)pc.W * pc.H >= (1LL << 30) || bound1 >= (1LL << 28))
     return ctd_fail_msg(CTD_ERR_UNSUPPORTED, "refine: too many window pixels in one batch");
-  const int cap1 = (int)bound1, cap2 = (int)bound2;
+  const int cap1 = (int)bound1;
   GET(t->h_bands, sizeof(TBand) * nbands, TBand, hb);
   std::memcpy(hb, bands.data(), sizeof(TBand) * nbands);
   GET(t->d_bands, sizeof(TBand) * nbands, TBand, db);
-  T_TRY(hipMemcpyAsync(db, hb, sizeof(TBand) * nbands, hipMemcpyHostToDevice, st));
   // ---- candidates rendered into one canvas, one labelling launch, merge rounds
-  const size_t cpx = (size_t)pc.W * pc.H, mpx = (size_t)pm.W * pm.H;
+  const size_t cpx = (size_t)pc.W * pc.H;
   GET(t->d_canvas, cpx, uint8_t, canvas);
   GET(t->d_clab, cpx * 4, int, clab);
   GET(t->d_cstats, (size_t)cap1 * 5 * 4, int, cstats);
   GET(t->d_ccl_ws, ccl_workspace_bytes(1, std::max(pc.H, pm.H), std::max(pc.W, pm.W)), uint8_t, ws);
   GET(t->d_cnt, ((size_t)cap1 + 1) * 8, unsigned, counters);
-  GET(t->d_merged, mpx * 3, uint8_t, merged_a);
-  uint8_t* merged_b = merged_a + mpx;
-  uint8_t* comp = merged_a + 2 * mpx;
-  GET(t->d_small, (size_t)n * 16 + 64, int, small);       // [n2 (1) | pad | count255 (n) | top2 (n,3)]
-  int* n_dev = small;
-  unsigned* count255 = (unsigned*)(small + 16);
-  int* top2 = small + 16 + n;
-  T_TRY(hipMemsetAsync(canvas, 0, cpx, st));
-  T_TRY(hipMemsetAsync(merged_a, 0, mpx * 3, st));
-  T_TRY(hipMemsetAsync(counters, 0, ((size_t)cap1 + 1) * 8, st));
-  T_TRY(hipMemsetAsync(count255, 0, (size_t)n * 4, st));
-  T_TRY(hipMemsetAsync(top2, 0xFF, (size_t)n * 12, st));
+  bt.copy(db, hb, sizeof(TBand) * nbands);
+  bt.fill(canvas, 0, cpx);
+  bt.fill(counters, 0, ((size_t)cap1 + 1) * 8);
+  bt.flush();
   launch_tw_render(dw, db, nbands, max_pix, canvas, pc.W, st);
   launch_ccl(canvas, 1, pc.H, pc.W, 0, 8, clab, n_dev, cstats, cap1, ws, st);
   for (int r = 0; r < rounds; ++r)
@@ -313,8 +367,6 @@ int refine_windows(ctd_tail* t, const std::vector<WinReq>& reqs, int refine_mode
   GET(t->d_mlab, mpx * 4, int, mlab);
   GET(t->d_mstats, (size_t)cap2 * 6 * 4, int, mstats);
   int* mfirst = mstats + (size_t)cap2 * 5;
-  GET(t->d_cnt2, ((size_t)cap2 + 1) * 8, unsigned, counters2);
-  T_TRY(hipMemsetAsync(counters2, 0, ((size_t)cap2 + 1) * 8, st));
   launch_ccl(comp, 1, pm.H, pm.W, 0, 8, mlab, n_dev, mstats, cap2, ws, st, 0, mfirst);
   launch_tw_holes(dw, n, max_pix, mlab, mstats, mfirst, cap2, count255, top2, merged_b, pm.W, counters2, st);
   launch_tw_commit(dw, n, max_pix, merged_b, pm.W, st);
@@ -415,11 +467,21 @@ int download_pages(ctd_tail* t, bool mask_too, uint8_t* const* mask_out, uint8_t
   hipStream_t st = t->st;
   GET(t->d_pmask, 0, uint8_t, pmask);
   GET(t->d_refined, 0, uint8_t, refined);
+  Batch bt(st);
+  auto one = [&](uint8_t* host, const uint8_t* dev, size_t nb) -> hipError_t {
+    if (void* dv = device_view(host)) {                  // page-locked array: a segment of the copy kernel
+      bt.copy(dv, dev, nb);
+      return hipSuccess;
+    }
+    return hipMemcpyAsync(host, dev, nb, hipMemcpyDeviceToHost, st);
+  };
   for (int b = 0; b < t->B; ++b) {
     const size_t nb = (size_t)t->pages[b].im_h * t->pages[b].im_w;
-    if (mask_too && mask_out && mask_out[b]) T_TRY(hipMemcpyAsync(mask_out[b], pmask + t->poff[b], nb, hipMemcpyDeviceToHost, st));
-    if (refined_out && refined_out[b]) T_TRY(hipMemcpyAsync(refined_out[b], refined + t->poff[b], nb, hipMemcpyDeviceToHost, st));
+    if (mask_too && mask_out && mask_out[b]) T_TRY(one(mask_out[b], pmask + t->poff[b], nb));
+    if (refined_out && refined_out[b]) T_TRY(one(refined_out[b], refined + t->poff[b], nb));
   }
+  bt.flush();
+  T_TRY(hipGetLastError());
   T_TRY(hipStreamSynchronize(st));
   return CTD_OK;
 }
@@ -441,8 +503,10 @@ struct DbStage {
   int* hhdr = nullptr;
 };
 
+// `pre`: fills this stage needs before its kernels (the caller may have added its own; flushed here);
+// `post`: receives the download of the per-page table header (the caller flushes it with its own copies).
 int db_enqueue(ctd_tail* t, DbStage& d, int B, int Hn, int Wn, const float* prob_dev, long long prob_stride,
-               const uint8_t* bitmap_dev) {
+               const uint8_t* bitmap_dev, Batch& pre, Batch& post) {
   hipStream_t st = t->st;
   const size_t hw = (size_t)Hn * Wn;
   const int cap = kCompCap, rcap = kRowCap;
@@ -470,9 +534,10 @@ int db_enqueue(ctd_tail* t, DbStage& d, int B, int Hn, int Wn, const float* prob
   GET(t->d_rows, 2 * (size_t)B * rcap * 4, int, rows);
   d.row_lo = rows, d.row_hi = rows + (size_t)B * rcap;
   // foreground 8-connected + background 4-connected components in one pass: signed label image
+  pre.fill(td, 0, 3 * bc * 8);
+  pre.fill(d.ring_cnt, 0, bc * 4);
+  pre.flush();
   launch_ccl_dual(bitmap_dev, B, Hn, Wn, 0, lab, d.n_f, d.n_b, d.st_f, d.st_b, d.first_f, d.first_b, cap, ccl_ws, st);
-  T_TRY(hipMemsetAsync(td, 0, 3 * bc * 8, st));
-  T_TRY(hipMemsetAsync(d.ring_cnt, 0, bc * 4, st));
   DbcTables dt;
   dt.B = B, dt.H = Hn, dt.W = Wn, dt.cap = cap, dt.rcap = rcap;
   dt.prob = prob_dev, dt.prob_stride = prob_stride;
@@ -483,7 +548,7 @@ int db_enqueue(ctd_tail* t, DbStage& d, int B, int Hn, int Wn, const float* prob
   launch_dbc(dt, st);
   GET(t->h_hdr, (size_t)B * 4 * 4, int, hhdr);
   d.hhdr = hhdr;
-  T_TRY(hipMemcpyAsync(hhdr, d.hdr, (size_t)B * 16, hipMemcpyDeviceToHost, st));
+  post.copy(hhdr, d.hdr, (size_t)B * 16);
   T_TRY(hipGetLastError());
   return CTD_OK;
 }
@@ -520,8 +585,10 @@ int db_collect(ctd_tail* t, const DbStage& d, const ctd_tail_params* prm) {
   double* h_ring_sum = (double*)take((size_t)B * nb * 8);
   int* h_row_lo = (int*)take((size_t)B * nr * 4);
   int* h_row_hi = (int*)take((size_t)B * nr * 4);
+  Batch bt(st);
   auto d2h = [&](void* dst, const void* src, size_t elem, size_t n_used, size_t n_cap) -> hipError_t {
-    return hipMemcpy2DAsync(dst, n_used * elem, src, n_cap * elem, n_used * elem, B, hipMemcpyDeviceToHost, st);
+    bt.copy2d(dst, n_used * elem, src, n_cap * elem, n_used * elem, B);
+    return hipSuccess;
   };
   if (nfm > 0) {
     T_TRY(d2h(h_st_f, d.st_f, 20, nf, cap));
@@ -543,6 +610,8 @@ int db_collect(ctd_tail* t, const DbStage& d, const ctd_tail_params* prm) {
     T_TRY(d2h(h_row_lo, d.row_lo, 4, nr, rcap));
     T_TRY(d2h(h_row_hi, d.row_hi, 4, nr, rcap));
   }
+  bt.flush();
+  T_TRY(hipGetLastError());
   const double td0 = now_ms();
   T_TRY(hipStreamSynchronize(st));
   t->ms_db_wait = now_ms() - td0;
@@ -689,14 +758,14 @@ static int tail_run_impl(ctd_tail* t, int32_t B, int32_t Hn, int32_t Wn, const f
   GET(t->d_nms_ws, nms_workspace_bytes(B, rows), uint8_t, nms_ws);
   launch_nms(blks_dev, B, rows, no, prm->conf_thresh, prm->nms_thresh, kMaxDet, 30000, 4096.f, dets, counts, nms_ws, st);
   GET(t->h_dets, (size_t)B * kMaxDet * 6 * 4 + (size_t)B * 4, float, hdets);
-  T_TRY(hipMemcpyAsync(hdets, dets, (size_t)B * kMaxDet * 6 * 4 + (size_t)B * 4, hipMemcpyDeviceToHost, st));
-  DbStage db;
-  if (int rc = db_enqueue(t, db, B, Hn, Wn, prob_dev, prob_stride, bitmap_dev)) return rc;
-
   // page masks: crop of the letterbox padding, resize to the page (inference.py:164-165)
   GET(t->d_pmask, t->ptotal, uint8_t, pmask);
   GET(t->d_refined, t->ptotal, uint8_t, refined);
-  T_TRY(hipMemsetAsync(refined, 0, t->ptotal, st));
+  Batch pre(st), post(st);                      // this stage's fills / its copies: one launch each
+  pre.fill(refined, 0, t->ptotal);
+  DbStage db;
+  if (int rc = db_enqueue(t, db, B, Hn, Wn, prob_dev, prob_stride, bitmap_dev, pre, post)) return rc;
+  post.copy(hdets, dets, (size_t)B * kMaxDet * 6 * 4 + (size_t)B * 4);
   size_t crop_px = 1;                       // pages whose letterbox padded the right side are cropped into a dense
   for (int b = 0; b < B; ++b)               // temporary first (one buffer: the stream runs the pages in order)
     if (pages[b].dw > 0) crop_px = std::max(crop_px, (size_t)(Hn - pages[b].dh) * (Wn - pages[b].dw));
@@ -704,9 +773,11 @@ static int tail_run_impl(ctd_tail* t, int32_t B, int32_t Hn, int32_t Wn, const f
   bool plain = true;                        // every page is the network input itself: one strided copy for the batch
   for (int b = 0; b < B; ++b)
     plain = plain && pages[b].im_h == Hn && pages[b].im_w == Wn && pages[b].dw == 0 && pages[b].dh == 0;
-  if (plain) {
+  GET(t->h_pmask, t->ptotal, uint8_t, hpmask);
+  if (plain) {   // device and host copy of the page masks both read the network's u8 mask: same launch, no ordering needed
     const size_t stride = B > 1 ? t->poff[1] - t->poff[0] : hw;
-    T_TRY(hipMemcpy2DAsync(pmask, stride, mask_u8_dev, hw, hw, B, hipMemcpyDeviceToDevice, st));
+    post.copy2d(pmask, stride, mask_u8_dev, hw, hw, B);
+    post.copy2d(hpmask, stride, mask_u8_dev, hw, hw, B);
   }
   for (int b = 0; b < B && !plain; ++b) {
     const ctd_tail_page& pg = pages[b];
@@ -722,8 +793,9 @@ static int tail_run_impl(ctd_tail* t, int32_t B, int32_t Hn, int32_t Wn, const f
       launch_resize_linear_u8(src, ch, cw, 1, dst, pg.im_h, pg.im_w, pg.im_h, pg.im_w, st);
     }
   }
-  GET(t->h_pmask, t->ptotal, uint8_t, hpmask);
-  T_TRY(hipMemcpyAsync(hpmask, pmask, t->ptotal, hipMemcpyDeviceToHost, st));
+  if (!plain) post.copy(hpmask, pmask, t->ptotal);
+  post.flush();
+  T_TRY(hipGetLastError());
   const double t1 = now_ms();
   T_TRY(hipStreamSynchronize(st));                                     // sync 1: counts are known
   const double t2 = now_ms();
@@ -833,7 +905,10 @@ static int tail_db_boxes_impl(ctd_tail* t, int32_t B, int32_t Hn, int32_t Wn, co
   t->B = B;
   t->out.assign(B, PageOut());
   DbStage db;
-  if (int rc = db_enqueue(t, db, B, Hn, Wn, prob_dev, prob_stride, bitmap_dev)) return rc;
+  Batch pre(t->st), post(t->st);
+  if (int rc = db_enqueue(t, db, B, Hn, Wn, prob_dev, prob_stride, bitmap_dev, pre, post)) return rc;
+  post.flush();
+  T_TRY(hipGetLastError());
   T_TRY(hipStreamSynchronize(t->st));
   ctd_tail_params prm;
   std::memset(&prm, 0, sizeof(prm));

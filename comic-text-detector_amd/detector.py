@@ -72,6 +72,7 @@ class TextDetector:
         self.net = BK.HipTextDetBackend(**self._net_args)
         self._lanes = [(self.net, None)]                      # (engine, stream) pairs of detect_stream, grown on demand
         self._stage_tl = threading.local()
+        self._pools = {}                                      # detect_stream's worker / loader pools, kept between calls
         self.backend = "hip"
         self.seg_rep = PP.SegRepresenter(thresh=0.3)          # inference.py:139
 
@@ -224,8 +225,11 @@ class TextDetector:
         `tail_split` cuts every batch's tail into that many page ranges, each a work item of its own for the workers
         (0 = one per worker): lower latency per batch and a shorter drain when the stream ends, for more, smaller
         native calls -- measured +6 % end to end at 32 pages per batch (2311 -> 2456 pages/s, 3 workers)."""
-        pool = ThreadPoolExecutor(max_workers=max(1, workers), thread_name_prefix="ctd-tail")
-        lpool = ThreadPoolExecutor(max_workers=max(1, loaders), thread_name_prefix="ctd-load")
+        # The pools live on the detector: their threads own the native `Tail` objects (a HIP stream, ~250 MB of
+        # fixed-capacity device tables at 32 pages, pinned buffers) and the pinned staging rings, which a pool per call
+        # would create and destroy every time.
+        pool = self._pool("tail", workers)
+        lpool = self._pool("load", loaders)
         pending = deque()
         engines = max(1, int(engines))
         tail_split = int(tail_split) if int(tail_split) > 0 else max(1, workers)
@@ -258,8 +262,32 @@ class TextDetector:
             while pending:
                 yield [r for f in pending.popleft() for r in f.result()]
         finally:
-            pool.shutdown(wait=True)
-            lpool.shutdown(wait=True)
+            for futs in pending:                          # the consumer stopped early: let the queued tails finish
+                for f in futs:
+                    f.cancel() or f.exception()
+
+    def _pool(self, kind: str, n: int) -> ThreadPoolExecutor:
+        n = max(1, int(n))
+        cur = self._pools.get(kind)
+        if cur is None or cur[1] != n:
+            if cur is not None:
+                cur[0].shutdown(wait=True)
+            cur = (ThreadPoolExecutor(max_workers=n, thread_name_prefix=f"ctd-{kind}"), n)
+            self._pools[kind] = cur
+        return cur[0]
+
+    def close(self) -> None:
+        """Stops `detect_stream`'s worker threads (their native tails and staging buffers go with them)."""
+        for ex, _ in self._pools.values():
+            ex.shutdown(wait=True)
+        self._pools = {}
+
+    def __del__(self):
+        try:
+            for ex, _ in getattr(self, "_pools", {}).values():
+                ex.shutdown(wait=False)
+        except Exception:
+            pass
 
     def tail_batch(self, pages: Sequence[Page], blks: torch.Tensor, mask_u8: torch.Tensor, prob: torch.Tensor,
                    bitmap: torch.Tensor, refine_mode=REFINEMASK_INPAINT, keep_undetected_mask=False, metas=None,

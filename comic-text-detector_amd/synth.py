@@ -156,7 +156,13 @@ def text_like_outputs(seed: int = 0, size: int = 1024, n_blocks: int = 10):
     return page, blks, mask_u8, prob, (prob > 0.3).astype(np.uint8)
 
 
-def make_blob_checkpoint(seed: int = 0) -> dict:
+# `make_blob_checkpoint(0, sparse_det=True)`: quantile of the objectness logit of the one anchor that fires (Detect level 2,
+# anchor 2) above which a cell stays on, and the gain that makes the decision sharp -- calibrated with the oracle network
+# on text-like pages at 1024x1024 by scripts/experiments/calibrate_sparse_det.py (top ~1.5 % of the cells: 5-21 boxes).
+_SPARSE_DET_Q, _SPARSE_DET_GAIN = 0.3289, 40.0
+
+
+def make_blob_checkpoint(seed: int = 0, sparse_det: bool = False) -> dict:
     """`make_checkpoint(seed)` with the LAST layers of the two sigmoid heads re-shaped so that the maps are
     decisive blobs instead of mid-grey noise: the transposed-conv taps of the DB tail and of the UNet's final
     layer are tied (a random ConvT 2x2 / 4x4 gives every sub-pixel position its own weight, i.e. a period-4
@@ -164,8 +170,23 @@ def make_blob_checkpoint(seed: int = 0) -> dict:
     page lies above the 0.3 threshold; the final UNet weights alternate in sign so its (bias-free) logit is
     centred.  Still random weights in the reference's checkpoint format -- but their outputs have contours,
     boxes above the score threshold, text lines and blocks, so the WHOLE detector (network + tail) can be
-    compared end to end between engines (tests/test_gpu_accept.py, bench.py `parity`)."""
+    compared end to end between engines (tests/test_gpu_accept.py, bench.py `parity`).
+
+    sparse_det (seed 0 only): with random weights the Detect head's confidences sit in a 0.02-wide band, so the ONE
+    anchor that passes the 0.4 gate passes it on every cell and NMS packs the page with ~65 boxes of ~160 px (1.5 page
+    areas of block windows).  The reference's only real fixture (data/examples/AisazuNihaIrarenai-003.jpg) has 16
+    blocks / 29 lines.  sparse_det sharpens that anchor's objectness around a high quantile of its logit, z' = G (z - q),
+    so that 5-21 boxes per text-like 1024x1024 page (0.1-0.55 page areas) remain: the block density bench.py times."""
     ck = make_checkpoint(seed)
+    if sparse_det:
+        if seed != 0:
+            raise ValueError("sparse_det is calibrated for seed 0 (scripts/experiments/calibrate_sparse_det.py)")
+        w8 = ck["blk_det"]["weights"]
+        det_i = max(int(k.split(".")[1]) for k in w8 if k.endswith(".anchors"))
+        ch = 2 * 7 + 4                                   # anchor 2, objectness (no = 5 + nc = 7)
+        wk, bk = f"model.{det_i}.m.2.weight", f"model.{det_i}.m.2.bias"
+        w8[wk][ch] = w8[wk][ch] * _SPARSE_DET_GAIN
+        w8[bk][ch] = (w8[bk][ch] - _SPARSE_DET_Q) * _SPARSE_DET_GAIN
 
     def tie(w):      # (cin, cout, k, k): one value for every tap of a (cin, cout) pair
         return (w.mean(dim=(2, 3), keepdim=True) * w.shape[2]).expand_as(w).clone()

@@ -94,7 +94,7 @@ class Tail:
         if not want_extras:
             L.check(lib.ctd_tail_page_fetch(self._h, b, recs, lines.ctypes.data, dist.ctypes.data, None, None, None, None,
                                             None), "ctd_tail_page_fetch")
-            return blocks_from_records(recs[: nb.value], lines, dist), None
+            return blocks_from_records(recs, lines, dist, nb.value), None
         boxes = np.empty((nx.value, 4, 2), np.int16)
         scores = np.empty((nx.value,), np.float32)
         yx = np.empty((ny.value, 4), np.int32)
@@ -104,7 +104,7 @@ class Tail:
                                         scores.ctypes.data, yx.ctypes.data, yc.ctypes.data, yf.ctypes.data),
                 "ctd_tail_page_fetch")
         extras = {"db_boxes": boxes, "db_scores": scores, "yolo": (yx, yc, np.round(yf, 3))}
-        return blocks_from_records(recs[: nb.value], lines, dist), extras
+        return blocks_from_records(recs, lines, dist, nb.value), extras
 
     # -- the whole tail ---------------------------------------------------------------------------
     def run(self, pages_gpu: Sequence[torch.Tensor], metas, blks: torch.Tensor, mask_u8: torch.Tensor,

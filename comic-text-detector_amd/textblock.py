@@ -35,30 +35,14 @@ _RECORD_TAIL = (
 )
 
 
-def rotate_polygons(center, polygons: np.ndarray, rotation, new_center=None, to_int: bool = True) -> np.ndarray:
-    """reference utils/imgproc_utils.py:68-84 (float32 arithmetic like the reference)."""
-    if new_center is None:
-        new_center = center
-    rotation = np.deg2rad(rotation)
-    s, c = np.sin(rotation), np.cos(rotation)
-    polygons = polygons.astype(np.float32)
-    polygons[:, 1::2] -= center[1]
-    polygons[:, ::2] -= center[0]
-    rotated = np.copy(polygons)
-    rotated[:, 1::2] = polygons[:, 1::2] * c - polygons[:, ::2] * s
-    rotated[:, ::2] = polygons[:, 1::2] * s + polygons[:, ::2] * c
-    rotated[:, 1::2] += new_center[1]
-    rotated[:, ::2] += new_center[0]
-    return rotated.astype(np.int64) if to_int else rotated
-
-
 class TextBlock:
     """The reference's TextBlock record (textblock.py:12-265): detection state first, then the
     fields later pipeline stages fill, in the reference's attribute order (that order is the key
-    order of the JSON record, `to_dict` :158-160), with the reference's numpy-only methods.
-    `get_transformed_region` (:162-196, cv2.findHomography / warpPerspective) and
-    `visualize_textblocks` (:510-523, cv2 drawing) belong to the OCR / debugging side and are not
-    part of this package."""
+    order of the JSON record, `to_dict` :158-160).  Only what the detector and the annotation writers use is here:
+    the geometry / colour / alignment helpers of the reference's class (`min_rect`, `bounding_rect`, `alignment`,
+    `get_font_colors`, `get_transformed_region`, ... :110-265) serve the OCR, rendering and GUI stages downstream of
+    `TextDetector.__call__` and are out of scope; a caller that needs them applies the
+    reference's own class to `to_dict()`'s record."""
 
     def __init__(self, xyxy: Sequence, lines: Optional[list] = None, language: str = "unknown",
                  vertical: bool = False, font_size: float = -1, distance=None, angle: int = 0, vec=None,
@@ -116,87 +100,6 @@ class TextBlock:
             self.distance = self.distance[order]
             self.lines = np.array(self.lines, dtype=np.int32)[order].tolist()
 
-    def aspect_ratio(self) -> float:
-        """textblock.py:110-115."""
-        min_rect = self.min_rect()
-        mid = (min_rect[:, [1, 2, 3, 0]] + min_rect) / 2
-        return np.linalg.norm(mid[:, 2] - mid[:, 0]) / np.linalg.norm(mid[:, 1] - mid[:, 3])
-
-    def min_rect(self, rotate_back: bool = True) -> np.ndarray:
-        """textblock.py:121-134: bounding rectangle of the lines in the block's rotated frame."""
-        angled = self.angle != 0
-        center = self.center()
-        polygons = self.lines_array().reshape(-1, 8)
-        if angled:
-            polygons = rotate_polygons(center, polygons, self.angle)
-        min_x, min_y = polygons[:, ::2].min(), polygons[:, 1::2].min()
-        max_x, max_y = polygons[:, ::2].max(), polygons[:, 1::2].max()
-        min_bbox = np.array([[min_x, min_y, max_x, min_y, max_x, max_y, min_x, max_y]])
-        if angled and rotate_back:
-            min_bbox = rotate_polygons(center, min_bbox, -self.angle)
-        return min_bbox.reshape(-1, 4, 2).astype(np.int64)
-
-    def bounding_rect(self):
-        """textblock.py:136-144: Qt-style [x, y, w, h], ignoring the angle."""
-        if self._bounding_rect is None:
-            min_bbox = self.min_rect(rotate_back=False)[0]
-            x, y = min_bbox[0]
-            w, h = min_bbox[2] - min_bbox[0]
-            return [x, y, w, h]
-        return self._bounding_rect
-
-    def get_text(self) -> str:
-        """textblock.py:198-201."""
-        if isinstance(self.text, str):
-            return self.text
-        return " ".join(self.text).strip()
-
-    def set_font_colors(self, frgb, srgb, accumulate: bool = True) -> None:
-        """textblock.py:203-211."""
-        self.accumulate_color = accumulate
-        num_lines = len(self.lines) if accumulate and len(self.lines) > 0 else 1
-        self.fg_r, self.fg_g, self.fg_b = np.array(frgb) * num_lines
-        self.bg_r, self.bg_g, self.bg_b = np.array(srgb) * num_lines
-
-    def get_font_colors(self, bgr: bool = False):
-        """textblock.py:213-228."""
-        num_lines = len(self.lines)
-        frgb = np.array([self.fg_r, self.fg_g, self.fg_b])
-        brgb = np.array([self.bg_r, self.bg_g, self.bg_b])
-        if self.accumulate_color:
-            if num_lines > 0:
-                frgb = (frgb / num_lines).astype(np.int32)
-                brgb = (brgb / num_lines).astype(np.int32)
-                return (frgb[::-1], brgb[::-1]) if bgr else (frgb, brgb)
-            return [0, 0, 0], [0, 0, 0]
-        return frgb, brgb
-
-    def alignment(self) -> int:
-        """textblock.py:234-255: 0 left, 1 centre."""
-        if self._alignment >= 0:
-            return self._alignment
-        if self.vertical:
-            return 0
-        lines = self.lines_array()
-        if len(lines) == 1:
-            return 0
-        polygons = lines.reshape(-1, 8)
-        if self.angle != 0:
-            polygons = rotate_polygons((0, 0), polygons, self.angle)
-        polygons = polygons.reshape(-1, 4, 2)
-        left_std = np.std(polygons[:, 0, 0])
-        center_std = np.std((polygons[:, 0, 0] + polygons[:, 1, 0]) / 2)
-        return 0 if left_std < center_std else 1
-
-    def target_lang(self):
-        return self._target_lang
-
-    @property
-    def stroke_width(self):
-        """textblock.py:260-265."""
-        var = np.abs(np.array([self.fg_r, self.fg_g, self.fg_b]) - np.array([self.bg_r, self.bg_g, self.bg_b])).sum()
-        return self.default_stroke_width if var > 40 else 0
-
     def to_dict(self) -> dict:
         """`copy.deepcopy(vars(self))` (textblock.py:158-160): every attribute, numpy values included;
         `annotations.RecordEncoder` turns it into the reference's JSON."""
@@ -206,6 +109,7 @@ class TextBlock:
 # --------------------------------------------------------------------------
 
 _TAIL_DEFAULTS = tuple((attr, default) for attr, _, default in _RECORD_TAIL)
+_TAIL_DICT = {attr: default for attr, default in _TAIL_DEFAULTS}          # "text" gets a fresh list per block
 
 
 def _fast_block(xyxy, lines, language, vertical, font_size, distance, angle, vec, norm, merged, weight) -> TextBlock:
@@ -219,24 +123,50 @@ def _fast_block(xyxy, lines, language, vertical, font_size, distance, angle, vec
     return t
 
 
-def blocks_from_records(recs, lines: np.ndarray, dist: np.ndarray) -> List[TextBlock]:
+# numpy view of `ctd_blk` (include/ctd_hip.h; _lib.CtdBlk): the records of a page become columns in one call
+_BLK_DT = np.dtype([("xyxy", "<i4", (4,)), ("language", "<i4"), ("vertical", "<i4"), ("angle", "<i4"),
+                    ("font_is_float", "<i4"), ("font_size", "<f8"), ("vec", "<f8", (2,)), ("norm", "<f8"),
+                    ("weight", "<f8"), ("merged", "<i4"), ("line_off", "<i4"), ("n_lines", "<i4"), ("dist_off", "<i4"),
+                    ("n_dist", "<i4"), ("pad_", "<i4")])
+assert _BLK_DT.itemsize == C.sizeof(L.CtdBlk)
+
+
+def blocks_from_records(recs, lines: np.ndarray, dist: np.ndarray, n: Optional[int] = None) -> List[TextBlock]:
     """Native records (`ctd_blk` array + line / distance pools) -> the reference's Python objects.
     `TextBlock.distance` is re-evaluated from its two operands with numpy's own arccos / sin
     (reference utils/textblock.py:327-328), so the record carries the bits the reference's numpy
-    expression gives on this machine (csrc/host_group.cpp decided with libm's)."""
+    expression gives on this machine (csrc/host_group.cpp decided with libm's).
+    Column-wise: the per-block Python work is one dict (the interpreter lock is what the tail workers of
+    `detect_stream` share, and a crowded page has 60+ blocks)."""
+    if isinstance(recs, list):                       # a slice of a ctypes array is a list of struct copies
+        n = len(recs)
+        recs = (L.CtdBlk * max(n, 1))(*recs)
+    n = len(recs) if n is None else n                # `recs`: the ctypes array the native call filled, first n entries used
+    if n == 0:
+        return []
+    a = np.frombuffer(recs, dtype=_BLK_DT, count=n)
     if len(dist):
         with np.errstate(divide="ignore", invalid="ignore"):
             dval = np.abs(np.sin(np.arccos(np.ascontiguousarray(dist[:, 1]))) * np.ascontiguousarray(dist[:, 2]))
     else:
         dval = np.zeros((0,), np.float64)
-    out = []
     all_lines = lines.reshape(-1, 4, 2).tolist()
-    for r in recs:
-        lo, do = r.line_off, r.dist_off
-        out.append(_fast_block(list(r.xyxy), all_lines[lo: lo + r.n_lines], LANG_LIST[r.language], bool(r.vertical),
-                               float(r.font_size) if r.font_is_float else int(r.font_size),
-                               dval[do: do + r.n_dist].copy(), int(r.angle), np.array((r.vec[0], r.vec[1]), np.float64),
-                               np.float64(r.norm), bool(r.merged), np.float64(r.weight)))
+    tail, new = _TAIL_DICT, TextBlock.__new__
+    out = []
+    # one row per block: plain Python values from .tolist() (C loops), np.float64 / (2,) float64 arrays where the
+    # reference holds numpy values (`norm`, `weight`, `vec`); `distance` is a view into this page's distance array
+    for xyxy, lang, vert, ang, mg, lo, nl, do, nd, fs, isf, vec, norm, weight in zip(
+            a["xyxy"].tolist(), a["language"].tolist(), a["vertical"].tolist(), a["angle"].tolist(), a["merged"].tolist(),
+            a["line_off"].tolist(), a["n_lines"].tolist(), a["dist_off"].tolist(), a["n_dist"].tolist(),
+            a["font_size"].tolist(), a["font_is_float"].tolist(), a["vec"].copy(), a["norm"], a["weight"]):
+        d = {"xyxy": xyxy, "lines": all_lines[lo: lo + nl], "vertical": vert != 0, "language": LANG_LIST[lang],
+             "font_size": fs if isf else int(fs), "distance": dval[do: do + nd], "angle": ang,
+             "vec": vec, "norm": norm, "merged": mg != 0, "weight": weight}
+        d.update(tail)                               # the record's non-detection fields, in the reference's order
+        d["text"] = []
+        t = new(TextBlock)
+        t.__dict__ = d
+        out.append(t)
     return out
 
 

@@ -295,6 +295,8 @@ def parity_block(pkg, ckpt, det, page: np.ndarray, size: int) -> dict:
     ob, om, ol = OracleNet(ckpt)(x)
     ref = R.detector_tail(page, ob.numpy(), om.numpy(), ol.numpy(), input_size=(size, size), refine_mode=0,
                           keep_undetected_mask=False)
+    ref_dets = np.asarray(R.non_max_suppression(ob.numpy(), 0.4, 0.35)[0])
+    BKm = importlib.import_module("comic-text-detector_amd.backend")
     out = {"page": f"first page of the benchmark input ({size}x{size}), benchmark checkpoint; oracle = CPU fp32 restatement "
                    "of the reference net + restated tail", "engines": {}}
     dev = det.net.device
@@ -309,17 +311,20 @@ def parity_block(pkg, ckpt, det, page: np.ndarray, size: int) -> dict:
                                   d.net.mask_u8[0].cpu().numpy(), FP16_BAND_EPS, prob=lines[0, 0].cpu().numpy(),
                                   mask=mask[0, 0].cpu().numpy())
         flips = band.pop("_flips")
-        band.update(accept.explain_geometry(got, ref, flips))
+        dets, counts = BKm.nms(blks, 0.4, 0.35)
+        band.update(accept.explain_geometry(got, ref, flips, dets=dets[0, : int(counts[0])].cpu().numpy(), ref_dets=ref_dets))
         rep["band"] = band
         out["engines"][prec] = rep
         if d is not det:
             del d
     b16 = out["engines"]["fp16"]["band"]
     out["fp16_band"] = {"eps": FP16_BAND_EPS,
-                        "claim": "every DB-bitmap (0.3) / mask@127 pixel of the fp16 engine that differs from the oracle's "
-                                 "lies within eps of the threshold in the ORACLE's map; every differing line / block "
-                                 "touches such a pixel (tests/test_gpu_accept.py)",
+                        "claim": "the fp16 engine's maps stay within eps of the oracle's; every DB-bitmap (0.3) / mask@127 pixel "
+                                 "that differs lies within eps of the threshold in the ORACLE's map; every differing line / "
+                                 "block is attributed to such a pixel, to an int32 truncation of coordinates < 1 px apart, or "
+                                 "to a detection NMS kept differently (tests/test_gpu_accept.py, oracle/accept.py)",
                         "holds": bool(b16["bitmap_flips_out_of_band"] == 0 and b16["mask127_flips_out_of_band"] == 0 and
+                                      b16["prob_max_abs_delta"] < FP16_BAND_EPS and b16["mask_max_abs_delta"] < FP16_BAND_EPS and
                                       b16["lines_unexplained"] == 0 and b16["blocks_unexplained"] == 0),
                         "in_band_pixel_frac": {"bitmap": b16["bitmap_in_band_frac"], "mask127": b16["mask127_in_band_frac"]}}
     out["tail"] = "bit-exact vs the oracle tail on identical network outputs (tests/test_gpu_e2e.py)"
@@ -783,9 +788,9 @@ def main() -> None:
                 ex = "fp32s" if args.precision != "fp32s" else "fp32"
                 d2 = DET.TextDetector(ckpt, input_size=S, device=dev, precision=ex)
                 p2 = Pipeline(d2, batches, canned, dev, 1, 0, B, D, args.workers, args.depth, args.tail_split)
-                dt2 = timed(p2.run, 8, 2, 6, 1, dev, p2.stats)
-                exact = {"engine": ex, "value": round(B * 8 / dt2, 2), "unit": "pages/s", "ms_per_step": round(dt2 / 8 * 1e3, 3),
-                         "steps": 8, "batch": B, "workload": "the headline's (same pages, checkpoint, pipeline)",
+                dt2 = timed(p2.run, 16, 2, 6, 1, dev, p2.stats)
+                exact = {"engine": ex, "value": round(B * 16 / dt2, 2), "unit": "pages/s", "ms_per_step": round(dt2 / 16 * 1e3, 3),
+                         "steps": 16, "batch": B, "workload": "the headline's (same pages, checkpoint, pipeline)",
                          "acceptance": "lines / blocks / refined mask identical to the oracle on the acceptance pages "
                                        "(tests/test_gpu_accept.py; `parity.engines` here)",
                          "net_ms_per_step": round(float(d2.net.profile(batches[0])["ms"].sum()), 3)}

@@ -950,6 +950,7 @@ int32_t ctd_engine_arena_generation(const ctd_engine* e) { return e ? e->arena_g
 int ctd_tuning_set(const char* key, int64_t value) {
   if (key && std::string(key) == "fuse") { g_fuse = (int)value; return CTD_OK; }
   if (key && std::string(key) == "split_wdma") { g_split_wdma = (int)value; return CTD_OK; }
+  if (key && std::string(key) == "split_bm256") { g_split_bm256 = (int)value; return CTD_OK; }
   if (key && std::string(key) == "db_up_mfma") { g_db_up_mfma = (int)value; return CTD_OK; }
   if (key && std::string(key) == "seg_final_mfma") { g_seg_final_mfma = (int)value; return CTD_OK; }
   if (key && std::string(key) == "c3_min_patches") { g_c3_min_patches = value; g_fuse_epoch++; return CTD_OK; }

@@ -40,7 +40,6 @@
 
 namespace {
 
-constexpr int SBM = 128;   // pixels per block
 constexpr int SBK = 32;    // channels per K step
 
 __device__ __forceinline__ void split8(const float4_t& a, const float4_t& b, half8_t& hi, half8_t& lo) {
@@ -55,17 +54,20 @@ __device__ __forceinline__ void split8(const float4_t& a, const float4_t& b, hal
 }
 
 // WDMA: weight tiles by LDS-DMA (global_load_lds, swizzle on the source chunk) instead of through registers
-template <int BN, int WGN, int WGM, bool WDMA>
+// SBM = pixels per block: 128, or 256 for the 64-channel outputs (the weight tile of a K step then feeds twice the MFMAs
+// and every wave holds a 2x2-fragment tile like the 128 x 128 configuration)
+template <int BN, int SBM, int WGN, int WGM, bool WDMA>
 __global__ __launch_bounds__(256, 2) void conv_split_kernel(ConvArgs a) {
   constexpr int TN = BN / (32 * WGN);
   constexpr int TM = SBM / (32 * WGM);
+  constexpr int AR = SBM / 64;                  // pixel rows each thread stages
   static_assert(WGN * WGM == 4, "4 waves");
   constexpr int XT = SBM * SBK;                 // halves of one pixel plane
   constexpr int WT = BN * SBK;                  // halves of one weight plane
   constexpr int WCH = BN * 4;                   // 16-B chunks of one weight plane
   constexpr int WROWS = (WCH + 255) / 256;
   // one LDS object (see kernels_igemm.hip: a second array costs a vmcnt(0) in front of every K step's first ds_read)
-  // pixels: [buf][hi, lo][128][32]; weights: [buf][hi, lo][BN][32]
+  // pixels: [buf][hi, lo][SBM][32]; weights: [buf][hi, lo][BN][32]
   __shared__ __attribute__((aligned(16))) half_t lds[4 * XT + 4 * WT];
   half_t* Xs = lds;
   half_t* Ws = lds + 4 * XT;
@@ -112,12 +114,12 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(ConvArgs a) {
   const int nk = a.K / SBK;
   auto swz = [](int row) { return (row >> 2) & 3; };
 
-  // this thread's two pixel rows (rows t/4 and t/4 + 64; 8 channels = two 16-B loads at chunk t%4)
+  // this thread's pixel rows (rows t/4 + 64 i; 8 channels = two 16-B loads at chunk t%4)
   const int seg = t & 3;
-  int pb[2], poy[2], pox[2];
-  bool pv[2];
+  int pb[AR], poy[AR], pox[AR];
+  bool pv[AR];
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
+  for (int i = 0; i < AR; ++i) {
     const int m = m0 + (t >> 2) + 64 * i;
     pv[i] = m < a.M;
     const int mm = pv[i] ? m : 0;
@@ -143,7 +145,7 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(ConvArgs a) {
     __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(plane + (i * 256 + wave * 64) * 8), 16, 0, 0);
   };
 
-  float4_t ra[2][2];
+  float4_t ra[AR][2];
   half8_t rwh[WROWS], rwl[WROWS];
   int nx_cc = 0, nx_ty = 0, nx_tx = 0;   // (channel offset, tap) of the NEXT tile to load
   auto load_tile = [&](int ks, int dbuf) {
@@ -155,7 +157,7 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(ConvArgs a) {
         const int tap = ks * 8 + seg * 2 + h;
         const int ty = tap / a.KW, tx = tap - ty * a.KW;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < AR; ++i) {
           const int iy = poy[i] * a.stride + dy0 + ty, ix = pox[i] * a.stride + dx0 + tx;
           const bool ok = pv[i] && ty < a.KH && (unsigned)iy < (unsigned)a.Hin && (unsigned)ix < (unsigned)a.Win;
           float4_t v = {0.f, 0.f, 0.f, 0.f};
@@ -174,7 +176,7 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(ConvArgs a) {
     const SrcView& s = first ? a.s0 : a.s1;
     const int ch = (first ? cc : cc - a.s0.c) + seg * 8;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < AR; ++i) {
       const int iy = poy[i] * a.stride + dy0 + ty, ix = pox[i] * a.stride + dx0 + tx;
       const bool ok = pv[i] && (unsigned)iy < (unsigned)a.Hin && (unsigned)ix < (unsigned)a.Win;
       const int sy = s.up ? iy >> 1 : iy, sx = s.up ? ix >> 1 : ix;
@@ -203,7 +205,7 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(ConvArgs a) {
   };
   auto store_tile = [&](int buf) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < AR; ++i) {
       const int r = (t >> 2) + 64 * i;
       half8_t hi, lo;
       split8(ra[i][0], ra[i][1], hi, lo);
@@ -309,18 +311,19 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(ConvArgs a) {
   }
 }
 
-template <int BN, int WGN, int WGM>
+template <int BN, int SBM, int WGN, int WGM>
 void launch_split_cfg(const ConvArgs& a, hipStream_t st) {
   const int ntn = a.Npad / BN;
   const int ntm = (a.M + SBM - 1) / SBM;
   const dim3 grid((unsigned)(ntn * ntm * a.nphase));
-  if (g_split_wdma) hipLaunchKernelGGL((conv_split_kernel<BN, WGN, WGM, true>), grid, dim3(256), 0, st, a);
-  else hipLaunchKernelGGL((conv_split_kernel<BN, WGN, WGM, false>), grid, dim3(256), 0, st, a);
+  if (g_split_wdma) hipLaunchKernelGGL((conv_split_kernel<BN, SBM, WGN, WGM, true>), grid, dim3(256), 0, st, a);
+  else hipLaunchKernelGGL((conv_split_kernel<BN, SBM, WGN, WGM, false>), grid, dim3(256), 0, st, a);
 }
 
 }  // namespace
 
 int g_split_wdma = 1;   // weight tiles by LDS-DMA (ctd_tuning_set("split_wdma", 0): through registers)
+int g_split_bm256 = 1;  // 256-pixel blocks for 64-channel N tiles on large maps (ctd_tuning_set("split_bm256", 0): 128)
 
 // f32 sources / destination with 16-B aligned channel rows, source channel counts multiples of 32
 bool conv_split_supported(const ConvArgs& a) {
@@ -336,11 +339,12 @@ bool conv_split_supported(const ConvArgs& a) {
 void launch_conv_split(const ConvArgs& a, hipStream_t st) {
   int bn = a.Npad % 128 == 0 ? 128 : (a.Npad % 64 == 0 ? 64 : 32);
   // small maps: narrower N tiles give 2-4x the blocks (the packing is in 32-row blocks, any multiple of 32 reads it)
-  const long long ntm = (a.M + SBM - 1) / SBM;
+  const long long ntm = (a.M + 127) / 128;
   while (bn > 32 && (a.Npad / bn) * ntm * a.nphase < 512) bn >>= 1;
-  if (bn == 128) launch_split_cfg<128, 2, 2>(a, st);
-  else if (bn == 64) launch_split_cfg<64, 1, 4>(a, st);
-  else launch_split_cfg<32, 1, 4>(a, st);
+  if (bn == 128) launch_split_cfg<128, 128, 2, 2>(a, st);
+  else if (bn == 64 && g_split_bm256 && (a.Npad / 64) * ((a.M + 255) / 256) * a.nphase >= 1024) launch_split_cfg<64, 256, 1, 4>(a, st);
+  else if (bn == 64) launch_split_cfg<64, 128, 1, 4>(a, st);
+  else launch_split_cfg<32, 128, 1, 4>(a, st);
 }
 
 // logical weights float [nphase][N][K] (K index = tap * Ctot + c) -> hi plane, lo plane ([nphase][npad/32][K/32][32][32]

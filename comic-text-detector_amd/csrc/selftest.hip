@@ -798,8 +798,11 @@ static void run_split_case(const Case& cs, int B, bool timing) {
   };
   const double ms_f = timing ? time_it([&]() { launch_conv_f32_mfma(af, 0); }) : 0;
   std::printf(" f32-MFMA: err vs f64 rms %.2e max %.2e, %.3f ms %.0f TF |", rms_f, mx_f, ms_f, flops / (ms_f * 1e-3) / 1e12);
-  for (int wdma = 1; wdma >= 0; --wdma) {
+  for (int var = 0; var < 3; ++var) {   // LDS-DMA weights (default) | weights through registers | 128-pixel blocks only
+    const int wdma = var != 1;
     g_split_wdma = wdma;
+    g_split_bm256 = var != 2;
+    if (var == 2 && !(Npad % 64 == 0 && Npad % 128 != 0)) continue;   // only 64-channel N tiles have the 256-pixel variant
     CK(hipMemset(dOut, 0xff, nout * 4));
     launch_conv_split(as, 0);
     CK(hipDeviceSynchronize());
@@ -818,10 +821,11 @@ static void run_split_case(const Case& cs, int B, bool timing) {
     if (fail) ++g_fail;
     const double ms_s = timing ? time_it([&]() { launch_conv_split(as, 0); }) : 0;
     std::printf(" split(%s): %s err vs f64 rms %.2e max %.2e, max|d| vs f32-MFMA %.2e (%zu > 2e-5), %.3f ms %.0f TF %.0f GB/s |",
-                wdma ? "dma" : "reg", fail ? "FAIL" : "ok", rms_s, mx_s, maxd, bad, ms_s, flops / (ms_s * 1e-3) / 1e12,
+                var == 0 ? "dma" : var == 1 ? "reg" : "dma,bm128", fail ? "FAIL" : "ok", rms_s, mx_s, maxd, bad, ms_s, flops / (ms_s * 1e-3) / 1e12,
                 bytes / (ms_s * 1e-3) / 1e9);
   }
   g_split_wdma = 1;
+  g_split_bm256 = 1;
   std::printf("\n");
   (void)hipFree(d0); (void)hipFree(d1); (void)hipFree(dOut); (void)hipFree(dRef); if (dRes) (void)hipFree(dRes);
   (void)hipFree(dWf); (void)hipFree(dWs); (void)hipFree(dBias); (void)hipFree(dOsc);

@@ -150,7 +150,29 @@ def lib() -> C.CDLL:
     if L.ctd_abi_version() != ABI_VERSION:
         raise CtdError("libctd_hip.so ABI version mismatch; rebuild")
     _lib = L
+    _apply_env_tuning(L)
     return L
+
+
+# The library reads no environment variables; dispatch knobs go through `ctd_tuning_set`.  For A/B runs of unchanged
+# scripts the host side applies CTD_TUNING="key=value,key=value" once at load time (and the older per-knob names).
+_LEGACY_ENV = {"CTD_FUSE": "fuse", "CTD_NO_REUSE": "no_reuse", "CTD_F32_MFMA": "f32_mfma", "CTD_HALO_PAIR": "halo_pair",
+               "CTD_HALO_MIN_PATCHES": "halo_min_patches", "CTD_DBUP_MFMA": "db_up_mfma", "CTD_SEGFINAL_MFMA": "seg_final_mfma"}
+
+
+def _apply_env_tuning(L) -> None:
+    items = []
+    for env, key in _LEGACY_ENV.items():
+        if env in os.environ:
+            v = os.environ[env]
+            items.append((key, 1 if (env == "CTD_NO_REUSE" and not v.lstrip("-").isdigit()) else int(v)))
+    for part in os.environ.get("CTD_TUNING", "").split(","):
+        if "=" in part:
+            k, v = part.split("=", 1)
+            items.append((k.strip(), int(v)))
+    for k, v in items:
+        if L.ctd_tuning_set(k.encode(), v) != OK:
+            raise CtdError(f"unknown tuning key {k!r} (CTD_TUNING / legacy environment knob)")
 
 
 def check(rc: int, what: str = "") -> None:

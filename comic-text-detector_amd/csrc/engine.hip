@@ -35,6 +35,8 @@ int fail(int code, const std::string& msg) {
   } while (0)
 
 int g_fuse_epoch = 0;   // bumped when a fusion threshold changes: cached plans are re-made
+int g_no_reuse = 0;     // engines created from now on: no arena reuse (debug: `read_tensor` of any activation); "no_reuse"
+int g_f32_mfma = 1;     // engines created from now on: fp32 convs on the f32 MFMA kernel (0: exact-order direct kernels); "f32_mfma"
 
 enum Impl { IMPL_POINT = 0, IMPL_IGEMM = 1, IMPL_IGEMM_T = 2, IMPL_DIRECT = 3, IMPL_FUSED = 4 };
 
@@ -802,6 +804,7 @@ int prepare(ctd_engine* e, int B, int H, int W, hipStream_t st = nullptr) {
 }  // namespace
 
 int ctd_fail_msg(int code, const std::string& msg) { return fail(code, msg); }
+extern int g_tail_priority;   // tail.hip
 
 extern "C" {
 
@@ -830,8 +833,8 @@ int ctd_engine_create(ctd_engine** out, const ctd_tensor* tensors, int32_t n_ten
   ctd_engine* e = new ctd_engine();
   e->device = device;
   e->prec = precision;
-  e->no_reuse = std::getenv("CTD_NO_REUSE") != nullptr;
-  if (const char* v = std::getenv("CTD_F32_MFMA")) e->f32_mfma = std::atoi(v) != 0;
+  e->no_reuse = g_no_reuse != 0;
+  e->f32_mfma = g_f32_mfma != 0;
 
   e->tensors.resize(n_tensors);
   for (int i = 0; i < n_tensors; ++i) e->tensors[i].t = tensors[i];
@@ -949,8 +952,13 @@ int32_t ctd_engine_arena_generation(const ctd_engine* e) { return e ? e->arena_g
 
 int ctd_tuning_set(const char* key, int64_t value) {
   if (key && std::string(key) == "fuse") { g_fuse = (int)value; return CTD_OK; }
+  if (key && std::string(key) == "tail_priority") { g_tail_priority = (int)value; return CTD_OK; }
+  if (key && std::string(key) == "no_reuse") { g_no_reuse = (int)value; return CTD_OK; }
+  if (key && std::string(key) == "f32_mfma") { g_f32_mfma = (int)value; return CTD_OK; }
   if (key && std::string(key) == "split_wdma") { g_split_wdma = (int)value; return CTD_OK; }
+#ifdef CTD_AB_VARIANTS
   if (key && std::string(key) == "split_bm256") { g_split_bm256 = (int)value; return CTD_OK; }
+#endif
   if (key && std::string(key) == "db_up_mfma") { g_db_up_mfma = (int)value; return CTD_OK; }
   if (key && std::string(key) == "seg_final_mfma") { g_seg_final_mfma = (int)value; return CTD_OK; }
   if (key && std::string(key) == "c3_min_patches") { g_c3_min_patches = value; g_fuse_epoch++; return CTD_OK; }

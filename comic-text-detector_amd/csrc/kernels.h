@@ -51,7 +51,9 @@ void launch_conv_f32_mfma(const ConvArgs& a, hipStream_t st);
 
 // ---- kernels_split.hip : split-operand (fp16 hi + lo, 3 MFMAs per product) conv on f32 tensors: the "fp32s" engine ----
 extern int g_split_wdma;   // 1: weight tiles by LDS-DMA, 0: through registers (ctd_tuning_set("split_wdma"))
-extern int g_split_bm256;  // 1: 256-pixel blocks for 64-channel N tiles (ctd_tuning_set("split_bm256"))
+#ifdef CTD_AB_VARIANTS
+extern int g_split_bm256;  // selftest build: 1 = 256-pixel blocks for 64-channel N tiles (ctd_tuning_set("split_bm256"))
+#endif
 bool conv_split_supported(const ConvArgs& a);
 void launch_conv_split(const ConvArgs& a, hipStream_t st);
 // logical f32 [nphase][N][K] -> hi plane + lo plane (halves, [nphase][npad/32][K/32][32][32] each) + oscale[npad]

@@ -320,12 +320,9 @@ __global__ __launch_bounds__(256, 2) void c3_fused_kernel(C3Args a) {
 }  // namespace
 
 // Multi-layer fusions of the fp16 engine, one bit each: 1 = C3 block (this file), 2 = SPPF's three pools
-// (kernels_basic.hip), 4 = stem + model.1 (kernels_fused.hip).  CTD_FUSE=0 runs the layer-per-launch program
-// (A/B knob; also ctd_tuning_set("fuse", mask)).
-int g_fuse = [] {
-  const char* e = std::getenv("CTD_FUSE");
-  return e ? std::atoi(e) : 7;
-}();
+// (kernels_basic.hip), 4 = stem + model.1 (kernels_fused.hip).  ctd_tuning_set("fuse", 0) runs the layer-per-launch
+// program (the bit-identity tests and A/B runs use it).
+int g_fuse = 7;
 
 long long g_c3_min_patches = 1024;   // fewer 128-pixel patches: the per-layer kernels (ctd_tuning_set("c3_min_patches"))
 

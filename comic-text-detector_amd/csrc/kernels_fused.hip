@@ -675,14 +675,8 @@ void launch_seg_final_f32(const float* src, int pitch, int C, int B, int H, int 
   (void)C;
 }
 
-int g_seg_final_mfma = [] {   // CTD_SEGFINAL_MFMA=0: the VALU kernel (A/B knob; ctd_tuning_set("seg_final_mfma"))
-  const char* e = std::getenv("CTD_SEGFINAL_MFMA");
-  return e ? std::atoi(e) : 1;
-}();
-int g_db_up_mfma = [] {   // CTD_DBUP_MFMA=0: the VALU kernel (A/B knob; ctd_tuning_set("db_up_mfma"))
-  const char* e = std::getenv("CTD_DBUP_MFMA");
-  return e ? std::atoi(e) : 1;
-}();
+int g_seg_final_mfma = 1;   // ctd_tuning_set("seg_final_mfma", 0): the VALU kernel (the fallback for odd pitches; A/B reference)
+int g_db_up_mfma = 1;   // ctd_tuning_set("db_up_mfma", 0): the VALU kernel (the fallback for odd pitches; A/B reference)
 
 void launch_db_up(const void* src, bool f32in, int pitch, int q, int nbr, int B, int H, int W, const float* params, float* lines,
                   uint8_t* bitmap, float thresh, hipStream_t st) {

@@ -23,10 +23,14 @@
 #include "kernels.h"
 
 int g_conv_halo = 1;   // selftest / tuning: 0 sends everything to the implicit-GEMM kernel
-int g_halo_tps = [] {   // taps per barrier of the halo kernel: 1 or 2 (CTD_HALO_TPS; A/B knob)
-  const char* e = std::getenv("CTD_HALO_TPS");
-  return e ? std::atoi(e) : 1;
-}();
+// A/B variants that lost their measurements (two taps per barrier, 1x1 layers through this kernel, the
+// cycle-stamped instantiation) exist in the selftest build only (-DCTD_AB_VARIANTS, csrc/Makefile); the product library
+// holds the kernels the engine launches, and no environment reads.
+#ifdef CTD_AB_VARIANTS
+int g_halo_tps = 1;     // taps per barrier of the halo kernel: 1 or 2 (conv_tuning_set("halo_tps"))
+#else
+constexpr int g_halo_tps = 1;
+#endif
 
 namespace {
 
@@ -356,30 +360,40 @@ void launch_halo_cfg(const ConvArgs& a, hipStream_t st) {
   const int ntn = a.Npad / BN;
   const int tilesX = (a.Mw + TWP - 1) / TWP, tilesY = (a.Mh + THP - 1) / THP;
   dim3 grid((unsigned)(ntn * a.nphase * tilesX * tilesY * a.B), 1, 1);
-  if ((a.k_rot & 16) && a.dbg) hipLaunchKernelGGL((conv_halo_kernel<BN, WGN, WGM, true>), grid, dim3(NTHR), 0, st, a);
-  else if (g_halo_tps == 2) hipLaunchKernelGGL((conv_halo_kernel<BN, WGN, WGM, false, 2>), grid, dim3(NTHR), 0, st, a);
-  else hipLaunchKernelGGL((conv_halo_kernel<BN, WGN, WGM, false>), grid, dim3(NTHR), 0, st, a);
+#ifdef CTD_AB_VARIANTS
+  if ((a.k_rot & 16) && a.dbg) {
+    hipLaunchKernelGGL((conv_halo_kernel<BN, WGN, WGM, true>), grid, dim3(NTHR), 0, st, a);
+    return;
+  }
+  if (g_halo_tps == 2) {
+    hipLaunchKernelGGL((conv_halo_kernel<BN, WGN, WGM, false, 2>), grid, dim3(NTHR), 0, st, a);
+    return;
+  }
+#endif
+  hipLaunchKernelGGL((conv_halo_kernel<BN, WGN, WGM, false>), grid, dim3(NTHR), 0, st, a);
 }
 
 }  // namespace
 
-// Dispatch knobs of the halo kernel.  Initialised ONCE from the environment (A/B runs of the selftest and the
-// bench), changeable at run time through ctd_tuning_set (tests force the halo kernel onto small maps that way:
-// an environment variable read at the first convolution cannot be changed by a later test of the same process).
-static long long env_ll(const char* name, long long dflt) {
-  const char* e = std::getenv(name);
-  return e ? std::atoll(e) : dflt;
-}
-long long g_halo_min_patches = env_ll("CTD_HALO_MIN_PATCHES", 1024);   // fewer 256-pixel patches: implicit GEMM
-int g_halo_1x1 = (int)env_ll("CTD_HALO_1X1", 0);                       // 1x1 layers through the halo kernel
-int g_halo_pair = (int)env_ll("CTD_HALO_PAIR", 1);                     // 64-channel ConvT: both px phases per block
+// Dispatch knobs of the halo kernel, changeable at run time through ctd_tuning_set (tests force the halo kernel onto
+// small maps that way; the host side applies CTD_TUNING="key=value,..." once after loading the library).
+long long g_halo_min_patches = 1024;   // fewer 256-pixel patches: implicit GEMM
+int g_halo_pair = 1;                   // 64-channel ConvT: both px phases per block
+#ifdef CTD_AB_VARIANTS
+int g_halo_1x1 = 0;                    // 1x1 layers through the halo kernel (measured slower: selftest only)
+#else
+constexpr int g_halo_1x1 = 0;
+#endif
 
 int conv_tuning_set(const char* key, long long value) {
   const std::string k(key ? key : "");
   if (k == "halo_min_patches") g_halo_min_patches = value;
-  else if (k == "halo_1x1") g_halo_1x1 = (int)value;
   else if (k == "halo_pair") g_halo_pair = (int)value;
   else if (k == "halo") g_conv_halo = (int)value;
+#ifdef CTD_AB_VARIANTS
+  else if (k == "halo_1x1") g_halo_1x1 = (int)value;
+  else if (k == "halo_tps") g_halo_tps = (int)value;
+#endif
   else return -1;
   return 0;
 }

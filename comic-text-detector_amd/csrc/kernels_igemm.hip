@@ -27,7 +27,7 @@
 
 #include "kernels.h"
 
-int g_igemm_occ_lo = 0;  // tuning: 1 = register-staged loads instead of LDS-DMA
+int g_igemm_occ_lo = 0;  // selftest build (-DCTD_AB_VARIANTS) only: 1 = register-staged loads instead of LDS-DMA
 
 namespace {
 
@@ -472,13 +472,15 @@ void launch_cfg(const ConvArgs& a, bool dst_f32, hipStream_t st) {
   (void)LO;
   if (dst_f32) {
     hipLaunchKernelGGL((conv_igemm_kernel<BN, BM, WGN, WGM, BK, true, HI, 1>), grid, dim3(256), 0, st, a);
-  } else if (g_igemm_occ_lo == 1) {   // tuning variant: register-staged loads (global -> VGPR -> ds_write)
+#ifdef CTD_AB_VARIANTS                // selftest build only: the A/B variants that lost, and the instrumented instantiations
+  } else if (g_igemm_occ_lo == 1) {   // register-staged loads (global -> VGPR -> ds_write)
     hipLaunchKernelGGL((conv_igemm_kernel<BN, BM, WGN, WGM, BK, false, HI, 1>), grid, dim3(256), 0, st, a);
-  } else if ((a.k_rot & 16) && a.dbg) {   // selftest: cycle-stamped instantiation
+  } else if ((a.k_rot & 16) && a.dbg) {   // cycle-stamped instantiation
     hipLaunchKernelGGL((conv_igemm_kernel<BN, BM, WGN, WGM, BK, false, HI, 2, true, true>), grid, dim3(256), 0, st, a);
-  } else if (a.k_rot) {                   // selftest: ablation instantiation
+  } else if (a.k_rot) {                   // ablation instantiation
     hipLaunchKernelGGL((conv_igemm_kernel<BN, BM, WGN, WGM, BK, false, HI, 2, false, true>), grid, dim3(256), 0, st, a);
-  } else {                            // default: LDS-DMA (global_load_lds, 16 B per lane), +5..10 % measured
+#endif
+  } else {                            // LDS-DMA (global_load_lds, 16 B per lane), +5..10 % measured
     hipLaunchKernelGGL((conv_igemm_kernel<BN, BM, WGN, WGM, BK, false, HI, 2>), grid, dim3(256), 0, st, a);
   }
 }

@@ -323,7 +323,9 @@ void launch_split_cfg(const ConvArgs& a, hipStream_t st) {
 }  // namespace
 
 int g_split_wdma = 1;   // weight tiles by LDS-DMA (ctd_tuning_set("split_wdma", 0): through registers)
-int g_split_bm256 = 1;  // 256-pixel blocks for 64-channel N tiles on large maps (ctd_tuning_set("split_bm256", 0): 128)
+#ifdef CTD_AB_VARIANTS    // selftest build only: 256-pixel blocks for 64-channel N tiles -- measured 3-20 % SLOWER than 128
+int g_split_bm256 = 0;    // (profiles/r03_split_selftest.txt): the 80-KB block leaves no LDS for a third block per CU
+#endif
 
 // f32 sources / destination with 16-B aligned channel rows, source channel counts multiples of 32
 bool conv_split_supported(const ConvArgs& a) {
@@ -342,7 +344,9 @@ void launch_conv_split(const ConvArgs& a, hipStream_t st) {
   const long long ntm = (a.M + 127) / 128;
   while (bn > 32 && (a.Npad / bn) * ntm * a.nphase < 512) bn >>= 1;
   if (bn == 128) launch_split_cfg<128, 128, 2, 2>(a, st);
+#ifdef CTD_AB_VARIANTS
   else if (bn == 64 && g_split_bm256 && (a.Npad / 64) * ((a.M + 255) / 256) * a.nphase >= 1024) launch_split_cfg<64, 256, 1, 4>(a, st);
+#endif
   else if (bn == 64) launch_split_cfg<64, 128, 1, 4>(a, st);
   else launch_split_cfg<32, 128, 1, 4>(a, st);
 }

@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <string>
 #include <vector>
 
 #include "kernels.h"
@@ -798,10 +799,10 @@ static void run_split_case(const Case& cs, int B, bool timing) {
   };
   const double ms_f = timing ? time_it([&]() { launch_conv_f32_mfma(af, 0); }) : 0;
   std::printf(" f32-MFMA: err vs f64 rms %.2e max %.2e, %.3f ms %.0f TF |", rms_f, mx_f, ms_f, flops / (ms_f * 1e-3) / 1e12);
-  for (int var = 0; var < 3; ++var) {   // LDS-DMA weights (default) | weights through registers | 128-pixel blocks only
+  for (int var = 0; var < 3; ++var) {   // LDS-DMA weights (default) | weights through registers | 256-pixel blocks for 64-channel tiles
     const int wdma = var != 1;
     g_split_wdma = wdma;
-    g_split_bm256 = var != 2;
+    g_split_bm256 = var == 2;
     if (var == 2 && !(Npad % 64 == 0 && Npad % 128 != 0)) continue;   // only 64-channel N tiles have the 256-pixel variant
     CK(hipMemset(dOut, 0xff, nout * 4));
     launch_conv_split(as, 0);
@@ -821,11 +822,11 @@ static void run_split_case(const Case& cs, int B, bool timing) {
     if (fail) ++g_fail;
     const double ms_s = timing ? time_it([&]() { launch_conv_split(as, 0); }) : 0;
     std::printf(" split(%s): %s err vs f64 rms %.2e max %.2e, max|d| vs f32-MFMA %.2e (%zu > 2e-5), %.3f ms %.0f TF %.0f GB/s |",
-                var == 0 ? "dma" : var == 1 ? "reg" : "dma,bm128", fail ? "FAIL" : "ok", rms_s, mx_s, maxd, bad, ms_s, flops / (ms_s * 1e-3) / 1e12,
+                var == 0 ? "dma" : var == 1 ? "reg" : "dma,bm256", fail ? "FAIL" : "ok", rms_s, mx_s, maxd, bad, ms_s, flops / (ms_s * 1e-3) / 1e12,
                 bytes / (ms_s * 1e-3) / 1e9);
   }
   g_split_wdma = 1;
-  g_split_bm256 = 1;
+  g_split_bm256 = 0;
   std::printf("\n");
   (void)hipFree(d0); (void)hipFree(d1); (void)hipFree(dOut); (void)hipFree(dRef); if (dRes) (void)hipFree(dRes);
   (void)hipFree(dWf); (void)hipFree(dWs); (void)hipFree(dBias); (void)hipFree(dOsc);
@@ -839,6 +840,19 @@ int main(int argc, char** argv) {
   int64_t hbm = 0;
   const int arch = ctd_device_info(0, name, &cus, &hbm);
   std::printf("device: %s gfx%d CUs=%d HBM=%.1f GB\n", name, arch, cus, hbm / 1e9);
+  if (const char* tu = std::getenv("CTD_TUNING")) {   // "key=value,key=value" -> ctd_tuning_set (this build has the A/B keys too)
+    std::string s(tu);
+    for (size_t p = 0; p < s.size();) {
+      const size_t e = s.find(',', p), q = s.find('=', p);
+      const size_t end = e == std::string::npos ? s.size() : e;
+      if (q != std::string::npos && q < end) {
+        const std::string k = s.substr(p, q - p);
+        const long long v = std::atoll(s.substr(q + 1, end - q - 1).c_str());
+        std::printf("tuning %s = %lld: %s\n", k.c_str(), v, ctd_tuning_set(k.c_str(), v) == CTD_OK ? "ok" : "UNKNOWN KEY");
+      }
+      p = end + 1;
+    }
+  }
   probe();
   const Case cases[] = {
       // name, kind, c0, c1, up0, N, k, s, H, res           (SURVEY App. B shapes)

@@ -29,6 +29,7 @@
 #include "tail.h"
 
 int ctd_fail_msg(int code, const std::string& msg);   // engine.hip: sets the thread-local error text
+int g_tail_priority = 0;                               // stream priority of tails created from now on (engine.hip: tuning)
 
 #define T_TRY(expr)                                                                                  \
   do {                                                                                               \
@@ -698,7 +699,10 @@ int ctd_tail_create(ctd_tail** out, int32_t device) {
   t->device = device;
   int lo = 0, hi = 0;
   (void)hipDeviceGetStreamPriorityRange(&lo, &hi);   // hi = numerically lowest = highest priority
-  if (hipStreamCreateWithPriority(&t->st, hipStreamNonBlocking, hi) != hipSuccess) {
+  // ctd_tuning_set("tail_priority"): 0 = highest (default: a batch's tail finishes early and frees its pipeline slot),
+  // 1 = the device's default priority, 2 = lowest (the forward's kernels go first, the tail fills the gaps)
+  const int prio = g_tail_priority == 2 ? lo : (g_tail_priority == 1 ? (lo + hi) / 2 : hi);
+  if (hipStreamCreateWithPriority(&t->st, hipStreamNonBlocking, prio) != hipSuccess) {
     delete t;
     return ctd_fail_msg(CTD_ERR_HIP, "hipStreamCreateWithPriority failed");
   }

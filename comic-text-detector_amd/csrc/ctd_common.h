@@ -82,6 +82,17 @@ template <int ACT> __device__ __forceinline__ float ctd_act_fast(float v) {
   if (ACT == CTD_ACT_SIGMOID) return __builtin_amdgcn_rcpf(1.0f + __expf(-v));
   return v;
 }
+// run-time activation with the arithmetic of ctd_act_fast (the stem kernels: their SiLU with a true division was a
+// dozen VALU instructions per element on 18 k elements per block)
+__device__ __forceinline__ float ctd_act_fast_rt(float v, int act) {
+  switch (act) {
+    case CTD_ACT_SILU: return ctd_act_fast<CTD_ACT_SILU>(v);
+    case CTD_ACT_LEAKY: return ctd_act_fast<CTD_ACT_LEAKY>(v);
+    case CTD_ACT_RELU: return ctd_act_fast<CTD_ACT_RELU>(v);
+    case CTD_ACT_SIGMOID: return ctd_act_fast<CTD_ACT_SIGMOID>(v);
+    default: return v;
+  }
+}
 // exact-ish variants for the fp32 parity mode (expf instead of the fast exp)
 __device__ __forceinline__ float ctd_act_precise(float v, int act) {
   switch (act) {

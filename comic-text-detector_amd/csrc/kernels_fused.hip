@@ -123,7 +123,7 @@ __global__ __launch_bounds__(256) void stem_mfma_kernel(const void* __restrict__
       const float4_t bv = *(const float4_t*)(bias + 8 * q + 4 * hi);
       half4_t o;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) o[e] = (half_t)ctd_act(acc[4 * q + e] * oscale + bv[e], act);
+      for (int e = 0; e < 4; ++e) o[e] = (half_t)ctd_act_fast_rt(acc[4 * q + e] * oscale + bv[e], act);
       *(half4_t*)(os + lx * SM_OP + 8 * q + 4 * hi) = o;
     }
     __builtin_amdgcn_wave_barrier();

@@ -190,7 +190,7 @@ __global__ __launch_bounds__(256, 2) void stem_conv2_kernel(Stem2Args a) {
       const float4_t bv = *(const float4_t*)(bias_s + 8 * g + 4 * khalf);
       half4_t o;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) o[e] = keep ? (half_t)ctd_act(acc[4 * g + e] * oscale + bv[e], ACT0) : (half_t)0.f;
+      for (int e = 0; e < 4; ++e) o[e] = keep ? (half_t)ctd_act_fast_rt(acc[4 * g + e] * oscale + bv[e], ACT0) : (half_t)0.f;
       *(half4_t*)(S + p * 32 + ((g ^ swz(p)) * 8) + 4 * khalf) = o;
     }
   }

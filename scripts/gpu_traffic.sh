@@ -3,12 +3,14 @@
 # their own --pmc passes, --kernel-trace only), on the same workload as bench.py.
 export TMPDIR=/tmp
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
-OUT=$ROOT/gpurun_out/traffic
+PREC=${1:-fp16}
+OUT=$ROOT/gpurun_out/traffic_$PREC
 mkdir -p $OUT
 cd /tmp
 for C in FETCH_SIZE WRITE_SIZE; do
   timeout 600 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/$C -o $C -- \
-     python $ROOT/bench.py --mode net --steps 1 --warmup 1 --spinup 0 --no-cpu-baseline > $OUT/$C.log 2>&1
+     python $ROOT/bench.py --precision $PREC --mode net --steps 1 --warmup 1 --spinup 0 --no-cpu-baseline --no-extras > $OUT/$C.log 2>&1
   echo "$C rc=$?"
 done
-python3 $ROOT/scripts/traffic_summary.py $OUT
+find $OUT -name "*kernel_trace.csv" -delete
+python3 $ROOT/scripts/traffic_summary.py $OUT $PREC

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
-"""Sum FETCH_SIZE / WRITE_SIZE of the conv_halo_kernel + conv_igemm_kernel (+ c3_fused_kernel) dispatches of a bench.py run
-(--mode net --steps 1 --warmup 1; the number of forwards in the run = the number of stem kernel dispatches)
-and write traffic.json."""
+"""Sum FETCH_SIZE / WRITE_SIZE of the conv family's dispatches of a bench.py run (--mode net --steps 1 --warmup 1; the number
+of forwards in the run = the number of seg-final kernel dispatches) and write traffic.json.
+usage: traffic_summary.py <dir> [fp16|fp32s|fp32]"""
 import collections
 import csv
 import glob
@@ -9,6 +9,9 @@ import json
 import sys
 
 out = sys.argv[1]
+# kernel family by engine: fp16 (default) | fp32s | fp32
+FAMILY = {"fp16": ("conv_igemm_kernel", "conv_halo_kernel", "c3_fused_kernel"), "fp32s": ("conv_split_kernel", "conv_f32_mfma_kernel"),
+          "fp32": ("conv_f32_mfma_kernel",)}[sys.argv[2] if len(sys.argv) > 2 else "fp16"]
 tot = collections.defaultdict(lambda: [0.0, 0])
 stems = collections.defaultdict(int)
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
@@ -16,10 +19,10 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
         for r in csv.DictReader(open(f)):
             if r["Counter_Name"] != c:
                 continue
-            if any(k in r["Kernel_Name"] for k in ("conv_igemm_kernel", "conv_halo_kernel", "c3_fused_kernel")):
+            if any(k in r["Kernel_Name"] for k in FAMILY):
                 tot[c][0] += float(r["Counter_Value"])
                 tot[c][1] += 1
-            if "stem_mfma_kernel" in r["Kernel_Name"] or "stem_conv2_kernel" in r["Kernel_Name"]:
+            if "seg_final" in r["Kernel_Name"]:          # one per forward in every engine
                 stems[c] += 1
 n_fwd = max(stems["FETCH_SIZE"], 1)
 res = {

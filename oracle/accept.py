@@ -121,7 +121,7 @@ def _box_iou(a, b) -> float:
 
 
 def explain_geometry(result, ref_result, flips: np.ndarray, ratio_xy=(1.0, 1.0), dets=None, ref_dets=None,
-                     margin: int = 3) -> dict:
+                     score_band_boxes=None, margin: int = 3) -> dict:
     """Attributes every text line / block that is not IDENTICAL between the product's result and the oracle's to one of
     the threshold-type decisions the network's small deviation can move (the tail itself is bit-exact on equal inputs):
 
@@ -132,6 +132,9 @@ def explain_geometry(result, ref_result, flips: np.ndarray, ratio_xy=(1.0, 1.0),
       det    it lies in the region of a yolo detection that NMS kept on one side only, or kept with coordinates more than
              1 px apart (`dets` / `ref_dets`: the float (n, >=4) NMS outputs of both sides, network coordinates): greedy NMS
              is order dependent, and random-weight confidences sit on a plateau where a 1e-3 change swaps the order;
+      score  it overlaps a DB box whose score in the ORACLE lies within eps of the 0.6 gate (reference inference.py:159;
+             `score_band_boxes`: those boxes, (n,4,2) in network coordinates): the score is a mean of the shrink map over the
+             box's polygon, so it moves by less than the map error and the line appears on one side only;
       lines  (blocks only) one of its lines differs, and that line is attributed above.
 
     `*_unexplained` must be 0 for the claim "every difference comes from a decision variable within the engine's error of
@@ -176,12 +179,20 @@ def explain_geometry(result, ref_result, flips: np.ndarray, ratio_xy=(1.0, 1.0),
     def in_changed(x1, y1, x2, y2, m=4):
         return any(not (x2 < c[0] - m or x1 > c[2] + m or y2 < c[1] - m or y1 > c[3] + m) for c in changed)
 
+    sb_boxes = []
+    if score_band_boxes is not None and len(score_band_boxes):
+        q = np.asarray(score_band_boxes, np.float64).reshape(-1, 4, 2)
+        sb_boxes = [np.array([b[:, 0].min() / rx, b[:, 1].min() / ry, b[:, 0].max() / rx, b[:, 1].max() / ry]) for b in q]
+
+    def in_score_band(x1, y1, x2, y2, m=4):
+        return any(not (x2 < c[0] - m or x1 > c[2] + m or y2 < c[1] - m or y1 > c[3] + m) for c in sb_boxes)
+
     la, ba = boxes_of(result)
     lb, bb = boxes_of(ref_result)
     keyl = lambda q: q.astype(np.int64).tobytes()          # noqa: E731
     sa, sb = {keyl(q) for q in la}, {keyl(q) for q in lb}
-    out = {"detections_changed": len(changed)}
-    cat = {"flip": 0, "near": 0, "det": 0, "unexplained": 0}
+    out = {"detections_changed": len(changed), "boxes_in_score_band": len(sb_boxes)}
+    cat = {"flip": 0, "near": 0, "det": 0, "score": 0, "unexplained": 0}
     for q, other in [(q, lb) for q in la if keyl(q) not in sb] + [(q, la) for q in lb if keyl(q) not in sa]:
         box = (q[:, 0].min(), q[:, 1].min(), q[:, 0].max(), q[:, 1].max())
         if touched(*box):
@@ -190,6 +201,8 @@ def explain_geometry(result, ref_result, flips: np.ndarray, ratio_xy=(1.0, 1.0),
             cat["near"] += 1
         elif in_changed(*box):
             cat["det"] += 1
+        elif in_score_band(*box):
+            cat["score"] += 1
         else:
             cat["unexplained"] += 1
     out["lines_differing"] = sum(cat.values())
@@ -199,7 +212,7 @@ def explain_geometry(result, ref_result, flips: np.ndarray, ratio_xy=(1.0, 1.0),
     ka, kb = [keyb(t) for t in ba], [keyb(t) for t in bb]
     ska, skb = set(ka), set(kb)
     both = sa & sb
-    cat = {"lines": 0, "near": 0, "flip": 0, "det": 0, "unexplained": 0}
+    cat = {"lines": 0, "near": 0, "flip": 0, "det": 0, "score": 0, "unexplained": 0}
     for (xy, ls), other in [(t, kb) for t in ka if t not in skb] + [(t, ka) for t in kb if t not in ska]:
         if any(ln not in both for ln in ls):
             cat["lines"] += 1
@@ -209,9 +222,21 @@ def explain_geometry(result, ref_result, flips: np.ndarray, ratio_xy=(1.0, 1.0),
             cat["flip"] += 1
         elif in_changed(*xy):
             cat["det"] += 1
+        elif in_score_band(*xy):
+            cat["score"] += 1
         else:
             cat["unexplained"] += 1
     out["blocks_differing"] = sum(cat.values())
     out["blocks_by_cause"] = dict(cat)
     out["blocks_unexplained"] = cat["unexplained"]
     return out
+
+
+def score_band_boxes(lines_map: np.ndarray, input_size, eps: float, box_thresh: float = 0.6) -> np.ndarray:
+    """The oracle's DB boxes (all contours, `SegDetectorRepresenter.__call__`) whose score lies within eps of the gate the
+    detector applies to them (reference inference.py:159-161): (n,4,2) in network coordinates."""
+    from . import postproc_ref as R
+    boxes, scores = R.seg_rep(input_size, lines_map)
+    b, sc = np.asarray(boxes[0]), np.asarray(scores[0])
+    keep = np.abs(sc.astype(np.float64) - box_thresh) < eps
+    return b[keep].reshape(-1, 4, 2)

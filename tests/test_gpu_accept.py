@@ -28,6 +28,7 @@ def blob_ckpt():
     return _CK[0]
 
 
+EPS_FP16 = 4e-3       # bound on the fp16 engine's map error (see the band test at the end of this file)
 _ORACLE = {}
 
 
@@ -42,7 +43,8 @@ def oracle_full(ck, page, size, key):
         ref = R.detector_tail(page, blks.numpy(), mask.numpy(), lines_map.numpy(), input_size=(size, size), dw=dw, dh=dh,
                               refine_mode=0, keep_undetected_mask=False)
         dets = R.non_max_suppression(blks.numpy(), 0.4, 0.35)[0]
-        _ORACLE[key] = (ref, mask[0, 0].numpy(), lines_map[0, 0].numpy(), (dw, dh), np.asarray(dets))
+        sbb = accept.score_band_boxes(lines_map.numpy(), (size, size), EPS_FP16)
+        _ORACLE[key] = (ref, mask[0, 0].numpy(), lines_map[0, 0].numpy(), (dw, dh), np.asarray(dets), sbb)
     return _ORACLE[key]
 
 
@@ -83,18 +85,16 @@ def test_detector_end_to_end_vs_oracle(prec, size, shape):
 #   (2) every pixel of the DB bitmap (threshold 0.3) or of the mask at u8 level 127 that differs from the oracle's lies
 #       within EPS of the threshold IN THE ORACLE'S MAP, and that band is a thin shell (< 1 % of the pixels);
 #   (3) every text line / block that is not identical to the oracle's is attributed to such a pixel, to an int32 truncation
-#       of coordinates a fraction of a pixel apart, or to a yolo detection NMS kept differently (oracle/accept.py
-#       explain_geometry) -- nothing is left unexplained.
+#       of coordinates a fraction of a pixel apart, to a yolo detection NMS kept differently, or to a DB box whose oracle score
+#       lies within EPS of the 0.6 gate (oracle/accept.py explain_geometry) -- nothing is left unexplained.
 # `bench.py`'s `parity.fp16_band` prints the same numbers for the benchmark's page.
-EPS_FP16 = 4e-3
-
 
 @pytest.mark.parametrize("size,shape", [(512, (512, 512)), (1024, (1024, 1024)), (512, (700, 495))])
 def test_fp16_engine_deviation_is_confined_to_the_threshold_band(size, shape):
     p = pkg()
     ck = blob_ckpt()
     page = p.synth.text_like_page(shape, 3, n_blocks=8)
-    ref, om, ol, (dw, dh), ref_dets = oracle_full(ck, page, size, (size, page.shape))
+    ref, om, ol, (dw, dh), ref_dets, sbb = oracle_full(ck, page, size, (size, page.shape))
     det = p.detector.TextDetector(ck, input_size=size, device="cuda", precision="fp16")
     got = det(page, refine_mode=0, keep_undetected_mask=False)
     net = det.net
@@ -106,7 +106,7 @@ def test_fp16_engine_deviation_is_confined_to_the_threshold_band(size, shape):
     flips = rep.pop("_flips")
     im_h, im_w = page.shape[:2]
     geo = accept.explain_geometry(got, ref, flips, ratio_xy=((size - dw) / im_w, (size - dh) / im_h),
-                                  dets=dets[0, : int(counts[0])].cpu().numpy(), ref_dets=ref_dets)
+                                  dets=dets[0, : int(counts[0])].cpu().numpy(), ref_dets=ref_dets, score_band_boxes=sbb)
     print(f"\nfp16 band size={size} page={shape}: {rep} {geo}")
     assert rep["prob_max_abs_delta"] < EPS_FP16 and rep["mask_max_abs_delta"] < EPS_FP16
     assert rep["bitmap_flips_out_of_band"] == 0 and rep["mask127_flips_out_of_band"] == 0

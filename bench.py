@@ -297,6 +297,7 @@ def parity_block(pkg, ckpt, det, page: np.ndarray, size: int) -> dict:
                           keep_undetected_mask=False)
     ref_dets = np.asarray(R.non_max_suppression(ob.numpy(), 0.4, 0.35)[0])
     sbb = accept.score_band_boxes(ol.numpy(), (size, size), FP16_BAND_EPS)
+    ref_cand = np.asarray(R.seg_rep((size, size), ol.numpy())[0][0])
     BKm = importlib.import_module("comic-text-detector_amd.backend")
     out = {"page": f"first page of the benchmark input ({size}x{size}), benchmark checkpoint; oracle = CPU fp32 restatement "
                    "of the reference net + restated tail", "engines": {}}
@@ -313,8 +314,9 @@ def parity_block(pkg, ckpt, det, page: np.ndarray, size: int) -> dict:
                                   mask=mask[0, 0].cpu().numpy())
         flips = band.pop("_flips")
         dets, counts = BKm.nms(blks, 0.4, 0.35)
+        extras = d.tail_batch([page], blks, d.net.mask_u8, lines[:, 0].contiguous(), d.net.bitmap, want_extras=True)[0][3]
         band.update(accept.explain_geometry(got, ref, flips, dets=dets[0, : int(counts[0])].cpu().numpy(), ref_dets=ref_dets,
-                                            score_band_boxes=sbb))
+                                            score_band_boxes=sbb, candidates=(extras["db_boxes"], ref_cand, 1000)))
         rep["band"] = band
         out["engines"][prec] = rep
         if d is not det:

@@ -121,7 +121,7 @@ def _box_iou(a, b) -> float:
 
 
 def explain_geometry(result, ref_result, flips: np.ndarray, ratio_xy=(1.0, 1.0), dets=None, ref_dets=None,
-                     score_band_boxes=None, margin: int = 3) -> dict:
+                     score_band_boxes=None, candidates=None, margin: int = 3) -> dict:
     """Attributes every text line / block that is not IDENTICAL between the product's result and the oracle's to one of
     the threshold-type decisions the network's small deviation can move (the tail itself is bit-exact on equal inputs):
 
@@ -135,6 +135,10 @@ def explain_geometry(result, ref_result, flips: np.ndarray, ratio_xy=(1.0, 1.0),
       score  it overlaps a DB box whose score in the ORACLE lies within eps of the 0.6 gate (reference inference.py:159;
              `score_band_boxes`: those boxes, (n,4,2) in network coordinates): the score is a mean of the shrink map over the
              box's polygon, so it moves by less than the map error and the line appears on one side only;
+      cut    the page has more contours than `max_candidates` (1000, reference utils/db_utils.py:33,137: only the FIRST
+             1000 contours are looked at) on both sides, and it overlaps a candidate box that made the cut on one side only:
+             a flipped pixel elsewhere adds or removes a contour and shifts the window (`candidates` = (ours (n,4,2), the
+             oracle's (m,4,2), max_candidates), network coordinates);
       lines  (blocks only) one of its lines differs, and that line is attributed above.
 
     `*_unexplained` must be 0 for the claim "every difference comes from a decision variable within the engine's error of
@@ -187,12 +191,24 @@ def explain_geometry(result, ref_result, flips: np.ndarray, ratio_xy=(1.0, 1.0),
     def in_score_band(x1, y1, x2, y2, m=4):
         return any(not (x2 < c[0] - m or x1 > c[2] + m or y2 < c[1] - m or y1 > c[3] + m) for c in sb_boxes)
 
+    cut_boxes = []
+    if candidates is not None:
+        ca, cb, cmax = candidates
+        ca, cb = np.asarray(ca).reshape(-1, 4, 2).astype(np.int64), np.asarray(cb).reshape(-1, 4, 2).astype(np.int64)
+        if len(ca) >= cmax and len(cb) >= cmax:
+            ka, kb = {q.tobytes() for q in ca}, {q.tobytes() for q in cb}
+            one = [q for q in ca if q.tobytes() not in kb] + [q for q in cb if q.tobytes() not in ka]
+            cut_boxes = [np.array([b[:, 0].min() / rx, b[:, 1].min() / ry, b[:, 0].max() / rx, b[:, 1].max() / ry]) for b in one]
+
+    def in_cut(x1, y1, x2, y2, m=4):
+        return any(not (x2 < c[0] - m or x1 > c[2] + m or y2 < c[1] - m or y1 > c[3] + m) for c in cut_boxes)
+
     la, ba = boxes_of(result)
     lb, bb = boxes_of(ref_result)
     keyl = lambda q: q.astype(np.int64).tobytes()          # noqa: E731
     sa, sb = {keyl(q) for q in la}, {keyl(q) for q in lb}
-    out = {"detections_changed": len(changed), "boxes_in_score_band": len(sb_boxes)}
-    cat = {"flip": 0, "near": 0, "det": 0, "score": 0, "unexplained": 0}
+    out = {"detections_changed": len(changed), "boxes_in_score_band": len(sb_boxes), "candidates_cut_differently": len(cut_boxes)}
+    cat = {"flip": 0, "near": 0, "det": 0, "score": 0, "cut": 0, "unexplained": 0}
     for q, other in [(q, lb) for q in la if keyl(q) not in sb] + [(q, la) for q in lb if keyl(q) not in sa]:
         box = (q[:, 0].min(), q[:, 1].min(), q[:, 0].max(), q[:, 1].max())
         if touched(*box):
@@ -203,6 +219,8 @@ def explain_geometry(result, ref_result, flips: np.ndarray, ratio_xy=(1.0, 1.0),
             cat["det"] += 1
         elif in_score_band(*box):
             cat["score"] += 1
+        elif in_cut(*box):
+            cat["cut"] += 1
         else:
             cat["unexplained"] += 1
     out["lines_differing"] = sum(cat.values())
@@ -212,7 +230,7 @@ def explain_geometry(result, ref_result, flips: np.ndarray, ratio_xy=(1.0, 1.0),
     ka, kb = [keyb(t) for t in ba], [keyb(t) for t in bb]
     ska, skb = set(ka), set(kb)
     both = sa & sb
-    cat = {"lines": 0, "near": 0, "flip": 0, "det": 0, "score": 0, "unexplained": 0}
+    cat = {"lines": 0, "near": 0, "flip": 0, "det": 0, "score": 0, "cut": 0, "unexplained": 0}
     for (xy, ls), other in [(t, kb) for t in ka if t not in skb] + [(t, ka) for t in kb if t not in ska]:
         if any(ln not in both for ln in ls):
             cat["lines"] += 1
@@ -224,6 +242,8 @@ def explain_geometry(result, ref_result, flips: np.ndarray, ratio_xy=(1.0, 1.0),
             cat["det"] += 1
         elif in_score_band(*xy):
             cat["score"] += 1
+        elif in_cut(*xy):
+            cat["cut"] += 1
         else:
             cat["unexplained"] += 1
     out["blocks_differing"] = sum(cat.values())

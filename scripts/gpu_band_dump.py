@@ -35,7 +35,12 @@ for size, shape in ((512, (512, 512)), (1024, (1024, 1024)), (512, (700, 495))):
     rep = accept.band_report(ol[0, 0].numpy(), om[0, 0].numpy(), det.net.bitmap[0].cpu().numpy(), det.net.mask_u8[0].cpu().numpy(), 4e-3)
     flips = rep.pop("_flips")
     # tail on the ORACLE's maps through the product tail (-> isolates the network's contribution)
-    out.append(dict(size=size, shape=shape, dwdh=(dw, dh),
+    ob_boxes, ob_scores = R.seg_rep((size, size), ol.numpy())
+    x8 = det._prepare([page])[0]
+    ext = det.tail_batch([page], blks, det.net.mask_u8, lines[:, 0].contiguous(), det.net.bitmap,
+                         metas=[(page.shape[0], page.shape[1], dw, dh)], want_extras=True)[0][3]
+    out.append(dict(size=size, shape=shape, dwdh=(dw, dh), ref_db=(np.asarray(ob_boxes[0]), np.asarray(ob_scores[0])),
+                    got_db=(ext["db_boxes"], ext["db_scores"]),
                     got=[(list(map(int, b.xyxy)), [np.asarray(l).tolist() for l in b.lines], b.language, bool(b.vertical)) for b in got[2]],
                     ref=[(list(map(int, b.xyxy)), [np.asarray(l).tolist() for l in b.lines], b.language, bool(b.vertical)) for b in ref[2]],
                     flips=np.argwhere(flips).astype(np.int16), dets=dets[0, : int(counts[0])].cpu().numpy(), ref_dets=np.asarray(rd),

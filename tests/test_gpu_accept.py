@@ -44,7 +44,8 @@ def oracle_full(ck, page, size, key):
                               refine_mode=0, keep_undetected_mask=False)
         dets = R.non_max_suppression(blks.numpy(), 0.4, 0.35)[0]
         sbb = accept.score_band_boxes(lines_map.numpy(), (size, size), EPS_FP16)
-        _ORACLE[key] = (ref, mask[0, 0].numpy(), lines_map[0, 0].numpy(), (dw, dh), np.asarray(dets), sbb)
+        cand = np.asarray(R.seg_rep((size, size), lines_map.numpy())[0][0])           # every candidate box (<= 1000)
+        _ORACLE[key] = (ref, mask[0, 0].numpy(), lines_map[0, 0].numpy(), (dw, dh), np.asarray(dets), sbb, cand)
     return _ORACLE[key]
 
 
@@ -85,8 +86,9 @@ def test_detector_end_to_end_vs_oracle(prec, size, shape):
 #   (2) every pixel of the DB bitmap (threshold 0.3) or of the mask at u8 level 127 that differs from the oracle's lies
 #       within EPS of the threshold IN THE ORACLE'S MAP, and that band is a thin shell (< 1 % of the pixels);
 #   (3) every text line / block that is not identical to the oracle's is attributed to such a pixel, to an int32 truncation
-#       of coordinates a fraction of a pixel apart, to a yolo detection NMS kept differently, or to a DB box whose oracle score
-#       lies within EPS of the 0.6 gate (oracle/accept.py explain_geometry) -- nothing is left unexplained.
+#       of coordinates a fraction of a pixel apart, to a yolo detection NMS kept differently, to a DB box whose oracle score
+#       lies within EPS of the 0.6 gate, or to the 1000-contour cut of a speckled map moving (oracle/accept.py
+#       explain_geometry) -- nothing is left unexplained.
 # `bench.py`'s `parity.fp16_band` prints the same numbers for the benchmark's page.
 
 @pytest.mark.parametrize("size,shape", [(512, (512, 512)), (1024, (1024, 1024)), (512, (700, 495))])
@@ -94,19 +96,22 @@ def test_fp16_engine_deviation_is_confined_to_the_threshold_band(size, shape):
     p = pkg()
     ck = blob_ckpt()
     page = p.synth.text_like_page(shape, 3, n_blocks=8)
-    ref, om, ol, (dw, dh), ref_dets, sbb = oracle_full(ck, page, size, (size, page.shape))
+    ref, om, ol, (dw, dh), ref_dets, sbb, ref_cand = oracle_full(ck, page, size, (size, page.shape))
     det = p.detector.TextDetector(ck, input_size=size, device="cuda", precision="fp16")
     got = det(page, refine_mode=0, keep_undetected_mask=False)
     net = det.net
     blks, mask, lines = net.forward_u8(det._prepare([page])[0])
     torch.cuda.synchronize()
     dets, counts = p.backend.nms(blks, 0.4, 0.35)
+    im_h, im_w = page.shape[:2]
+    extras = det.tail_batch([page], blks, net.mask_u8, lines[:, 0].contiguous(), net.bitmap, metas=[(im_h, im_w, dw, dh)],
+                            want_extras=True)[0][3]
     rep = accept.band_report(ol, om, net.bitmap[0].cpu().numpy(), net.mask_u8[0].cpu().numpy(), EPS_FP16,
                              prob=lines[0, 0].cpu().numpy(), mask=mask[0, 0].cpu().numpy())
     flips = rep.pop("_flips")
-    im_h, im_w = page.shape[:2]
     geo = accept.explain_geometry(got, ref, flips, ratio_xy=((size - dw) / im_w, (size - dh) / im_h),
-                                  dets=dets[0, : int(counts[0])].cpu().numpy(), ref_dets=ref_dets, score_band_boxes=sbb)
+                                  dets=dets[0, : int(counts[0])].cpu().numpy(), ref_dets=ref_dets, score_band_boxes=sbb,
+                                  candidates=(extras["db_boxes"], ref_cand, 1000))
     print(f"\nfp16 band size={size} page={shape}: {rep} {geo}")
     assert rep["prob_max_abs_delta"] < EPS_FP16 and rep["mask_max_abs_delta"] < EPS_FP16
     assert rep["bitmap_flips_out_of_band"] == 0 and rep["mask127_flips_out_of_band"] == 0

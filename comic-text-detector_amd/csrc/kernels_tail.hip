@@ -385,7 +385,11 @@ __device__ __forceinline__ unsigned pred_on4(const TWin& w, const Grp& g) {
 // A thread owns four consecutive pixels, consecutive lanes consecutive groups.  Threads whose pixels all
 // carry one (label, prediction) key -- the inside of a component -- are merged into wave-level runs that
 // their first lane adds once (a candidate's big components would otherwise serialise on two words);
-// threads on a component's edge add their pixels one by one.
+// threads on a component's edge add their pixels one by one.  Either way the additions go to a per-block LDS table
+// first (open addressing on the key, a few probes, global atomic as the fallback) and reach HBM once per block and key:
+// stroke-like candidates are mostly edges, i.e. up to four L2 atomics per thread (rocprofv3: 81 us per launch of this
+// kernel alone against 9 us for the apply kernel that walks the same pixels).
+constexpr int TWA_HN = 1024;
 __global__ __launch_bounds__(256) void tw_accept_count_kernel(const TWin* __restrict__ wins, const TBand* __restrict__ bands,
                                                               int round, const int* __restrict__ labels, int canvas_w,
                                                               int max_labels, const uint8_t* __restrict__ merged,
@@ -394,7 +398,24 @@ __global__ __launch_bounds__(256) void tw_accept_count_kernel(const TWin* __rest
   if (round >= 0 && bd.round != round) return;
   const TWin w = wins[bd.win];
   const int ng = win_groups(w);
+  if ((int)blockIdx.x * 256 >= ng) return;          // block-uniform: nothing to count, nothing to flush
   const int lane = threadIdx.x & 63;
+  __shared__ int hkey[TWA_HN];
+  __shared__ unsigned hcnt[TWA_HN];
+  for (int i = threadIdx.x; i < TWA_HN; i += 256) hkey[i] = 0, hcnt[i] = 0;
+  __syncthreads();
+  auto add = [&](int key, unsigned n) {
+    unsigned h = ((unsigned)key * 2654435761u) >> 22;          // 10 bits
+#pragma unroll
+    for (int probe = 0; probe < 4; ++probe, h = (h + 1) & (TWA_HN - 1)) {
+      const int prev = atomicCAS(&hkey[h], 0, key);
+      if (prev == 0 || prev == key) {
+        atomicAdd(&hcnt[h], n);
+        return;
+      }
+    }
+    atomicAdd(counters + (size_t)key, n);
+  };
   for (int g0 = blockIdx.x * 256; g0 < ng; g0 += gridDim.x * 256) {
     const int gi = g0 + threadIdx.x;
     int ukey = 0, ulen = 0;                         // this thread's contribution to a wave-level run
@@ -429,7 +450,7 @@ __global__ __launch_bounds__(256) void tw_accept_count_kernel(const TWin* __rest
         } else {
 #pragma unroll
           for (int k = 0; k < 4; ++k)
-            if (key[k]) atomicAdd(counters + (size_t)key[k], 1u);
+            if (key[k]) add(key[k], 1u);
         }
       }
     }
@@ -445,8 +466,11 @@ __global__ __launch_bounds__(256) void tw_accept_count_kernel(const TWin* __rest
     const unsigned long long later = lane == 63 ? 0ull : (heads >> (lane + 1));
     const int lanes = later ? __ffsll((long long)later) : 64 - lane;
     const int tail = __shfl(ps, lane + lanes - 1);
-    if (head && ukey) atomicAdd(counters + (size_t)ukey, (unsigned)(tail - ps + ulen));
+    if (head && ukey) add(ukey, (unsigned)(tail - ps + ulen));
   }
+  __syncthreads();
+  for (int i = threadIdx.x; i < TWA_HN; i += 256)
+    if (hkey[i]) atomicAdd(counters + (size_t)hkey[i], hcnt[i]);
 }
 
 // OR a component into the merged mask iff its bbox has >= min_box pixels (:98-99) and it lowers the

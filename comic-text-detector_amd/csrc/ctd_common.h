@@ -54,6 +54,8 @@ struct ConvArgs {
   int k_rot;               // igemm: selftest ablation bits (0 in the product): 1 no K-loop loads, 2 no MFMAs, 4 no stores
   const void* w2;          // split kernel (kernels_split.hip): the lo plane of the weights (`w` is the hi plane)
   const float* oscale;     // split kernel: per output channel 1 / (power of two its weights were scaled by), padded to Npad
+  int x_sp, d_sp, r_sp;    // split kernel: sources / destination / residual are SPLIT-PLANE tensors (kernels_split.hip): per pixel
+                           // and 32-channel group 32 hi halves then 32 lo halves, in the 128 B the 32 floats would occupy
 };
 
 __device__ __forceinline__ float ctd_act(float v, int act) {
@@ -90,6 +92,38 @@ __device__ __forceinline__ float ctd_act_fast_rt(float v, int act) {
     case CTD_ACT_LEAKY: return ctd_act_fast<CTD_ACT_LEAKY>(v);
     case CTD_ACT_RELU: return ctd_act_fast<CTD_ACT_RELU>(v);
     case CTD_ACT_SIGMOID: return ctd_act_fast<CTD_ACT_SIGMOID>(v);
+    default: return v;
+  }
+}
+// fp32-grade SiLU / sigmoid for the split-operand engine's epilogue (kernels_split.hip): ~2 ulp in a dozen instructions --
+// exp2 of a two-piece product (v_exp_f32 is 1 ulp), reciprocal + one Newton step + a corrected quotient -- where expf and
+// an IEEE division are ~35 with their range and scale handling.  The exponent is clamped so that 1 + e stays finite
+// (SiLU of v < -87 is below 1e-36 either way).
+__device__ __forceinline__ float ctd_exp_neg_f32(float v) {   // exp(-v), -v clamped to [-100, 87]
+  const float x = fminf(fmaxf(-v, -100.f), 87.f);
+  const float t = x * 1.44269504088896341f;
+  const float r = fmaf(x, 1.44269504088896341f, -t) + x * 1.925963033500011e-08f;   // low part of x * log2(e)
+  const float e = __builtin_amdgcn_exp2f(t);
+  return fmaf(e * 0.6931471805599453f, r, e);                                        // e * 2^r
+}
+__device__ __forceinline__ float ctd_silu_f32(float v) {
+  const float d = 1.0f + ctd_exp_neg_f32(v);
+  float rc = __builtin_amdgcn_rcpf(d);
+  rc = fmaf(fmaf(-d, rc, 1.0f), rc, rc);
+  const float q = v * rc;
+  return fmaf(fmaf(-d, q, v), rc, q);
+}
+__device__ __forceinline__ float ctd_sigmoid_f32(float v) {
+  const float d = 1.0f + ctd_exp_neg_f32(v);
+  const float rc = __builtin_amdgcn_rcpf(d);
+  return fmaf(fmaf(-d, rc, 1.0f), rc, rc);
+}
+__device__ __forceinline__ float ctd_act_f32(float v, int act) {
+  switch (act) {
+    case CTD_ACT_SILU: return ctd_silu_f32(v);
+    case CTD_ACT_LEAKY: return v > 0.f ? v : 0.1f * v;
+    case CTD_ACT_RELU: return v > 0.f ? v : 0.f;
+    case CTD_ACT_SIGMOID: return ctd_sigmoid_f32(v);
     default: return v;
   }
 }

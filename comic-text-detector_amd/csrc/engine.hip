@@ -36,6 +36,7 @@ int fail(int code, const std::string& msg) {
 
 int g_fuse_epoch = 0;   // bumped when a fusion threshold changes: cached plans are re-made
 int g_no_reuse = 0;     // engines created from now on: no arena reuse (debug: `read_tensor` of any activation); "no_reuse"
+int g_split_planes = 1;  // fp32s engine: keep conv-to-conv tensors split in HBM (0: fp32 everywhere, split in the K loop); "split_planes"
 int g_f32_mfma = 1;     // engines created from now on: fp32 convs on the f32 MFMA kernel (0: exact-order direct kernels); "f32_mfma"
 
 enum Impl { IMPL_POINT = 0, IMPL_IGEMM = 1, IMPL_IGEMM_T = 2, IMPL_DIRECT = 3, IMPL_FUSED = 4 };
@@ -69,6 +70,7 @@ struct TensorState {
   size_t bytes = 0;
   int H = 0, W = 0;
   int first_def = -1, last_use = -1;
+  bool sp = false;     // fp32s engine: stored split-plane (kernels_split.hip) -- every writer and reader is the split kernel
 };
 
 }  // namespace
@@ -489,6 +491,47 @@ int plan(ctd_engine* e, int B, int H, int W, hipStream_t cap_stream = nullptr) {
     e->arena_bytes = top;
   }
 
+  // fp32s: which tensors live split-plane.  A tensor qualifies when every op that writes it and every op that reads it
+  // is a launch of the split kernel on 32-channel-aligned slices; the two sources of one launch must agree.
+  for (auto& t : e->tensors) t.sp = false;
+  if (e->prec == CTD_PREC_F32S && g_split_planes) {
+    std::vector<char> sp(nT, 0);
+    for (int t = 0; t < nT; ++t) sp[t] = e->tensors[t].esize == 4 && e->tensors[t].t.dtype != 1 && e->tensors[t].t.channels % 32 == 0;
+    auto split_conv = [&](const OpState& s) {
+      return s.split && ((s.op.kind == CTD_OP_CONV && s.impl == IMPL_IGEMM) || (s.op.kind == CTD_OP_CONVT && s.impl == IMPL_IGEMM_T));
+    };
+    for (int i = 0; i < nO; ++i) {
+      const OpState& s = e->ops[i];
+      const ctd_op& o = s.op;
+      const bool sc = split_conv(s);
+      switch (o.kind) {
+        case CTD_OP_CONV:
+        case CTD_OP_CONVT:
+          if (!(sc && o.src0_coff % 32 == 0 && o.src0_c % 32 == 0)) sp[o.src0] = 0;
+          if (o.src1 >= 0 && !(sc && o.src1_coff % 32 == 0 && o.src1_c % 32 == 0)) sp[o.src1] = 0;
+          if (o.res >= 0 && !(sc && o.res_coff % 32 == 0 && o.cout % 32 == 0)) sp[o.res] = 0;
+          if (!(sc && o.dst_coff % 32 == 0 && o.cout % 32 == 0)) sp[o.dst] = 0;
+          break;
+        case CTD_OP_INPUT:
+        case CTD_OP_STEM: sp[o.dst] = 0; break;
+        case CTD_OP_MAXPOOL:
+        case CTD_OP_AVGPOOL2: sp[o.src0] = 0; sp[o.dst] = 0; break;
+        default: if (o.src0 >= 0) sp[o.src0] = 0; break;
+      }
+    }
+    for (bool changed = true; changed;) {
+      changed = false;
+      for (int i = 0; i < nO; ++i) {
+        const ctd_op& o = e->ops[i].op;
+        if ((o.kind == CTD_OP_CONV || o.kind == CTD_OP_CONVT) && o.src1 >= 0 && sp[o.src0] != sp[o.src1]) {
+          sp[o.src0] = sp[o.src1] = 0;
+          changed = true;
+        }
+      }
+    }
+    for (int t = 0; t < nT; ++t) e->tensors[t].sp = sp[t] != 0;
+  }
+
   // per-op launch arguments
   const bool f16 = e->prec == CTD_PREC_F16;
   for (int i = 0; i < nO; ++i) {
@@ -579,6 +622,9 @@ int plan(ctd_engine* e, int B, int H, int W, hipStream_t cap_stream = nullptr) {
         if (o.kind == CTD_OP_CONV) a.K = s.kpad;
         a.w2 = (const half_t*)s.w_dev + (size_t)a.nphase * s.npad * a.K;
         a.oscale = s.oscale_dev;
+        a.x_sp = e->tensors[o.src0].sp;
+        a.d_sp = td.sp;
+        a.r_sp = o.res >= 0 && e->tensors[o.res].sp;
       }
       if ((s.impl == IMPL_IGEMM || s.impl == IMPL_IGEMM_T) &&
           !(f16 ? igemm_supported(a) : s.split ? conv_split_supported(a) : conv_f32_mfma_supported(a)))
@@ -939,6 +985,13 @@ int ctd_engine_read_tensor(ctd_engine* e, int32_t tensor_id, float* host_out, in
   HIP_TRY(hipDeviceSynchronize());
   if (t.esize == 4) {
     HIP_TRY(hipMemcpy(host_out, e->arena + t.offset, n * 4, hipMemcpyDeviceToHost));
+    if (t.sp) {   // split-plane: 32 hi halves + 32 lo halves per 32-channel group -> hi + lo
+      for (int64_t g = 0; g < n / 32; ++g) {
+        half_t h[64];
+        std::memcpy(h, host_out + 32 * g, 128);
+        for (int c = 0; c < 32; ++c) host_out[32 * g + c] = (float)h[c] + (float)h[32 + c];
+      }
+    }
   } else {
     std::vector<half_t> tmp(n);
     HIP_TRY(hipMemcpy(tmp.data(), e->arena + t.offset, n * 2, hipMemcpyDeviceToHost));
@@ -955,8 +1008,9 @@ int ctd_tuning_set(const char* key, int64_t value) {
   if (key && std::string(key) == "tail_priority") { g_tail_priority = (int)value; return CTD_OK; }
   if (key && std::string(key) == "no_reuse") { g_no_reuse = (int)value; return CTD_OK; }
   if (key && std::string(key) == "f32_mfma") { g_f32_mfma = (int)value; return CTD_OK; }
-  if (key && std::string(key) == "split_wdma") { g_split_wdma = (int)value; return CTD_OK; }
+  if (key && std::string(key) == "split_planes") { g_split_planes = (int)value; ++g_fuse_epoch; return CTD_OK; }
 #ifdef CTD_AB_VARIANTS
+  if (key && std::string(key) == "split_wdma") { g_split_wdma = (int)value; return CTD_OK; }
   if (key && std::string(key) == "split_bm256") { g_split_bm256 = (int)value; return CTD_OK; }
 #endif
   if (key && std::string(key) == "db_up_mfma") { g_db_up_mfma = (int)value; return CTD_OK; }

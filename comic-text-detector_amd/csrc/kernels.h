@@ -50,8 +50,8 @@ bool conv_f32_mfma_supported(const ConvArgs& a);
 void launch_conv_f32_mfma(const ConvArgs& a, hipStream_t st);
 
 // ---- kernels_split.hip : split-operand (fp16 hi + lo, 3 MFMAs per product) conv on f32 tensors: the "fp32s" engine ----
-extern int g_split_wdma;   // 1: weight tiles by LDS-DMA, 0: through registers (ctd_tuning_set("split_wdma"))
 #ifdef CTD_AB_VARIANTS
+extern int g_split_wdma;   // selftest build: 0 = weight tiles through registers instead of LDS-DMA (ctd_tuning_set("split_wdma"))
 extern int g_split_bm256;  // selftest build: 1 = 256-pixel blocks for 64-channel N tiles (ctd_tuning_set("split_bm256"))
 #endif
 bool conv_split_supported(const ConvArgs& a);

@@ -28,6 +28,14 @@
 // element and K step; ~1/5 of the MFMA cycles of a step).  No scaling: a value beyond fp16's range (|x| > 65504)
 // becomes inf - inf = NaN in the output, loudly.
 //
+// Split-plane activations (`x_sp` / `d_sp` / `r_sp`): a tensor that only this kernel writes and reads is kept SPLIT in
+// HBM -- per pixel and 32-channel group the 32 hi halves followed by the 32 lo halves, in the 128 B its 32 floats would
+// occupy (same pitch, same offsets for channel slices at multiples of 32).  The producer's epilogue splits each value
+// once; every consumer (each tap, each N tile) then moves 16-B chunks straight to LDS by LDS-DMA like the weights, with
+// no conversion and no register staging in the K loop.  hi + lo is what the matrix cores saw before, so a layer's
+// result is unchanged; only a residual input is hi + lo (22 bits) instead of the fp32 value.  The engine decides per
+// tensor (engine.hip: every writer and reader must be this kernel).
+//
 // Tiling: 256 threads = 4 waves, BN x 128-pixel tile, K step 32 channels.  LDS rows of 32 halves (64 B, XOR-swizzled
 // 16-B chunks), hi and lo planes for pixels and weights, double buffered: 64 KB at BN = 128 (2 blocks per CU).  Per K
 // step and wave at BN = 128: 16 ds_read_b128 feed 24 MFMAs.
@@ -56,7 +64,9 @@ __device__ __forceinline__ void split8(const float4_t& a, const float4_t& b, hal
 // WDMA: weight tiles by LDS-DMA (global_load_lds, swizzle on the source chunk) instead of through registers
 // SBM = pixels per block: 128, or 256 for the 64-channel outputs (the weight tile of a K step then feeds twice the MFMAs
 // and every wave holds a 2x2-fragment tile like the 128 x 128 configuration)
-template <int BN, int SBM, int WGN, int WGM, bool WDMA>
+// XSP: the sources are stored SPLIT (see "Split-plane activations" above): their 16-B chunks go to LDS by LDS-DMA like the
+// weights, and nothing is converted in the K loop
+template <int BN, int SBM, int WGN, int WGM, bool WDMA, bool XSP>
 __global__ __launch_bounds__(256, 2) void conv_split_kernel(ConvArgs a) {
   constexpr int TN = BN / (32 * WGN);
   constexpr int TM = SBM / (32 * WGM);
@@ -149,7 +159,27 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(ConvArgs a) {
   half8_t rwh[WROWS], rwl[WROWS];
   int nx_cc = 0, nx_ty = 0, nx_tx = 0;   // (channel offset, tap) of the NEXT tile to load
   auto load_tile = [&](int ks, int dbuf) {
-    if (Ct == 4) {
+    if (XSP) {
+      const int cc = nx_cc, ty = nx_ty, tx = nx_tx;
+      nx_cc += SBK;
+      if (nx_cc == Ct) {
+        nx_cc = 0;
+        if (++nx_tx == a.KW) nx_tx = 0, ++nx_ty;
+      }
+      const bool first = cc < a.s0.c;
+      const SrcView& s = first ? a.s0 : a.s1;
+      const int ch = first ? cc : cc - a.s0.c;                       // a multiple of 32: one 128-B group per pixel
+      const int srcb = (seg ^ ((t >> 4) & 3)) * 16;                  // swz(row): rows t/4 + 64 i share it
+#pragma unroll
+      for (int i = 0; i < AR; ++i) {
+        const int iy = poy[i] * a.stride + dy0 + ty, ix = pox[i] * a.stride + dx0 + tx;
+        const bool ok = pv[i] && (unsigned)iy < (unsigned)a.Hin && (unsigned)ix < (unsigned)a.Win;
+        const int sy = s.up ? iy >> 1 : iy, sx = s.up ? ix >> 1 : ix;
+        const char* p = (const char*)((const float*)s.ptr + ((size_t)((size_t)pb[i] * s.H + sy) * s.W + sx) * s.pitch + ch) + srcb;
+        dma(ok ? (const void*)p : a.zeros, Xs + (dbuf * 2 + 0) * XT, i);
+        dma(ok ? (const void*)(p + 64) : a.zeros, Xs + (dbuf * 2 + 1) * XT, i);
+      }
+    } else if (Ct == 4) {
       // the stem: the image is stored with a zero 4th channel, so one tap = one 16-B chunk and a K step = 8 taps
       // (this thread's two chunks are taps 8 ks + 2 seg, + 1); taps beyond KH * KW pad K to a multiple of 32 (zero weights)
 #pragma unroll
@@ -205,7 +235,7 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(ConvArgs a) {
   };
   auto store_tile = [&](int buf) {
 #pragma unroll
-    for (int i = 0; i < AR; ++i) {
+    for (int i = 0; i < (XSP ? 0 : AR); ++i) {
       const int r = (t >> 2) + 64 * i;
       half8_t hi, lo;
       split8(ra[i][0], ra[i][1], hi, lo);
@@ -274,56 +304,127 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(ConvArgs a) {
     __syncthreads();
   }
 
-  // ---- epilogue: undo the weight scale, bias + activation (+ residual) -> NHWC f32, 16 B per lane ----
-  const int hi = lane >> 5;
-#pragma unroll
-  for (int j = 0; j < TM; ++j) {
-    const int m = m0 + (wm * TM + j) * 32 + l31;
-    if (m >= a.M) continue;
-    const int ox = m % a.Mw, q = m / a.Mw, oy = q % a.Mh, b = q / a.Mh;
-    const size_t opix = ((size_t)b * a.oH + (oy * a.osy + ooy)) * a.oW + (ox * a.osx + oox);
+  // ---- epilogue: undo the weight scale + bias -> LDS tile -> activation (+ residual) -> NHWC, whole lines per wave ----
+  // Straight from the accumulators a lane stored 16-B pieces of 32 different pixel rows per instruction, with the
+  // activation switched per value and every store variant inlined per register group: 8 200 of the kernel's 8 900
+  // instructions, most of a short-K block's life and more code than the instruction cache holds.  The tile goes through
+  // LDS instead (the K loop's buffers are free; 16-B chunks XOR-swizzled by the pixel) and a short run-time loop hands
+  // every thread 8 consecutive channels of one pixel: residual loads and stores are coalesced 16-B accesses (8 lanes
+  // per 128-B line), and the code is a few hundred instructions.
+  {
+    constexpr int NCH = BN / 4;                        // 16-B chunks per tile row
+    float* stg = (float*)lds;                          // [SBM][BN] floats <= the K loop's buffers (64 KB at BN = 128)
+    static_assert(SBM * BN * 4 <= (4 * XT + 4 * WT) * 2, "staging tile fits the K loop's LDS");
+    const int hi = lane >> 5;
 #pragma unroll
     for (int i = 0; i < TN; ++i)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        const int n = n0 + (wn * TN + i) * 32 + 4 * hi + 8 * g;
-        if (n >= a.N) continue;
-        float v[4];
+        const int nl = (wn * TN + i) * 32 + 4 * hi + 8 * g;
+        const float4_t os = *(const float4_t*)(a.oscale + n0 + nl), bs = *(const float4_t*)(a.bias + n0 + nl);   // padded to Npad
 #pragma unroll
-        for (int e = 0; e < 4; ++e)   // bias / oscale padded to Npad; oscale is a power of two (exact product)
-          v[e] = ctd_act_precise(acc[i][j][4 * g + e] * a.oscale[n + e] + a.bias[n + e], a.act);
-        if (n + 3 < a.N) {
+        for (int j = 0; j < TM; ++j) {
+          const int p = (wm * TM + j) * 32 + l31;
+          float4_t v;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * g + e] * os[e] + bs[e];   // oscale is a power of two (exact product)
+          *(float4_t*)(stg + p * BN + (((nl >> 2) ^ (p & (NCH - 1))) << 2)) = v;
+        }
+      }
+    __syncthreads();
+    constexpr int UR = BN / 8;                         // 8-channel units per tile row
+    auto body = [&](auto act_c) {
+      constexpr int ACT = decltype(act_c)::value;
+      for (int u = t; u < SBM * UR; u += 256) {
+        const int p = u / UR, cu = u % UR;
+        const int m = m0 + p, n = n0 + cu * 8;
+        if (m >= a.M || n >= a.N) continue;
+        const unsigned tq = (unsigned)(((unsigned long long)(unsigned)m * a.mw_mul) >> a.mw_sh);
+        const int ox = m - (int)tq * a.Mw;
+        const unsigned bb = (unsigned)(((unsigned long long)tq * a.mh_mul) >> a.mh_sh);
+        const int oy = (int)tq - (int)bb * a.Mh;
+        const size_t opix = ((size_t)bb * a.oH + (oy * a.osy + ooy)) * a.oW + (ox * a.osx + oox);
+        const int sw = p & (NCH - 1);
+        const float4_t v0 = *(const float4_t*)(stg + p * BN + (((2 * cu) ^ sw) << 2));
+        const float4_t v1 = *(const float4_t*)(stg + p * BN + (((2 * cu + 1) ^ sw) << 2));
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          v[e] = ACT == CTD_ACT_SILU ? ctd_silu_f32(v0[e]) : ctd_act_f32(v0[e], a.act);
+          v[4 + e] = ACT == CTD_ACT_SILU ? ctd_silu_f32(v1[e]) : ctd_act_f32(v1[e], a.act);
+        }
+        if (n + 7 < a.N) {
           if (a.res) {
-            const float4_t rv = *(const float4_t*)((const float*)a.res + opix * a.pitchR + n);
+            if (a.r_sp) {       // split-plane residual: 8 hi halves + 8 lo halves; hi + lo is exact in fp32
+              const char* gp = (const char*)((const float*)a.res + opix * a.pitchR + (n & ~31)) + (n & 31) * 2;
+              const half8_t rh = *(const half8_t*)gp, rl = *(const half8_t*)(gp + 64);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] += rv[e];
+              for (int e = 0; e < 8; ++e) v[e] += (float)rh[e] + (float)rl[e];
+            } else {
+              const float* rp = (const float*)a.res + opix * a.pitchR + n;
+              const float4_t r0 = *(const float4_t*)rp, r1 = *(const float4_t*)(rp + 4);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] += r0[e], v[4 + e] += r1[e];
+            }
           }
-          float4_t o = {v[0], v[1], v[2], v[3]};
-          *(float4_t*)((float*)a.dst + opix * a.pitchD + n) = o;
-        } else {
-          for (int e = 0; e < 4 && n + e < a.N; ++e) {
+          if (a.d_sp) {         // split once here, for every consumer, tap and N tile that will read it
+            half8_t oh, ol;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              oh[e] = (half_t)v[e];
+              ol[e] = (half_t)(v[e] - (float)oh[e]);
+            }
+            char* gp = (char*)((float*)a.dst + opix * a.pitchD + (n & ~31)) + (n & 31) * 2;
+            *(half8_t*)gp = oh;
+            *(half8_t*)(gp + 64) = ol;
+          } else {
+            float* dp = (float*)a.dst + opix * a.pitchD + n;
+            const float4_t o0 = {v[0], v[1], v[2], v[3]}, o1 = {v[4], v[5], v[6], v[7]};
+            *(float4_t*)dp = o0;
+            *(float4_t*)(dp + 4) = o1;
+          }
+        } else {                // fp32 tensors only (conv_split_supported): the last unit of a channel count like 21
+          for (int e = 0; e < 8 && n + e < a.N; ++e) {
             float r = v[e];
             if (a.res) r += ((const float*)a.res)[opix * a.pitchR + n + e];
             ((float*)a.dst)[opix * a.pitchD + n + e] = r;
           }
         }
       }
+    };
+    if (a.act == CTD_ACT_SILU) body(std::integral_constant<int, CTD_ACT_SILU>{});
+    else body(std::integral_constant<int, -1>{});
   }
 }
 
+// n / d == (uint64(n) * mul) >> sh for every n < 2^31 (Granlund-Montgomery, 31-bit dividend)
+void split_magic_div(int d, unsigned& mul, unsigned& sh) {
+  int L = 0;
+  while ((1ll << L) < d) ++L;
+  sh = 31 + L;
+  mul = (unsigned)(((1ull << sh) / (unsigned)d) + 1);
+}
+
 template <int BN, int SBM, int WGN, int WGM>
-void launch_split_cfg(const ConvArgs& a, hipStream_t st) {
+void launch_split_cfg(const ConvArgs& a_in, hipStream_t st) {
+  ConvArgs a = a_in;
+  split_magic_div(a.Mw, a.mw_mul, a.mw_sh);
+  split_magic_div(a.Mh, a.mh_mul, a.mh_sh);
   const int ntn = a.Npad / BN;
   const int ntm = (a.M + SBM - 1) / SBM;
   const dim3 grid((unsigned)(ntn * ntm * a.nphase));
-  if (g_split_wdma) hipLaunchKernelGGL((conv_split_kernel<BN, SBM, WGN, WGM, true>), grid, dim3(256), 0, st, a);
-  else hipLaunchKernelGGL((conv_split_kernel<BN, SBM, WGN, WGM, false>), grid, dim3(256), 0, st, a);
+  if (a.x_sp) { hipLaunchKernelGGL((conv_split_kernel<BN, SBM, WGN, WGM, true, true>), grid, dim3(256), 0, st, a); return; }
+#ifdef CTD_AB_VARIANTS
+  if (!g_split_wdma) { hipLaunchKernelGGL((conv_split_kernel<BN, SBM, WGN, WGM, false, false>), grid, dim3(256), 0, st, a); return; }
+#endif
+  hipLaunchKernelGGL((conv_split_kernel<BN, SBM, WGN, WGM, true, false>), grid, dim3(256), 0, st, a);
 }
 
 }  // namespace
 
-int g_split_wdma = 1;   // weight tiles by LDS-DMA (ctd_tuning_set("split_wdma", 0): through registers)
-#ifdef CTD_AB_VARIANTS    // selftest build only: 256-pixel blocks for 64-channel N tiles -- measured 3-20 % SLOWER than 128
+#ifdef CTD_AB_VARIANTS    // selftest build only: weight tiles through registers instead of LDS-DMA (7 % slower)
+int g_split_wdma = 1;
+// ... and 256-pixel blocks for 64-channel N tiles -- measured 3-20 % SLOWER than 128
 int g_split_bm256 = 0;    // (profiles/r03_split_selftest.txt): the 80-KB block leaves no LDS for a third block per CU
 #endif
 
@@ -335,6 +436,10 @@ bool conv_split_supported(const ConvArgs& a) {
   if (a.res && a.pitchR % 4) return false;
   if (a.K % SBK || a.Npad % 32) return false;
   if (!a.w2 || !a.oscale) return false;
+  // split-plane tensors are addressed in 32-channel groups of 128 B
+  if (a.x_sp && (stem || a.s0.pitch % 32 || (a.s1.c && a.s1.pitch % 32))) return false;
+  if (a.d_sp && (a.N % 32 || a.pitchD % 32)) return false;
+  if (a.r_sp && (!a.res || a.N % 32 || a.pitchR % 32)) return false;
   return a.nphase == 1 || a.nphase == 4;
 }
 

@@ -827,6 +827,91 @@ static void run_split_case(const Case& cs, int B, bool timing) {
   }
   g_split_wdma = 1;
   g_split_bm256 = 0;
+  // split-plane tensors: sources, residual and destination stored as 32 hi halves + 32 lo halves per 32-channel group
+  if (cs.c0 % 32 == 0 && cs.c1 % 32 == 0 && cs.N % 32 == 0) {
+    auto to_sp = [](const std::vector<float>& f) {
+      std::vector<float> out(f.size());
+      for (size_t g = 0; g + 32 <= f.size(); g += 32) {
+        half_t h[64];
+        for (int c = 0; c < 32; ++c) {
+          h[c] = (half_t)f[g + c];
+          h[32 + c] = (half_t)(f[g + c] - (float)h[c]);
+        }
+        std::memcpy(&out[g], h, 128);
+      }
+      return out;
+    };
+    const std::vector<float> s0 = to_sp(h0), s1 = n1 ? to_sp(h1) : std::vector<float>(1), sres = cs.res ? to_sp(hres) : std::vector<float>();
+    float *d0s = dev_alloc<float>(n0), *d1s = dev_alloc<float>(n1 ? n1 : 1), *dRs = cs.res ? dev_alloc<float>(nout) : nullptr;
+    CK(hipMemcpy(d0s, s0.data(), n0 * 4, hipMemcpyHostToDevice));
+    if (n1) CK(hipMemcpy(d1s, s1.data(), n1 * 4, hipMemcpyHostToDevice));
+    if (cs.res) CK(hipMemcpy(dRs, sres.data(), nout * 4, hipMemcpyHostToDevice));
+    ConvArgs ap = as;
+    ap.s0.ptr = d0s;
+    if (cs.c1) ap.s1.ptr = d1s;
+    ap.res = dRs;
+    ap.x_sp = 1; ap.d_sp = 1; ap.r_sp = cs.res ? 1 : 0;
+    static void* zeros = nullptr;                    // padding rows of the LDS-DMA loads
+    if (!zeros) { CK(hipMalloc(&zeros, 256)); CK(hipMemset(zeros, 0, 256)); }
+    ap.zeros = zeros;
+    if (!conv_split_supported(ap)) {
+      std::printf(" split(planes): unsupported FAIL |");
+      ++g_fail;
+    } else {
+      CK(hipMemset(dOut, 0xff, nout * 4));
+      launch_conv_split(ap, 0);
+      CK(hipDeviceSynchronize());
+      CK(hipMemcpy(o.data(), dOut, nout * 4, hipMemcpyDeviceToHost));
+      for (size_t g = 0; g + 32 <= nout; g += 32) {
+        half_t h[64];
+        std::memcpy(h, &o[g], 128);
+        for (int c = 0; c < 32; ++c) o[g + c] = (float)h[c] + (float)h[32 + c];
+      }
+      double maxd = 0;
+      size_t bad = 0;
+      for (size_t i = 0; i < nout; ++i) {
+        const double e = std::fabs((double)o[i] - (double)r[i]);
+        maxd = std::fmax(maxd, e / (1.0 + std::fabs((double)r[i])));
+        if (!(e <= 2e-5 * (1.0 + std::fabs((double)r[i])))) ++bad;
+      }
+      double rms_s, mx_s;
+      err64(o, rms_s, mx_s);
+      const bool fail = bad || !(rms_s <= 3.0 * rms_f + 2e-7);
+      if (fail) ++g_fail;
+      const double ms_s = timing ? time_it([&]() { launch_conv_split(ap, 0); }) : 0;
+      std::printf(" split(planes): %s err vs f64 rms %.2e max %.2e, max|d| vs f32-MFMA %.2e (%zu > 2e-5), %.3f ms %.0f TF %.0f GB/s |",
+                  fail ? "FAIL" : "ok", rms_s, mx_s, maxd, bad, ms_s, flops / (ms_s * 1e-3) / 1e12, bytes / (ms_s * 1e-3) / 1e9);
+      // mixed: fp32 sources -> split-plane destination and back (the stem side and the heads' side of the network)
+      ConvArgs am = as;
+      am.d_sp = 1;
+      CK(hipMemset(dOut, 0xff, nout * 4));
+      launch_conv_split(am, 0);
+      CK(hipDeviceSynchronize());
+      std::vector<float> o2(nout);
+      CK(hipMemcpy(o2.data(), dOut, nout * 4, hipMemcpyDeviceToHost));
+      size_t bad2 = 0;
+      for (size_t g = 0; g + 32 <= nout; g += 32) {
+        half_t h[64];
+        std::memcpy(h, &o2[g], 128);
+        for (int c = 0; c < 32; ++c) {
+          const float v = (float)h[c] + (float)h[32 + c];
+          if (!(std::fabs((double)v - (double)r[g + c]) <= 2e-5 * (1.0 + std::fabs((double)r[g + c])))) ++bad2;
+        }
+      }
+      ConvArgs an = ap;
+      an.d_sp = 0;
+      CK(hipMemset(dOut, 0xff, nout * 4));
+      launch_conv_split(an, 0);
+      CK(hipDeviceSynchronize());
+      CK(hipMemcpy(o2.data(), dOut, nout * 4, hipMemcpyDeviceToHost));
+      size_t bad3 = 0;
+      for (size_t i = 0; i < nout; ++i)
+        if (!(std::fabs((double)o2[i] - (double)r[i]) <= 2e-5 * (1.0 + std::fabs((double)r[i])))) ++bad3;
+      if (bad2 || bad3) ++g_fail;
+      std::printf(" f32->planes %s, planes->f32 %s |", bad2 ? "FAIL" : "ok", bad3 ? "FAIL" : "ok");
+    }
+    (void)hipFree(d0s); (void)hipFree(d1s); if (dRs) (void)hipFree(dRs);
+  }
   std::printf("\n");
   (void)hipFree(d0); (void)hipFree(d1); (void)hipFree(dOut); (void)hipFree(dRef); if (dRes) (void)hipFree(dRes);
   (void)hipFree(dWf); (void)hipFree(dWs); (void)hipFree(dBias); (void)hipFree(dOsc);

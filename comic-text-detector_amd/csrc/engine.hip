@@ -1008,6 +1008,8 @@ int ctd_tuning_set(const char* key, int64_t value) {
   if (key && std::string(key) == "tail_priority") { g_tail_priority = (int)value; return CTD_OK; }
   if (key && std::string(key) == "no_reuse") { g_no_reuse = (int)value; return CTD_OK; }
   if (key && std::string(key) == "f32_mfma") { g_f32_mfma = (int)value; return CTD_OK; }
+  if (key && std::string(key) == "split_halo") { g_split_halo = (int)value; return CTD_OK; }
+  if (key && std::string(key) == "split_halo_min_patches") { g_split_halo_min_patches = value; return CTD_OK; }
   if (key && std::string(key) == "split_planes") { g_split_planes = (int)value; ++g_fuse_epoch; return CTD_OK; }
 #ifdef CTD_AB_VARIANTS
   if (key && std::string(key) == "split_wdma") { g_split_wdma = (int)value; return CTD_OK; }

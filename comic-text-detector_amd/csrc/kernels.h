@@ -55,7 +55,12 @@ extern int g_split_wdma;   // selftest build: 0 = weight tiles through registers
 extern int g_split_bm256;  // selftest build: 1 = 256-pixel blocks for 64-channel N tiles (ctd_tuning_set("split_bm256"))
 #endif
 bool conv_split_supported(const ConvArgs& a);
-void launch_conv_split(const ConvArgs& a, hipStream_t st);
+void launch_conv_split(const ConvArgs& a, hipStream_t st);   // dispatches to the halo kernel below when it applies
+// ---- kernels_split_halo.hip : the same arithmetic on a 256-pixel haloed patch staged once per channel chunk (3x3 / ConvT) ----
+extern int g_split_halo;                    // 0 disables ("split_halo")
+extern long long g_split_halo_min_patches;  // "split_halo_min_patches"
+bool conv_split_halo_supported(const ConvArgs& a);
+void launch_conv_split_halo(const ConvArgs& a, hipStream_t st);
 // logical f32 [nphase][N][K] -> hi plane + lo plane (halves, [nphase][npad/32][K/32][32][32] each) + oscale[npad]
 void split_pack_weights(const float* logical, int nphase, int N, int K, int npad, std::vector<half_t>& out,
                         std::vector<float>& oscale);

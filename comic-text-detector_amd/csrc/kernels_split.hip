@@ -45,6 +45,7 @@
 #include <vector>
 
 #include "kernels.h"
+#include "split_epilogue.h"
 
 namespace {
 
@@ -312,7 +313,6 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(ConvArgs a) {
   // every thread 8 consecutive channels of one pixel: residual loads and stores are coalesced 16-B accesses (8 lanes
   // per 128-B line), and the code is a few hundred instructions.
   {
-    constexpr int NCH = BN / 4;                        // 16-B chunks per tile row
     float* stg = (float*)lds;                          // [SBM][BN] floats <= the K loop's buffers (64 KB at BN = 128)
     static_assert(SBM * BN * 4 <= (4 * XT + 4 * WT) * 2, "staging tile fits the K loop's LDS");
     const int hi = lane >> 5;
@@ -328,72 +328,20 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(ConvArgs a) {
           float4_t v;
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * g + e] * os[e] + bs[e];   // oscale is a power of two (exact product)
-          *(float4_t*)(stg + p * BN + (((nl >> 2) ^ (p & (NCH - 1))) << 2)) = v;
+          *(float4_t*)(stg + p * BN + (split_stg_chunk<BN>(p, nl >> 2) << 2)) = v;
         }
       }
     __syncthreads();
-    constexpr int UR = BN / 8;                         // 8-channel units per tile row
-    auto body = [&](auto act_c) {
-      constexpr int ACT = decltype(act_c)::value;
-      for (int u = t; u < SBM * UR; u += 256) {
-        const int p = u / UR, cu = u % UR;
-        const int m = m0 + p, n = n0 + cu * 8;
-        if (m >= a.M || n >= a.N) continue;
-        const unsigned tq = (unsigned)(((unsigned long long)(unsigned)m * a.mw_mul) >> a.mw_sh);
-        const int ox = m - (int)tq * a.Mw;
-        const unsigned bb = (unsigned)(((unsigned long long)tq * a.mh_mul) >> a.mh_sh);
-        const int oy = (int)tq - (int)bb * a.Mh;
-        const size_t opix = ((size_t)bb * a.oH + (oy * a.osy + ooy)) * a.oW + (ox * a.osx + oox);
-        const int sw = p & (NCH - 1);
-        const float4_t v0 = *(const float4_t*)(stg + p * BN + (((2 * cu) ^ sw) << 2));
-        const float4_t v1 = *(const float4_t*)(stg + p * BN + (((2 * cu + 1) ^ sw) << 2));
-        float v[8];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          v[e] = ACT == CTD_ACT_SILU ? ctd_silu_f32(v0[e]) : ctd_act_f32(v0[e], a.act);
-          v[4 + e] = ACT == CTD_ACT_SILU ? ctd_silu_f32(v1[e]) : ctd_act_f32(v1[e], a.act);
-        }
-        if (n + 7 < a.N) {
-          if (a.res) {
-            if (a.r_sp) {       // split-plane residual: 8 hi halves + 8 lo halves; hi + lo is exact in fp32
-              const char* gp = (const char*)((const float*)a.res + opix * a.pitchR + (n & ~31)) + (n & 31) * 2;
-              const half8_t rh = *(const half8_t*)gp, rl = *(const half8_t*)(gp + 64);
-#pragma unroll
-              for (int e = 0; e < 8; ++e) v[e] += (float)rh[e] + (float)rl[e];
-            } else {
-              const float* rp = (const float*)a.res + opix * a.pitchR + n;
-              const float4_t r0 = *(const float4_t*)rp, r1 = *(const float4_t*)(rp + 4);
-#pragma unroll
-              for (int e = 0; e < 4; ++e) v[e] += r0[e], v[4 + e] += r1[e];
-            }
-          }
-          if (a.d_sp) {         // split once here, for every consumer, tap and N tile that will read it
-            half8_t oh, ol;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-              oh[e] = (half_t)v[e];
-              ol[e] = (half_t)(v[e] - (float)oh[e]);
-            }
-            char* gp = (char*)((float*)a.dst + opix * a.pitchD + (n & ~31)) + (n & 31) * 2;
-            *(half8_t*)gp = oh;
-            *(half8_t*)(gp + 64) = ol;
-          } else {
-            float* dp = (float*)a.dst + opix * a.pitchD + n;
-            const float4_t o0 = {v[0], v[1], v[2], v[3]}, o1 = {v[4], v[5], v[6], v[7]};
-            *(float4_t*)dp = o0;
-            *(float4_t*)(dp + 4) = o1;
-          }
-        } else {                // fp32 tensors only (conv_split_supported): the last unit of a channel count like 21
-          for (int e = 0; e < 8 && n + e < a.N; ++e) {
-            float r = v[e];
-            if (a.res) r += ((const float*)a.res)[opix * a.pitchR + n + e];
-            ((float*)a.dst)[opix * a.pitchD + n + e] = r;
-          }
-        }
-      }
-    };
-    if (a.act == CTD_ACT_SILU) body(std::integral_constant<int, CTD_ACT_SILU>{});
-    else body(std::integral_constant<int, -1>{});
+    split_store_tile<BN, SBM, 256>(stg, a, n0, t, [&](int p, int, size_t& opix) {
+      const int m = m0 + p;
+      if (m >= a.M) return false;
+      const unsigned tq = (unsigned)(((unsigned long long)(unsigned)m * a.mw_mul) >> a.mw_sh);
+      const int ox = m - (int)tq * a.Mw;
+      const unsigned bb = (unsigned)(((unsigned long long)tq * a.mh_mul) >> a.mh_sh);
+      const int oy = (int)tq - (int)bb * a.Mh;
+      opix = ((size_t)bb * a.oH + (oy * a.osy + ooy)) * a.oW + (ox * a.osx + oox);
+      return true;
+    });
   }
 }
 
@@ -444,6 +392,7 @@ bool conv_split_supported(const ConvArgs& a) {
 }
 
 void launch_conv_split(const ConvArgs& a, hipStream_t st) {
+  if (conv_split_halo_supported(a)) return launch_conv_split_halo(a, st);
   int bn = a.Npad % 128 == 0 ? 128 : (a.Npad % 64 == 0 ? 64 : 32);
   // small maps: narrower N tiles give 2-4x the blocks (the packing is in 32-row blocks, any multiple of 32 reads it)
   const long long ntm = (a.M + 127) / 128;

@@ -858,6 +858,11 @@ static void run_split_case(const Case& cs, int B, bool timing) {
       std::printf(" split(planes): unsupported FAIL |");
       ++g_fail;
     } else {
+     const long long minp = g_split_halo_min_patches;
+     g_split_halo_min_patches = 1;                       // ragged cases too
+     for (int halo = 0; halo < 2; ++halo) {             // the 128-pixel kernel | the 256-pixel haloed-patch kernel (3x3 s1 / ConvT)
+      g_split_halo = halo;
+      if (halo && !conv_split_halo_supported(ap)) continue;
       CK(hipMemset(dOut, 0xff, nout * 4));
       launch_conv_split(ap, 0);
       CK(hipDeviceSynchronize());
@@ -879,7 +884,8 @@ static void run_split_case(const Case& cs, int B, bool timing) {
       const bool fail = bad || !(rms_s <= 3.0 * rms_f + 2e-7);
       if (fail) ++g_fail;
       const double ms_s = timing ? time_it([&]() { launch_conv_split(ap, 0); }) : 0;
-      std::printf(" split(planes): %s err vs f64 rms %.2e max %.2e, max|d| vs f32-MFMA %.2e (%zu > 2e-5), %.3f ms %.0f TF %.0f GB/s |",
+      std::printf(halo ? " split(planes,halo):" : " split(planes):");
+      std::printf(" %s err vs f64 rms %.2e max %.2e, max|d| vs f32-MFMA %.2e (%zu > 2e-5), %.3f ms %.0f TF %.0f GB/s |",
                   fail ? "FAIL" : "ok", rms_s, mx_s, maxd, bad, ms_s, flops / (ms_s * 1e-3) / 1e12, bytes / (ms_s * 1e-3) / 1e9);
       // mixed: fp32 sources -> split-plane destination and back (the stem side and the heads' side of the network)
       ConvArgs am = as;
@@ -909,6 +915,9 @@ static void run_split_case(const Case& cs, int B, bool timing) {
         if (!(std::fabs((double)o2[i] - (double)r[i]) <= 2e-5 * (1.0 + std::fabs((double)r[i])))) ++bad3;
       if (bad2 || bad3) ++g_fail;
       std::printf(" f32->planes %s, planes->f32 %s |", bad2 ? "FAIL" : "ok", bad3 ? "FAIL" : "ok");
+     }
+     g_split_halo = 1;
+     g_split_halo_min_patches = minp;
     }
     (void)hipFree(d0s); (void)hipFree(d1s); if (dRs) (void)hipFree(dRs);
   }
@@ -969,7 +978,11 @@ int main(int argc, char** argv) {
                            {"1x1 cat(32up,64)->21 @12", 0, 32, 64, 1, 21, 1, 1, 12, 0},
                            {"convT4 64->32 @9", 1, 64, 0, 0, 32, 4, 2, 9, 0},
                            {"3x3 64->16 @24 (db branch)", 0, 64, 0, 0, 16, 3, 1, 24, 0},
-                           {"stem 6x6s2 4->32 @44 ragged", 0, 4, 0, 0, 32, 6, 2, 44, 0}};
+                           {"stem 6x6s2 4->32 @44 ragged", 0, 4, 0, 0, 32, 6, 2, 44, 0},
+                           {"3x3 64->64 @21 +res (halo)", 0, 64, 0, 0, 64, 3, 1, 21, 1},
+                           {"3x3 cat(32,32)->128 @18 (halo)", 0, 32, 32, 0, 128, 3, 1, 18, 0},
+                           {"convT4 64->64 @19 (halo)", 1, 64, 0, 0, 64, 4, 2, 19, 0},
+                           {"convT4 96->128 @33 (halo)", 1, 96, 0, 0, 128, 4, 2, 33, 0}};
     for (const Case& c : ragged) run_split_case(c, 3, false);
     run_split_case(Case{"stem 6x6s2 4->32 @1024", 0, 4, 0, 0, 32, 6, 2, 1024, 0}, B, true);
     const char* sel = std::getenv("ST_CASES");

@@ -36,6 +36,7 @@ int fail(int code, const std::string& msg) {
 
 int g_fuse_epoch = 0;   // bumped when a fusion threshold changes: cached plans are re-made
 int g_no_reuse = 0;     // engines created from now on: no arena reuse (debug: `read_tensor` of any activation); "no_reuse"
+int g_split_stem = 1;    // fp32s engine: the first conv reads the network input itself (kernels_split_stem.hip); "split_stem"
 int g_split_planes = 1;  // fp32s engine: keep conv-to-conv tensors split in HBM (0: fp32 everywhere, split in the K loop); "split_planes"
 int g_f32_mfma = 1;     // engines created from now on: fp32 convs on the f32 MFMA kernel (0: exact-order direct kernels); "f32_mfma"
 
@@ -59,6 +60,7 @@ struct OpState {
   bool skip = false;      // ... and the other three launch nothing (also: pools 2, 3 of a fused SPPF)
   bool sppf_head = false; // first of SPPF's three chained max pools: one launch does all three
   bool stem2_head = false; // STEM op that also computes the following 3x3/s2 conv (which is `skip`)
+  bool stemsp_head = false; // fp32s: first conv reads the network input itself (kernels_split_stem.hip); its INPUT op is `skip`
   Stem2Args st2{};
   C3Args c3{};
 };
@@ -635,7 +637,19 @@ int plan(ctd_engine* e, int B, int H, int W, hipStream_t cap_stream = nullptr) {
                 (double)a.N * o.k * o.k * cin * es;
     }
     s.args = a;
-    s.c3_head = s.skip = s.sppf_head = s.stem2_head = false;
+    s.c3_head = s.skip = s.sppf_head = s.stem2_head = s.stemsp_head = false;
+  }
+  // ---- fp32s: INPUT (page -> fp32 NHWC, zero 4th channel) + the 6x6/s2 first conv -> one launch that reads the page itself
+  for (int i = 0; e->prec == CTD_PREC_F32S && g_split_stem && i + 1 < nO; ++i) {
+    OpState &S0 = e->ops[i], &S1 = e->ops[i + 1];
+    const ctd_op &o0 = S0.op, &o1 = S1.op;
+    if (o0.kind != CTD_OP_INPUT || o1.kind != CTD_OP_CONV || !S1.split || S1.impl != IMPL_IGEMM) continue;
+    const int T0 = o0.dst;
+    if (o1.src0 != T0 || o1.src0_coff != 0 || o1.src1 >= 0 || o1.res >= 0) continue;
+    if (e->tensors[T0].first_def != i || e->tensors[T0].last_use != i + 1) continue;
+    if (!stem_split_supported(S1.args)) continue;
+    S0.skip = true;
+    S1.stemsp_head = true;
   }
   // ---- stem + layer 1: the stem's output has one consumer, a 3x3/s2 conv 32 -> 64 -> one launch, never stored
   for (int i = 0; f16 && (g_fuse & 4) && i + 1 < nO; ++i) {
@@ -744,6 +758,7 @@ int launch_op(ctd_engine* e, int i, const Outs& x, hipStream_t st) {
   };
   switch (o.kind) {
     case CTD_OP_INPUT: {
+      if (s.skip) break;
       void* d = tptr(o.dst, 0);
       const int pitch = e->tensors[o.dst].t.channels;
       if (x.in_fmt == CTD_IN_NCHW_F32) launch_input_nchw((const float*)x.input, d, pitch, B, H, W, f16, st);
@@ -766,6 +781,7 @@ int launch_op(ctd_engine* e, int i, const Outs& x, hipStream_t st) {
     case CTD_OP_CONV:
       if (s.skip) break;
       if (s.c3_head) { launch_c3_fused(s.c3, st); break; }
+      if (s.stemsp_head) { launch_stem_split(s.args, x.input, x.in_fmt, st); break; }
       if (s.impl == IMPL_IGEMM && s.split) launch_conv_split(s.args, st);
       else if (s.impl == IMPL_IGEMM && !f16) launch_conv_f32_mfma(s.args, st);
       else if (s.impl == IMPL_IGEMM) launch_conv_igemm(s.args, e->tensors[o.dst].esize == 4, st);
@@ -1010,6 +1026,7 @@ int ctd_tuning_set(const char* key, int64_t value) {
   if (key && std::string(key) == "f32_mfma") { g_f32_mfma = (int)value; return CTD_OK; }
   if (key && std::string(key) == "split_halo") { g_split_halo = (int)value; return CTD_OK; }
   if (key && std::string(key) == "split_halo_min_patches") { g_split_halo_min_patches = value; return CTD_OK; }
+  if (key && std::string(key) == "split_stem") { g_split_stem = (int)value; ++g_fuse_epoch; return CTD_OK; }
   if (key && std::string(key) == "split_planes") { g_split_planes = (int)value; ++g_fuse_epoch; return CTD_OK; }
 #ifdef CTD_AB_VARIANTS
   if (key && std::string(key) == "split_wdma") { g_split_wdma = (int)value; return CTD_OK; }

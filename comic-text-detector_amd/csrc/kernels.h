@@ -56,6 +56,9 @@ extern int g_split_bm256;  // selftest build: 1 = 256-pixel blocks for 64-channe
 #endif
 bool conv_split_supported(const ConvArgs& a);
 void launch_conv_split(const ConvArgs& a, hipStream_t st);   // dispatches to the halo kernel below when it applies
+// ---- kernels_split_stem.hip : the fp32s engine's first layer straight from the network input (no INPUT launch) ----
+bool stem_split_supported(const ConvArgs& a);
+void launch_stem_split(const ConvArgs& a, const void* input, int in_fmt, hipStream_t st);
 // ---- kernels_split_halo.hip : the same arithmetic on a 256-pixel haloed patch staged once per channel chunk (3x3 / ConvT) ----
 extern int g_split_halo;                    // 0 disables ("split_halo")
 extern long long g_split_halo_min_patches;  // "split_halo_min_patches"

@@ -926,6 +926,100 @@ static void run_split_case(const Case& cs, int B, bool timing) {
   (void)hipFree(dWf); (void)hipFree(dWs); (void)hipFree(dBias); (void)hipFree(dOsc);
 }
 
+// The fp32s first layer straight from the page (kernels_split_stem.hip) against INPUT + the generic split kernel's stem path
+static void run_stem_split_case(int B, int H, bool timing) {
+  const int W = H, Ho = H / 2, Wo = W / 2, N = 32, K = 144, Ks = 160;
+  const size_t npx = (size_t)B * H * W;
+  std::vector<uint8_t> img(npx * 3);
+  for (auto& v : img) { g_seed = g_seed * 1664525u + 1013904223u; v = (uint8_t)(g_seed >> 24); }
+  std::vector<float> planes(npx * 3);
+  for (int b = 0; b < B; ++b)
+    for (size_t p = 0; p < (size_t)H * W; ++p)
+      for (int c = 0; c < 3; ++c) planes[((size_t)b * 3 + c) * H * W + p] = (float)img[((size_t)b * H * W + p) * 3 + c] / 255.0f;
+  uint8_t* dImg = dev_alloc<uint8_t>(img.size());
+  float *dPl = dev_alloc<float>(planes.size()), *dIn4 = dev_alloc<float>(npx * 4);
+  CK(hipMemcpy(dImg, img.data(), img.size(), hipMemcpyHostToDevice));
+  CK(hipMemcpy(dPl, planes.data(), planes.size() * 4, hipMemcpyHostToDevice));
+  std::vector<float> lg((size_t)N * Ks, 0.f), bias(N);
+  for (int n = 0; n < N; ++n) {
+    const float ch = std::ldexp(1.f, (int)(frand() * 8.f) - 2);
+    for (int tap = 0; tap < 36; ++tap)
+      for (int c = 0; c < 3; ++c) lg[(size_t)n * Ks + tap * 4 + c] = frand() * 0.2f * ch;      // 4th channel and taps 36..39: zero
+    bias[n] = frand();
+  }
+  (void)K;
+  std::vector<half_t> ws;
+  std::vector<float> osc;
+  split_pack_weights(lg.data(), 1, N, Ks, 32, ws, osc);
+  half_t* dWs = dev_alloc<half_t>(ws.size());
+  float *dBias = dev_alloc<float>(32), *dOsc = dev_alloc<float>(32);
+  CK(hipMemcpy(dWs, ws.data(), ws.size() * 2, hipMemcpyHostToDevice));
+  CK(hipMemcpy(dBias, bias.data(), 32 * 4, hipMemcpyHostToDevice));
+  CK(hipMemcpy(dOsc, osc.data(), 32 * 4, hipMemcpyHostToDevice));
+  const size_t nout = (size_t)B * Ho * Wo * N;
+  float *dRef = dev_alloc<float>(nout), *dOut = dev_alloc<float>(nout);
+  ConvArgs a{};
+  a.s0 = SrcView{dIn4, 4, 4, 0, H, W};
+  a.B = B; a.Hin = H; a.Win = W; a.Mh = Ho; a.Mw = Wo; a.KH = a.KW = 6; a.stride = 2; a.dy0 = a.dx0 = -2;
+  a.bias = dBias; a.pitchD = N; a.oH = Ho; a.oW = Wo; a.act = CTD_ACT_SILU; a.N = N; a.Npad = 32; a.K = Ks; a.M = B * Ho * Wo;
+  a.nphase = 1; a.osy = a.osx = 1;
+  a.w = dWs; a.w2 = dWs + (size_t)32 * Ks; a.oscale = dOsc; a.dst = dRef;
+  std::printf("[stem-split] %dx%dx%d -> %dx%dx32 |", B, H, W, Ho, Wo);
+  if (!conv_split_supported(a) || !stem_split_supported(a)) { std::printf(" unsupported FAIL\n"); ++g_fail; return; }
+  launch_input_u8(dImg, dIn4, 4, B, H, W, false, 0);
+  launch_conv_split(a, 0);
+  CK(hipDeviceSynchronize());
+  std::vector<float> r(nout), o(nout);
+  CK(hipMemcpy(r.data(), dRef, nout * 4, hipMemcpyDeviceToHost));
+  ConvArgs an = a;
+  an.dst = dOut;
+  for (int var = 0; var < 3; ++var) {          // uint8 page -> fp32 rows | uint8 page -> split-plane rows | float planes -> fp32 rows
+    an.d_sp = var == 1;
+    CK(hipMemset(dOut, 0xff, nout * 4));
+    if (var == 2) launch_stem_split(an, dPl, CTD_IN_NCHW_F32, 0);
+    else launch_stem_split(an, dImg, CTD_IN_NHWC_U8, 0);
+    CK(hipDeviceSynchronize());
+    CK(hipMemcpy(o.data(), dOut, nout * 4, hipMemcpyDeviceToHost));
+    if (var == 1)
+      for (size_t g = 0; g + 32 <= nout; g += 32) {
+        half_t h[64];
+        std::memcpy(h, &o[g], 128);
+        for (int c = 0; c < 32; ++c) o[g + c] = (float)h[c] + (float)h[32 + c];
+      }
+    double maxd = 0;
+    size_t bad = 0;
+    for (size_t i = 0; i < nout; ++i) {
+      const double e = std::fabs((double)o[i] - (double)r[i]);
+      maxd = std::fmax(maxd, e / (1.0 + std::fabs((double)r[i])));
+      if (!(e <= 2e-5 * (1.0 + std::fabs((double)r[i])))) ++bad;
+    }
+    if (bad) ++g_fail;
+    std::printf(" %s: %s max|d| %.2e (%zu > 2e-5)", var == 0 ? "u8->f32" : var == 1 ? "u8->planes" : "nchw->f32", bad ? "FAIL" : "ok", maxd, bad);
+  }
+  if (timing) {
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    auto tm = [&](auto&& fn) {
+      for (int i = 0; i < 3; ++i) fn();
+      CK(hipEventRecord(e0, 0));
+      for (int i = 0; i < 20; ++i) fn();
+      CK(hipEventRecord(e1, 0));
+      CK(hipEventSynchronize(e1));
+      float ms;
+      CK(hipEventElapsedTime(&ms, e0, e1));
+      return ms / 20;
+    };
+    an.d_sp = 1;
+    const float t_new = tm([&]() { launch_stem_split(an, dImg, CTD_IN_NHWC_U8, 0); });
+    const float t_old = tm([&]() { launch_input_u8(dImg, dIn4, 4, B, H, W, false, 0); launch_conv_split(a, 0); });
+    std::printf(" | INPUT + generic %.3f ms, from the page %.3f ms (%.0f GB/s of its bytes)", t_old, t_new,
+                ((double)npx * 3 + (double)nout * 4) / (t_new * 1e-3) / 1e9);
+  }
+  std::printf("\n");
+  (void)hipFree(dImg); (void)hipFree(dPl); (void)hipFree(dIn4); (void)hipFree(dWs); (void)hipFree(dBias); (void)hipFree(dOsc);
+  (void)hipFree(dRef); (void)hipFree(dOut);
+}
+
 int main(int argc, char** argv) {
   const int B = argc > 1 ? std::atoi(argv[1]) : 4;
   const bool quick = argc > 2;
@@ -984,6 +1078,8 @@ int main(int argc, char** argv) {
                            {"convT4 64->64 @19 (halo)", 1, 64, 0, 0, 64, 4, 2, 19, 0},
                            {"convT4 96->128 @33 (halo)", 1, 96, 0, 0, 128, 4, 2, 33, 0}};
     for (const Case& c : ragged) run_split_case(c, 3, false);
+    run_stem_split_case(3, 88, false);      // 44 x 44 outputs: partial tiles
+    run_stem_split_case(B, 1024, true);
     run_split_case(Case{"stem 6x6s2 4->32 @1024", 0, 4, 0, 0, 32, 6, 2, 1024, 0}, B, true);
     const char* sel = std::getenv("ST_CASES");
     for (int i = 0; i < ncase; ++i) {

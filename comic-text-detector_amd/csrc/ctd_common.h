@@ -54,6 +54,7 @@ struct ConvArgs {
   int k_rot;               // igemm: selftest ablation bits (0 in the product): 1 no K-loop loads, 2 no MFMAs, 4 no stores
   const void* w2;          // split kernel (kernels_split.hip): the lo plane of the weights (`w` is the hi plane)
   const float* oscale;     // split kernel: per output channel 1 / (power of two its weights were scaled by), padded to Npad
+  int prio;                // 1: the kernel raises its waves' issue priority (s_setprio): the forward's kernels against a co-running tail
   int x_sp, d_sp, r_sp;    // split kernel: sources / destination / residual are SPLIT-PLANE tensors (kernels_split.hip): per pixel
                            // and 32-channel group 32 hi halves then 32 lo halves, in the 128 B the 32 floats would occupy
 };

@@ -36,6 +36,8 @@ int fail(int code, const std::string& msg) {
 
 int g_fuse_epoch = 0;   // bumped when a fusion threshold changes: cached plans are re-made
 int g_no_reuse = 0;     // engines created from now on: no arena reuse (debug: `read_tensor` of any activation); "no_reuse"
+int g_fwd_prio = 1;      // the network's big kernels raise their waves' issue priority (s_setprio 3): a co-running tail stretched the
+                         // VALU-bound stem kernel from 0.42 to 2.1 ms (rocprofv3 timeline); "fwd_prio"
 int g_split_stem = 1;    // fp32s engine: the first conv reads the network input itself (kernels_split_stem.hip); "split_stem"
 int g_split_planes = 1;  // fp32s engine: keep conv-to-conv tensors split in HBM (0: fp32 everywhere, split in the K loop); "split_planes"
 int g_f32_mfma = 1;     // engines created from now on: fp32 convs on the f32 MFMA kernel (0: exact-order direct kernels); "f32_mfma"
@@ -583,6 +585,7 @@ int plan(ctd_engine* e, int B, int H, int W, hipStream_t cap_stream = nullptr) {
       a.zeros = e->zeros;
       a.w_tiled = e->w_tiled;
       a.k_rot = 0;
+      a.prio = g_fwd_prio;
       const int cin = o.src0_c + (o.src1 >= 0 ? o.src1_c : 0);
       a.nphase = 1;
       a.osy = a.osx = 1;
@@ -663,6 +666,7 @@ int plan(ctd_engine* e, int B, int H, int W, hipStream_t cap_stream = nullptr) {
       continue;
     if (e->tensors[T0].first_def != i || e->tensors[T0].last_use != i + 1 || e->tensors[o1.dst].esize != 2) continue;
     Stem2Args f{};
+    f.prio = g_fwd_prio;
     f.B = B; f.H = H; f.W = W;
     f.wfrag = (const half_t*)S0.w_dev; f.bias0 = S0.b_dev; f.act0 = o0.act;
     f.w1 = (const half_t*)S1.w_dev; f.bias1 = S1.b_dev; f.act1 = o1.act;
@@ -717,6 +721,7 @@ int plan(ctd_engine* e, int B, int H, int W, hipStream_t cap_stream = nullptr) {
       continue;
     if (e->tensors[d.dst].esize != 2 || e->tensors[Y].esize != 2 || e->tensors[T].esize != 2) continue;
     C3Args f{};
+    f.prio = g_fwd_prio;
     f.s0 = A.args.s0;
     f.s1 = A.args.s1;
     f.B = B; f.H = A.args.Hin; f.W = A.args.Win;
@@ -867,6 +872,7 @@ int prepare(ctd_engine* e, int B, int H, int W, hipStream_t st = nullptr) {
 
 int ctd_fail_msg(int code, const std::string& msg) { return fail(code, msg); }
 extern int g_tail_priority;   // tail.hip
+extern long long g_tail_dma_min;
 
 extern "C" {
 
@@ -1021,11 +1027,13 @@ int32_t ctd_engine_arena_generation(const ctd_engine* e) { return e ? e->arena_g
 
 int ctd_tuning_set(const char* key, int64_t value) {
   if (key && std::string(key) == "fuse") { g_fuse = (int)value; return CTD_OK; }
+  if (key && std::string(key) == "tail_dma_min") { g_tail_dma_min = value; return CTD_OK; }
   if (key && std::string(key) == "tail_priority") { g_tail_priority = (int)value; return CTD_OK; }
   if (key && std::string(key) == "no_reuse") { g_no_reuse = (int)value; return CTD_OK; }
   if (key && std::string(key) == "f32_mfma") { g_f32_mfma = (int)value; return CTD_OK; }
   if (key && std::string(key) == "split_halo") { g_split_halo = (int)value; return CTD_OK; }
   if (key && std::string(key) == "split_halo_min_patches") { g_split_halo_min_patches = value; return CTD_OK; }
+  if (key && std::string(key) == "fwd_prio") { g_fwd_prio = (int)value; ++g_fuse_epoch; return CTD_OK; }
   if (key && std::string(key) == "split_stem") { g_split_stem = (int)value; ++g_fuse_epoch; return CTD_OK; }
   if (key && std::string(key) == "split_planes") { g_split_planes = (int)value; ++g_fuse_epoch; return CTD_OK; }
 #ifdef CTD_AB_VARIANTS

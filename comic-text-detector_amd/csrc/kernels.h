@@ -86,6 +86,7 @@ struct C3Args {
   int pitchD;
   int act;
   const void* zeros;       // >= 16 B of zeros in HBM (source of out-of-image rows)
+  int prio;                // as ConvArgs::prio
   half_t* dbg;             // selftest only: three (B,H,W,32) planes receiving y2, t, b of every patch pixel; null in the product
 };
 extern int g_fuse;         // fusion bit mask (CTD_FUSE / ctd_tuning_set("fuse")): 1 C3 block, 2 SPPF pools, 4 stem + model.1
@@ -100,6 +101,7 @@ struct Stem2Args {
   const half_t* wfrag; const float* bias0; int act0;    // stem: stem_pack_weights fragments
   const half_t* w1; const float* bias1; int act1;       // layer 1: implicit-GEMM packing [9 taps][64][32]
   half_t* dst; int pitchD;             // (B, H/4, W/4, pitchD), 64 channels written
+  int prio;                            // as ConvArgs::prio
 };
 bool stem_conv2_supported(const Stem2Args& a);
 void launch_stem_conv2(const Stem2Args& a, hipStream_t st);

@@ -56,6 +56,7 @@ static_assert(C3_WM1 + 32 * 32 <= 2 * C3_XBUF, "tap tiles fit the x buffers");
 // DBG: selftest-only instantiation that also dumps the block's intermediates (y2, t, b on the patch pixels) to a.dbg
 template <int ACT, bool DBG = false>
 __global__ __launch_bounds__(256, 2) void c3_fused_kernel(C3Args a) {
+  if (a.prio) __builtin_amdgcn_s_setprio(3);   // ahead of a co-running tail's waves in the issue arbiter
   __shared__ __attribute__((aligned(16))) half_t lds[C3_LDS + 2 * 192];
   float* bias_s = (float*)(lds + C3_LDS);   // [0,64) cv1|cv2, [64,96) m.cv1, [96,128) m.cv2, [128,192) cv3
 

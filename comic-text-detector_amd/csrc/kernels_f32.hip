@@ -29,6 +29,7 @@ constexpr int FBK = 16;    // floats per K step
 
 template <int BN, int WGN, int WGM>
 __global__ __launch_bounds__(256) void conv_f32_mfma_kernel(ConvArgs a) {
+  if (a.prio) __builtin_amdgcn_s_setprio(3);   // ahead of a co-running tail's waves in the issue arbiter
   constexpr int TN = BN / (32 * WGN);
   constexpr int TM = FBM / (32 * WGM);
   static_assert(WGN * WGM == 4, "4 waves");

@@ -50,6 +50,7 @@ constexpr int NTHR = 512;
 // MFMAs) instead of 1x2 (3 reads per 2 MFMAs).
 template <int BN, int WGN, int WGM, bool PROF, int TPS = 1, bool PAIR = false>
 __global__ __launch_bounds__(NTHR, 4) void conv_halo_kernel(ConvArgs a) {   // 4 waves / SIMD = 2 blocks / CU
+  if (a.prio) __builtin_amdgcn_s_setprio(3);   // ahead of a co-running tail's waves in the issue arbiter
   constexpr int TN = BN / (32 * WGN);
   constexpr int TM = BMH / (32 * WGM);
   static_assert(WGN * WGM == 8, "8 waves");

@@ -36,6 +36,7 @@ namespace {
 // instantiations (ABL = false) every hook below is a compile-time zero.
 template <int BN, int BM, int WGN, int WGM, int BK, bool DST_F32, int MINW, int PF, bool PROF = false, bool ABL = false>
 __global__ __launch_bounds__(256, MINW) void conv_igemm_kernel(ConvArgs a) {
+  if (a.prio) __builtin_amdgcn_s_setprio(3);   // ahead of a co-running tail's waves in the issue arbiter
   constexpr int LP = BK;                            // LDS row pitch in halves (XOR swizzled, no pad)
   constexpr int SEGS = BK / 8;                      // 16-B chunks per row
   constexpr int RPP = 256 / SEGS;                   // rows staged per pass of the 256 threads

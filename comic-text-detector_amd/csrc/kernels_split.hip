@@ -69,6 +69,7 @@ __device__ __forceinline__ void split8(const float4_t& a, const float4_t& b, hal
 // weights, and nothing is converted in the K loop
 template <int BN, int SBM, int WGN, int WGM, bool WDMA, bool XSP>
 __global__ __launch_bounds__(256, 2) void conv_split_kernel(ConvArgs a) {
+  if (a.prio) __builtin_amdgcn_s_setprio(3);   // ahead of a co-running tail's waves in the issue arbiter
   constexpr int TN = BN / (32 * WGN);
   constexpr int TM = SBM / (32 * WGM);
   constexpr int AR = SBM / 64;                  // pixel rows each thread stages

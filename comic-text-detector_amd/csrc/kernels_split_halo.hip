@@ -33,6 +33,7 @@ constexpr int NTHR = 512;
 // 2x2-fragment tile of the 128-channel layers (as in kernels_halo.hip).
 template <int BN, int WGN, int WGM, bool PAIR = false>
 __global__ __launch_bounds__(NTHR, 2) void conv_split_halo_kernel(ConvArgs a) {
+  if (a.prio) __builtin_amdgcn_s_setprio(3);   // ahead of a co-running tail's waves in the issue arbiter
   constexpr int TN = BN / (32 * WGN);
   constexpr int TM = BMH / (32 * WGM);
   static_assert(WGN * WGM == 8, "8 waves");

@@ -22,6 +22,7 @@ constexpr int KK = 10;                 // K = 160 = 10 x 16 (40 taps x 4 channel
 // IN_U8: (B, H, W, 3) uint8; otherwise (B, 3, H, W) float
 template <bool IN_U8>
 __global__ __launch_bounds__(256) void stem_split_kernel(ConvArgs a, const void* __restrict__ in) {
+  if (a.prio) __builtin_amdgcn_s_setprio(3);   // ahead of a co-running tail's waves in the issue arbiter
   // patch planes [SP * SP pixels][4 halves] (hi | lo), then the fp32 output tile [256][32]
   __shared__ __attribute__((aligned(16))) char lds[ST * ST * 32 * 4 + 256 * 4];
   static_assert(2 * SP * SP * 8 <= ST * ST * 32 * 4, "patch planes fit the output tile");

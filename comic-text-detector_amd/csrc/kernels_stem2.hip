@@ -44,6 +44,7 @@ static_assert(S2_TW * S2_TH * S2_OP <= S2_SROWS * 32, "output tile fits the stem
 // switch on a run-time value)
 template <int ACT0, int ACT1>
 __global__ __launch_bounds__(256, 2) void stem_conv2_kernel(Stem2Args a) {
+  if (a.prio) __builtin_amdgcn_s_setprio(3);   // ahead of a co-running tail's waves in the issue arbiter
   __shared__ __attribute__((aligned(16))) half_t lds[S2_LDS + 2 * 96];
   float* bias_s = (float*)(lds + S2_LDS);     // [0,32) stem, [32,96) layer 1
   half_t* patch = lds + S2_IN;

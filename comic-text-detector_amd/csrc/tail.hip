@@ -133,6 +133,10 @@ void parallel_for(int n, int max_threads, F f) {
   for (auto& x : th) x.join();
 }
 
+}  // namespace
+long long g_tail_dma_min = 256 << 10;   // device -> host copies of at least this many bytes use the copy engines ("tail_dma_min"; huge = never)
+namespace {
+
 // A stage's copies and fills as segments of one kernel launch (launch_multi_copy, kernels_tail.hip).
 struct Batch {
   MSegs m;
@@ -151,6 +155,22 @@ struct Batch {
   }
   void fill(void* dst, int byte, size_t bytes) { seg(dst, nullptr, bytes, 1, 0, 0, byte); }
   void flush() { launch_multi_copy(m, st); }
+  // Device -> page-locked host.  Large ones go to the copy engines (hipMemcpyAsync): a KERNEL that stores to host memory
+  // stalls every other kernel's memory traffic for as long as it runs (selftest ST_CORUN: the network's first kernel takes
+  // 4.9 ms instead of 0.43 ms next to a kernel streaming 64 MB to pinned memory -- and the tail's mask downloads are
+  // 64 MB per 32 pages).  Small ones stay segments of the stage's launch.  Earlier segments of this batch are launched
+  // first: the stream order is the call order.
+  hipError_t d2h(void* host, const void* dev, size_t bytes) {
+    if (bytes < (size_t)g_tail_dma_min) { copy(host, dev, bytes); return hipSuccess; }
+    flush();
+    return hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, st);
+  }
+  hipError_t d2h2d(void* host, size_t dpitch, const void* dev, size_t spitch, size_t width, int rows) {
+    if (rows == 1 || (dpitch == width && spitch == width)) return d2h(host, dev, width * (size_t)rows);
+    if (width * (size_t)rows < (size_t)g_tail_dma_min) { copy2d(host, dpitch, dev, spitch, width, rows); return hipSuccess; }
+    flush();
+    return hipMemcpy2DAsync(host, dpitch, dev, spitch, width, (size_t)rows, hipMemcpyDeviceToHost, st);
+  }
 };
 
 // Device-visible address of a caller's host array when it is page-locked (hipHostMalloc / hipHostRegister), else null:
@@ -300,7 +320,7 @@ int refine_windows(ctd_tail* t, const std::vector<WinReq>& reqs, int refine_mode
   bt.flush();
   // ---- histograms -> rules
   launch_tw_hist(dw, n, max_pix, dhist, st);
-  bt.copy(hhist, dhist, (size_t)n * 1024 * 4);
+  T_TRY(bt.d2h(hhist, dhist, (size_t)n * 1024 * 4));
   bt.flush();
   const double tr0 = now_ms();
   T_TRY(hipStreamSynchronize(st));
@@ -313,7 +333,7 @@ int refine_windows(ctd_tail* t, const std::vector<WinReq>& reqs, int refine_mode
   bt.flush();
   // ---- xor distances -> polarity and merge order
   launch_tw_xor(dw, drules, n, max_pix, dsums, st);
-  bt.copy(hsums, dsums, (size_t)n * 6 * 8);
+  T_TRY(bt.d2h(hsums, dsums, (size_t)n * 6 * 8));
   bt.flush();
   const double tr2 = now_ms();
   T_TRY(hipStreamSynchronize(st));
@@ -470,11 +490,12 @@ int download_pages(ctd_tail* t, bool mask_too, uint8_t* const* mask_out, uint8_t
   GET(t->d_refined, 0, uint8_t, refined);
   Batch bt(st);
   auto one = [&](uint8_t* host, const uint8_t* dev, size_t nb) -> hipError_t {
-    if (void* dv = device_view(host)) {                  // page-locked array: a segment of the copy kernel
-      bt.copy(dv, dev, nb);
-      return hipSuccess;
-    }
-    return hipMemcpyAsync(host, dev, nb, hipMemcpyDeviceToHost, st);
+    if (nb < (size_t)g_tail_dma_min)
+      if (void* dv = device_view(host)) {                // small page-locked array: a segment of the copy kernel
+        bt.copy(dv, dev, nb);
+        return hipSuccess;
+      }
+    return hipMemcpyAsync(host, dev, nb, hipMemcpyDeviceToHost, st);   // page-locked arrays make these DMA transfers
   };
   for (int b = 0; b < t->B; ++b) {
     const size_t nb = (size_t)t->pages[b].im_h * t->pages[b].im_w;
@@ -549,7 +570,7 @@ int db_enqueue(ctd_tail* t, DbStage& d, int B, int Hn, int Wn, const float* prob
   launch_dbc(dt, st);
   GET(t->h_hdr, (size_t)B * 4 * 4, int, hhdr);
   d.hhdr = hhdr;
-  post.copy(hhdr, d.hdr, (size_t)B * 16);
+  T_TRY(post.d2h(hhdr, d.hdr, (size_t)B * 16));
   T_TRY(hipGetLastError());
   return CTD_OK;
 }
@@ -588,8 +609,7 @@ int db_collect(ctd_tail* t, const DbStage& d, const ctd_tail_params* prm) {
   int* h_row_hi = (int*)take((size_t)B * nr * 4);
   Batch bt(st);
   auto d2h = [&](void* dst, const void* src, size_t elem, size_t n_used, size_t n_cap) -> hipError_t {
-    bt.copy2d(dst, n_used * elem, src, n_cap * elem, n_used * elem, B);
-    return hipSuccess;
+    return bt.d2h2d(dst, n_used * elem, src, n_cap * elem, n_used * elem, B);
   };
   if (nfm > 0) {
     T_TRY(d2h(h_st_f, d.st_f, 20, nf, cap));
@@ -769,7 +789,7 @@ static int tail_run_impl(ctd_tail* t, int32_t B, int32_t Hn, int32_t Wn, const f
   pre.fill(refined, 0, t->ptotal);
   DbStage db;
   if (int rc = db_enqueue(t, db, B, Hn, Wn, prob_dev, prob_stride, bitmap_dev, pre, post)) return rc;
-  post.copy(hdets, dets, (size_t)B * kMaxDet * 6 * 4 + (size_t)B * 4);
+  T_TRY(post.d2h(hdets, dets, (size_t)B * kMaxDet * 6 * 4 + (size_t)B * 4));
   size_t crop_px = 1;                       // pages whose letterbox padded the right side are cropped into a dense
   for (int b = 0; b < B; ++b)               // temporary first (one buffer: the stream runs the pages in order)
     if (pages[b].dw > 0) crop_px = std::max(crop_px, (size_t)(Hn - pages[b].dh) * (Wn - pages[b].dw));
@@ -781,7 +801,7 @@ static int tail_run_impl(ctd_tail* t, int32_t B, int32_t Hn, int32_t Wn, const f
   if (plain) {   // device and host copy of the page masks both read the network's u8 mask: same launch, no ordering needed
     const size_t stride = B > 1 ? t->poff[1] - t->poff[0] : hw;
     post.copy2d(pmask, stride, mask_u8_dev, hw, hw, B);
-    post.copy2d(hpmask, stride, mask_u8_dev, hw, hw, B);
+    T_TRY(post.d2h2d(hpmask, stride, mask_u8_dev, hw, hw, B));
   }
   for (int b = 0; b < B && !plain; ++b) {
     const ctd_tail_page& pg = pages[b];
@@ -797,7 +817,7 @@ static int tail_run_impl(ctd_tail* t, int32_t B, int32_t Hn, int32_t Wn, const f
       launch_resize_linear_u8(src, ch, cw, 1, dst, pg.im_h, pg.im_w, pg.im_h, pg.im_w, st);
     }
   }
-  if (!plain) post.copy(hpmask, pmask, t->ptotal);
+  if (!plain) T_TRY(post.d2h(hpmask, pmask, t->ptotal));
   post.flush();
   T_TRY(hipGetLastError());
   const double t1 = now_ms();

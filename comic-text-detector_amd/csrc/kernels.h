@@ -34,6 +34,7 @@ void launch_db_step(const float* lines, float k, float* out, uint8_t* bitmap, fl
 
 // ---- kernels_igemm.hip : MFMA implicit-GEMM conv (fp16 in, fp32 acc) ------
 // weights: half [nphase][Npad][K], K index = (ty*KW+tx)*(c0+c1) + c
+extern int g_tail_max_blocks;   // kernels_post.hip: grid cap of the tail's big-grid kernels ("tail_max_blocks")
 extern int g_igemm_occ_lo;
 extern int g_igemm_force_bk;  // tuning knob: 0 = heuristic, 32 / 64 = forced K step
 int igemm_pick_bk(int c0, int c1, int K, int N, int log2_down);

@@ -4,6 +4,12 @@
 
 #include "kernels.h"
 
+// The labelling kernels of the tail run NEXT TO the network's forward of the following batch.  A neighbour that fills every
+// wave slot (8 waves per SIMD of short blocks) stretches the forward's VALU-bound kernels 2.5-4x; at <= 4 waves per SIMD
+// they keep their speed (selftest ST_CORUN).  So the big-grid tail kernels are launched with at most this many blocks of
+// 256 threads (measured: no effect on the end-to-end rate between 768 and no cap, 7 % lower at 384, 30 % at 192 where the tail becomes the bottleneck) and walk their tiles; "tail_max_blocks".
+int g_tail_max_blocks = 1024;
+
 namespace {
 
 // ===========================================================================
@@ -213,11 +219,11 @@ constexpr int RK_PER_T = RK_CHUNK / 256;
 // version issued up to four LDS union chains per foreground pixel; on page backgrounds and window
 // complements (runs of 32) that was 30x the work (rocprofv3: 0.36 ms per 32 Mpixel launch before).
 template <int CONN>
-__global__ __launch_bounds__(256) void ccl_local_kernel(const uint8_t* __restrict__ img, int* __restrict__ parent_all,
+__device__ __forceinline__ void ccl_local_body(int vb, const uint8_t* __restrict__ img, int* __restrict__ parent_all,
                                                         int H, int W, int tiles_x, int tiles_y, int thresh, int invert) {
   __shared__ int lp[CT * CT];
   __shared__ unsigned rowmask[CT];
-  int bid = blockIdx.x;
+  int bid = vb;
   const int tx = bid % tiles_x;
   bid /= tiles_x;
   const int ty = bid % tiles_y;
@@ -277,6 +283,16 @@ __global__ __launch_bounds__(256) void ccl_local_kernel(const uint8_t* __restric
       v = (y0 + (r >> 5)) * W + x0 + (r & 31);
     }
     parent_all[base + (size_t)gy * W + gx] = v;
+  }
+}
+// a block walks several tiles / chunks: the launcher caps the grid (tail_max_blocks) so that these kernels hold a few
+// waves per SIMD next to the network, not all of them
+template <int CONN>
+__global__ __launch_bounds__(256) void ccl_local_kernel(const uint8_t* __restrict__ img, int* __restrict__ parent_all,
+                                                        int H, int W, int tiles_x, int tiles_y, int thresh, int invert, int nvb) {
+  for (int vb = blockIdx.x; vb < nvb; vb += gridDim.x) {
+    ccl_local_body<CONN>(vb, img, parent_all, H, W, tiles_x, tiles_y, thresh, invert);
+    __syncthreads();
   }
 }
 
@@ -348,10 +364,10 @@ __device__ __forceinline__ int block_exclusive_scan(int v, int* sh, int* total);
 
 // Path flattening fused with pass 1 of the ranking: a block owns one rank chunk, replaces every parent by
 // its root and counts the roots of the chunk (a pixel is a root iff it is its own parent).
-__global__ __launch_bounds__(256) void ccl_flatten_count_kernel(int* __restrict__ parent_all, int hw, int nchunks,
+__device__ __forceinline__ void ccl_flatten_count_body(int vb, int* __restrict__ parent_all, int hw, int nchunks,
                                                                 int* __restrict__ chunk_cnt) {
   __shared__ int sh[4];
-  const int b = blockIdx.x / nchunks, ch = blockIdx.x % nchunks;
+  const int b = vb / nchunks, ch = vb % nchunks;
   int* parent = parent_all + (size_t)b * hw;
   const int p0 = ch * RK_CHUNK + threadIdx.x;
   int local = 0;
@@ -369,7 +385,16 @@ __global__ __launch_bounds__(256) void ccl_flatten_count_kernel(int* __restrict_
   }
   int total;
   block_exclusive_scan(local, sh, &total);
-  if (threadIdx.x == 0) chunk_cnt[blockIdx.x] = total;
+  if (threadIdx.x == 0) chunk_cnt[vb] = total;
+}
+// a block walks several tiles / chunks: the launcher caps the grid (tail_max_blocks) so that these kernels hold a few
+// waves per SIMD next to the network, not all of them
+__global__ __launch_bounds__(256) void ccl_flatten_count_kernel(int* __restrict__ parent_all, int hw, int nchunks,
+                                                                int* __restrict__ chunk_cnt, int nvb) {
+  for (int vb = blockIdx.x; vb < nvb; vb += gridDim.x) {
+    ccl_flatten_count_body(vb, parent_all, hw, nchunks, chunk_cnt);
+    __syncthreads();
+  }
 }
 
 __device__ __forceinline__ int block_exclusive_scan(int v, int* sh, int* total) {
@@ -390,14 +415,14 @@ __device__ __forceinline__ int block_exclusive_scan(int v, int* sh, int* total) 
 }
 
 // pass 3: assign raster-order ids to the roots (pass 1, the per-chunk count, is fused into the flattening).
-__global__ __launch_bounds__(256) void ccl_rank_kernel(const int* __restrict__ parent_all, int hw, int nchunks,
+__device__ __forceinline__ void ccl_rank_body(int vb, const int* __restrict__ parent_all, int hw, int nchunks,
                                                        const int* __restrict__ chunk_cnt, int* __restrict__ ids_all,
                                                        int* __restrict__ first, int max_labels) {
   // A wave owns 1024 consecutive pixels of the chunk, 64 at a time (coalesced); the root masks of the 16
   // groups stay in scalar registers between the counting and the numbering sweep.
   static_assert(RK_CHUNK == 4 * 16 * 64, "4 waves x 16 groups x 64 lanes");
   __shared__ int sh[4];
-  const int b = blockIdx.x / nchunks, ch = blockIdx.x % nchunks;
+  const int b = vb / nchunks, ch = vb % nchunks;
   const int* parent = parent_all + (size_t)b * hw;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int base = ch * RK_CHUNK + w * 1024 + lane;
@@ -411,7 +436,7 @@ __global__ __launch_bounds__(256) void ccl_rank_kernel(const int* __restrict__ p
   }
   if (lane == 0) sh[w] = cnt;
   __syncthreads();
-  int id0 = chunk_cnt[blockIdx.x];   // exclusive offset of the chunk (after ccl_scan_chunks_kernel)
+  int id0 = chunk_cnt[vb];   // exclusive offset of the chunk (after ccl_scan_chunks_kernel)
   for (int i = 0; i < w; ++i) id0 += sh[i];
   int* ids = ids_all + (size_t)b * hw;
   const unsigned long long below = lane ? (~0ull >> (64 - lane)) : 0ull;
@@ -424,6 +449,16 @@ __global__ __launch_bounds__(256) void ccl_rank_kernel(const int* __restrict__ p
       if (first && id <= max_labels) first[(size_t)b * max_labels + id - 1] = p;   // root = first pixel in raster order
     }
     id0 += __popcll(m[j]);
+  }
+}
+// a block walks several tiles / chunks: the launcher caps the grid (tail_max_blocks) so that these kernels hold a few
+// waves per SIMD next to the network, not all of them
+__global__ __launch_bounds__(256) void ccl_rank_kernel(const int* __restrict__ parent_all, int hw, int nchunks,
+                                                       const int* __restrict__ chunk_cnt, int* __restrict__ ids_all,
+                                                       int* __restrict__ first, int max_labels, int nvb) {
+  for (int vb = blockIdx.x; vb < nvb; vb += gridDim.x) {
+    ccl_rank_body(vb, parent_all, hw, nchunks, chunk_cnt, ids_all, first, max_labels);
+    __syncthreads();
   }
 }
 
@@ -464,13 +499,13 @@ __global__ void ccl_stats_init_kernel(int* __restrict__ stats, const int* __rest
 constexpr int LB_CHUNK = 8192;
 constexpr int LB_SLOTS = 128;
 
-__global__ __launch_bounds__(256) void ccl_label_kernel(int* __restrict__ labels_all, const int* __restrict__ ids_all,
+__device__ __forceinline__ void ccl_label_body(int vb, int* __restrict__ labels_all, const int* __restrict__ ids_all,
                                                         int B, int H, int W, int chunks, int* __restrict__ stats,
                                                         int max_labels) {
   __shared__ int hkey[LB_SLOTS];
   __shared__ int hst[LB_SLOTS * 5];
   const int hw = H * W;
-  const int b = blockIdx.x / chunks, ch = blockIdx.x % chunks;
+  const int b = vb / chunks, ch = vb % chunks;
   const int p_begin = ch * LB_CHUNK, p_end = min(hw, p_begin + LB_CHUNK);
   const size_t base = (size_t)b * hw;
   if (stats) {
@@ -531,6 +566,16 @@ __global__ __launch_bounds__(256) void ccl_label_kernel(int* __restrict__ labels
     }
   }
 }
+// a block walks several tiles / chunks: the launcher caps the grid (tail_max_blocks) so that these kernels hold a few
+// waves per SIMD next to the network, not all of them
+__global__ __launch_bounds__(256) void ccl_label_kernel(int* __restrict__ labels_all, const int* __restrict__ ids_all,
+                                                        int B, int H, int W, int chunks, int* __restrict__ stats,
+                                                        int max_labels, int nvb) {
+  for (int vb = blockIdx.x; vb < nvb; vb += gridDim.x) {
+    ccl_label_body(vb, labels_all, ids_all, B, H, W, chunks, stats, max_labels);
+    __syncthreads();
+  }
+}
 
 __global__ void ccl_stats_final_kernel(int* __restrict__ stats, const int* __restrict__ n_out, int max_labels) {
   const int b = blockIdx.y;
@@ -550,11 +595,11 @@ __global__ void ccl_stats_final_kernel(int* __restrict__ stats, const int* __res
 // both -- the two separate launches read and wrote every int32 plane twice.  Output: ONE signed label image
 // (+id foreground, -id background, ids per class in raster order of the first pixel) and per-class stats.
 // ======================================================================================================
-__global__ __launch_bounds__(256) void ccl2_local_kernel(const uint8_t* __restrict__ img, int* __restrict__ parent_all,
+__device__ __forceinline__ void ccl2_local_body(int vb, const uint8_t* __restrict__ img, int* __restrict__ parent_all,
                                                          int H, int W, int tiles_x, int tiles_y, int thresh) {
   __shared__ int lp[CT * CT];
   __shared__ unsigned mrow[2][CT];                 // row masks: [0] foreground, [1] background (pixels inside the image)
-  int bid = blockIdx.x;
+  int bid = vb;
   const int tx = bid % tiles_x;
   bid /= tiles_x;
   const int ty = bid % tiles_y;
@@ -612,6 +657,15 @@ __global__ __launch_bounds__(256) void ccl2_local_kernel(const uint8_t* __restri
     if (gx >= W || gy >= H) continue;
     const int r = lds_find(lp, lp[li]);
     parent_all[base + (size_t)gy * W + gx] = (y0 + (r >> 5)) * W + x0 + (r & 31);
+  }
+}
+// a block walks several tiles / chunks: the launcher caps the grid (tail_max_blocks) so that these kernels hold a few
+// waves per SIMD next to the network, not all of them
+__global__ __launch_bounds__(256) void ccl2_local_kernel(const uint8_t* __restrict__ img, int* __restrict__ parent_all,
+                                                         int H, int W, int tiles_x, int tiles_y, int thresh, int nvb) {
+  for (int vb = blockIdx.x; vb < nvb; vb += gridDim.x) {
+    ccl2_local_body(vb, img, parent_all, H, W, tiles_x, tiles_y, thresh);
+    __syncthreads();
   }
 }
 
@@ -678,10 +732,10 @@ __global__ __launch_bounds__(256) void ccl2_border_v_kernel(int* __restrict__ pa
 }
 
 // chunk_cnt: (B, 2, nchunks) -- class 0 = foreground roots, 1 = background roots
-__global__ __launch_bounds__(256) void ccl2_flatten_count_kernel(int* __restrict__ parent_all, const uint8_t* __restrict__ img_all,
+__device__ __forceinline__ void ccl2_flatten_count_body(int vb, int* __restrict__ parent_all, const uint8_t* __restrict__ img_all,
                                                                  int thresh, int hw, int nchunks, int* __restrict__ chunk_cnt) {
   __shared__ int sh[4];
-  const int b = blockIdx.x / nchunks, ch = blockIdx.x % nchunks;
+  const int b = vb / nchunks, ch = vb % nchunks;
   int* parent = parent_all + (size_t)b * hw;
   const uint8_t* img = img_all + (size_t)b * hw;
   const int p0 = ch * RK_CHUNK + threadIdx.x;
@@ -706,6 +760,15 @@ __global__ __launch_bounds__(256) void ccl2_flatten_count_kernel(int* __restrict
     chunk_cnt[((size_t)b * 2 + 1) * nchunks + ch] = tb;
   }
 }
+// a block walks several tiles / chunks: the launcher caps the grid (tail_max_blocks) so that these kernels hold a few
+// waves per SIMD next to the network, not all of them
+__global__ __launch_bounds__(256) void ccl2_flatten_count_kernel(int* __restrict__ parent_all, const uint8_t* __restrict__ img_all,
+                                                                 int thresh, int hw, int nchunks, int* __restrict__ chunk_cnt, int nvb) {
+  for (int vb = blockIdx.x; vb < nvb; vb += gridDim.x) {
+    ccl2_flatten_count_body(vb, parent_all, img_all, thresh, hw, nchunks, chunk_cnt);
+    __syncthreads();
+  }
+}
 
 // one block per (image, class): exclusive scan of that class's chunk counts; the totals go to n_f / n_b
 __global__ __launch_bounds__(256) void ccl2_scan_chunks_kernel(int* __restrict__ chunk_cnt, int nchunks, int* __restrict__ n_f,
@@ -726,12 +789,12 @@ __global__ __launch_bounds__(256) void ccl2_scan_chunks_kernel(int* __restrict__
 }
 
 // ids: +rank for a foreground root, -rank for a background root (ranks per class, raster order)
-__global__ __launch_bounds__(256) void ccl2_rank_kernel(const int* __restrict__ parent_all, const uint8_t* __restrict__ img_all,
+__device__ __forceinline__ void ccl2_rank_body(int vb, const int* __restrict__ parent_all, const uint8_t* __restrict__ img_all,
                                                         int thresh, int hw, int nchunks, const int* __restrict__ chunk_cnt,
                                                         int* __restrict__ ids_all, int* __restrict__ first_f,
                                                         int* __restrict__ first_b, int max_labels) {
   __shared__ int sh[2][4];
-  const int b = blockIdx.x / nchunks, ch = blockIdx.x % nchunks;
+  const int b = vb / nchunks, ch = vb % nchunks;
   const int* parent = parent_all + (size_t)b * hw;
   const uint8_t* img = img_all + (size_t)b * hw;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -770,16 +833,27 @@ __global__ __launch_bounds__(256) void ccl2_rank_kernel(const int* __restrict__ 
     idb += __popcll(mb[j]);
   }
 }
+// a block walks several tiles / chunks: the launcher caps the grid (tail_max_blocks) so that these kernels hold a few
+// waves per SIMD next to the network, not all of them
+__global__ __launch_bounds__(256) void ccl2_rank_kernel(const int* __restrict__ parent_all, const uint8_t* __restrict__ img_all,
+                                                        int thresh, int hw, int nchunks, const int* __restrict__ chunk_cnt,
+                                                        int* __restrict__ ids_all, int* __restrict__ first_f,
+                                                        int* __restrict__ first_b, int max_labels, int nvb) {
+  for (int vb = blockIdx.x; vb < nvb; vb += gridDim.x) {
+    ccl2_rank_body(vb, parent_all, img_all, thresh, hw, nchunks, chunk_cnt, ids_all, first_f, first_b, max_labels);
+    __syncthreads();
+  }
+}
 
 // signed final labels + the statistics of both classes (aggregation as in ccl_label_kernel)
-__global__ __launch_bounds__(256) void ccl2_label_kernel(int* __restrict__ labels_all, const int* __restrict__ ids_all, int B, int H,
+__device__ __forceinline__ void ccl2_label_body(int vb, int* __restrict__ labels_all, const int* __restrict__ ids_all, int B, int H,
                                                          int W, int chunks, int* __restrict__ st_f, int* __restrict__ st_b,
                                                          int max_labels) {
   constexpr int EMPTY = (int)0x80000000;
   __shared__ int hkey[LB_SLOTS];
   __shared__ int hst[LB_SLOTS * 5];
   const int hw = H * W;
-  const int b = blockIdx.x / chunks, ch = blockIdx.x % chunks;
+  const int b = vb / chunks, ch = vb % chunks;
   const int p_begin = ch * LB_CHUNK, p_end = min(hw, p_begin + LB_CHUNK);
   const size_t base = (size_t)b * hw;
   for (int s = threadIdx.x; s < LB_SLOTS; s += 256) {
@@ -835,11 +909,24 @@ __global__ __launch_bounds__(256) void ccl2_label_kernel(int* __restrict__ label
     atomicAdd(s + 4, hst[5 * sl + 4]);
   }
 }
+// a block walks several tiles / chunks: the launcher caps the grid (tail_max_blocks) so that these kernels hold a few
+// waves per SIMD next to the network, not all of them
+__global__ __launch_bounds__(256) void ccl2_label_kernel(int* __restrict__ labels_all, const int* __restrict__ ids_all, int B, int H,
+                                                         int W, int chunks, int* __restrict__ st_f, int* __restrict__ st_b,
+                                                         int max_labels, int nvb) {
+  for (int vb = blockIdx.x; vb < nvb; vb += gridDim.x) {
+    ccl2_label_body(vb, labels_all, ids_all, B, H, W, chunks, st_f, st_b, max_labels);
+    __syncthreads();
+  }
+}
 
+
+// grid of a kernel whose blocks walk `nvb` tiles / chunks: at most g_tail_max_blocks blocks
+inline int capped(int nvb) { return std::max(1, std::min(nvb, g_tail_max_blocks)); }
 
 inline int grid_for(long long total, int block = 256) {
   long long g = (total + block - 1) / block;
-  if (g > 256LL * 32) g = 256LL * 32;
+  if (g > (long long)g_tail_max_blocks) g = g_tail_max_blocks;
   if (g < 1) g = 1;
   return (int)g;
 }
@@ -882,22 +969,23 @@ void launch_ccl(const uint8_t* img, int B, int H, int W, int thresh, int conn, i
   int* chunk_cnt = (int*)((char*)ws + ((size_t)total * sizeof(int) + 255) / 256 * 256);
   const int tiles_x = (W + CT - 1) / CT, tiles_y = (H + CT - 1) / CT;
   if (conn == 8) {
-    hipLaunchKernelGGL((ccl_local_kernel<8>), dim3(B * tiles_x * tiles_y), dim3(256), 0, st, img, labels, H, W, tiles_x,
-                       tiles_y, thresh, invert);
+    hipLaunchKernelGGL((ccl_local_kernel<8>), dim3(capped(B * tiles_x * tiles_y)), dim3(256), 0, st, img, labels, H, W, tiles_x,
+                       tiles_y, thresh, invert, B * tiles_x * tiles_y);
     launch_border<8>(labels, B, H, W, st);
   } else {
-    hipLaunchKernelGGL((ccl_local_kernel<4>), dim3(B * tiles_x * tiles_y), dim3(256), 0, st, img, labels, H, W, tiles_x,
-                       tiles_y, thresh, invert);
+    hipLaunchKernelGGL((ccl_local_kernel<4>), dim3(capped(B * tiles_x * tiles_y)), dim3(256), 0, st, img, labels, H, W, tiles_x,
+                       tiles_y, thresh, invert, B * tiles_x * tiles_y);
     launch_border<4>(labels, B, H, W, st);
   }
-  hipLaunchKernelGGL(ccl_flatten_count_kernel, dim3(B * nchunks), dim3(256), 0, st, labels, hw, nchunks, chunk_cnt);
+  hipLaunchKernelGGL(ccl_flatten_count_kernel, dim3(capped(B * nchunks)), dim3(256), 0, st, labels, hw, nchunks, chunk_cnt, B * nchunks);
   hipLaunchKernelGGL(ccl_scan_chunks_kernel, dim3(B), dim3(256), 0, st, chunk_cnt, nchunks, n_out);
-  hipLaunchKernelGGL(ccl_rank_kernel, dim3(B * nchunks), dim3(256), 0, st, labels, hw, nchunks, chunk_cnt, ids, first,
-                     max_labels);
+  hipLaunchKernelGGL(ccl_rank_kernel, dim3(capped(B * nchunks)), dim3(256), 0, st, labels, hw, nchunks, chunk_cnt, ids, first,
+                     max_labels, B * nchunks);
   const int sgrid = std::max(1, std::min(64, (max_labels + 255) / 256));
   if (stats) hipLaunchKernelGGL(ccl_stats_init_kernel, dim3(sgrid, B), dim3(256), 0, st, stats, n_out, max_labels, H, W);
   const int lchunks = (hw + LB_CHUNK - 1) / LB_CHUNK;
-  hipLaunchKernelGGL(ccl_label_kernel, dim3(B * lchunks), dim3(256), 0, st, labels, ids, B, H, W, lchunks, stats, max_labels);
+  hipLaunchKernelGGL(ccl_label_kernel, dim3(capped(B * lchunks)), dim3(256), 0, st, labels, ids, B, H, W, lchunks, stats, max_labels,
+                     B * lchunks);
   if (stats) hipLaunchKernelGGL(ccl_stats_final_kernel, dim3(sgrid, B), dim3(256), 0, st, stats, n_out, max_labels);
 }
 
@@ -909,21 +997,22 @@ void launch_ccl_dual(const uint8_t* img, int B, int H, int W, int thresh, int* l
   int* ids = (int*)ws;
   int* chunk_cnt = (int*)((char*)ws + ((size_t)total * sizeof(int) + 255) / 256 * 256);   // (B, 2, nchunks)
   const int tiles_x = (W + CT - 1) / CT, tiles_y = (H + CT - 1) / CT;
-  hipLaunchKernelGGL(ccl2_local_kernel, dim3(B * tiles_x * tiles_y), dim3(256), 0, st, img, labels, H, W, tiles_x, tiles_y,
-                     thresh);
+  hipLaunchKernelGGL(ccl2_local_kernel, dim3(capped(B * tiles_x * tiles_y)), dim3(256), 0, st, img, labels, H, W, tiles_x, tiles_y,
+                     thresh, B * tiles_x * tiles_y);
   const int nh = (H - 1) / CT, nv = (W - 1) / CT;
   if (nh > 0) hipLaunchKernelGGL(ccl2_border_h_kernel, dim3((W + 255) / 256, nh, B), dim3(256), 0, st, labels, img, thresh, H, W);
   if (nv > 0) hipLaunchKernelGGL(ccl2_border_v_kernel, dim3((H + 255) / 256, nv, B), dim3(256), 0, st, labels, img, thresh, H, W);
-  hipLaunchKernelGGL(ccl2_flatten_count_kernel, dim3(B * nchunks), dim3(256), 0, st, labels, img, thresh, hw, nchunks, chunk_cnt);
+  hipLaunchKernelGGL(ccl2_flatten_count_kernel, dim3(capped(B * nchunks)), dim3(256), 0, st, labels, img, thresh, hw, nchunks, chunk_cnt,
+                     B * nchunks);
   hipLaunchKernelGGL(ccl2_scan_chunks_kernel, dim3(2 * B), dim3(256), 0, st, chunk_cnt, nchunks, n_f, n_b);
-  hipLaunchKernelGGL(ccl2_rank_kernel, dim3(B * nchunks), dim3(256), 0, st, labels, img, thresh, hw, nchunks, chunk_cnt, ids,
-                     first_f, first_b, max_labels);
+  hipLaunchKernelGGL(ccl2_rank_kernel, dim3(capped(B * nchunks)), dim3(256), 0, st, labels, img, thresh, hw, nchunks, chunk_cnt, ids,
+                     first_f, first_b, max_labels, B * nchunks);
   const int sgrid = std::max(1, std::min(64, (max_labels + 255) / 256));
   hipLaunchKernelGGL(ccl_stats_init_kernel, dim3(sgrid, B), dim3(256), 0, st, st_f, n_f, max_labels, H, W);
   hipLaunchKernelGGL(ccl_stats_init_kernel, dim3(sgrid, B), dim3(256), 0, st, st_b, n_b, max_labels, H, W);
   const int lchunks = (hw + LB_CHUNK - 1) / LB_CHUNK;
-  hipLaunchKernelGGL(ccl2_label_kernel, dim3(B * lchunks), dim3(256), 0, st, labels, ids, B, H, W, lchunks, st_f, st_b,
-                     max_labels);
+  hipLaunchKernelGGL(ccl2_label_kernel, dim3(capped(B * lchunks)), dim3(256), 0, st, labels, ids, B, H, W, lchunks, st_f, st_b,
+                     max_labels, B * lchunks);
   hipLaunchKernelGGL(ccl_stats_final_kernel, dim3(sgrid, B), dim3(256), 0, st, st_f, n_f, max_labels);
   hipLaunchKernelGGL(ccl_stats_final_kernel, dim3(sgrid, B), dim3(256), 0, st, st_b, n_b, max_labels);
 }

@@ -20,7 +20,7 @@ namespace {
 
 inline int grid_for(long long total, int block = 256) {
   long long g = (total + block - 1) / block;
-  if (g > 256LL * 32) g = 256LL * 32;
+  if (g > (long long)g_tail_max_blocks) g = g_tail_max_blocks;
   if (g < 1) g = 1;
   return (int)g;
 }
@@ -633,6 +633,8 @@ __global__ void copy2d_u8_kernel(const uint8_t* __restrict__ src, int spitch, ui
 }
 
 inline int win_gx(int max_pix) { return max(1, min(64, (max_pix + 4095) / 4096)); }
+// x extent of a (gx, n) window grid under the block cap (the window kernels stride over their window in x)
+inline int win_gx(int max_pix, int n) { return max(1, min(win_gx(max_pix), g_tail_max_blocks / max(1, n))); }
 
 // ---- one launch for many copies / fills -----------------------------------------------------------------------------
 // The tail moves dozens of small tables per batch (counts, contour tables, window / rule / band tables, histograms,
@@ -692,27 +694,27 @@ void launch_dbc(const DbcTables& t, hipStream_t st) {
   hipLaunchKernelGGL(dbc_prep_kernel, dim3((t.cap + 255) / 256, t.B), dim3(256), 0, st, t);
   hipLaunchKernelGGL(dbc_scan_kernel, dim3(t.B), dim3(256), 0, st, t);
   hipLaunchKernelGGL(dbc_init_kernel, dim3(grid_for((long long)t.B * t.rcap)), dim3(256), 0, st, t);
-  const int per_page = std::max(1, std::min((t.H * t.W + 255) / 256, 8192 / std::max(1, t.B)));
+  const int per_page = std::max(1, std::min((t.H * t.W + 255) / 256, g_tail_max_blocks / std::max(1, t.B)));
   hipLaunchKernelGGL(dbc_accum_kernel, dim3(per_page, t.B), dim3(256), 0, st, t);
 }
 
 void launch_tw_hist(const TWin* wins, int n, int max_pix, unsigned* hist, hipStream_t st) {
-  hipLaunchKernelGGL(tw_hist_kernel, dim3(win_gx(max_pix), n), dim3(256), 0, st, wins, hist);
+  hipLaunchKernelGGL(tw_hist_kernel, dim3(win_gx(max_pix, n), n), dim3(256), 0, st, wins, hist);
 }
 
 void launch_tw_xor(const TWin* wins, const TRule* rules, int n, int max_pix, unsigned long long* sums, hipStream_t st) {
-  hipLaunchKernelGGL(tw_xor_kernel, dim3(win_gx(max_pix), n), dim3(256), 0, st, wins, rules, sums);
+  hipLaunchKernelGGL(tw_xor_kernel, dim3(win_gx(max_pix, n), n), dim3(256), 0, st, wins, rules, sums);
 }
 
 void launch_tw_render(const TWin* wins, const TBand* bands, int nbands, int max_pix, uint8_t* canvas, int canvas_w,
                       hipStream_t st) {
-  hipLaunchKernelGGL(tw_render_kernel, dim3(win_gx(max_pix), nbands), dim3(256), 0, st, wins, bands, canvas, canvas_w);
+  hipLaunchKernelGGL(tw_render_kernel, dim3(win_gx(max_pix, nbands), nbands), dim3(256), 0, st, wins, bands, canvas, canvas_w);
 }
 
 void launch_tw_accept(const TWin* wins, const TBand* bands, int nbands, int max_pix, int round, const int* labels,
                       int canvas_w, const int* stats, int max_labels, int min_box, uint8_t* merged, int merged_w,
                       unsigned* counters, hipStream_t st) {
-  const dim3 g(win_gx(max_pix), nbands);
+  const dim3 g(win_gx(max_pix, nbands), nbands);
   hipLaunchKernelGGL(tw_accept_count_kernel, g, dim3(256), 0, st, wins, bands, round, labels, canvas_w, max_labels, merged,
                      merged_w, counters);
   hipLaunchKernelGGL(tw_accept_apply_kernel, g, dim3(256), 0, st, wins, bands, round, labels, canvas_w, stats, max_labels,
@@ -721,21 +723,21 @@ void launch_tw_accept(const TWin* wins, const TBand* bands, int nbands, int max_
 
 void launch_tw_dilate(const TWin* wins, int n, int max_pix, const uint8_t* in, uint8_t* out, uint8_t* comp, int merged_w,
                       unsigned* count255, int dilate, hipStream_t st) {
-  hipLaunchKernelGGL(tw_dilate_kernel, dim3(win_gx(max_pix), n), dim3(256), 0, st, wins, in, out, comp, merged_w, count255,
+  hipLaunchKernelGGL(tw_dilate_kernel, dim3(win_gx(max_pix, n), n), dim3(256), 0, st, wins, in, out, comp, merged_w, count255,
                      dilate);
 }
 
 void launch_tw_holes(const TWin* wins, int n, int max_pix, const int* labels2, const int* stats2, const int* first2,
                      int max_labels, const unsigned* count255, int* top2, uint8_t* merged, int merged_w,
                      unsigned* counters2, hipStream_t st) {
-  const dim3 g(win_gx(max_pix), n);
+  const dim3 g(win_gx(max_pix, n), n);
   for (int pass = 0; pass < 4; ++pass)
     hipLaunchKernelGGL(tw_holes_kernel, g, dim3(256), 0, st, wins, pass, labels2, stats2, first2, max_labels, count255, top2,
                        merged, merged_w, counters2);
 }
 
 void launch_tw_commit(const TWin* wins, int n, int max_pix, const uint8_t* merged, int merged_w, hipStream_t st) {
-  hipLaunchKernelGGL(tw_commit_kernel, dim3(win_gx(max_pix), n), dim3(256), 0, st, wins, merged, merged_w);
+  hipLaunchKernelGGL(tw_commit_kernel, dim3(win_gx(max_pix, n), n), dim3(256), 0, st, wins, merged, merged_w);
 }
 
 void launch_mask_clear_where(uint8_t* mask, const uint8_t* refined, long long n, int thr, hipStream_t st) {

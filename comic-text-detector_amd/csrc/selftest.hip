@@ -417,6 +417,12 @@ static void launch_disturber(int kind, int* a, int* b, int* tab, int* host, size
     case 3: hipLaunchKernelGGL(dist_lds_kernel, dim3(65536), dim3(256), 0, st, tab, 200); break;
     case 4: hipLaunchKernelGGL(dist_hostwrite_kernel, dim3(128), dim3(256), 0, st, (int4*)host, (size_t)(64u << 20) / 16); break;
     case 5: hipLaunchKernelGGL(dist_valu_kernel, dim3(256), dim3(256), 0, st, tab, 400000); break;
+    case 7: hipLaunchKernelGGL(dist_valu_kernel, dim3(512), dim3(256), 0, st, tab, 200000); break;
+    case 8: hipLaunchKernelGGL(dist_valu_kernel, dim3(1024), dim3(256), 0, st, tab, 100000); break;
+    case 9: hipLaunchKernelGGL(dist_valu_kernel, dim3(2048), dim3(256), 0, st, tab, 50000); break;
+    case 10: hipLaunchKernelGGL(dist_lds_kernel, dim3(512), dim3(256), 0, st, tab, 30000); break;
+    case 11: hipLaunchKernelGGL(dist_lds_kernel, dim3(1024), dim3(256), 0, st, tab, 15000); break;
+    case 12: hipLaunchKernelGGL(dist_copy_kernel, dim3(512), dim3(256), 0, st, (const int4*)a, (int4*)b, nw / 4); break;
     case 6: (void)hipMemcpyAsync(host, a, (size_t)64u << 20, hipMemcpyDeviceToHost, st); break;   // the copy engines
   }
 }
@@ -504,9 +510,9 @@ static void run_stem2_case(const char* name, int B, int H, int W, int in_fmt, in
   if (diff) std::printf(", first at pixel %zu ch %zu", first / 64, first % 64);
   std::printf(") | 2 launches %.3f ms, fused %.3f ms = %.0f GB/s of in+out\n", ms_u, ms_f, io / (ms_f * 1e-3) / 1e9);
   if (std::getenv("ST_CORUN")) {   // which kind of neighbour stretches this kernel?  (the end-to-end timeline shows it at 2.1 ms next to the tail)
-    hipStream_t sa, sb;
+    hipStream_t sa, sb0;
     CK(hipStreamCreateWithFlags(&sa, hipStreamNonBlocking));
-    CK(hipStreamCreateWithFlags(&sb, hipStreamNonBlocking));
+    CK(hipStreamCreateWithFlags(&sb0, hipStreamNonBlocking));
     const size_t NW = 32u << 20;                       // 128 MB of int32
     int *dA = dev_alloc<int>(NW), *dBb = dev_alloc<int>(NW), *dTab = dev_alloc<int>(4096);
     void* hostbuf = nullptr;
@@ -518,9 +524,21 @@ static void run_stem2_case(const char* name, int B, int H, int W, int in_fmt, in
     struct D { const char* name; int kind; };
     const D ds[] = {{"alone", -1}, {"valu, no LDS, 8 waves/SIMD", 0}, {"streaming copy 128 MB", 1}, {"contended atomics (64 words)", 2},
                     {"4-KB-LDS short blocks", 3}, {"stores to pinned host memory", 4}, {"valu, one wave per SIMD", 5},
-                    {"hipMemcpyAsync 64 MB to pinned host", 6}};
+                    {"hipMemcpyAsync 64 MB to pinned host", 6}, {"valu, 2 waves per SIMD", 7}, {"valu, 4 waves per SIMD", 8},
+                    {"valu, 8 waves per SIMD (2048 blocks)", 9}, {"4-KB-LDS blocks, 2 per CU", 10}, {"4-KB-LDS blocks, 4 per CU", 11},
+                    {"streaming copy, 2 blocks per CU", 12}};
+    // the same neighbours confined to every 4th CU (hipExtStreamCreateWithCUMask): does the rest of the chip keep its speed?
+    hipStream_t sm;
+    {
+      uint32_t mask[8];
+      for (auto& w : mask) w = 0x11111111u;
+      CK(hipExtStreamCreateWithCUMask(&sm, 8, mask));
+    }
+    for (int masked = 0; masked < 2; ++masked)
     for (const D& d : ds) {
-      for (int prio = 0; prio < 2; ++prio) {
+      if (masked && !(d.kind == 0 || d.kind == 3 || d.kind == 2)) continue;
+      hipStream_t sb = masked ? sm : sb0;
+      for (int prio = masked ? 1 : 0; prio < 2; ++prio) {
         Stem2Args fp = f;
         fp.prio = prio;
         CK(hipDeviceSynchronize());
@@ -535,7 +553,8 @@ static void run_stem2_case(const char* name, int B, int H, int W, int in_fmt, in
         float tms;
         CK(hipEventElapsedTime(&tms, e0, e1));
         CK(hipDeviceSynchronize());
-        std::printf("[corun] stem+layer1 next to %-34s prio %d: %.3f ms per launch%s\n", d.name, prio, tms / 10, still ? "" : "  (neighbour finished early)");
+        std::printf("[corun] stem+layer1 next to %-34s%s prio %d: %.3f ms per launch%s\n", d.name, masked ? " on 64 of 256 CUs" : "", prio, tms / 10,
+                    still ? "" : "  (neighbour finished early)");
       }
     }
     (void)hipFree(dA); (void)hipFree(dBb); (void)hipFree(dTab); (void)hipHostFree(hostbuf);

@@ -3,6 +3,8 @@
 #pragma once
 #include "ctd_common.h"
 
+extern int g_tail_max_blocks;   // kernels_post.hip: grid cap of the tail's big-grid kernels ("tail_max_blocks")
+
 // ---- DB text-line stage: per-contour tables compacted on the device ---------------------------------
 // Inputs: the dual labelling of a page batch (8-connected foreground of the bitmap, 4-connected
 // background, one signed label image) with per-component stats and first pixels.  Outputs per page, fixed capacities `cap`

@@ -165,6 +165,11 @@ struct Batch {
     flush();
     return hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, st);
   }
+  hipError_t h2d(void* dev, const void* host, size_t bytes) {      // page-locked host -> device, same rule
+    if (bytes < (size_t)g_tail_dma_min) { copy(dev, host, bytes); return hipSuccess; }
+    flush();
+    return hipMemcpyAsync(dev, host, bytes, hipMemcpyHostToDevice, st);
+  }
   hipError_t d2h2d(void* host, size_t dpitch, const void* dev, size_t spitch, size_t width, int rows) {
     if (rows == 1 || (dpitch == width && spitch == width)) return d2h(host, dev, width * (size_t)rows);
     if (width * (size_t)rows < (size_t)g_tail_dma_min) { copy2d(host, dpitch, dev, spitch, width, rows); return hipSuccess; }
@@ -310,7 +315,7 @@ int refine_windows(ctd_tail* t, const std::vector<WinReq>& reqs, int refine_mode
   int* top2 = small + 16 + n;
   GET(t->d_cnt2, ((size_t)cap2 + 1) * 8, unsigned, counters2);
   Batch bt(st);
-  bt.copy(dw, hw, sizeof(TWin) * n);
+  T_TRY(bt.h2d(dw, hw, sizeof(TWin) * n));
   bt.fill(dhist, 0, (size_t)n * 1024 * 4);
   bt.fill(dsums, 0, (size_t)n * 6 * 8);
   bt.fill(merged_a, 0, mpx * 3);
@@ -329,7 +334,7 @@ int refine_windows(ctd_tail* t, const std::vector<WinReq>& reqs, int refine_mode
   parallel_for(n, t->host_threads, [&](int i) { refine_rules(hhist + (size_t)i * 1024, hrules + (size_t)i * 6); });
   static_assert(sizeof(RRule) == sizeof(TRule), "rule layouts must agree");
   GET(t->d_rules, sizeof(TRule) * 6 * n, TRule, drules);
-  bt.copy(drules, hrules, sizeof(TRule) * 6 * n);
+  T_TRY(bt.h2d(drules, hrules, sizeof(TRule) * 6 * n));
   bt.flush();
   // ---- xor distances -> polarity and merge order
   launch_tw_xor(dw, drules, n, max_pix, dsums, st);
@@ -375,7 +380,7 @@ int refine_windows(ctd_tail* t, const std::vector<WinReq>& reqs, int refine_mode
   GET(t->d_cstats, (size_t)cap1 * 5 * 4, int, cstats);
   GET(t->d_ccl_ws, ccl_workspace_bytes(1, std::max(pc.H, pm.H), std::max(pc.W, pm.W)), uint8_t, ws);
   GET(t->d_cnt, ((size_t)cap1 + 1) * 8, unsigned, counters);
-  bt.copy(db, hb, sizeof(TBand) * nbands);
+  T_TRY(bt.h2d(db, hb, sizeof(TBand) * nbands));
   bt.fill(canvas, 0, cpx);
   bt.fill(counters, 0, ((size_t)cap1 + 1) * 8);
   bt.flush();

@@ -64,7 +64,8 @@ PEAK_TF = {"fp16": MFMA_F16_PEAK_TFLOPS, "fp32": MFMA_F32_PEAK_TFLOPS, "fp32s": 
 DTYPE = {"fp16": "f16", "fp32": "f32", "fp32s": "f32"}
 FAMILY = {"fp16": "conv_halo_kernel + conv_igemm_kernel + c3_fused_kernel (MFMA conv / convT family)",
           "fp32": "conv_f32_mfma_kernel (f32-operand MFMA conv / convT family)",
-          "fp32s": "conv_split_kernel (split-operand conv / convT family: 3 fp16 MFMAs per product on fp32 tensors)"}
+          "fp32s": "conv_split_kernel + conv_split_halo_kernel + stem_split_kernel (split-operand conv / convT family: 3 fp16 MFMAs "
+                   "per product; conv-to-conv tensors split-plane in HBM)"}
 
 
 def host_info() -> dict:
@@ -623,9 +624,9 @@ def roofline_block(be, x, precision: str, B: int, S: int, dump_ops: str = "") ->
     # --pmc passes: scripts/gpu_traffic.sh).  PMC cannot be collected inside this process; the committed measurement of
     # this engine at this shape is attached when it exists (and says which round it is from).
     traffic, tnote = None, None
-    for tname in ("r03_traffic_pmc.json", "r02_traffic_pmc.json"):
+    for tname in {"fp16": ("r03_traffic_pmc.json", "r02_traffic_pmc.json"), "fp32s": ("r03_traffic_pmc_fp32s.json",)}.get(precision, ()):
         tpath = os.path.join(ROOT, "profiles", tname)
-        if os.path.isfile(tpath) and (B, S, precision) == (32, 1024, "fp16"):
+        if os.path.isfile(tpath) and (B, S) == (32, 1024):
             try:
                 traffic = float(json.load(open(tpath))["hbm_bytes_per_forward_corrected"])
                 tnote = f"bytes per forward of this kernel family from profiles/{tname} (rocprofv3 PMC passes of this " \

@@ -653,6 +653,8 @@ int plan(ctd_engine* e, int B, int H, int W, hipStream_t cap_stream = nullptr) {
     if (!stem_split_supported(S1.args)) continue;
     S0.skip = true;
     S1.stemsp_head = true;
+    // algorithmic bytes: the page (3 B per pixel as uint8; the float format is 12) in, the 32-channel map out, the weights
+    S1.bytes = (double)B * H * W * 3 + (double)B * S1.args.oH * S1.args.oW * S1.args.N * 4 + (double)S1.args.N * 36 * 3 * 4;
   }
   // ---- stem + layer 1: the stem's output has one consumer, a 3x3/s2 conv 32 -> 64 -> one launch, never stored
   for (int i = 0; f16 && (g_fuse & 4) && i + 1 < nO; ++i) {

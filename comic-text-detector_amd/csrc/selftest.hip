@@ -510,7 +510,9 @@ static void run_stem2_case(const char* name, int B, int H, int W, int in_fmt, in
   if (diff) std::printf(", first at pixel %zu ch %zu", first / 64, first % 64);
   std::printf(") | 2 launches %.3f ms, fused %.3f ms = %.0f GB/s of in+out\n", ms_u, ms_f, io / (ms_f * 1e-3) / 1e9);
   if (std::getenv("ST_CORUN")) {   // which kind of neighbour stretches this kernel?  (the end-to-end timeline shows it at 2.1 ms next to the tail)
-    hipStream_t sa, sb0;
+    hipStream_t sa, sb0, sc1, sc2;
+    CK(hipStreamCreateWithFlags(&sc1, hipStreamNonBlocking));
+    CK(hipStreamCreateWithFlags(&sc2, hipStreamNonBlocking));
     CK(hipStreamCreateWithFlags(&sa, hipStreamNonBlocking));
     CK(hipStreamCreateWithFlags(&sb0, hipStreamNonBlocking));
     const size_t NW = 32u << 20;                       // 128 MB of int32
@@ -521,12 +523,36 @@ static void run_stem2_case(const char* name, int B, int H, int W, int in_fmt, in
     CK(hipMemset(dTab, 0, 4096 * 4));
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    // a REAL neighbour: the DB stage's dual labelling of 11 pages of 1024x1024 blob bitmaps (what a tail work item launches first)
+    const int cB = 11, cH = 1024, cW = 1024, cL = 4096;
+    std::vector<uint8_t> bm((size_t)cB * cH * cW, 0);
+    for (int b = 0; b < cB; ++b)
+      for (int k = 0; k < 40; ++k) {                       // 40 boxes per page, ~15 % foreground
+        g_seed = g_seed * 1664525u + 1013904223u; const int x0 = (g_seed >> 8) % 900;
+        g_seed = g_seed * 1664525u + 1013904223u; const int y0 = (g_seed >> 8) % 980;
+        g_seed = g_seed * 1664525u + 1013904223u; const int w = 30 + (g_seed >> 8) % 200, h = 12 + (g_seed >> 12) % 40;
+        for (int y = y0; y < std::min(cH, y0 + h); ++y) std::memset(&bm[((size_t)b * cH + y) * cW + x0], 255, std::min(w, cW - x0));
+      }
+    uint8_t* dBm = dev_alloc<uint8_t>(bm.size());
+    CK(hipMemcpy(dBm, bm.data(), bm.size(), hipMemcpyHostToDevice));
+    int* dLab[3]; int* dCnt[3]; void* dWs[3];               // one set per stream: concurrent labellings must not share a union-find
+    for (int q = 0; q < 3; ++q) {
+      dLab[q] = dev_alloc<int>((size_t)cB * cH * cW);
+      dCnt[q] = dev_alloc<int>((size_t)cB * 2 + (size_t)cB * cL * 12 + 64);
+      CK(hipMalloc(&dWs[q], ccl_workspace_bytes(cB, cH, cW)));
+    }
+    auto ccl_dual = [&](hipStream_t st, int q) {
+      int* n_f = dCnt[q]; int* n_b = n_f + cB; int* st_f = n_f + 2 * cB; int* st_b = st_f + (size_t)cB * cL * 5;
+      int* first_f = st_b + (size_t)cB * cL * 5; int* first_b = first_f + (size_t)cB * cL;
+      launch_ccl_dual(dBm, cB, cH, cW, 127, dLab[q], n_f, n_b, st_f, st_b, first_f, first_b, cL, dWs[q], st);
+    };
     struct D { const char* name; int kind; };
     const D ds[] = {{"alone", -1}, {"valu, no LDS, 8 waves/SIMD", 0}, {"streaming copy 128 MB", 1}, {"contended atomics (64 words)", 2},
                     {"4-KB-LDS short blocks", 3}, {"stores to pinned host memory", 4}, {"valu, one wave per SIMD", 5},
                     {"hipMemcpyAsync 64 MB to pinned host", 6}, {"valu, 2 waves per SIMD", 7}, {"valu, 4 waves per SIMD", 8},
                     {"valu, 8 waves per SIMD (2048 blocks)", 9}, {"4-KB-LDS blocks, 2 per CU", 10}, {"4-KB-LDS blocks, 4 per CU", 11},
-                    {"streaming copy, 2 blocks per CU", 12}};
+                    {"streaming copy, 2 blocks per CU", 12}, {"the dual labelling of 11 pages (real kernels)", 20},
+                    {"... on three streams at a time (real kernels)", 21}};
     // the same neighbours confined to every 4th CU (hipExtStreamCreateWithCUMask): does the rest of the chip keep its speed?
     hipStream_t sm;
     {
@@ -543,7 +569,11 @@ static void run_stem2_case(const char* name, int B, int H, int W, int in_fmt, in
         fp.prio = prio;
         CK(hipDeviceSynchronize());
         const int nd = d.kind < 0 ? 0 : 60;
-        for (int i = 0; i < nd; ++i) launch_disturber(d.kind, dA, dBb, dTab, (int*)hostbuf, NW, sb);
+        for (int i = 0; i < nd; ++i) {
+          if (d.kind == 20) { for (int r = 0; r < 3; ++r) ccl_dual(sb, 0); }
+          else if (d.kind == 21) { ccl_dual(sb, 0); ccl_dual(sc1, 1); ccl_dual(sc2, 2); }     // three work items at a time, as in the pipeline
+          else launch_disturber(d.kind, dA, dBb, dTab, (int*)hostbuf, NW, sb);
+        }
         for (int i = 0; i < 2; ++i) launch_stem_conv2(fp, sa);
         CK(hipEventRecord(e0, sa));
         for (int i = 0; i < 10; ++i) launch_stem_conv2(fp, sa);

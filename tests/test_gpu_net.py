@@ -283,3 +283,39 @@ def test_split_engine_tracks_the_f32_engine_at_full_size():
     assert dm < 1e-5 and dl < 1e-5
     assert du < 1e-3 and dbm < 1e-4
     torch.testing.assert_close(bb, ba, rtol=1e-4, atol=2e-3)
+
+
+def test_split_engine_layouts_and_kernels_agree():
+    """The fp32s engine with its round-3 machinery switched off piece by piece (`ctd_tuning_set`): fp32 tensors instead of
+    split-plane ones, the 128-pixel kernel instead of the haloed-patch kernel, INPUT + generic kernel instead of the first
+    layer from the page.  Every variant forms the same products from the same (hi, lo) operands -- only the summation order
+    of a K loop and the 22-bit residual inputs differ -- so the maps agree to a few 1e-7, far inside the tolerance against
+    the oracle, and the first-layer switch alone changes nothing at all."""
+    p = pkg()
+    L = p._lib.lib()
+    pages = torch.from_numpy(np.stack([p.synth.text_like_page((512, 512), s) for s in (3, 4)])).cuda()
+
+    def run(**knobs):
+        for k, v in knobs.items():
+            assert L.ctd_tuning_set(k.encode(), v) == p._lib.OK
+        try:
+            be = p.backend.HipTextDetBackend(checkpoint(0), device="cuda", precision="fp32s")
+            blks, mask, lines = [t.clone() for t in be.forward_u8(pages)]
+            torch.cuda.synchronize()
+            return blks, mask, lines, be.mask_u8.clone(), be.bitmap.clone()
+        finally:
+            for k in knobs:
+                assert L.ctd_tuning_set(k.encode(), 1) == p._lib.OK
+
+    ref = run()
+    assert all(torch.isfinite(t).all() for t in ref[:3])
+    same = run(split_stem=0)
+    for a, b in zip(ref, same):
+        assert torch.equal(a, b)                      # the first layer from the page is bit-identical to INPUT + generic kernel
+    for knobs in (dict(split_halo=0), dict(split_planes=0), dict(split_planes=0, split_halo=0, split_stem=0)):
+        got = run(**knobs)
+        dm, dl = float((ref[1] - got[1]).abs().max()), float((ref[2] - got[2]).abs().max())
+        du = float((ref[3] != got[3]).float().mean())
+        print(f"fp32s {knobs}: max|dmask| {dm:.2e}, max|dlines| {dl:.2e}, u8 mask differs on {du:.2e}")
+        assert dm < 3e-6 and dl < 3e-6 and du < 2e-4
+        torch.testing.assert_close(got[0], ref[0], rtol=1e-4, atol=1e-3)

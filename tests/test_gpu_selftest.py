@@ -26,3 +26,21 @@ def test_selftest_of_the_fused_and_mfma_head_tail_kernels():
         assert "ok(bit-exact)" in ln or "unsupported (falls back)" in ln, ln
     tol = [ln for ln in lines if ln.startswith(("[dbup]", "[segfinal]"))]
     assert len(tol) >= 6 and all("| ok:" in ln for ln in tol), "\n".join(tol)
+
+
+def test_selftest_of_the_split_operand_kernels():
+    """`ST_SPLIT=1`: the fp32s engine's kernels (kernels_split*.hip) against the f32-operand MFMA kernel and a float64 host
+    reference -- fp32 tensors, split-plane tensors on the 128-pixel and on the haloed-patch kernel, mixed layouts, ragged
+    maps; the first layer straight from the page against INPUT + the generic kernel.  B = 32 lines: profiles/r03_split_selftest.txt."""
+    L = pkg()._lib
+    r = subprocess.run([L.SELFTEST_PATH, "2"], env={**os.environ, "ST_SPLIT": "1", "ST_CASES": "3,10,16,18"}, capture_output=True,
+                       text=True, timeout=600)
+    out = r.stdout
+    assert r.returncode == 0 and "selftest: PASSED (0 failures)" in out, out[-4000:]
+    lines = out.splitlines()
+    sp = [ln for ln in lines if ln.startswith("[split]")]
+    assert len(sp) >= 12 and not any("FAIL" in ln for ln in sp), "\n".join(sp)
+    assert sum("split(planes,halo): ok" in ln for ln in sp) >= 5           # ragged halo / PAIR cases + the selected network shapes
+    assert sum("f32->planes ok, planes->f32 ok" in ln for ln in sp) >= 8
+    st = [ln for ln in lines if ln.startswith("[stem-split]")]
+    assert len(st) == 2 and all(ln.count(": ok") == 3 for ln in st), "\n".join(st)

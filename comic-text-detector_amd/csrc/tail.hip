@@ -18,6 +18,7 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <mutex>
 #include <cmath>
 #include <cstring>
 #include <string>
@@ -133,6 +134,37 @@ void parallel_for(int n, int max_threads, F f) {
   for (auto& x : th) x.join();
 }
 
+}  // namespace
+// Three work items' labellings at a time stretch the network's first kernel 3.5x, one at a time 1.4x (selftest ST_CORUN).
+// "tail_chain": 1 = the stage-1 kernels (NMS, labelling, contour tables) of concurrent work items of this process run one
+// after the other on the GPU (an event chain across their streams) instead of next to each other; 2 = the refine stage's
+// big enqueue (render, labelling, accept rounds, dilate, labelling, holes) too; 0 = side by side.
+int g_tail_chain = 1;
+namespace {
+struct GpuChain {
+  hipStream_t st;
+  bool on;
+  std::unique_lock<std::mutex> lk;
+  static std::mutex& mu() { static std::mutex m; return m; }
+  static hipEvent_t& last() { static hipEvent_t e = nullptr; return e; }
+  GpuChain(hipStream_t s, bool enabled) : st(s), on(enabled), lk(mu(), std::defer_lock) {}
+  hipError_t begin() {                       // the lock is held while this section is being enqueued (~0.1 ms of host time)
+    if (!on) return hipSuccess;
+    lk.lock();
+    return last() ? hipStreamWaitEvent(st, last(), 0) : hipSuccess;
+  }
+  hipError_t end() {
+    if (!on || !lk.owns_lock()) return hipSuccess;
+    static hipEvent_t ring[16] = {};
+    static unsigned next = 0;
+    hipEvent_t& ev = ring[next++ % 16];
+    hipError_t e = ev ? hipSuccess : hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventRecord(ev, st);
+    if (e == hipSuccess) last() = ev;
+    lk.unlock();
+    return e;
+  }
+};
 }  // namespace
 long long g_tail_dma_min = 256 << 10;   // device -> host copies of at least this many bytes use the copy engines ("tail_dma_min"; huge = never)
 namespace {
@@ -384,6 +416,8 @@ int refine_windows(ctd_tail* t, const std::vector<WinReq>& reqs, int refine_mode
   bt.fill(canvas, 0, cpx);
   bt.fill(counters, 0, ((size_t)cap1 + 1) * 8);
   bt.flush();
+  GpuChain chain(st, g_tail_chain >= 2);
+  T_TRY(chain.begin());
   launch_tw_render(dw, db, nbands, max_pix, canvas, pc.W, st);
   launch_ccl(canvas, 1, pc.H, pc.W, 0, 8, clab, n_dev, cstats, cap1, ws, st);
   for (int r = 0; r < rounds; ++r)
@@ -396,6 +430,7 @@ int refine_windows(ctd_tail* t, const std::vector<WinReq>& reqs, int refine_mode
   launch_ccl(comp, 1, pm.H, pm.W, 0, 8, mlab, n_dev, mstats, cap2, ws, st, 0, mfirst);
   launch_tw_holes(dw, n, max_pix, mlab, mstats, mfirst, cap2, count255, top2, merged_b, pm.W, counters2, st);
   launch_tw_commit(dw, n, max_pix, merged_b, pm.W, st);
+  T_TRY(chain.end());
   T_TRY(hipGetLastError());
   t->ms_stage[4] += tr1 - tr0;
   t->ms_stage[5] += tr3 - tr2;
@@ -782,6 +817,8 @@ static int tail_run_impl(ctd_tail* t, int32_t B, int32_t Hn, int32_t Wn, const f
   const size_t hw = (size_t)Hn * Wn;
 
   // ================= stage 1: NMS, two labelling passes, contour tables, page masks =================
+  GpuChain chain(st, g_tail_chain >= 1);
+  T_TRY(chain.begin());
   GET(t->d_dets, (size_t)B * kMaxDet * 6 * 4 + (size_t)B * 4, float, dets);
   int* counts = (int*)(dets + (size_t)B * kMaxDet * 6);
   GET(t->d_nms_ws, nms_workspace_bytes(B, rows), uint8_t, nms_ws);
@@ -825,6 +862,7 @@ static int tail_run_impl(ctd_tail* t, int32_t B, int32_t Hn, int32_t Wn, const f
   if (!plain) T_TRY(post.d2h(hpmask, pmask, t->ptotal));
   post.flush();
   T_TRY(hipGetLastError());
+  T_TRY(chain.end());
   const double t1 = now_ms();
   T_TRY(hipStreamSynchronize(st));                                     // sync 1: counts are known
   const double t2 = now_ms();

@@ -1037,6 +1037,9 @@ int ctd_tuning_set(const char* key, int64_t value) {
   if (key && std::string(key) == "no_reuse") { g_no_reuse = (int)value; return CTD_OK; }
   if (key && std::string(key) == "f32_mfma") { g_f32_mfma = (int)value; return CTD_OK; }
   if (key && std::string(key) == "split_halo") { g_split_halo = (int)value; return CTD_OK; }
+#ifdef CTD_AB_VARIANTS
+  if (key && std::string(key) == "split_halo_small") { g_split_halo_small = (int)value; return CTD_OK; }
+#endif
   if (key && std::string(key) == "split_halo_min_patches") { g_split_halo_min_patches = value; return CTD_OK; }
   if (key && std::string(key) == "fwd_prio") { g_fwd_prio = (int)value; ++g_fuse_epoch; return CTD_OK; }
   if (key && std::string(key) == "split_stem") { g_split_stem = (int)value; ++g_fuse_epoch; return CTD_OK; }

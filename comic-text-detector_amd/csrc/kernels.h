@@ -62,6 +62,9 @@ bool stem_split_supported(const ConvArgs& a);
 void launch_stem_split(const ConvArgs& a, const void* input, int in_fmt, hipStream_t st);
 // ---- kernels_split_halo.hip : the same arithmetic on a 256-pixel haloed patch staged once per channel chunk (3x3 / ConvT) ----
 extern int g_split_halo;                    // 0 disables ("split_halo")
+#ifdef CTD_AB_VARIANTS
+extern int g_split_halo_small;              // selftest build: 64-channel layers on 16x8 patches ("split_halo_small")
+#endif
 extern long long g_split_halo_min_patches;  // "split_halo_min_patches"
 bool conv_split_halo_supported(const ConvArgs& a);
 void launch_conv_split_halo(const ConvArgs& a, hipStream_t st);

@@ -21,22 +21,24 @@
 
 namespace {
 
-constexpr int TWP = 16, THP = 16;     // pixel patch
-constexpr int BMH = TWP * THP;        // 256 pixels per block
+constexpr int TWP = 16;               // pixel patch width; the height THP is 16 (256 pixels, 8 waves) or 8 (128 pixels, 4 waves)
 constexpr int BKH = 32;               // channels per K chunk (64-B LDS rows per plane)
-constexpr int AROWS_PAD = 336;        // 18x18 = 324 haloed rows, rounded up to whole waves of the third DMA pass
-constexpr int NTHR = 512;
 
 // PAIR (ConvT 4x4/s2 with 64 output channels, BN = 128): a block computes the two sub-pixel phases (py, px = 0) and
 // (py, px = 1) of its patch -- N columns 0-63 are phase px = 0, 64-127 phase px = 1.  The two phases read the same input
 // rows and overlapping columns (dx in {-1,0} and {0,+1}), so ONE 17x18 patch serves both, and the wave tile is the
 // 2x2-fragment tile of the 128-channel layers (as in kernels_halo.hip).
-template <int BN, int WGN, int WGM, bool PAIR = false>
-__global__ __launch_bounds__(NTHR, 2) void conv_split_halo_kernel(ConvArgs a) {
+// THP = 8 (selftest build only, measured equal to the implicit-GEMM kernel): a 16x8 patch, 256 threads, 64 KB of LDS at
+// BN = 64 -- two blocks per CU for the 64-channel 3x3 layers.
+template <int BN, int WGN, int WGM, bool PAIR = false, int THP = 16>
+__global__ __launch_bounds__(32 * THP, 2) void conv_split_halo_kernel(ConvArgs a) {
+  constexpr int BMH = TWP * THP;                  // pixels per block
+  constexpr int NTHR = 2 * BMH;                   // 512 / 256 threads
+  constexpr int AROWS_PAD = THP == 16 ? 336 : 192;   // 18 x (THP + 2) haloed rows, rounded up to whole waves of the third DMA pass
   if (a.prio) __builtin_amdgcn_s_setprio(3);   // ahead of a co-running tail's waves in the issue arbiter
   constexpr int TN = BN / (32 * WGN);
   constexpr int TM = BMH / (32 * WGM);
-  static_assert(WGN * WGM == 8, "8 waves");
+  static_assert(WGN * WGM == NTHR / 64, "one wave per 32 x 32-pixel-by-channel fragment group");
   constexpr int A_BUF = AROWS_PAD * BKH;          // halves of one plane of one patch buffer
   constexpr int W_TILE = BN * BKH;                // halves of one plane of one tap's weight tile
   constexpr int LDS_STAGE = 4 * A_BUF + 4 * W_TILE;            // [2 buffers][hi, lo] each
@@ -134,7 +136,7 @@ __global__ __launch_bounds__(NTHR, 2) void conv_split_halo_kernel(ConvArgs a) {
     const long long off = first ? aoff0[i] : aoff1[i];
     const char* g = base + off;
     half_t* dst = As + (size_t)(chunk & 1) * 2 * A_BUF + (size_t)(i * NTHR + wave_u * 64) * 8;
-    if ((i * NTHR + wave_u * 64) / 4 < AROWS_PAD) {   // pass 2: waves 0..4 cover rows 256..335
+    if ((i * NTHR + wave_u * 64) / 4 < AROWS_PAD) {   // the last pass is partial (THP = 16: waves 0..4 cover rows 256..335)
       __builtin_amdgcn_global_load_lds((gptr_t)(aok[i] ? (const void*)g : a.zeros), (lptr_t)dst, 16, 0, 0);
       __builtin_amdgcn_global_load_lds((gptr_t)(aok[i] ? (const void*)(g + 64) : a.zeros), (lptr_t)(dst + A_BUF), 16, 0, 0);
     }
@@ -171,7 +173,7 @@ __global__ __launch_bounds__(NTHR, 2) void conv_split_halo_kernel(ConvArgs a) {
   // prologue: patch of chunk 0 + weights of step 0
   dma_a(0, 0);
   dma_a(0, 1);
-  if (HH * HW > 256) dma_a(0, 2);
+  if (HH * HW > 2 * (NTHR / 4)) dma_a(0, 2);
   dma_w(0, 0, 0);
   __syncthreads();
 
@@ -256,22 +258,25 @@ __global__ __launch_bounds__(NTHR, 2) void conv_split_halo_kernel(ConvArgs a) {
 }
 
 void launch_split_halo_pair(const ConvArgs& a, hipStream_t st) {
-  const int tilesX = (a.Mw + TWP - 1) / TWP, tilesY = (a.Mh + THP - 1) / THP;
+  const int tilesX = (a.Mw + TWP - 1) / TWP, tilesY = (a.Mh + 15) / 16;
   dim3 grid((unsigned)(2 * tilesX * tilesY * a.B), 1, 1);
-  hipLaunchKernelGGL((conv_split_halo_kernel<128, 2, 4, true>), grid, dim3(NTHR), 0, st, a);
+  hipLaunchKernelGGL((conv_split_halo_kernel<128, 2, 4, true>), grid, dim3(512), 0, st, a);
 }
 
-template <int BN, int WGN, int WGM>
+template <int BN, int WGN, int WGM, int THP>
 void launch_split_halo_cfg(const ConvArgs& a, hipStream_t st) {
   const int ntn = a.Npad / BN;
   const int tilesX = (a.Mw + TWP - 1) / TWP, tilesY = (a.Mh + THP - 1) / THP;
   dim3 grid((unsigned)(ntn * a.nphase * tilesX * tilesY * a.B), 1, 1);
-  hipLaunchKernelGGL((conv_split_halo_kernel<BN, WGN, WGM>), grid, dim3(NTHR), 0, st, a);
+  hipLaunchKernelGGL((conv_split_halo_kernel<BN, WGN, WGM, false, THP>), grid, dim3(32 * THP), 0, st, a);
 }
 
 }  // namespace
 
 int g_split_halo = 1;                       // 0: everything through the 128-pixel kernel ("split_halo")
+#ifdef CTD_AB_VARIANTS   // selftest build only: 64-channel 3x3 layers on 16x8 patches, two blocks per CU -- measured equal to the 128-pixel
+int g_split_halo_small = 1;   // implicit-GEMM kernel (0.223 vs 0.225 ms; forward 24.69 vs 24.78 ms): those layers are not traffic-bound
+#endif
 long long g_split_halo_min_patches = 512;   // fewer 256-pixel patches (x phases x N tiles): the 128-pixel kernel ("split_halo_min_patches")
 
 static bool split_halo_pair(const ConvArgs& a) { return a.nphase == 4 && a.N == 64 && a.Npad == 64; }
@@ -284,15 +289,25 @@ bool conv_split_halo_supported(const ConvArgs& a) {
   if (a.Mh != a.Hin || a.Mw != a.Win) return false;
   if (a.s0.H != a.Hin || a.s0.W != a.Win || (a.s1.c && (a.s1.H != a.Hin || a.s1.W != a.Win))) return false;
   if (a.N % 8 || a.K != a.KH * a.KW * (a.s0.c + a.s1.c)) return false;
-  // 128-channel N tiles, or the two px phases of a 64-channel ConvT as one (64-channel tiles leave a wave 12 MFMAs per
-  // tap step with one block per CU: measured 8-11 % slower than the 128-pixel kernel)
+  // 128-channel N tiles on 256-pixel patches; the two px phases of a 64-channel ConvT as one such tile; other 64-channel
+  // layers on 128-pixel patches with two blocks per CU (on 256-pixel patches a 64-row weight tile leaves a wave 12 MFMAs
+  // per tap step with one block per CU: measured 8-11 % slower than the 128-pixel implicit-GEMM kernel)
   const bool pair = split_halo_pair(a);
-  if (!pair && a.Npad % 128) return false;
-  const long long patches = (long long)a.B * ((a.Mh + THP - 1) / THP) * ((a.Mw + TWP - 1) / TWP) * (pair ? 2 : a.nphase * (a.Npad / 128));
-  return patches >= g_split_halo_min_patches;
+#ifdef CTD_AB_VARIANTS
+  const bool small = !pair && a.Npad == 64 && g_split_halo_small;
+#else
+  const bool small = false;
+#endif
+  if (!pair && !small && a.Npad % 128) return false;
+  const int thp = small ? 8 : 16;
+  const long long patches = (long long)a.B * ((a.Mh + thp - 1) / thp) * ((a.Mw + TWP - 1) / TWP) * (pair ? 2 : a.nphase * (small ? 1 : a.Npad / 128));
+  return patches >= g_split_halo_min_patches * (small ? 2 : 1);
 }
 
 void launch_conv_split_halo(const ConvArgs& a, hipStream_t st) {
   if (split_halo_pair(a)) launch_split_halo_pair(a, st);
-  else launch_split_halo_cfg<128, 2, 4>(a, st);
+#ifdef CTD_AB_VARIANTS
+  else if (a.Npad == 64) launch_split_halo_cfg<64, 1, 4, 8>(a, st);
+#endif
+  else launch_split_halo_cfg<128, 2, 4, 16>(a, st);
 }

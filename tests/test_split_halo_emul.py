@@ -6,28 +6,27 @@ tests/test_split_emul.py's subject): what is checked is that every product lands
 GPU side is `ST_SPLIT=1 ctd_selftest` (tests/test_gpu_selftest.py)."""
 import numpy as np
 
-TWP = THP = 16
+TWP = 16
 BKH = 32
-AROWS_PAD = 336
-NTHR = 512
 
 
 def swz(row):
     return (row >> 2) & 3
 
 
-def run_block(x, wpk, Hin, Win, y0, x0, dy0, dx0, KH, KW, BN, pair, phase_stride_rows=None):
+def run_block(x, wpk, Hin, Win, y0, x0, dy0, dx0, KH, KW, BN, pair, THP=16, WGN=2, WGM=4):
     """One block: x (Hin, Win, C) input, wpk packed weight rows as the kernel addresses them: wpk[row, ks, 32] where `row` is
     the LDS weight row (0..BN-1) already resolved to its source row (PAIR: rows 64.. come from the next phase), ks = tap * nchunk
-    + chunk.  Returns out[256 tile pixels, BN staged columns]."""
+    + chunk.  THP = 16: 256-pixel patch, 512 threads; THP = 8: 128-pixel patch, 256 threads.  Returns out[tile pixels, BN staged columns]."""
+    NTHR, AROWS_PAD, NW = 32 * THP, (336 if THP == 16 else 192), THP // 2
+    assert WGN * WGM == NW
     C = x.shape[2]
     nchunk = C // BKH
     HW = TWP + (3 if pair else KW) - 1
     HH = THP + KH - 1
     taps = KH * KW
-    WGN, WGM = 2, 4
-    TN, TM = BN // (32 * WGN), 256 // (32 * WGM)
-    acc = np.zeros((8, TN, TM, 64, 16))                           # [wave][i][j][lane][register]
+    TN, TM = BN // (32 * WGN), 16 * THP // (32 * WGM)
+    acc = np.zeros((NW, TN, TM, 64, 16))                          # [wave][i][j][lane][register]
     lanes = np.arange(64)
     l31, khalf = lanes & 31, lanes >> 5
     xrot = np.where(l31 < 16, l31, (l31 - (HW - 16)) & 15)
@@ -53,7 +52,7 @@ def run_block(x, wpk, Hin, Win, y0, x0, dy0, dx0, KH, KW, BN, pair, phase_stride
                 wr, pos = t >> 2, t & 3
                 src = pos ^ swz(wr)
                 wl[wr, pos] = wpk[wr, ks, src * 8: src * 8 + 8]
-            for wave in range(8):
+            for wave in range(NW):
                 wn, wm = wave % WGN, wave // WGN
                 tapoff = ty * HW + tx + (wn if pair else 0)
                 for kk in range(2):
@@ -78,8 +77,8 @@ def run_block(x, wpk, Hin, Win, y0, x0, dy0, dx0, KH, KW, BN, pair, phase_stride
                                     for e in range(4):
                                         acc[wave, i, j, ln, 4 * g + e] += D[4 * hi + 8 * g + e, l31[ln]]
     # ---- epilogue: register (lane, g, e) of fragment (i, j) -> staged tile [pixel][column]
-    out = np.zeros((256, BN))
-    for wave in range(8):
+    out = np.zeros((16 * THP, BN))
+    for wave in range(NW):
         wn, wm = wave % WGN, wave // WGN
         for i in range(TN):
             for j in range(TM):
@@ -156,3 +155,23 @@ def test_convt_phase_and_the_phase_pair_match_direct_phase_convolutions():
                 oy, ox = p >> 4, 16 + (p & 15)
                 if oy < H and ox < W:
                     np.testing.assert_allclose(out[p, 64 * px: 64 * px + 64], ref[oy, ox], rtol=0, atol=1e-9)
+
+
+def test_3x3_on_16x8_patches_64_channels():
+    """the 64-channel configuration: 16x8 patches, four waves of 64 channels x 32 pixels each"""
+    rng = np.random.RandomState(2)
+    H, W = 13, 21
+    C, N = 32, 64
+    x = rng.standard_normal((H, W, C))
+    w = rng.standard_normal((N, 9 * C))
+    ref = np.zeros((H, W, N))
+    xp = np.pad(x, ((1, 1), (1, 1), (0, 0)))
+    for ty in range(3):
+        for tx in range(3):
+            ref += xp[ty: ty + H, tx: tx + W] @ w[:, (ty * 3 + tx) * C: (ty * 3 + tx + 1) * C].T
+    for y0, x0 in ((0, 0), (8, 16)):
+        out = run_block(x, pack(w, N, 9 * C), H, W, y0, x0, -1, -1, 3, 3, 64, False, THP=8, WGN=1, WGM=4)
+        for p in range(128):
+            oy, ox = y0 + (p >> 4), x0 + (p & 15)
+            if oy < H and ox < W:
+                np.testing.assert_allclose(out[p], ref[oy, ox], rtol=0, atol=1e-9)

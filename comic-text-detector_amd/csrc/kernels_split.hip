@@ -16,7 +16,9 @@
 //
 // Covers what kernels_f32.hip covers for channel counts that are multiples of 32: Conv k x k stride 1 / 2 (+ folded
 // BN, activation, residual), two concatenated sources, nearest x2 upsampled sources, ConvTranspose 4x4/s2/p1 as four
-// 2x2-tap phase GEMMs.  (The 3-channel stem stays on the f32-operand kernel.)
+// 2x2-tap phase GEMMs, and the first layer over the 4-channel image (K = 8 taps per step).  Two siblings share its weight
+// packing and its epilogue (split_epilogue.h): kernels_split_halo.hip (3x3 / ConvT on 256-pixel haloed patches of
+// split-plane tensors -- launch_conv_split dispatches to it) and kernels_split_stem.hip (the first layer from the page).
 //
 // Weights: split once on the host.  Each output channel is first scaled by a power of two so that its largest
 // weight lies in [512, 1024) -- exact, undone by `oscale` in the epilogue -- which keeps the low halves of all but
@@ -24,9 +26,9 @@
 // block per 32 output channels and K step, so any N tile that is a multiple of 32 reads contiguous blocks), hi
 // plane followed by the lo plane.
 //
-// Activations: split in the kernel between the global load and the LDS store (2 x v_cvt_f16_f32 + v_sub per
-// element and K step; ~1/5 of the MFMA cycles of a step).  No scaling: a value beyond fp16's range (|x| > 65504)
-// becomes inf - inf = NaN in the output, loudly.
+// fp32 activations (the image, tensors the heads or the pools touch): split in the kernel between the global load and
+// the LDS store (2 x v_cvt_f16_f32 + v_sub per element and K step; ~1/5 of the MFMA cycles of a step).  No scaling: a
+// value beyond fp16's range (|x| > 65504) becomes inf - inf = NaN in the output, loudly.
 //
 // Split-plane activations (`x_sp` / `d_sp` / `r_sp`): a tensor that only this kernel writes and reads is kept SPLIT in
 // HBM -- per pixel and 32-channel group the 32 hi halves followed by the 32 lo halves, in the 128 B its 32 floats would
@@ -38,7 +40,8 @@
 //
 // Tiling: 256 threads = 4 waves, BN x 128-pixel tile, K step 32 channels.  LDS rows of 32 halves (64 B, XOR-swizzled
 // 16-B chunks), hi and lo planes for pixels and weights, double buffered: 64 KB at BN = 128 (2 blocks per CU).  Per K
-// step and wave at BN = 128: 16 ds_read_b128 feed 24 MFMAs.
+// step and wave at BN = 128: 16 ds_read_b128 feed 24 MFMAs.  Epilogue: accumulators x oscale + bias -> an fp32 tile in LDS
+// (the K loop's buffers) -> split_store_tile: activation, residual, coalesced 16-B stores of fp32 or split-plane rows.
 #include <cmath>
 #include <cstring>
 #include <type_traits>

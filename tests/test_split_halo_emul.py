@@ -175,3 +175,59 @@ def test_3x3_on_16x8_patches_64_channels():
             oy, ox = y0 + (p >> 4), x0 + (p & 15)
             if oy < H and ox < W:
                 np.testing.assert_allclose(out[p], ref[oy, ox], rtol=0, atol=1e-9)
+
+
+# ---- the first layer straight from the page (csrc/kernels_split_stem.hip) -------------------------------------------------------
+def test_first_layer_tap_pairs_and_tile_map_match_a_direct_convolution():
+    """6x6 / stride 2 / pad 2 over a 3-channel page: a block owns 16x16 outputs and keeps the 36x36 input patch as 8-B pixels
+    (4 channels, the 4th zero); a lane's K = 16 operand at step kk is taps (4 kk + 2 khalf, + 1) -- two horizontally adjacent
+    pixels = 16 contiguous bytes -- with taps 36..39 padding K to 160 (zero weights, any finite operand).  K index = tap * 4 + c."""
+    rng = np.random.RandomState(3)
+    H, W = 44, 52                                  # outputs 22 x 26: partial tiles
+    x = rng.standard_normal((H, W, 3))
+    w = rng.standard_normal((32, 36, 3))           # [n][tap = ty * 6 + tx][c]
+    Ho, Wo = H // 2, W // 2
+    xp = np.pad(x, ((2, 2), (2, 2), (0, 0)))
+    ref = np.zeros((Ho, Wo, 32))
+    for ty in range(6):
+        for tx in range(6):
+            ref += xp[ty: ty + 2 * Ho: 2, tx: tx + 2 * Wo: 2] @ w[:, ty * 6 + tx].T
+    wk = np.zeros((32, 160))                       # packed K axis: tap * 4 + c, taps 36..39 and channel 3 zero
+    for tap in range(36):
+        wk[:, tap * 4: tap * 4 + 3] = w[:, tap]
+    ST, SP = 16, 36
+    lanes = np.arange(64)
+    l31, khalf = lanes & 31, lanes >> 5
+    for y0, x0 in ((0, 0), (16, 16)):
+        patch = np.zeros((SP * SP, 4))
+        for q in range(SP * SP):
+            hy, hx = divmod(q, SP)
+            iy, ix = 2 * y0 - 2 + hy, 2 * x0 - 2 + hx
+            if 0 <= iy < H and 0 <= ix < W:
+                patch[q, :3] = x[iy, ix]
+        flat = patch.reshape(-1)                   # halves of one plane: pixel q at [4 q, 4 q + 4)
+        out = np.zeros((256, 32))
+        for wave in range(4):
+            for j in range(2):
+                py, px = 4 * wave + 2 * j + (l31 >> 4), l31 & 15
+                base = (2 * py) * SP + 2 * px
+                D = np.zeros((32, 32))                                            # [n][pixel column]
+                for kk in range(10):
+                    tp = np.minimum(kk * 4 + khalf * 2, 34)
+                    ty, tx = tp // 6, tp % 6
+                    o = (ty * SP + tx) * 4
+                    Bm = np.zeros((32, 16))
+                    An = np.zeros((32, 16))
+                    for ln in range(64):
+                        s = base[ln] * 4 + o[ln]
+                        Bm[l31[ln], khalf[ln] * 8: khalf[ln] * 8 + 8] = flat[s: s + 8]
+                        k0 = kk * 16 + khalf[ln] * 8
+                        An[l31[ln], khalf[ln] * 8: khalf[ln] * 8 + 8] = wk[l31[ln], k0: k0 + 8]
+                    D += An @ Bm.T
+                for ln in range(32):
+                    p = (2 * wave + j) * 32 + ln                                  # tile pixel of MFMA column ln
+                    out[p] = D[:, ln]
+        for p in range(256):
+            oy, ox = y0 + (p >> 4), x0 + (p & 15)
+            if oy < Ho and ox < Wo:
+                np.testing.assert_allclose(out[p], ref[oy, ox], rtol=0, atol=1e-9)

@@ -99,6 +99,15 @@ def thread_budget(world: int) -> dict:
 # workload
 # =====================================================================================================================
 
+def blob_checkpoint(pkg, args):
+    """The benchmark's checkpoint: random weights whose maps have contours (synth.make_blob_checkpoint).  Default (round 4):
+    the LINE density of the reference's one real page (~29 lines per page; ~27 blocks, see synth._FIXTURE_DET_Q);
+    `--line-density r3`: round 3's pages (16 blocks / 16 lines); `--dense-blocks`: every cell of one Detect anchor fires."""
+    if args.dense_blocks:
+        return pkg.synth.make_blob_checkpoint(0)
+    return pkg.synth.make_blob_checkpoint(0, sparse_det=True, line_density="fixture" if args.line_density == "fixture" else None)
+
+
 def make_workload(pkg, args, rank: int, nloc: int, dev):
     """Returns (checkpoint, batches, canned, canned_sample): `batches` = list of (B,H,W,3) u8 tensors resident in HBM
     (distinct pages), `canned` = None or the text-like network outputs of batch 0's pages (`--tail-input canned`)."""
@@ -114,7 +123,7 @@ def make_workload(pkg, args, rank: int, nloc: int, dev):
             lines_map=torch.from_numpy(np.stack([samples[i % NS][3] for i in range(nloc)])).to(dev),
             bitmap=torch.from_numpy(np.stack([samples[i % NS][4] for i in range(nloc)])).to(dev))
         return ckpt, [x], canned, samples[0]
-    ckpt = pkg.synth.make_blob_checkpoint(0, sparse_det=not args.dense_blocks)
+    ckpt = blob_checkpoint(pkg, args)
     nb = max(1, args.batches)
     batches = []
     for k in range(nb):
@@ -128,11 +137,11 @@ class Pipeline:
     while worker threads run the tail work items of step k; (N>1) the record gather on its own stream."""
 
     def __init__(self, det, batches, canned, dev, world, rank, total_pages, D, workers, depth, tail_split,
-                 host_input=False, loaders=2, engines=1, keep_undetected=False):
+                 host_input=False, loaders=2, engines=1, keep_undetected=False, lazy=True):
         self.det, self.batches, self.canned, self.dev = det, batches, canned, dev
         self.world, self.rank, self.total_pages, self.D = world, rank, total_pages, D
         self.workers, self.depth, self.tail_split = max(1, workers), max(1, depth), max(1, tail_split)
-        self.engines, self.keep_undetected = max(1, engines), keep_undetected
+        self.engines, self.keep_undetected, self.lazy = max(1, engines), keep_undetected, lazy
         self.nloc = batches[0].shape[0]
         self.pool = ThreadPoolExecutor(max_workers=self.workers, thread_name_prefix="ctd-tail")
         self.host_batches = [[p for p in b.cpu().numpy()] for b in batches] if host_input else None
@@ -170,7 +179,8 @@ class Pipeline:
                 self.D.gather_results(res, self.total_pages, self.rank, self.world, device=self.dev, pin=True)
         self.stats["pages"] += len(res)
         self.stats["blocks"] += sum(len(r[2]) for r in res)
-        self.stats["lines"] += sum(len(b.lines) for r in res for b in r[2])
+        # lazy results: the counts come from the native records (no TextBlock is built for the bookkeeping)
+        self.stats["lines"] += sum(r[2].n_lines if hasattr(r[2], "n_lines") else sum(len(b.lines) for b in r[2]) for r in res)
 
     def run(self, n):
         det, pending, ahead, issued = self.det, deque(), deque(), 0
@@ -187,7 +197,7 @@ class Pipeline:
                 pg, ev = ahead.popleft().result()
                 main.wait_event(ev)
             job = self.forward_job(i, pg)
-            pending.append([self.pool.submit(det._tail, job, 0, self.keep_undetected, lo, hi, self.records)
+            pending.append([self.pool.submit(det._tail, job, 0, self.keep_undetected, lo, hi, self.records, self.lazy)
                             for lo, hi in det._split(self.nloc, self.tail_split)])
             while len(pending) >= self.depth:
                 self.finish(collect(pending.popleft()))
@@ -228,10 +238,13 @@ def timed(run, steps, warmup, spinup, world, dev, stats=None):
 # baselines and parity legs (rank 0, N = 1)
 # =====================================================================================================================
 
-def cpu_baseline(pkg, ckpt, size: int, page: np.ndarray, canned_sample=None, budget_s: float = 14.0, max_pages: int = 8):
-    """The reference's CPU path restated: oracle forward (CPU fp32, bit-exact with the reference's torch modules) + the
-    oracle tail (the reference's post-processing restated in numpy) at bs=1, like `TextDetector.__call__` on the host, on
-    one page of the benchmark input (the tail consumes the oracle forward's own outputs, as the GPU step does)."""
+def cpu_baseline(pkg, ckpt, size: int, pages, canned_sample=None, budget_s: float = 14.0, max_pages: int = 16):
+    """The reference's CPU path restated, both legs at the SAME core budget: the oracle forward (CPU fp32, bit-exact with
+    the reference's torch modules) at bs=1 like `TextDetector.__call__`, on the thread count that is fastest on this host;
+    and the oracle tail (the reference's post-processing restated in numpy, single-threaded per page like the reference's
+    cv2 / numpy code) for those pages' own forward outputs on a pool of as many PROCESSES (oracle/tail_pool.py) -- what a
+    host-only deployment with that many cores would do.  value = pages / (forward time + pooled tail time)."""
+    import tempfile
     from oracle.net_ref import OracleNet
     from oracle import postproc_ref as R
     hi = host_info()
@@ -251,31 +264,63 @@ def cpu_baseline(pkg, ckpt, size: int, page: np.ndarray, canned_sample=None, bud
             best = (dt, nt)
     cores = best[1]
     torch.set_num_threads(cores)
-    x = torch.from_numpy(np.ascontiguousarray(page.transpose(2, 0, 1)[None])).float() / 255
-    net(x)                                          # warm-up (allocator, oneDNN primitives)
+    pages = list(pages)[:max_pages]
+    x0 = torch.from_numpy(np.ascontiguousarray(pages[0].transpose(2, 0, 1)[None])).float() / 255
+    net(x0)                                         # warm-up (allocator, oneDNN primitives)
+    outs, t_net = [], 0.0
     t0 = time.perf_counter()
-    n, t_net, t_tail = 0, 0.0, 0.0
-    while n < max_pages and (time.perf_counter() - t0) < budget_s:
+    for pg in pages:
+        if outs and (time.perf_counter() - t0) > budget_s:
+            break
+        x = torch.from_numpy(np.ascontiguousarray(pg.transpose(2, 0, 1)[None])).float() / 255
         ta = time.perf_counter()
         ob, om, ol = net(x)
-        tb = time.perf_counter()
+        t_net += time.perf_counter() - ta
         if canned_sample is not None:
             _, blks, mask_u8, prob, _ = canned_sample
-            R.detector_tail(page, blks, ((mask_u8.astype(np.float32) + 0.5) / 255)[None, None],
-                            np.stack([prob, np.zeros_like(prob)])[None], input_size=(size, size), refine_mode=0,
-                            keep_undetected_mask=False)
+            outs.append((blks[0], ((mask_u8.astype(np.float32) + 0.5) / 255)[None], np.stack([prob, np.zeros_like(prob)])))
         else:
-            R.detector_tail(page, ob.numpy(), om.numpy(), ol.numpy(), input_size=(size, size), refine_mode=0,
-                            keep_undetected_mask=False)
-        tc = time.perf_counter()
-        t_net += tb - ta
-        t_tail += tc - tb
-        n += 1
-    dt = time.perf_counter() - t0
-    return {"value": round(n / dt, 4), "unit": "pages/s", "cores": cores, "kind": "port", "host": hi,
-            "sample": f"{n} pages of {size}x{size} at bs=1: torch CPU fp32 oracle forward ({t_net / n * 1e3:.0f} ms/page, "
-                      f"{cores} threads) + oracle tail in numpy ({t_tail / n * 1e3:.0f} ms/page, 1 thread) on "
-                      + ("text-like maps of the same page" if canned_sample is not None else "that forward's own outputs")}
+            outs.append((ob.numpy()[0], om.numpy()[0], ol.numpy()[0]))
+    n = len(outs)
+    pages = pages[:n]
+    # tail leg: a pool of `cores` processes, in a child interpreter without torch / HIP (fork-safe)
+    pool = None
+    try:
+        with tempfile.TemporaryDirectory() as td:
+            path = os.path.join(td, "in.npz")
+            np.savez(path, pages=np.stack(pages), blks=np.stack([o[0] for o in outs]), mask=np.stack([o[1] for o in outs]),
+                     lines=np.stack([o[2] for o in outs]))
+            env = dict(os.environ, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1")
+            p = subprocess.run([sys.executable, "-m", "oracle.tail_pool", path, str(cores), str(size)], capture_output=True,
+                               text=True, timeout=120, cwd=ROOT, env=env)
+            line = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+            pool = json.loads(line[-1]) if line else {"error": (p.stderr or "no output")[-300:]}
+    except Exception as e:                          # fall back to one page in this process
+        pool = {"error": repr(e)[:300]}
+    if "wall_s" in pool:
+        t_tail_pooled = pool["wall_s"]
+        t_tail_single = float(np.mean(pool["per_page_single_s"]))
+        procs = pool["processes"]
+    else:
+        ta = time.perf_counter()
+        R.detector_tail(pages[0], outs[0][0][None], outs[0][1][None], outs[0][2][None], input_size=(size, size), refine_mode=0,
+                        keep_undetected_mask=False)
+        t_tail_single = time.perf_counter() - ta
+        t_tail_pooled, procs = t_tail_single * n, 1
+    value = n / (t_net + t_tail_pooled)
+    return {"value": round(value, 4), "unit": "pages/s", "cores": cores, "kind": "port", "host": hi,
+            "forward_threads": cores, "tail_processes": procs,
+            "forward_ms_per_page": round(t_net / n * 1e3, 1), "tail_ms_per_page_one_process": round(t_tail_single * 1e3, 1),
+            "tail_ms_per_page_pooled": round(t_tail_pooled / n * 1e3, 1),
+            "serial_one_page_pages_per_s": round(1.0 / (t_net / n + t_tail_single), 4),
+            "pool": {k: v for k, v in pool.items() if k in ("error", "blocks", "lines")},
+            "sample": f"{n} pages of {size}x{size}: torch CPU fp32 oracle forward at bs=1 ({t_net / n * 1e3:.0f} ms/page on "
+                      f"{cores} threads, the fastest count on this {avail}-CPU host) + oracle tail in numpy on "
+                      + ("text-like maps of the same pages" if canned_sample is not None else "those forwards' own outputs")
+                      + f" ({t_tail_single * 1e3:.0f} ms/page in one process; {t_tail_pooled / n * 1e3:.0f} ms/page on a pool of "
+                      f"{procs} processes = the same core budget); value = pages / (forward + pooled tail); a single "
+                      f"`TextDetector.__call__` at a time (forward, then a one-thread tail) gives "
+                      f"{1.0 / (t_net / n + t_tail_single):.2f} pages/s"}
 
 
 FP16_BAND_EPS = 4e-3            # = tests/test_gpu_accept.py EPS_FP16
@@ -385,7 +430,8 @@ def rocm_baseline_main(args) -> None:
 
 def rocm_baseline_subprocess(args, timeout_s: float):
     """Runs `--mode rocm-baseline` in a child process with a wall-clock limit (MIOpen compiles its kernels at first use on
-    a fresh box: minutes).  Falls back to the committed measurement under profiles/ when the child does not finish."""
+    a fresh box: minutes).  When the child measures nothing in time the entries are null: the line carries numbers of
+    this run only."""
     cmd = [sys.executable, os.path.abspath(__file__), "--mode", "rocm-baseline", "--batch", str(args.batch), "--size",
            str(args.size), "--rocm-budget", str(max(20.0, timeout_s - 30))]
     env = dict(os.environ)
@@ -413,15 +459,10 @@ def rocm_baseline_subprocess(args, timeout_s: float):
             last = d["rocm_baseline_partial"]
     res = res or last
     have = isinstance(res, dict) and any(isinstance(v, dict) and "ms_per_forward" in v for v in res.values())
-    if not have:
-        path = os.path.join(ROOT, "profiles", "r03_rocm_baseline.json")
-        if os.path.isfile(path):
-            try:
-                res = json.load(open(path))
-                note = (note or "child produced nothing") + "; numbers from profiles/r03_rocm_baseline.json (same command, " \
-                       "longer limit), not from this run"
-            except Exception:
-                pass
+    if not have:                                     # nothing measured in THIS run: say so, never a committed figure
+        return {"fp16_bs32": None, "fp32_bs32": None, "fp32_bs8": None,
+                "note": (note or "child produced nothing") + "; no number from this run (an earlier measurement of the same "
+                        "command is in profiles/r03_rocm_baseline.json)"}
     if isinstance(res, dict) and note:
         res["note"] = note
     return res if isinstance(res, dict) else {"error": note or "no output"}
@@ -513,7 +554,7 @@ def mixed_stream(pkg, D, BK, det, rank, world, dev, steps, warmup, with_tail=Tru
         for r in fut.result():
             stats["pages"] += 1
             stats["blocks"] += len(r[2])
-            stats["lines"] += sum(len(b.lines) for b in r[2])
+            stats["lines"] += r[2].n_lines if hasattr(r[2], "n_lines") else sum(len(b.lines) for b in r[2])
 
     def run_steps(k):
         for _ in range(k):
@@ -536,7 +577,7 @@ def mixed_stream(pkg, D, BK, det, rank, world, dev, steps, warmup, with_tail=Tru
                 ev.record(torch.cuda.current_stream(dev))
                 job = dict(gpu=[x[j] for j in range(n)], metas=[(s, s, 0, 0)] * n, blks=blks, mask_u8=g["mask_u8"],
                            lines_map=lines, bitmap=g["bitmap"], ev=ev)
-                g["busy"] = pool.submit(det._tail, job, 0, False)
+                g["busy"] = pool.submit(det._tail, job, 0, False, None, None, None, True)
             for inst in graphs.values():
                 for g in inst:
                     if g["busy"] is not None:
@@ -701,6 +742,9 @@ def main() -> None:
     ap.add_argument("--dense-blocks", action="store_true",
                     help="blob checkpoint without `sparse_det`: ~65 text blocks of ~160 px per page (1.5 page areas of block "
                          "windows) instead of the reference fixture's density (~15 blocks); also a sub-run of the default line")
+    ap.add_argument("--line-density", default="fixture", choices=["fixture", "r3"],
+                    help="fixture (default): ~29 text lines per page, the count on the reference's real page "
+                         "(data/examples/AisazuNihaIrarenai-003.jpg: 16 blocks / 29 lines); r3: round 3's pages (16 / 16)")
     ap.add_argument("--workers", type=int, default=0, help="tail worker threads (e2e); 0 = from the host-thread budget")
     ap.add_argument("--depth", type=int, default=4, help="batches in flight (e2e)")
     ap.add_argument("--tail-split", type=int, default=int(os.environ.get("BENCH_TAIL_SPLIT", "0")),
@@ -711,6 +755,9 @@ def main() -> None:
     ap.add_argument("--loaders", type=int, default=2, help="loader threads of --host-input")
     ap.add_argument("--engines", type=int, default=1, help="engine copies on their own streams (e2e)")
     ap.add_argument("--keep-undetected", action="store_true", help="also run refine_undetected_mask in the tail")
+    ap.add_argument("--eager-blocks", action="store_true",
+                    help="e2e: the tail workers build the Python TextBlock objects of every page (detect_batch's return type) "
+                         "instead of handing over the native records as lazily materialised BlockLists (detect_stream's default)")
     ap.add_argument("--spinup", type=int, default=int(os.environ.get("BENCH_SPINUP", "100")),
                     help="untimed steps before the warm-up steps (clock / host-side spin-up of a fresh process)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -753,7 +800,7 @@ def main() -> None:
     nloc = hi - lo
 
     if args.mode == "mixed":
-        ckpt = pkg.synth.make_blob_checkpoint(0, sparse_det=not args.dense_blocks)
+        ckpt = blob_checkpoint(pkg, args)
         det = DET.TextDetector(ckpt, input_size=1024, device=dev, precision=args.precision)
         out = mixed_stream(pkg, D, BK, det, rank, world, dev, args.steps, args.warmup, with_tail=True)
         if rank == 0:
@@ -773,7 +820,7 @@ def main() -> None:
     e2e = args.mode == "e2e"
     pipe = Pipeline(det, batches, canned, dev, world, rank, total_pages, D, args.workers, args.depth, args.tail_split,
                     host_input=args.host_input and e2e, loaders=args.loaders, engines=args.engines,
-                    keep_undetected=args.keep_undetected)
+                    keep_undetected=args.keep_undetected, lazy=not args.eager_blocks)
 
     net_k = [0]
 
@@ -811,7 +858,7 @@ def main() -> None:
         cpu = parity = exact = extra = rocm = None
         solo = n_gpus == 1
         if solo and not args.no_cpu_baseline:
-            cpu = cpu_baseline(pkg, ckpt, S, page0, canned_sample)
+            cpu = cpu_baseline(pkg, ckpt, S, batches[0][:16].cpu().numpy(), canned_sample)
             try:
                 parity = parity_block(pkg, ckpt, det, page0, S)
             except Exception as e:                      # never lose the bench line to the extra check
@@ -862,8 +909,12 @@ def main() -> None:
         real = canned is None
         workload = (f"BASELINE configs[2]: bs={B}/GPU {S}x{S} u8 pages {where}, {len(batches)} distinct batches rotated; "
                     f"fused HIP forward (YOLOv5s+UNet+DB, "
-                    + ("synth.make_blob_checkpoint(" + ("dense" if args.dense_blocks else "sparse_det: block density of the "
-                       "reference's fixture page") + "): random weights whose maps have contours, text-like pages" if real else
+                    + ("synth.make_blob_checkpoint(" + ("dense" if args.dense_blocks else
+                       ("sparse_det + line_density=fixture: ~29 text lines per page, the LINE count of the reference's real "
+                        "page (16 blocks / 29 lines); random weights cannot align lines into multi-line blocks, so blocks ~ "
+                        "lines (~27 windows per page, more than the fixture's 16)" if args.line_density == "fixture" else
+                        "sparse_det: round 3's pages, 16 blocks / 16 lines"))
+                       + "): random weights whose maps have contours, text-like pages" if real else
                        "seeded random weights") + ", DB binarize + u8 mask fused)")
         if e2e:
             workload += (" + the WHOLE native tail per page: GPU NMS, DB boxes (2x GPU labelling + contour tables, host "

@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, "libctd_hip.so")
 SELFTEST_PATH = os.path.join(_HERE, "ctd_selftest")
 
 # ---- constants mirrored from include/ctd_hip.h -------------------------------
-ABI_VERSION = 3
+ABI_VERSION = 4
 OK = 0
 PREC_F32, PREC_F16, PREC_F32S = 0, 1, 2
 ACT = {"none": 0, "silu": 1, "leaky": 2, "relu": 3, "sigmoid": 4}
@@ -96,6 +96,8 @@ SYMBOLS = {
     "ctd_tail_page_counts": (_i32, [_vp, _i32, C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i32),
                                     C.POINTER(_i32)]),
     "ctd_tail_page_fetch": (_i32, [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "ctd_tail_batch_counts": (_i32, [_vp, _vp]),
+    "ctd_tail_batch_fetch": (_i32, [_vp, _vp, _vp, _vp]),
     "ctd_tail_pack_records": (_i32, [_vp, _i32, _i32, _vp]),
     "ctd_tail_set_threads": (_i32, [_vp, _i32]),
     "ctd_db_boxes_compact": (_i32, [_i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,

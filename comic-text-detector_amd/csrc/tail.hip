@@ -141,26 +141,38 @@ void parallel_for(int n, int max_threads, F f) {
 // big enqueue (render, labelling, accept rounds, dilate, labelling, holes) too; 0 = side by side.
 int g_tail_chain = 1;
 namespace {
+// The chain is PER DEVICE: events belong to the device that was current when they were created, a stream can only record
+// its own device's events (hipErrorInvalidHandle otherwise), and tails on different GPUs have nothing to serialise.
+struct ChainState {
+  std::mutex mu;
+  hipEvent_t last = nullptr;
+  hipEvent_t ring[16] = {};
+  unsigned next = 0;
+};
+constexpr int kChainDevices = 64;
+inline ChainState* chain_state(int device) {
+  static ChainState states[kChainDevices];
+  return device >= 0 && device < kChainDevices ? &states[device] : nullptr;
+}
 struct GpuChain {
   hipStream_t st;
-  bool on;
+  ChainState* cs;                            // null: chaining off (or a device index beyond the table)
   std::unique_lock<std::mutex> lk;
-  static std::mutex& mu() { static std::mutex m; return m; }
-  static hipEvent_t& last() { static hipEvent_t e = nullptr; return e; }
-  GpuChain(hipStream_t s, bool enabled) : st(s), on(enabled), lk(mu(), std::defer_lock) {}
+  // `device` must be the current device of the calling thread (the entry points call hipSetDevice(t->device) first)
+  GpuChain(hipStream_t s, int device, bool enabled) : st(s), cs(enabled ? chain_state(device) : nullptr) {
+    if (cs) lk = std::unique_lock<std::mutex>(cs->mu, std::defer_lock);
+  }
   hipError_t begin() {                       // the lock is held while this section is being enqueued (~0.1 ms of host time)
-    if (!on) return hipSuccess;
+    if (!cs) return hipSuccess;
     lk.lock();
-    return last() ? hipStreamWaitEvent(st, last(), 0) : hipSuccess;
+    return cs->last ? hipStreamWaitEvent(st, cs->last, 0) : hipSuccess;
   }
   hipError_t end() {
-    if (!on || !lk.owns_lock()) return hipSuccess;
-    static hipEvent_t ring[16] = {};
-    static unsigned next = 0;
-    hipEvent_t& ev = ring[next++ % 16];
+    if (!cs || !lk.owns_lock()) return hipSuccess;
+    hipEvent_t& ev = cs->ring[cs->next++ % 16];
     hipError_t e = ev ? hipSuccess : hipEventCreateWithFlags(&ev, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventRecord(ev, st);
-    if (e == hipSuccess) last() = ev;
+    if (e == hipSuccess) cs->last = ev;
     lk.unlock();
     return e;
   }
@@ -240,6 +252,7 @@ struct ctd_tail {
   int B = 0;
   std::vector<ctd_tail_page> pages;
   std::vector<size_t> poff;           // byte offset of page b in the page-mask / refined buffers
+  std::vector<uint8_t*> hmask;        // host copy of page b's mask during a run (the caller's array or h_pmask)
   size_t ptotal = 0;
   std::vector<PageOut> out;
   // host wall clock of the last run, ms: [0] enqueue of stage 1, [1] wait for stage 1, [2] table download +
@@ -247,6 +260,7 @@ struct ctd_tail {
   // enqueue of the merge stage, [7] undetected pass, [8] final wait + copies, [9] total
   double ms_stage[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   double ms_db_wait = 0;              // inside [2]: waiting for the table download
+  double ms_sub[5] = {0, 0, 0, 0, 0}; // inside [0]: NMS + buffers, labelling + contour tables, page-mask copies; inside [8]: the wait
   int host_threads = 8;               // threads of the per-page / per-window host loops
 };
 
@@ -416,7 +430,7 @@ int refine_windows(ctd_tail* t, const std::vector<WinReq>& reqs, int refine_mode
   bt.fill(canvas, 0, cpx);
   bt.fill(counters, 0, ((size_t)cap1 + 1) * 8);
   bt.flush();
-  GpuChain chain(st, g_tail_chain >= 2);
+  GpuChain chain(st, t->device, g_tail_chain >= 2);
   T_TRY(chain.begin());
   launch_tw_render(dw, db, nbands, max_pix, canvas, pc.W, st);
   launch_ccl(canvas, 1, pc.H, pc.W, 0, 8, clab, n_dev, cstats, cap1, ws, st);
@@ -544,7 +558,9 @@ int download_pages(ctd_tail* t, bool mask_too, uint8_t* const* mask_out, uint8_t
   }
   bt.flush();
   T_TRY(hipGetLastError());
+  const double w0 = now_ms();
   T_TRY(hipStreamSynchronize(st));
+  t->ms_sub[3] = now_ms() - w0;
   return CTD_OK;
 }
 
@@ -817,7 +833,7 @@ static int tail_run_impl(ctd_tail* t, int32_t B, int32_t Hn, int32_t Wn, const f
   const size_t hw = (size_t)Hn * Wn;
 
   // ================= stage 1: NMS, two labelling passes, contour tables, page masks =================
-  GpuChain chain(st, g_tail_chain >= 1);
+  GpuChain chain(st, t->device, g_tail_chain >= 1);
   T_TRY(chain.begin());
   GET(t->d_dets, (size_t)B * kMaxDet * 6 * 4 + (size_t)B * 4, float, dets);
   int* counts = (int*)(dets + (size_t)B * kMaxDet * 6);
@@ -829,6 +845,7 @@ static int tail_run_impl(ctd_tail* t, int32_t B, int32_t Hn, int32_t Wn, const f
   GET(t->d_refined, t->ptotal, uint8_t, refined);
   Batch pre(st), post(st);                      // this stage's fills / its copies: one launch each
   pre.fill(refined, 0, t->ptotal);
+  const double t0a = now_ms();
   DbStage db;
   if (int rc = db_enqueue(t, db, B, Hn, Wn, prob_dev, prob_stride, bitmap_dev, pre, post)) return rc;
   T_TRY(post.d2h(hdets, dets, (size_t)B * kMaxDet * 6 * 4 + (size_t)B * 4));
@@ -839,11 +856,25 @@ static int tail_run_impl(ctd_tail* t, int32_t B, int32_t Hn, int32_t Wn, const f
   bool plain = true;                        // every page is the network input itself: one strided copy for the batch
   for (int b = 0; b < B; ++b)
     plain = plain && pages[b].im_h == Hn && pages[b].im_w == Wn && pages[b].dw == 0 && pages[b].dh == 0;
-  GET(t->h_pmask, t->ptotal, uint8_t, hpmask);
+  // Host copy of the page masks (`group_output` reads it, and it IS the `mask` the caller gets unless
+  // refine_undetected_mask edits the masks later): straight into the caller's arrays when there are any -- a second
+  // 1 MB-per-page memcpy at the end of the call was 3 ms per 32 pages -- else into this object's pinned buffer.
+  const bool mask_final = !(prm->refine && prm->keep_undetected_mask);
+  bool direct = mask_final && mask_out != nullptr;
+  for (int b = 0; b < B && direct; ++b) direct = mask_out[b] != nullptr;
+  GET(t->h_pmask, direct ? 256 : t->ptotal, uint8_t, hpmask);
+  t->hmask.assign(B, nullptr);
+  for (int b = 0; b < B; ++b) t->hmask[b] = direct ? mask_out[b] : hpmask + t->poff[b];
+  bool dense = direct;                      // the caller's arrays lie back to back (one pinned allocation per batch)
+  for (int b = 1; b < B && dense; ++b) dense = mask_out[b] == mask_out[b - 1] + (size_t)pages[b - 1].im_h * pages[b - 1].im_w;
+  const double t0b = now_ms();
   if (plain) {   // device and host copy of the page masks both read the network's u8 mask: same launch, no ordering needed
     const size_t stride = B > 1 ? t->poff[1] - t->poff[0] : hw;
     post.copy2d(pmask, stride, mask_u8_dev, hw, hw, B);
-    T_TRY(post.d2h2d(hpmask, stride, mask_u8_dev, hw, hw, B));
+    if (dense) T_TRY(post.d2h(mask_out[0], mask_u8_dev, hw * (size_t)B));
+    else if (direct)
+      for (int b = 0; b < B; ++b) T_TRY(post.d2h(mask_out[b], mask_u8_dev + (size_t)b * hw, hw));
+    else T_TRY(post.d2h2d(hpmask, stride, mask_u8_dev, hw, hw, B));
   }
   for (int b = 0; b < B && !plain; ++b) {
     const ctd_tail_page& pg = pages[b];
@@ -859,11 +890,16 @@ static int tail_run_impl(ctd_tail* t, int32_t B, int32_t Hn, int32_t Wn, const f
       launch_resize_linear_u8(src, ch, cw, 1, dst, pg.im_h, pg.im_w, pg.im_h, pg.im_w, st);
     }
   }
-  if (!plain) T_TRY(post.d2h(hpmask, pmask, t->ptotal));
+  if (!plain) {
+    if (!direct) T_TRY(post.d2h(hpmask, pmask, t->ptotal));
+    else
+      for (int b = 0; b < B; ++b) T_TRY(post.d2h(mask_out[b], pmask + t->poff[b], (size_t)pages[b].im_h * pages[b].im_w));
+  }
   post.flush();
   T_TRY(hipGetLastError());
   T_TRY(chain.end());
   const double t1 = now_ms();
+  t->ms_sub[0] = t0a - t0, t->ms_sub[1] = t0b - t0a, t->ms_sub[2] = t1 - t0b;
   T_TRY(hipStreamSynchronize(st));                                     // sync 1: counts are known
   const double t2 = now_ms();
 
@@ -908,7 +944,7 @@ static int tail_run_impl(ctd_tail* t, int32_t B, int32_t Hn, int32_t Wn, const f
     po.dist.resize((size_t)std::max(dcap, 1) * 3);
     int nb_out = 0, nl_out = 0, nd_out = 0;
     if (int rc = ctd_group_output(po.yolo.data(), po.yolo_cls.data(), nd, lines.data(), nl, pg.im_w, pg.im_h,
-                                  hpmask + t->poff[b], pg.im_w, po.blks.data(), bcap, po.lines.data(), bcap, po.dist.data(),
+                                  t->hmask[b], pg.im_w, po.blks.data(), bcap, po.lines.data(), bcap, po.dist.data(),
                                   dcap, &nb_out, &nl_out, &nd_out))
       return ctd_fail_msg(rc, "ctd_group_output failed");
     po.blks.resize(nb_out);
@@ -938,11 +974,11 @@ static int tail_run_impl(ctd_tail* t, int32_t B, int32_t Hn, int32_t Wn, const f
   int rc = CTD_OK;
   if (prm->refine && prm->keep_undetected_mask) {
     rc = download_pages(t, true, mask_out, refined_out);
-  } else {   // the mask was not edited: the early download is the result
+  } else {   // the mask was not edited: the early download is the result (already in the caller's arrays when `direct`)
     rc = download_pages(t, false, nullptr, prm->refine ? refined_out : nullptr);
-    if (!rc && mask_out)
+    if (!rc && mask_out && !direct)
       for (int b = 0; b < B; ++b)
-        if (mask_out[b]) std::memcpy(mask_out[b], hpmask + t->poff[b], (size_t)pages[b].im_h * pages[b].im_w);
+        if (mask_out[b]) std::memcpy(mask_out[b], t->hmask[b], (size_t)pages[b].im_h * pages[b].im_w);
   }
   const double t7 = now_ms();
   t->ms_stage[0] = t1 - t0, t->ms_stage[1] = t2 - t1, t->ms_stage[2] = t3 - t2, t->ms_stage[3] = t4 - t3;
@@ -958,10 +994,11 @@ int ctd_tail_run(ctd_tail* t, int32_t B, int32_t Hn, int32_t Wn, const float* bl
                                   mask_out, refined_out, ready_event));
 }
 
-int ctd_tail_timings(const ctd_tail* t, double* ms10) {   // 11 entries
-  if (!t || !ms10) return ctd_fail_msg(CTD_ERR_INVALID, "null argument");
-  std::memcpy(ms10, t->ms_stage, sizeof(t->ms_stage));
-  ms10[10] = t->ms_db_wait;
+int ctd_tail_timings(const ctd_tail* t, double* ms16) {   // 16 entries
+  if (!t || !ms16) return ctd_fail_msg(CTD_ERR_INVALID, "null argument");
+  std::memcpy(ms16, t->ms_stage, sizeof(t->ms_stage));
+  ms16[10] = t->ms_db_wait;
+  for (int i = 0; i < 5; ++i) ms16[11 + i] = t->ms_sub[i];
   return CTD_OK;
 }
 
@@ -1038,6 +1075,30 @@ int ctd_tail_page_counts(const ctd_tail* t, int32_t page, int32_t* n_blocks, int
   if (n_dist) *n_dist = (int32_t)(po.dist.size() / 3);
   if (n_db_boxes) *n_db_boxes = (int32_t)po.db_scores.size();
   if (n_yolo) *n_yolo = (int32_t)po.yolo_cls.size();
+  return CTD_OK;
+}
+
+int ctd_tail_batch_counts(const ctd_tail* t, int32_t* counts) {
+  if (!t || !counts) return ctd_fail_msg(CTD_ERR_INVALID, "ctd_tail_batch_counts: null argument");
+  for (size_t b = 0; b < t->out.size(); ++b) {
+    const PageOut& po = t->out[b];
+    int32_t* c = counts + 5 * b;
+    c[0] = (int32_t)po.blks.size(), c[1] = (int32_t)(po.lines.size() / 8), c[2] = (int32_t)(po.dist.size() / 3);
+    c[3] = (int32_t)po.db_scores.size(), c[4] = (int32_t)po.yolo_cls.size();
+  }
+  return CTD_OK;
+}
+
+int ctd_tail_batch_fetch(const ctd_tail* t, ctd_blk* blocks, int32_t* lines, double* dist) {
+  if (!t) return ctd_fail_msg(CTD_ERR_INVALID, "ctd_tail_batch_fetch: null tail");
+  for (const PageOut& po : t->out) {
+    if (blocks && !po.blks.empty()) std::memcpy(blocks, po.blks.data(), po.blks.size() * sizeof(ctd_blk));
+    if (blocks) blocks += po.blks.size();
+    if (lines && !po.lines.empty()) std::memcpy(lines, po.lines.data(), po.lines.size() * 4);
+    if (lines) lines += po.lines.size();
+    if (dist && !po.dist.empty()) std::memcpy(dist, po.dist.data(), po.dist.size() * 8);
+    if (dist) dist += po.dist.size();
+  }
   return CTD_OK;
 }
 

@@ -194,13 +194,14 @@ class TextDetector:
             self._lanes[i] = (net, st)
         return net, st
 
-    def _tail(self, job, refine_mode, keep_undetected_mask, lo=None, hi=None, records=None):
+    def _tail(self, job, refine_mode, keep_undetected_mask, lo=None, hi=None, records=None, lazy=False):
         """The native tail of pages [lo, hi) of a forwarded batch (default: all of it) on the calling thread's `Tail`.
         records=(cap_blk, cap_line): the pages come back as `PageResult`s carrying their multi-GPU gather records."""
         sl = slice(lo, hi)
         return thread_tail(self.net.device).run(job["gpu"][sl], job["metas"][sl], job["blks"][sl], job["mask_u8"][sl],
                                                 job["lines_map"][sl], job["bitmap"][sl], self.conf_thresh, self.nms_thresh,
-                                                0.6, True, refine_mode, keep_undetected_mask, job["ev"], records=records)
+                                                0.6, True, refine_mode, keep_undetected_mask, job["ev"], records=records,
+                                                lazy=lazy)
 
     @staticmethod
     def _split(n: int, parts: int):
@@ -217,14 +218,20 @@ class TextDetector:
     @torch.no_grad()
     def detect_stream(self, batches: Iterable[Sequence[Page]], refine_mode=REFINEMASK_INPAINT,
                       keep_undetected_mask=False, workers: int = 2, depth: int = 3, engines: int = 1,
-                      loaders: int = 2, tail_split: int = 0) -> Iterator[list]:
+                      loaders: int = 2, tail_split: int = 0, lazy: bool = True) -> Iterator[list]:
         """Yields `detect_batch(batch)` for every batch, in order, with up to `depth` batches in flight:
         the forward of the next batches is launched while `workers` threads run the tails of earlier ones.
         Host (numpy) pages are staged to the GPU by `loaders` threads up to `depth` batches ahead (`_stage`).
         `engines` > 1 alternates the batches over that many engine copies on their own streams (`_lane`).
         `tail_split` cuts every batch's tail into that many page ranges, each a work item of its own for the workers
         (0 = one per worker): lower latency per batch and a shorter drain when the stream ends, for more, smaller
-        native calls -- measured +6 % end to end at 32 pages per batch (2311 -> 2456 pages/s, 3 workers)."""
+        native calls -- measured +6 % end to end at 32 pages per batch (2311 -> 2456 pages/s, 3 workers).
+        `lazy` (default): every page's blk_list is a `textblock.BlockList` -- the native records, complete on the host,
+        which builds the `TextBlock` objects when first iterated / indexed, on the consumer's thread; `lazy=False` builds
+        plain lists on the worker threads as `detect_batch` does (the workers then spend most of their time holding the
+        interpreter lock: 0.37 ms of Python per page against 0.3 ms of native work).
+        The pools stay alive between calls (`close()` stops them): each worker thread keeps a native tail object with a
+        HIP stream and ~250 MB of device tables at 32 pages per batch."""
         # The pools live on the detector: their threads own the native `Tail` objects (a HIP stream, ~250 MB of
         # fixed-capacity device tables at 32 pages, pinned buffers) and the pinned staging rings, which a pool per call
         # would create and destroy every time.
@@ -255,7 +262,7 @@ class TextDetector:
                     st.wait_stream(main)                  # pages the caller produced on its stream
                     with torch.cuda.stream(st):
                         job = self._forward(batch, net)
-                pending.append([pool.submit(self._tail, job, refine_mode, keep_undetected_mask, lo, hi)
+                pending.append([pool.submit(self._tail, job, refine_mode, keep_undetected_mask, lo, hi, None, lazy)
                                 for lo, hi in self._split(len(job["metas"]), tail_split)])
                 while len(pending) >= depth:
                     yield [r for f in pending.popleft() for r in f.result()]

@@ -16,7 +16,7 @@ import numpy as np
 import torch
 
 from . import _lib as L
-from .textblock import TextBlock, blocks_from_records
+from .textblock import BLK_DTYPE, BlockList, TextBlock, blocks_from_records
 
 
 def _pinned_u8(h: int, w: int) -> np.ndarray:
@@ -106,15 +106,34 @@ class Tail:
         extras = {"db_boxes": boxes, "db_scores": scores, "yolo": (yx, yc, np.round(yf, 3))}
         return blocks_from_records(recs, lines, dist, nb.value), extras
 
+    def _block_lists(self, B: int) -> List[BlockList]:
+        """The grouped blocks of every page of the last run: two native calls and three arrays for the batch, per-page
+        views of them wrapped as `BlockList`s (no per-block Python here)."""
+        lib = self._lib
+        cnt = np.empty((B, 5), np.int32)
+        L.check(lib.ctd_tail_batch_counts(self._h, cnt.ctypes.data), "ctd_tail_batch_counts")
+        nb, nl, nd = (int(v) for v in cnt[:, :3].sum(0))
+        recs = np.empty((max(nb, 1),), BLK_DTYPE)
+        lines = np.empty((max(nl, 1), 8), np.int32)
+        dist = np.empty((max(nd, 1), 3), np.float64)
+        L.check(lib.ctd_tail_batch_fetch(self._h, recs.ctypes.data, lines.ctypes.data, dist.ctypes.data), "ctd_tail_batch_fetch")
+        ob = np.concatenate(([0], np.cumsum(cnt[:, 0]))).tolist()
+        ol = np.concatenate(([0], np.cumsum(cnt[:, 1]))).tolist()
+        od = np.concatenate(([0], np.cumsum(cnt[:, 2]))).tolist()
+        return [BlockList(recs[ob[b]: ob[b + 1]], lines[ol[b]: ol[b + 1]], dist[od[b]: od[b + 1]]) for b in range(B)]
+
     # -- the whole tail ---------------------------------------------------------------------------
     def run(self, pages_gpu: Sequence[torch.Tensor], metas, blks: torch.Tensor, mask_u8: torch.Tensor,
             lines_map: torch.Tensor, bitmap: torch.Tensor, conf_thresh=0.4, nms_thresh=0.35, box_thresh=0.6,
             refine: bool = True, refine_mode: int = 0, keep_undetected_mask: bool = False,
-            ready_event: Optional[torch.cuda.Event] = None, want_extras: bool = False, records=None):
+            ready_event: Optional[torch.cuda.Event] = None, want_extras: bool = False, records=None,
+            lazy: bool = False):
         """metas[b] = (im_h, im_w, dw, dh); blks (B,rows,no) f32, mask_u8 (B,Hn,Wn) u8, lines_map (B,2,Hn,Wn) f32
         or its plane 0 (B,Hn,Wn), bitmap (B,Hn,Wn) u8 -- all on the GPU.  Returns per page
         (mask, mask_refined, blk_list[, extras]) as the reference's `TextDetector.__call__` does.
-        records=(cap_blk, cap_line): every page's tuple is a `PageResult` whose `.record` is its gather record."""
+        records=(cap_blk, cap_line): every page's tuple is a `PageResult` whose `.record` is its gather record.
+        lazy: blk_list is a `BlockList` (the native records; `TextBlock` objects are built when first accessed, by whoever
+        accesses them) instead of a list built here -- what `detect_stream`'s workers return."""
         B = len(metas)
         for tns in (blks, mask_u8, lines_map, bitmap):
             if not tns.is_cuda:
@@ -122,16 +141,22 @@ class Tail:
         Hn, Wn = mask_u8.shape[-2:]
         # The native tail reads these buffers on ITS stream and waits for `ready_event` only.  A layout / dtype
         # conversion here runs on torch's current stream AFTER that event: order the tail behind it with a fresh event.
-        converted = not (blks.is_contiguous() and mask_u8.is_contiguous() and bitmap.is_contiguous())
-        blks = blks.contiguous()
-        mask_u8 = mask_u8.contiguous()
-        bitmap = bitmap.contiguous()
-        if lines_map.dtype != torch.float32 or lines_map.stride(-1) != 1 or lines_map.stride(-2) != Wn:
-            lines_map = lines_map.float().contiguous()
-            converted = True
-        if converted:
+        need = not (blks.is_contiguous() and mask_u8.is_contiguous() and bitmap.is_contiguous()) or \
+            lines_map.dtype != torch.float32 or lines_map.stride(-1) != 1 or lines_map.stride(-2) != Wn
+        if need:
+            # The conversion kernels run on THIS thread's current stream, which has not necessarily seen the forward
+            # (a `detect_stream` lane, a caller's side stream): make it wait for the producer's event first, then hand
+            # the native tail a fresh event recorded behind the conversions.
+            cur = torch.cuda.current_stream(self.device)
+            if ready_event is not None:
+                cur.wait_event(ready_event)
+            blks = blks.contiguous()
+            mask_u8 = mask_u8.contiguous()
+            bitmap = bitmap.contiguous()
+            if lines_map.dtype != torch.float32 or lines_map.stride(-1) != 1 or lines_map.stride(-2) != Wn:
+                lines_map = lines_map.float().contiguous()
             ready_event = torch.cuda.Event()
-            ready_event.record(torch.cuda.current_stream(self.device))
+            ready_event.record(cur)
         prob_stride = lines_map.stride(0)
         tab = self._page_table(pages_gpu, metas)
         prm = L.CtdTailParams(conf_thresh, nms_thresh, box_thresh, 1000, 1.5, int(bool(refine)), int(refine_mode),
@@ -151,9 +176,13 @@ class Tail:
             rec = np.empty((B, 4 + 12 * cb + 8 * cl), np.float64)
             L.check(self._lib.ctd_tail_pack_records(self._h, cb, cl, rec.ctypes.data), "ctd_tail_pack_records")
         out = []
+        lists = self._block_lists(B) if not want_extras else None
         for b in range(B):
-            blk_list, extras = self._blocks(b, want_extras)
-            r = (masks[b], refined[b], blk_list, extras) if want_extras else (masks[b], refined[b], blk_list)
+            if want_extras:
+                blk_list, extras = self._blocks(b, True)
+                r = (masks[b], refined[b], blk_list, extras)
+            else:
+                r = (masks[b], refined[b], lists[b] if lazy else lists[b].to_list())
             if rec is not None:
                 r = PageResult(r)
                 r.record = rec[b]
@@ -162,10 +191,11 @@ class Tail:
 
     def timings(self) -> dict:
         """Host wall clock (ms) of the stages of the last `run`."""
-        ms = (C.c_double * 11)()
+        ms = (C.c_double * 16)()
         L.check(self._lib.ctd_tail_timings(self._h, ms), "ctd_tail_timings")
         keys = ("enqueue1", "wait1", "db_tables+geometry", "yolo+group_output", "refine_wait_hist", "refine_wait_xor",
-                "refine_host+enqueue", "undetected", "final_wait+copies", "total", "db_table_wait")
+                "refine_host+enqueue", "undetected", "final_wait+copies", "total", "db_table_wait", "enq1_nms+buffers",
+                "enq1_labelling+tables", "enq1_mask_copies", "final_wait_only")
         return {k: round(v, 3) for k, v in zip(keys, ms)}
 
     # -- SegDetectorRepresenter alone -----------------------------------------------------------------

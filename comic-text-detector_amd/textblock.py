@@ -35,14 +35,33 @@ _RECORD_TAIL = (
 )
 
 
+def _turn(pts: np.ndarray, about, degrees) -> np.ndarray:
+    """Points (..., 2) turned by `degrees` about `about`, truncated to int64 -- the arithmetic of the reference's
+    `rotate_polygons` (utils/imgproc_utils.py:68-84): float32 coordinates, y' = y cos - x sin, x' = y sin + x cos in
+    image coordinates, the products formed exactly as numpy forms them there (so the result follows the installed
+    numpy's promotion rules like the reference's does)."""
+    a = np.deg2rad(degrees)
+    s, c = np.sin(a), np.cos(a)
+    p = np.asarray(pts).astype(np.float32)               # a copy: shifted in place, in float32 like the reference's
+    p[..., 1] -= about[1]
+    p[..., 0] -= about[0]
+    x, y = p[..., 0], p[..., 1]
+    out = np.empty_like(p)
+    out[..., 1] = y * c - x * s
+    out[..., 0] = y * s + x * c
+    out[..., 1] += about[1]
+    out[..., 0] += about[0]
+    return out.astype(np.int64)
+
+
 class TextBlock:
     """The reference's TextBlock record (textblock.py:12-265): detection state first, then the
     fields later pipeline stages fill, in the reference's attribute order (that order is the key
-    order of the JSON record, `to_dict` :158-160).  Only what the detector and the annotation writers use is here:
-    the geometry / colour / alignment helpers of the reference's class (`min_rect`, `bounding_rect`, `alignment`,
-    `get_font_colors`, `get_transformed_region`, ... :110-265) serve the OCR, rendering and GUI stages downstream of
-    `TextDetector.__call__` and are out of scope; a caller that needs them applies the
-    reference's own class to `to_dict()`'s record."""
+    order of the JSON record, `to_dict` :158-160).  The numpy-only helpers downstream stages call on the
+    returned `blk_list` (`min_rect`, `bounding_rect`, `aspect_ratio`, `alignment`, `get_text`, the font-colour
+    accessors, `stroke_width`, `target_lang` :110-265) are here as well, checked against the reference's own class in
+    tests/test_textblock_helpers.py; they cost nothing on the hot path (`blocks_from_records` fills `__dict__`
+    directly).  Only `get_transformed_region` (:162-196, cv2 homography of the OCR stage) is left out."""
 
     def __init__(self, xyxy: Sequence, lines: Optional[list] = None, language: str = "unknown",
                  vertical: bool = False, font_size: float = -1, distance=None, angle: int = 0, vec=None,
@@ -100,6 +119,85 @@ class TextBlock:
             self.distance = self.distance[order]
             self.lines = np.array(self.lines, dtype=np.int32)[order].tolist()
 
+    # -- geometry / text / colour helpers of the reference's class (used by OCR, rendering, GUI code downstream) ------
+    def _frame(self, about, sign: int = 1) -> np.ndarray:
+        """The lines' corner points (n,4,2), turned by `sign * angle` degrees about `about` when the block is angled."""
+        pts = self.lines_array().reshape(-1, 4, 2)
+        return _turn(pts, about, sign * self.angle) if self.angle != 0 else pts
+
+    def min_rect(self, rotate_back: bool = True) -> np.ndarray:
+        """(1,4,2) int64 corners of the lines' bounding rectangle in the block's own (rotated) frame, turned back into
+        page coordinates unless `rotate_back` is False (reference textblock.py:121-134)."""
+        c = self.center()
+        pts = self._frame(c)
+        lo, hi = pts.reshape(-1, 2).min(0), pts.reshape(-1, 2).max(0)
+        box = np.array([[[lo[0], lo[1]], [hi[0], lo[1]], [hi[0], hi[1]], [lo[0], hi[1]]]])
+        if rotate_back and self.angle != 0:
+            box = _turn(box, c, -self.angle)
+        return box.astype(np.int64)
+
+    def bounding_rect(self):
+        """Qt-style [x, y, w, h] in the rotated frame, or the rectangle a GUI stored (textblock.py:136-144)."""
+        if self._bounding_rect is not None:
+            return self._bounding_rect
+        (x0, y0), _, (x1, y1), _ = self.min_rect(rotate_back=False)[0]
+        return [x0, y0, x1 - x0, y1 - y0]
+
+    def aspect_ratio(self) -> float:
+        """Height over width of `min_rect()`, measured between the midpoints of opposite edges (textblock.py:110-115)."""
+        r = self.min_rect()[0].astype(np.float64)
+        mid = (r + np.roll(r, -1, axis=0)) / 2          # midpoints of edges 0-1, 1-2, 2-3, 3-0
+        return np.linalg.norm(mid[2] - mid[0]) / np.linalg.norm(mid[1] - mid[3])
+
+    def alignment(self) -> int:
+        """0 = left aligned, 1 = centred: a stored value wins; vertical and one-line blocks are left aligned; otherwise
+        whichever of the lines' left edges / centres scatters less (textblock.py:234-255)."""
+        if self._alignment >= 0:
+            return self._alignment
+        if self.vertical or len(self.lines) == 1:
+            return 0
+        pts = self._frame((0, 0))
+        left, right = pts[:, 0, 0], pts[:, 1, 0]
+        return 0 if np.std(left) < np.std((left + right) / 2) else 1
+
+    def target_lang(self):
+        return self._target_lang
+
+    def get_text(self) -> str:
+        """The recognised text: a string as it is, a list of line strings joined by blanks (textblock.py:198-201)."""
+        return self.text if isinstance(self.text, str) else " ".join(self.text).strip()
+
+    def _colour_scale(self) -> int:
+        return len(self.lines) if len(self.lines) > 0 else 1
+
+    def set_font_colors(self, frgb, srgb, accumulate: bool = True) -> None:
+        """Stores the fill / stroke colours; with `accumulate` as SUMS over the lines, which is what the per-line OCR
+        results add up to (textblock.py:203-211)."""
+        self.accumulate_color = accumulate
+        k = self._colour_scale() if accumulate else 1
+        self.fg_r, self.fg_g, self.fg_b = np.array(frgb) * k
+        self.bg_r, self.bg_g, self.bg_b = np.array(srgb) * k
+
+    def get_font_colors(self, bgr: bool = False):
+        """(fill, stroke) colours; accumulated sums are averaged over the lines and truncated to int32
+        (textblock.py:213-228; like the reference, `bgr` only matters for accumulated colours)."""
+        fg = np.array([self.fg_r, self.fg_g, self.fg_b])
+        bg = np.array([self.bg_r, self.bg_g, self.bg_b])
+        if not self.accumulate_color:
+            return fg, bg
+        n = len(self.lines)
+        if n == 0:
+            return [0, 0, 0], [0, 0, 0]
+        fg, bg = (fg / n).astype(np.int32), (bg / n).astype(np.int32)
+        return (fg[::-1], bg[::-1]) if bgr else (fg, bg)
+
+    @property
+    def stroke_width(self):
+        """`default_stroke_width` when fill and stroke colours differ by more than 40 in total, else 0 (:260-265)."""
+        diff = np.abs(np.array([self.fg_r, self.fg_g, self.fg_b]) - np.array([self.bg_r, self.bg_g, self.bg_b])).sum()
+        return self.default_stroke_width if diff > 40 else 0
+
+
     def to_dict(self) -> dict:
         """`copy.deepcopy(vars(self))` (textblock.py:158-160): every attribute, numpy values included;
         `annotations.RecordEncoder` turns it into the reference's JSON."""
@@ -124,7 +222,7 @@ def _fast_block(xyxy, lines, language, vertical, font_size, distance, angle, vec
 
 
 # numpy view of `ctd_blk` (include/ctd_hip.h; _lib.CtdBlk): the records of a page become columns in one call
-_BLK_DT = np.dtype([("xyxy", "<i4", (4,)), ("language", "<i4"), ("vertical", "<i4"), ("angle", "<i4"),
+BLK_DTYPE = _BLK_DT = np.dtype([("xyxy", "<i4", (4,)), ("language", "<i4"), ("vertical", "<i4"), ("angle", "<i4"),
                     ("font_is_float", "<i4"), ("font_size", "<f8"), ("vec", "<f8", (2,)), ("norm", "<f8"),
                     ("weight", "<f8"), ("merged", "<i4"), ("line_off", "<i4"), ("n_lines", "<i4"), ("dist_off", "<i4"),
                     ("n_dist", "<i4"), ("pad_", "<i4")])
@@ -144,7 +242,7 @@ def blocks_from_records(recs, lines: np.ndarray, dist: np.ndarray, n: Optional[i
     n = len(recs) if n is None else n                # `recs`: the ctypes array the native call filled, first n entries used
     if n == 0:
         return []
-    a = np.frombuffer(recs, dtype=_BLK_DT, count=n)
+    a = recs[:n] if isinstance(recs, np.ndarray) else np.frombuffer(recs, dtype=_BLK_DT, count=n)
     if len(dist):
         with np.errstate(divide="ignore", invalid="ignore"):
             dval = np.abs(np.sin(np.arccos(np.ascontiguousarray(dist[:, 1]))) * np.ascontiguousarray(dist[:, 2]))
@@ -168,6 +266,57 @@ def blocks_from_records(recs, lines: np.ndarray, dist: np.ndarray, n: Optional[i
         t.__dict__ = d
         out.append(t)
     return out
+
+
+class BlockList:
+    """A page's `blk_list` as the native tail left it -- `ctd_blk` records plus line / distance pools, views into the
+    batch's arrays -- that turns into the reference's `TextBlock` objects when somebody looks at them.  It behaves like
+    the list `TextDetector.__call__` returns (len, iteration, indexing, slicing, `==` with a list, truth value); the
+    objects are built once, on first access, on the CONSUMER's thread -- not on the tail worker that produced the page:
+    the workers of `detect_stream` share the interpreter lock with each other and with the thread that launches the
+    forwards, and at 30-70 blocks per page the per-block Python work was the pipeline's critical resource.
+    Columnar access without building anything: `.records` (structured array, one row per block: xyxy, language,
+    vertical, angle, font_size, vec, norm, weight, merged, line_off, n_lines, ...), `.line_quads` (n,4,2) i32 in block
+    order, `.n_lines`."""
+    __slots__ = ("records", "_lines", "_dist", "_built")
+
+    def __init__(self, records: np.ndarray, lines: np.ndarray, dist: np.ndarray):
+        self.records, self._lines, self._dist, self._built = records, lines, dist, None
+
+    # -- columnar -------------------------------------------------------------------------------------
+    @property
+    def line_quads(self) -> np.ndarray:
+        return self._lines.reshape(-1, 4, 2)
+
+    @property
+    def n_lines(self) -> int:
+        return int(self.records["n_lines"].sum()) if len(self.records) else 0
+
+    # -- the reference's list ---------------------------------------------------------------------------
+    def to_list(self) -> List["TextBlock"]:
+        if self._built is None:
+            self._built = blocks_from_records(self.records, self._lines, self._dist)
+        return self._built
+
+    def __len__(self) -> int:
+        return len(self.records)
+
+    def __iter__(self):
+        return iter(self.to_list())
+
+    def __getitem__(self, i):
+        return self.to_list()[i]
+
+    def __bool__(self) -> bool:
+        return len(self.records) > 0
+
+    def __eq__(self, other):
+        if isinstance(other, BlockList):
+            other = other.to_list()
+        return self.to_list() == other
+
+    def __repr__(self) -> str:
+        return f"BlockList({len(self)} blocks, {self.n_lines} lines)"
 
 
 def group_output_native(blines: np.ndarray, cls: np.ndarray, lines, im_w: int, im_h: int,

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define CTD_ABI_VERSION 3
+#define CTD_ABI_VERSION 4
 
 /* ---- error codes ------------------------------------------------------ */
 #define CTD_OK 0
@@ -293,7 +293,8 @@ int ctd_tail_run(ctd_tail* t, int32_t B, int32_t Hn, int32_t Wn, const float* bl
  * page masks, [1] wait for them, [2] table download + contour geometry, [3] yolo unpack + group_output,
  * [4] refine: wait for the histograms, [5] refine: wait for the xor sums, [6] refine: host decisions + enqueue,
  * [7] refine_undetected_mask, [8] final wait + copies, [9] total, [10] the part of [2] spent waiting for the
- * table download.  ms must hold 11 doubles. */
+ * table download, [11]-[13] parts of [0]: NMS + buffers, labelling + contour tables, page-mask copies, [14] the part
+ * of [8] spent waiting for the refine stage's kernels, [15] reserved.  ms must hold 16 doubles. */
 int ctd_tail_timings(const ctd_tail* t, double* ms);
 
 /* The DB text-line stage alone (`SegDetectorRepresenter.__call__`, reference utils/db_utils.py:40-69): boxes and
@@ -316,6 +317,14 @@ int ctd_tail_page_counts(const ctd_tail* t, int32_t page, int32_t* n_blocks, int
 struct ctd_blk;
 int ctd_tail_page_fetch(const ctd_tail* t, int32_t page, struct ctd_blk* blocks, int32_t* lines, double* dist,
                         int16_t* db_boxes, float* db_scores, int32_t* yolo_xyxy, int32_t* yolo_cls, float* yolo_conf);
+
+/* The same grouped blocks for the WHOLE batch of the last ctd_tail_run in two calls (the per-page pair above costs the
+ * Python host side two foreign calls and three allocations per page, under the interpreter lock its tail workers share):
+ * counts (B,5) i32 = per page n_blocks, n_lines, n_dist, n_db_boxes, n_yolo; then the pages' ctd_blk records, line
+ * quads (n,8) i32 and distance triples (m,3) f64 back to back in page order (a block's line_off / dist_off stay
+ * relative to ITS page's first line / triple).  Any output may be NULL.  Pure host code. */
+int ctd_tail_batch_counts(const ctd_tail* t, int32_t* counts);
+int ctd_tail_batch_fetch(const ctd_tail* t, struct ctd_blk* blocks, int32_t* lines, double* dist);
 
 /* The grouped blocks of EVERY page of the last ctd_tail_run as fixed-capacity f64 records, the unit of the multi-GPU
  * record gather (comic-text-detector_amd/dist.py): per page

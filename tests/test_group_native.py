@@ -122,3 +122,23 @@ def test_native_group_output_equals_reference_code(seed):
     same_blocks(got, theirs)
     for a, b in zip(got, theirs):
         assert type(a.font_size) is type(b.font_size)
+
+
+def test_block_list_is_the_lazy_form_of_the_same_blocks():
+    """`BlockList` (what `detect_stream`'s workers hand over): len / counts / columns come from the native records without
+    building anything; iteration, indexing, comparison give the `TextBlock` objects `blocks_from_records` builds."""
+    p = pkg()
+    TBm = p.textblock
+    for seed in (3, 7, 11):
+        blks, lines, im_w, im_h, mask = random_page(seed)
+        recs, lout, dout = TBm.group_output_native(blks[0], blks[1], lines, im_w, im_h, mask)
+        eager = TBm.blocks_from_records(list(recs), lout, dout)
+        arr = np.frombuffer((p._lib.CtdBlk * max(len(recs), 1))(*recs), dtype=TBm.BLK_DTYPE, count=len(recs)).copy()
+        lazy = TBm.BlockList(arr, lout, dout)
+        assert lazy._built is None and len(lazy) == len(eager) and bool(lazy) == bool(eager)
+        assert lazy.n_lines == sum(len(b.lines) for b in eager) and lazy._built is None
+        assert lazy.line_quads.shape == (len(lout), 4, 2)
+        same_blocks(lazy, eager)
+        assert lazy._built is not None and lazy[0] is lazy.to_list()[0] and len(lazy[:2]) == min(2, len(eager))
+    empty = TBm.BlockList(np.empty((0,), TBm.BLK_DTYPE), np.empty((0, 8), np.int32), np.empty((0, 3)))
+    assert len(empty) == 0 and not empty and list(empty) == [] and empty == [] and empty.n_lines == 0

@@ -12,6 +12,8 @@ typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
 typedef float float4_t __attribute__((ext_vector_type(4)));
 typedef float float16_t __attribute__((ext_vector_type(16)));
 
+constexpr int CTD_ZEROS_BYTES = 8192;
+
 // One concatenated-source view: NHWC tensor slice.
 struct SrcView {
   const void* ptr;  // already offset by the channel offset
@@ -47,7 +49,8 @@ struct ConvArgs {
   int nphase;              // 1, or 4 for convT 4x4 s2 (blockIdx.z)
   int bk;                  // igemm K step the weights were packed for (32 / 64)
   int w_tiled;             // igemm weights are tile-major [phase][n_tile][k_step][BN][bk]
-  const void* zeros;       // >= 16 B of zeros in HBM: source of padding rows for LDS-DMA loads
+  const void* zeros;       // CTD_ZEROS_BYTES of zeros in HBM: source of padding rows for LDS-DMA loads (kernels_halo2.hip walks
+                           // a padding piece through it in step with the channel chunks: 2 B per input channel)
   long long* dbg;          // selftest only (k_rot & 16): per-block cycle stamps [nblk][8]; null in the product
   unsigned mw_mul, mw_sh;  // igemm: n / Mw == (uint64(n) * mw_mul) >> mw_sh for n < 2^31 (filled by the launcher)
   unsigned mh_mul, mh_sh;  //        same for Mh

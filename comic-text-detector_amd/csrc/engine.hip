@@ -95,7 +95,7 @@ struct ctd_engine {
   bool f32_mfma = true;  // fp32 engine: f32-operand MFMA kernel (CTD_F32_MFMA=0: exact-order direct kernels only)
   int det_rows_per_unit = 0;
   int det_no = 0;
-  void* zeros = nullptr;  // 256 B of zeros (padding source of the LDS-DMA loads)
+  void* zeros = nullptr;  // CTD_ZEROS_BYTES of zeros (padding source of the LDS-DMA loads)
 };
 
 namespace {
@@ -912,7 +912,7 @@ int ctd_engine_create(ctd_engine** out, const ctd_tensor* tensors, int32_t n_ten
   e->ops.resize(n_ops);
   for (int i = 0; i < n_ops; ++i) e->ops[i].op = ops[i];
   {
-    std::vector<uint8_t> z(256, 0);
+    std::vector<uint8_t> z(CTD_ZEROS_BYTES, 0);
     if (int zrc = upload(e, z, &e->zeros)) { ctd_engine_destroy(e); return zrc; }
   }
   int rc = validate(e);

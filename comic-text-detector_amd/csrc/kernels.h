@@ -78,6 +78,13 @@ bool conv_halo_supported(const ConvArgs& a, bool dst_f32);
 int conv_tuning_set(const char* key, long long value);   // dispatch knobs of the MFMA conv kernels (kernels_halo.hip)
 void launch_conv_halo(const ConvArgs& a, hipStream_t st);
 
+// ---- kernels_halo2.hip : 256-pixel x 256-column (phase, channel) tiles for the ConvTranspose layers, one block per CU ----
+extern long long g_halo2;              // 0 disables ("halo2")
+extern long long g_halo2_min_blocks;   // "halo2_min_blocks"
+bool conv_halo2_supported(const ConvArgs& a, bool dst_f32);
+void launch_conv_halo2(const ConvArgs& a, hipStream_t st);
+int halo2_tuning_set(const char* key, long long value);
+
 // ---- kernels_c3.hip : one-kernel C3 block (32 hidden channels, one bottleneck) -------------
 // Weights / biases are the packed arrays of the four unfused ops (tile-major, 32-channel K step):
 // w12 [Cin/32][64][32] (cv1 rows 0-31, cv2 rows 32-63), wm1 [32][32], wm2 [9 taps][32][32], wc3 [2][64][32].

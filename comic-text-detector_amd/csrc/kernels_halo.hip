@@ -395,7 +395,7 @@ int conv_tuning_set(const char* key, long long value) {
   else if (k == "halo_1x1") g_halo_1x1 = (int)value;
   else if (k == "halo_tps") g_halo_tps = (int)value;
 #endif
-  else return -1;
+  else return halo2_tuning_set(key, value);
   return 0;
 }
 

@@ -113,7 +113,7 @@ static void run_case(const Case& cs, int B, bool timing) {
   a.res = dRes; a.pitchR = pitchD; a.act = CTD_ACT_SILU; a.N = cs.N; a.nphase = 1; a.osy = a.osx = 1;
 
   static void* zeros = nullptr;
-  if (!zeros) { CK(hipMalloc(&zeros, 256)); CK(hipMemset(zeros, 0, 256)); }
+  if (!zeros) { CK(hipMalloc(&zeros, CTD_ZEROS_BYTES)); CK(hipMemset(zeros, 0, CTD_ZEROS_BYTES)); }
   a.zeros = zeros;
   ConvArgs ig = a, dr = a;
   std::vector<float> lg;       // logical igemm weights [nphase][N][K]
@@ -178,10 +178,10 @@ static void run_case(const Case& cs, int B, bool timing) {
   const double flops = cs.kind ? 2.0 * B * Hin * Win * 16.0 * cin * cs.N : 2.0 * (double)ig.M * cs.N * ig.K;
   const double bytes = 2.0 * ((double)n0 + n1 + (double)B * Ho * Wo * cs.N * (cs.res ? 2 : 1) + (double)cs.N * cin * k * k);
   std::printf("[case] %-32s B=%d out %dx%dx%d |", cs.name, B, Ho, Wo, cs.N);
-  struct Var { const char* name; int bk, tiled, rot, abl; };
+  struct Var { const char* name; int bk, tiled, rot, abl, h1 = 0; };   // h1: big-tile ConvT kernel (kernels_halo2.hip) off
   // ST_ABL=1 appends ablations of the default kernel (wrong results by construction, timing only)
   // rot: 0 = default dispatch (halo kernel where it applies), 2 = implicit-GEMM kernel only, 1 = register staged
-  const Var vars[] = {{"default", 32, 1, 0, 0}, {"igemm", 32, 1, 2, 0}, {"bk32/reg", 32, 1, 1, 0}, {"bk64/glds", 64, 1, 2, 0},
+  const Var vars[] = {{"default", 32, 1, 0, 0}, {"halo1", 32, 1, 0, 0, 1}, {"igemm", 32, 1, 2, 0}, {"bk32/reg", 32, 1, 1, 0}, {"bk64/glds", 64, 1, 2, 0},
                       // ablations of the implicit-GEMM kernel (rot 2 keeps the halo kernel out of the way)
                       {"noload", 32, 1, 2, 1}, {"nomfma", 32, 1, 2, 2}, {"nostore", 32, 1, 2, 4},
                       {"loadonly", 32, 1, 2, 6}, {"mfmaonly", 32, 1, 2, 5}, {"phasemajor", 32, 1, 2, 8},
@@ -197,6 +197,15 @@ static void run_case(const Case& cs, int B, bool timing) {
     ig.bk = bk; ig.w_tiled = v.tiled; ig.k_rot = v.abl;
     g_igemm_occ_lo = v.rot == 1;   // staging mode: 0 = LDS-DMA, 1 = register staged
     g_conv_halo = v.rot == 0;
+    if (v.h1) {                                       // only where the default variant ran the big-tile kernel
+      ConvArgs q = ig;
+      q.bk = 32, q.w_tiled = 1, q.k_rot = 0;
+      g_halo2 = 1;
+      g_conv_halo = 1;
+      if (!conv_halo2_supported(q, false) || !conv_halo_supported(q, false)) continue;   // (small grids go to the implicit GEMM)
+    }
+    g_halo2 = (v.rot == 0 && !v.h1) ? (std::getenv("ST_H2_NOPRIO") ? 2 : 1) : 0;
+    if (g_halo2 && std::getenv("ST_H2_ABL")) g_halo2 = 1 + 16 * std::atoi(std::getenv("ST_H2_ABL"));   // timing-only ablation of the big-tile kernel
     {
       std::vector<half_t> wig;
       igemm_pack_weights(lg.data(), nphase, cs.N, Kig, bn, bk, v.tiled, wig);
@@ -215,6 +224,30 @@ static void run_case(const Case& cs, int B, bool timing) {
       if (!(e <= 4e-3 * (1.0 + std::fabs((double)r[i])))) ++bad;
     }
     if (bad && !v.abl) ++g_fail;
+    static std::vector<half_t> o_default;             // the big-tile kernel must reproduce the 256 x 128 kernel bit for bit
+    if (&v == vars) o_default = o;
+    if (&v == vars && g_halo2 == 1 && conv_halo2_supported(ig, false)) {
+      // its LDS hand-offs are ordered by counted waits and barriers only: repeat the launch and demand identical bits
+      // (a race shows as a run-to-run difference long before it shows as an error beyond the tolerance)
+      size_t racy = 0;
+      std::vector<half_t> o2(nout);
+      for (int rep = 0; rep < 6; ++rep) {
+        CK(hipMemset(dOut, 0xff, nout * 2));
+        launch_conv_igemm(ig, false, 0);
+        CK(hipDeviceSynchronize());
+        CK(hipMemcpy(o2.data(), dOut, nout * 2, hipMemcpyDeviceToHost));
+        if (std::memcmp(o2.data(), o.data(), nout * 2) != 0) ++racy;
+      }
+      std::printf("  [halo2 x6 repeat: %s]", racy ? "DIFFERS RUN TO RUN" : "stable");
+      if (racy) ++g_fail;
+    }
+    if (v.h1) {
+      size_t diff = 0;
+      for (size_t i = 0; i < nout; ++i)
+        if ((int)(i % pitchD) < cs.N && std::memcmp(&o[i], &o_default[i], 2) != 0) ++diff;
+      std::printf("  [halo2 vs halo1: %s]", diff ? "DIFFERENT" : "bit-identical");
+      if (diff) { std::printf(" %zu values", diff); ++g_fail; }
+    }
     double ms = 0;
     if (timing) {
       hipEvent_t e0, e1;
@@ -231,7 +264,48 @@ static void run_case(const Case& cs, int B, bool timing) {
     }
     std::printf("  %s: %s %.3f ms %.0f TF %.0f GB/s |", v.name, v.abl ? "--" : bad ? "FAIL" : "ok", ms,
                 flops / (ms * 1e-3) / 1e12, bytes / (ms * 1e-3) / 1e9);
-    if (std::getenv("ST_PROF") && !v.abl && (v.rot == 2 || v.rot == 0) && bk == 32) {
+    if (std::getenv("ST_PROF") && &v == vars && conv_halo2_supported(ig, false)) {
+      const size_t nblk = (size_t)B * ((Hin + 15) / 16) * ((Win + 15) / 16) * 4;
+      long long* dd = nullptr;
+      CK(hipMalloc(&dd, (nblk * 16 + 256) * sizeof(long long)));
+      CK(hipMemset(dd, 0, (nblk * 16 + 256) * sizeof(long long)));
+      ig.dbg = dd;
+      launch_conv_igemm(ig, false, 0);
+      CK(hipDeviceSynchronize());
+      ig.dbg = nullptr;
+      std::vector<long long> hd(nblk * 16 + 256);
+      CK(hipMemcpy(hd.data(), dd, hd.size() * sizeof(long long), hipMemcpyDeviceToHost));
+      double m[2][8] = {{0}};
+      size_t used = 0, same_simd = 0;
+      for (size_t bq = 0; bq < nblk; ++bq) {
+        if (!hd[bq * 16 + 7]) continue;
+        ++used;
+        same_simd += ((hd[bq * 16 + 6] >> 4) & 3) == ((hd[bq * 16 + 8 + 6] >> 4) & 3);     // HW_ID[5:4] of waves 0 and 4
+        for (int h = 0; h < 2; ++h) {
+          hd[(bq * 2 + h) * 8 + 6] >>= 8;
+          for (int q = 0; q < 8; ++q) m[h][q] += (double)hd[(bq * 2 + h) * 8 + q];
+        }
+      }
+      std::printf("\n      [halo2 prof] waves 0 and 4 on the same SIMD in %zu of %zu blocks", same_simd, used);
+      {   // block 0: when each wave starts LOAD, reaches / leaves the barrier after it, ends its MFMAs, leaves the second barrier
+        const size_t nb_launched = (size_t)B * ((Hin + 15) / 16) * ((Win + 15) / 16) * (4 / (cs.N == 256 ? 1 : (cs.N == 128 ? 2 : 4)));
+        const long long* tl = hd.data() + nb_launched * 16;
+        const long long t0 = tl[0];
+        for (int st_ = 0; st_ < 8; ++st_)
+          for (int h = 0; h < 2; ++h) {
+            const long long* q = tl + ((size_t)h * 12 + st_) * 6;
+            std::printf("\n        step %d wave %d: LOAD starts %6lld  at barrier %6lld  released %6lld  MFMAs issued %6lld  released %6lld", st_,
+                        h * 4, q[0] - t0, q[1] - t0, q[2] - t0, q[3] - t0, q[4] - t0);
+          }
+      }
+      const int nst = ig.K / 32;
+      for (int h = 0; h < 2; ++h)
+        std::printf("\n      [halo2 prof, wave %d, cycles per K step (%d steps, %zu blocks)] reads %.0f  dma-issue %.0f  waitcnt %.0f  barrier1 %.0f  mfma %.0f  barrier2 %.0f | epilogue+store %.0f  block total %.0f",
+                    h * 4, nst, used, m[h][0] / used / nst, m[h][1] / used / nst, m[h][2] / used / nst, m[h][3] / used / nst,
+                    m[h][4] / used / nst, m[h][5] / used / nst, m[h][6] / used, m[h][7] / used);
+      std::printf("\n      ");
+      (void)hipFree(dd);
+    } else if (std::getenv("ST_PROF") && !v.abl && (v.rot == 2 || v.rot == 0) && bk == 32) {
       // cycle stamps of wave 0 of every block (s_memtime): mean over blocks
       const int bnp = igemm_ntile(cs.N);
       const size_t nblk = (size_t)((cs.N + bnp - 1) / bnp) * ((ig.M + 127) / 128) * nphase;   // >= halo grid too
@@ -273,7 +347,7 @@ static void run_c3_case(const C3Case& cs, int B, int Hh, int Ww) {
   half_t *dY = dev_alloc<half_t>(npx * 64), *dT = dev_alloc<half_t>(npx * 32), *dZ = dev_alloc<half_t>(npx * 64),
          *dF = dev_alloc<half_t>(npx * 64);
   static void* zeros = nullptr;
-  if (!zeros) { CK(hipMalloc(&zeros, 256)); CK(hipMemset(zeros, 0, 256)); }
+  if (!zeros) { CK(hipMalloc(&zeros, CTD_ZEROS_BYTES)); CK(hipMemset(zeros, 0, CTD_ZEROS_BYTES)); }
 
   // the four convs: logical weights [N][K] (K index = tap * cin + c), packed exactly as engine.hip packs them
   struct L { int N, cin, k; half_t* w; float* b; };
@@ -458,7 +532,7 @@ static void run_stem2_case(const char* name, int B, int H, int W, int in_fmt, in
   CK(hipMemcpy(dB0, b0.data(), 32 * 4, hipMemcpyHostToDevice));
   CK(hipMemcpy(dB1, b1.data(), 64 * 4, hipMemcpyHostToDevice));
   static void* zeros = nullptr;
-  if (!zeros) { CK(hipMalloc(&zeros, 256)); CK(hipMemset(zeros, 0, 256)); }
+  if (!zeros) { CK(hipMalloc(&zeros, CTD_ZEROS_BYTES)); CK(hipMemset(zeros, 0, CTD_ZEROS_BYTES)); }
   ConvArgs c{};
   c.s0 = SrcView{dS, 32, 32, 0, Hs, Ws};
   c.B = B; c.Hin = Hs; c.Win = Ws; c.Mh = Ho; c.Mw = Wo; c.KH = c.KW = 3; c.stride = 2; c.dy0 = c.dx0 = -1;
@@ -976,7 +1050,7 @@ static void run_split_case(const Case& cs, int B, bool timing) {
     ap.res = dRs;
     ap.x_sp = 1; ap.d_sp = 1; ap.r_sp = cs.res ? 1 : 0;
     static void* zeros = nullptr;                    // padding rows of the LDS-DMA loads
-    if (!zeros) { CK(hipMalloc(&zeros, 256)); CK(hipMemset(zeros, 0, 256)); }
+    if (!zeros) { CK(hipMalloc(&zeros, CTD_ZEROS_BYTES)); CK(hipMemset(zeros, 0, CTD_ZEROS_BYTES)); }
     ap.zeros = zeros;
     if (!conv_split_supported(ap)) {
       std::printf(" split(planes): unsupported FAIL |");

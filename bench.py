@@ -147,8 +147,9 @@ class Pipeline:
         self.host_batches = [[p for p in b.cpu().numpy()] for b in batches] if host_input else None
         self.lpool = ThreadPoolExecutor(max_workers=max(1, loaders), thread_name_prefix="ctd-load") if host_input else None
         self.comm_stream = torch.cuda.Stream(dev) if world > 1 else None
-        self.stats = {"blocks": 0, "lines": 0, "pages": 0}
+        self.stats = {"blocks": 0, "lines": 0, "pages": 0, "cpu_cores": 0.0}
         self.k = 0                                           # batches rotate across calls too
+        self.fixed_job = None
         # N > 1: the tail builds every page's gather record natively (dist.pack_results then only stacks them)
         self.records = (D.CAP_BLK, D.CAP_LINE) if world > 1 else None
 
@@ -158,6 +159,8 @@ class Pipeline:
             self.lpool.shutdown(wait=True)
 
     def forward_job(self, i, pg=None):
+        if self.fixed_job is not None:                       # --tail-only: no forward; every step's tail reads the same outputs
+            return dict(self.fixed_job)
         if pg is None:
             x = self.batches[i % len(self.batches)]
             pg = [x[j] for j in range(x.shape[0])]           # slices of one batch tensor: no torch.stack in the detector
@@ -221,12 +224,14 @@ def timed(run, steps, warmup, spinup, world, dev, stats=None):
     if stats is not None:
         for k in stats:
             stats[k] = 0
-    t0 = time.perf_counter()
+    t0, c0 = time.perf_counter(), time.process_time()
     run(steps)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
+    if stats is not None:                        # CPU time of this process (all its threads) per second of wall clock
+        stats["cpu_cores"] = (time.process_time() - c0) / max(dt, 1e-9)
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev if dist.get_backend() != "gloo" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -755,6 +760,11 @@ def main() -> None:
     ap.add_argument("--loaders", type=int, default=2, help="loader threads of --host-input")
     ap.add_argument("--engines", type=int, default=1, help="engine copies on their own streams (e2e)")
     ap.add_argument("--keep-undetected", action="store_true", help="also run refine_undetected_mask in the tail")
+    ap.add_argument("--tail-only", action="store_true",
+                    help="e2e pipeline WITHOUT the forward: one forward at set-up, then every step runs the native tail on those "
+                         "outputs (workers, work items, record gather as in e2e).  With --gpus N on one device (rehearsal) this "
+                         "measures what N ranks' HOST sides -- interpreter pipelines, tail workers x geometry threads, pinned "
+                         "buffers, the gather -- cost each other; not a detector rate")
     ap.add_argument("--eager-blocks", action="store_true",
                     help="e2e: the tail workers build the Python TextBlock objects of every page (detect_batch's return type) "
                          "instead of handing over the native records as lazily materialised BlockLists (detect_stream's default)")
@@ -821,6 +831,12 @@ def main() -> None:
     pipe = Pipeline(det, batches, canned, dev, world, rank, total_pages, D, args.workers, args.depth, args.tail_split,
                     host_input=args.host_input and e2e, loaders=args.loaders, engines=args.engines,
                     keep_undetected=args.keep_undetected, lazy=not args.eager_blocks)
+
+    if args.tail_only and e2e:
+        fj = pipe.forward_job(0)
+        torch.cuda.synchronize()
+        fj["ev"] = None
+        pipe.fixed_job = fj
 
     net_k = [0]
 
@@ -932,7 +948,8 @@ def main() -> None:
         if n_gpus > 1:
             workload += " + RCCL all-gather of the per-page block records"
         out = {
-            "metric": f"pages/sec at {S}x{S} bs={B}" + (" (end-to-end detector" + ("" if real else ", canned tail inputs")
+            "metric": f"pages/sec at {S}x{S} bs={B}" + ((" (TAIL ONLY: no forward in the step; host-side rehearsal" if args.tail_only
+                                                          else " (end-to-end detector" + ("" if real else ", canned tail inputs"))
                                                          + ", device-resident pages)" if e2e else " (network + NMS)"),
             "value": round(total_pages * args.steps / dt, 2),
             "unit": "pages/s",
@@ -956,7 +973,8 @@ def main() -> None:
                                          if (e2e and args.host_input) else "HBM",
                        "blocks_per_page": round(stats["blocks"] / max(stats["pages"], 1), 2) if e2e else None,
                        "lines_per_page": round(stats["lines"] / max(stats["pages"], 1), 2) if e2e else None,
-                       "one_device_rehearsal": one_device,
+                       "host_cpu_cores_used": round(float(stats.get("cpu_cores", 0.0)), 2),
+                       "one_device_rehearsal": one_device, "tail_only": bool(args.tail_only and e2e),
                        "parallelism": f"dp{n_gpus} (pages sharded, no data-path collective except the final record "
                                       f"gather; ranks={world}, backend={dist.get_backend() if world > 1 else 'none'}"
                                       + (", ALL RANKS ON ONE DEVICE: rehearsal, not a measurement" if one_device else "") + ")"},

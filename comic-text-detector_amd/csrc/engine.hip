@@ -876,6 +876,7 @@ int ctd_fail_msg(int code, const std::string& msg) { return fail(code, msg); }
 extern int g_tail_priority;   // tail.hip
 extern long long g_tail_dma_min;
 extern int g_tail_chain;
+extern int g_tail_fused_rounds;
 
 extern "C" {
 
@@ -1032,6 +1033,7 @@ int ctd_tuning_set(const char* key, int64_t value) {
   if (key && std::string(key) == "fuse") { g_fuse = (int)value; return CTD_OK; }
   if (key && std::string(key) == "tail_max_blocks") { g_tail_max_blocks = (int)std::max<int64_t>(1, value); return CTD_OK; }
   if (key && std::string(key) == "tail_chain") { g_tail_chain = (int)value; return CTD_OK; }
+  if (key && std::string(key) == "tail_fused_rounds") { g_tail_fused_rounds = (int)value; return CTD_OK; }
   if (key && std::string(key) == "tail_dma_min") { g_tail_dma_min = value; return CTD_OK; }
   if (key && std::string(key) == "tail_priority") { g_tail_priority = (int)value; return CTD_OK; }
   if (key && std::string(key) == "no_reuse") { g_no_reuse = (int)value; return CTD_OK; }

@@ -106,7 +106,6 @@ __global__ __launch_bounds__(NTHR, 2) void conv_halo2_kernel(ConvArgs a) {   // 
   const int dx0 = NPH == 1 ? ((pg & 1) ? 0 : -1) : -1;
   const int Ct = a.s0.c + a.s1.c;
   const int nchunk = Ct / BKH;
-  const int nsteps = nchunk * 4;                      // 4 taps (2x2) per channel chunk
 
   using gptr_t = const __attribute__((address_space(1))) void*;
   using lptr_t = __attribute__((address_space(3))) void*;

@@ -499,6 +499,180 @@ __global__ __launch_bounds__(256) void tw_accept_apply_kernel(const TWin* __rest
   }
 }
 
+// ---- one block per window: every merge round of `merge_mask_list` (reference utils/textmask.py:73-104) -------------------
+// The per-round launches above walk every window of the batch with a grid sized for the largest one, twice per round
+// (count, apply), 2-4 rounds: 5-9 launches per work item whose time is the largest window's at three blocks (rocprofv3,
+// round 4: 3.7 ms of kernel time per step at 29 windows per page, the biggest entry of the tail).  A window's rounds
+// depend on each other (a round counts the pixels the earlier rounds have NOT merged), different windows do not: one block
+// of 512 threads takes a window through all of its bands.  Counters live in an LDS table per band (2048 slots, open
+// addressing; keys that do not fit go to the global counters, which stay zero otherwise), so the decision of a component
+// = LDS entry + global entry.  Only this block touches the window's pixels of `merged`: __syncthreads orders its rounds.
+constexpr int TWB_THREADS = 512, TWB_HN = 2048;
+__global__ __launch_bounds__(TWB_THREADS) void tw_accept_all_kernel(const TWin* __restrict__ wins, const TBand* __restrict__ bands,
+                                                                    const int* __restrict__ labels, int canvas_w,
+                                                                    const int* __restrict__ stats, int max_labels, int min_box,
+                                                                    uint8_t* __restrict__ merged, int merged_w,
+                                                                    unsigned* __restrict__ counters) {
+  const TWin w = wins[blockIdx.x];
+  const int ng = win_groups(w);
+  const int lane = threadIdx.x & 63;
+  __shared__ int hkey[TWB_HN];
+  __shared__ unsigned hcnt[TWB_HN];
+  auto add = [&](int key, unsigned n) {
+    unsigned h = ((unsigned)key * 2654435761u) >> 21;          // 11 bits
+#pragma unroll
+    for (int probe = 0; probe < 4; ++probe, h = (h + 1) & (TWB_HN - 1)) {
+      const int prev = atomicCAS(&hkey[h], 0, key);
+      if (prev == 0 || prev == key) {
+        atomicAdd(&hcnt[h], n);
+        return;
+      }
+    }
+    atomicAdd(counters + (size_t)key, n);
+  };
+  auto total = [&](int key) -> unsigned {                     // LDS entry (if any) + what overflowed to the global table
+    unsigned v = __hip_atomic_load(counters + (size_t)key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned h = ((unsigned)key * 2654435761u) >> 21;
+#pragma unroll
+    for (int probe = 0; probe < 4; ++probe, h = (h + 1) & (TWB_HN - 1)) {
+      const int k = hkey[h];
+      if (k == key) return v + hcnt[h];
+      if (k == 0) break;
+    }
+    return v;
+  };
+  for (int r = 0; r < w.nband; ++r) {
+    const TBand bd = bands[w.band0 + r];
+    for (int i = threadIdx.x; i < TWB_HN; i += TWB_THREADS) hkey[i] = 0, hcnt[i] = 0;
+    __syncthreads();                                           // also: the previous round's writes to `merged` are visible
+    // ---- count: pixels of every component of this band not merged yet, split by the prediction (as tw_accept_count)
+    for (int g0 = 0; g0 < ng; g0 += TWB_THREADS) {
+      const int gi = g0 + threadIdx.x;
+      int ukey = 0, ulen = 0;
+      if (gi < ng) {
+        const Grp g = win_group(w, gi);
+        int l[4];
+        load_lab4(labels + (size_t)(bd.cy + g.y) * canvas_w + bd.cx + g.x, g, l);
+        const uint8_t* mr = merged + (size_t)(w.my + g.y) * merged_w + w.mx + g.x;
+        uint8_t mg[4];
+        if (g.nv == 4) {
+          __builtin_memcpy(mg, mr, 4);
+        } else {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) mg[k] = k < g.nv ? mr[k] : 255;
+        }
+        bool any = false;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          if (!(k < g.nv && l[k] > 0 && l[k] <= max_labels && mg[k] == 0)) l[k] = 0;
+          any |= l[k] != 0;
+        }
+        if (any) {
+          const unsigned pred = pred_on4(w, g);
+          int key[4];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) key[k] = l[k] ? 2 * l[k] + (((pred >> k) & 1u) ? 0 : 1) : 0;
+          bool same = true;
+#pragma unroll
+          for (int k = 1; k < 4; ++k) same &= k >= g.nv || key[k] == key[0];
+          if (same) {
+            ukey = key[0], ulen = g.nv;
+          } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+              if (key[k]) add(key[k], 1u);
+          }
+        }
+      }
+      if (!__ballot(ukey != 0)) continue;
+      const int prev = __shfl_up(ukey, 1);
+      const bool head = lane == 0 || prev != ukey;
+      const unsigned long long heads = __ballot(head);
+      int ps = ulen;
+      for (int off = 1; off < 64; off <<= 1) {
+        const int u = __shfl_up(ps, off);
+        if (lane >= off) ps += u;
+      }
+      const unsigned long long later = lane == 63 ? 0ull : (heads >> (lane + 1));
+      const int lanes = later ? __ffsll((long long)later) : 64 - lane;
+      const int tail = __shfl(ps, lane + lanes - 1);
+      if (head && ukey) add(ukey, (unsigned)(tail - ps + ulen));
+    }
+    __syncthreads();
+    // ---- apply: OR a component in iff its bbox has >= min_box pixels and it lowers the xor distance (as tw_accept_apply)
+    for (int gi = threadIdx.x; gi < ng; gi += TWB_THREADS) {
+      const Grp g = win_group(w, gi);
+      int l[4];
+      load_lab4(labels + (size_t)(bd.cy + g.y) * canvas_w + bd.cx + g.x, g, l);
+      int lprev = 0;
+      bool okprev = false;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int lk = l[k];
+        if (lk <= 0 || lk > max_labels) continue;
+        if (lk != lprev) {                                     // neighbours mostly share their component: decide once
+          lprev = lk;
+          okprev = stats[(size_t)(lk - 1) * 5 + 2] * stats[(size_t)(lk - 1) * 5 + 3] >= min_box &&
+                   total(2 * lk) > total(2 * lk + 1);
+        }
+        if (okprev) merged[(size_t)(w.my + g.y) * merged_w + w.mx + g.x + k] = 255;
+      }
+    }
+    __syncthreads();                                           // before the table is cleared for the next band
+  }
+}
+
+// ---- one block per window: the four passes of the hole filling (reference utils/textmask.py:113-131) ---------------------
+__global__ __launch_bounds__(TWB_THREADS) void tw_holes_all_kernel(const TWin* __restrict__ wins, const int* __restrict__ labels2,
+                                                                   const int* __restrict__ stats2, const int* __restrict__ first2,
+                                                                   int max_labels, const unsigned* __restrict__ count255,
+                                                                   uint8_t* __restrict__ merged, int merged_w,
+                                                                   unsigned* __restrict__ counters2) {
+  const TWin w = wins[blockIdx.x];
+  const int ng = win_groups(w);
+  __shared__ int tp[3];                                        // [maximum, multiplicity - 1, runner-up]
+  if (threadIdx.x < 3) tp[threadIdx.x] = -1;
+  __syncthreads();
+  const int a0 = (int)count255[blockIdx.x];                    // the background entry: pixels already set
+  for (int pass = 0; pass < 4; ++pass) {
+    if (pass <= 1 && threadIdx.x == 0) {
+      if (pass == 0) atomicMax(&tp[0], a0);
+      else if (a0 == tp[0]) atomicAdd(&tp[1], 1);
+      else atomicMax(&tp[2], a0);
+    }
+    const int m1 = pass >= 1 ? tp[0] : 0;
+    const int thr = pass >= 2 ? (tp[1] >= 1 ? tp[0] : tp[2]) : 0;
+    if (pass >= 2 && thr < 0) break;                           // block-uniform: nothing can be filled
+    for (int gi = threadIdx.x; gi < ng; gi += TWB_THREADS) {
+      const Grp g = win_group(w, gi);
+      const size_t c0 = (size_t)(w.my + g.y) * merged_w + w.mx + g.x;
+      int lab[4];
+      load_lab4(labels2 + c0, g, lab);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int l = lab[k];
+        if (l <= 0 || l > max_labels) continue;
+        const size_t ci = c0 + k;
+        const int area = stats2[(size_t)(l - 1) * 5 + 4];
+        if (pass <= 1) {
+          if (first2[l - 1] != (int)ci) continue;              // one representative pixel per component
+          if (pass == 0) atomicMax(&tp[0], area);
+          else if (area == m1) atomicAdd(&tp[1], 1);
+          else atomicMax(&tp[2], area);
+        } else if (pass == 2) {
+          if (area < thr && merged[ci] == 0) atomicAdd(counters2 + 2 * (size_t)l + (pred_on(w, g.x + k, g.y) ? 0 : 1), 1u);
+        } else {
+          if (area < thr &&
+              __hip_atomic_load(counters2 + 2 * (size_t)l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >
+                  __hip_atomic_load(counters2 + 2 * (size_t)l + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+            merged[ci] = 255;
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
 // 3x3 rect dilation inside the window (REFINEMASK_INPAINT, textmask.py:110-111) or a copy; also the
 // complement canvas for the hole-filling labelling (:113) and the count of set pixels per window
 __global__ __launch_bounds__(256) void tw_dilate_kernel(const TWin* __restrict__ wins, const uint8_t* __restrict__ in,
@@ -719,6 +893,18 @@ void launch_tw_accept(const TWin* wins, const TBand* bands, int nbands, int max_
                      merged_w, counters);
   hipLaunchKernelGGL(tw_accept_apply_kernel, g, dim3(256), 0, st, wins, bands, round, labels, canvas_w, stats, max_labels,
                      min_box, merged, merged_w, counters);
+}
+
+void launch_tw_accept_all(const TWin* wins, const TBand* bands, int n, const int* labels, int canvas_w, const int* stats,
+                          int max_labels, int min_box, uint8_t* merged, int merged_w, unsigned* counters, hipStream_t st) {
+  hipLaunchKernelGGL(tw_accept_all_kernel, dim3(n), dim3(TWB_THREADS), 0, st, wins, bands, labels, canvas_w, stats, max_labels,
+                     min_box, merged, merged_w, counters);
+}
+
+void launch_tw_holes_all(const TWin* wins, int n, const int* labels2, const int* stats2, const int* first2, int max_labels,
+                         const unsigned* count255, uint8_t* merged, int merged_w, unsigned* counters2, hipStream_t st) {
+  hipLaunchKernelGGL(tw_holes_all_kernel, dim3(n), dim3(TWB_THREADS), 0, st, wins, labels2, stats2, first2, max_labels, count255,
+                     merged, merged_w, counters2);
 }
 
 void launch_tw_dilate(const TWin* wins, int n, int max_pix, const uint8_t* in, uint8_t* out, uint8_t* comp, int merged_w,

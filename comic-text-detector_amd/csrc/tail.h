@@ -42,6 +42,7 @@ struct TWin {
   int img_w, mask_w, out_w;   // row pitches in pixels
   int x1, y1, w, h;     // window in the page
   int mx, my;           // top-left of the window's band in the merged canvas
+  int band0, nband;     // this window's candidate bands: bands[band0 .. band0 + nband), in merge order (round = index)
 };
 struct TRule {          // candidate rule of a window
   int kind;             // -1 unused; 0 grey range [lo, hi]; 1..3 channel B/G/R > lo
@@ -62,6 +63,10 @@ void launch_tw_render(const TWin* wins, const TBand* bands, int nbands, int max_
 void launch_tw_accept(const TWin* wins, const TBand* bands, int nbands, int max_pix, int round, const int* labels,
                       int canvas_w, const int* stats, int max_labels, int min_box, uint8_t* merged, int merged_w,
                       unsigned* counters, hipStream_t st);
+// ALL merge rounds of every window in one launch: a block owns a window and walks its bands in merge order (count,
+// decide, apply, next band) -- the rounds of a window depend on each other, windows do not
+void launch_tw_accept_all(const TWin* wins, const TBand* bands, int n, const int* labels, int canvas_w, const int* stats,
+                          int max_labels, int min_box, uint8_t* merged, int merged_w, unsigned* counters, hipStream_t st);
 void launch_tw_dilate(const TWin* wins, int n, int max_pix, const uint8_t* in, uint8_t* out, uint8_t* comp, int merged_w,
                       unsigned* count255, int dilate, hipStream_t st);
 // hole filling (reference utils/textmask.py:113-131) on the labelled complement canvas: per-window
@@ -70,6 +75,9 @@ void launch_tw_dilate(const TWin* wins, int n, int max_pix, const uint8_t* in, u
 void launch_tw_holes(const TWin* wins, int n, int max_pix, const int* labels2, const int* stats2, const int* first2,
                      int max_labels, const unsigned* count255, int* top2, uint8_t* merged, int merged_w,
                      unsigned* counters2, hipStream_t st);
+// the four passes of the hole filling as one launch, a block per window
+void launch_tw_holes_all(const TWin* wins, int n, const int* labels2, const int* stats2, const int* first2, int max_labels,
+                         const unsigned* count255, uint8_t* merged, int merged_w, unsigned* counters2, hipStream_t st);
 void launch_tw_commit(const TWin* wins, int n, int max_pix, const uint8_t* merged, int merged_w, hipStream_t st);
 // mask[p] = 0 where refined[p] > thr (reference utils/textmask.py:136)
 void launch_mask_clear_where(uint8_t* mask, const uint8_t* refined, long long n, int thr, hipStream_t st);

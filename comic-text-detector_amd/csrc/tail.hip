@@ -140,6 +140,9 @@ void parallel_for(int n, int max_threads, F f) {
 // after the other on the GPU (an event chain across their streams) instead of next to each other; 2 = the refine stage's
 // big enqueue (render, labelling, accept rounds, dilate, labelling, holes) too; 0 = side by side.
 int g_tail_chain = 1;
+// "tail_fused_rounds": 1 = a window's merge rounds and its hole-filling passes as one launch each (a block per window);
+// 0 = one count + one apply launch per round and four hole-filling launches over all windows (rounds 2-3)
+int g_tail_fused_rounds = 1;
 namespace {
 // The chain is PER DEVICE: events belong to the device that was current when they were created, a stream can only record
 // its own device's events (hipErrorInvalidHandle otherwise), and tails on different GPUs have nothing to serialise.
@@ -338,6 +341,7 @@ int refine_windows(ctd_tail* t, const std::vector<WinReq>& reqs, int refine_mode
     w.img_w = pg.im_w, w.mask_w = pg.im_w, w.out_w = pg.im_w;
     w.x1 = reqs[i].x1, w.y1 = reqs[i].y1, w.w = ww[i], w.h = wh[i];
     w.mx = pm.x[i], w.my = pm.y[i];
+    w.band0 = 0, w.nband = 0;
   }
   GET(t->d_wins, sizeof(TWin) * n, TWin, dw);
   // ---- everything whose size depends on the windows only: one launch uploads the window table and zeroes the
@@ -396,6 +400,7 @@ int refine_windows(ctd_tail* t, const std::vector<WinReq>& reqs, int refine_mode
     RCand c[4];
     const int nc = refine_candidates(hrules + (size_t)i * 6, hsums + (size_t)i * 6, (long long)ww[i] * wh[i], c);
     rounds = std::max(rounds, nc);
+    hw[i].band0 = (int)bands.size(), hw[i].nband = nc;     // the window's bands are contiguous, in merge order
     for (int r = 0; r < nc; ++r) {
       const RRule& rl = hrules[(size_t)i * 6 + c[r].rule];
       TBand b;
@@ -427,6 +432,7 @@ int refine_windows(ctd_tail* t, const std::vector<WinReq>& reqs, int refine_mode
   GET(t->d_ccl_ws, ccl_workspace_bytes(1, std::max(pc.H, pm.H), std::max(pc.W, pm.W)), uint8_t, ws);
   GET(t->d_cnt, ((size_t)cap1 + 1) * 8, unsigned, counters);
   T_TRY(bt.h2d(db, hb, sizeof(TBand) * nbands));
+  T_TRY(bt.h2d(dw, hw, sizeof(TWin) * n));                   // again: with every window's band range (the stream is idle here)
   bt.fill(canvas, 0, cpx);
   bt.fill(counters, 0, ((size_t)cap1 + 1) * 8);
   bt.flush();
@@ -434,15 +440,20 @@ int refine_windows(ctd_tail* t, const std::vector<WinReq>& reqs, int refine_mode
   T_TRY(chain.begin());
   launch_tw_render(dw, db, nbands, max_pix, canvas, pc.W, st);
   launch_ccl(canvas, 1, pc.H, pc.W, 0, 8, clab, n_dev, cstats, cap1, ws, st);
-  for (int r = 0; r < rounds; ++r)
-    launch_tw_accept(dw, db, nbands, max_pix, r, clab, pc.W, cstats, cap1, 3, merged_a, pm.W, counters, st);
+  if (g_tail_fused_rounds) {
+    launch_tw_accept_all(dw, db, n, clab, pc.W, cstats, cap1, 3, merged_a, pm.W, counters, st);
+  } else {
+    for (int r = 0; r < rounds; ++r)
+      launch_tw_accept(dw, db, nbands, max_pix, r, clab, pc.W, cstats, cap1, 3, merged_a, pm.W, counters, st);
+  }
   launch_tw_dilate(dw, n, max_pix, merged_a, merged_b, comp, pm.W, count255, refine_mode == 0 ? 1 : 0, st);
   // ---- hole filling on the complement, then the OR into the pages
   GET(t->d_mlab, mpx * 4, int, mlab);
   GET(t->d_mstats, (size_t)cap2 * 6 * 4, int, mstats);
   int* mfirst = mstats + (size_t)cap2 * 5;
   launch_ccl(comp, 1, pm.H, pm.W, 0, 8, mlab, n_dev, mstats, cap2, ws, st, 0, mfirst);
-  launch_tw_holes(dw, n, max_pix, mlab, mstats, mfirst, cap2, count255, top2, merged_b, pm.W, counters2, st);
+  if (g_tail_fused_rounds) launch_tw_holes_all(dw, n, mlab, mstats, mfirst, cap2, count255, merged_b, pm.W, counters2, st);
+  else launch_tw_holes(dw, n, max_pix, mlab, mstats, mfirst, cap2, count255, top2, merged_b, pm.W, counters2, st);
   launch_tw_commit(dw, n, max_pix, merged_b, pm.W, st);
   T_TRY(chain.end());
   T_TRY(hipGetLastError());
@@ -551,10 +562,25 @@ int download_pages(ctd_tail* t, bool mask_too, uint8_t* const* mask_out, uint8_t
       }
     return hipMemcpyAsync(host, dev, nb, hipMemcpyDeviceToHost, st);   // page-locked arrays make these DMA transfers
   };
+  // the caller's arrays usually lie back to back (one pinned allocation per batch): equal-size pages then go as ONE
+  // strided copy (device pitch = the padded page slot) instead of one copy per page
+  const size_t nb0 = (size_t)t->pages[0].im_h * t->pages[0].im_w;
+  const size_t slot = t->B > 1 ? t->poff[1] - t->poff[0] : nb0;
+  auto dense = [&](uint8_t* const* out) {
+    if (!out || !out[0] || t->B < 2) return false;
+    for (int b = 0; b < t->B; ++b) {
+      if ((size_t)t->pages[b].im_h * t->pages[b].im_w != nb0 || t->poff[b] != (size_t)b * slot) return false;
+      if (out[b] != out[0] + (size_t)b * nb0) return false;
+    }
+    return true;
+  };
+  const bool dm = mask_too && dense(mask_out), dr = dense(refined_out);
+  if (dm) T_TRY(hipMemcpy2DAsync(mask_out[0], nb0, pmask, slot, nb0, (size_t)t->B, hipMemcpyDeviceToHost, st));
+  if (dr) T_TRY(hipMemcpy2DAsync(refined_out[0], nb0, refined, slot, nb0, (size_t)t->B, hipMemcpyDeviceToHost, st));
   for (int b = 0; b < t->B; ++b) {
     const size_t nb = (size_t)t->pages[b].im_h * t->pages[b].im_w;
-    if (mask_too && mask_out && mask_out[b]) T_TRY(one(mask_out[b], pmask + t->poff[b], nb));
-    if (refined_out && refined_out[b]) T_TRY(one(refined_out[b], refined + t->poff[b], nb));
+    if (mask_too && !dm && mask_out && mask_out[b]) T_TRY(one(mask_out[b], pmask + t->poff[b], nb));
+    if (!dr && refined_out && refined_out[b]) T_TRY(one(refined_out[b], refined + t->poff[b], nb));
   }
   bt.flush();
   T_TRY(hipGetLastError());

@@ -190,3 +190,25 @@ def test_bench_two_ranks_on_one_device():
     assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 8
     assert "ranks=2" in out["config"]["parallelism"] and out["config"]["one_device_rehearsal"] is True
     assert out["value"] > 0 and out["config"]["blocks_per_page"] > 0
+
+
+@pytest.mark.gpu
+def test_bench_four_ranks_tail_only_on_one_device():
+    """Four ranks (four interpreter pipelines, 4 x tail workers x native threads, four pinned arenas, the record gather
+    inside the step) on one device, forward left out (`--tail-only`): the host-side rehearsal of the N > 1 launch."""
+    import json
+    import subprocess
+    import sys
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    env["CTD_BENCH_ONE_DEVICE"] = "1"
+    env["CTD_DIST_BACKEND"] = "gloo"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--tail-only", "--steps", "3", "--warmup",
+                        "1", "--spinup", "2", "--batch", "4", "--size", "512", "--batches", "1", "--no-cpu-baseline", "--no-extras"],
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert out["n_gpus"] == 4 and out["config"]["global_batch"] == 16 and out["config"]["tail_only"] is True
+    assert out["config"]["host_threads"]["per_rank"] * 4 <= max(16, out["config"]["host_threads"]["usable_cpus"])
+    assert out["value"] > 0 and out["config"]["blocks_per_page"] > 0 and out["config"]["host_cpu_cores_used"] > 0

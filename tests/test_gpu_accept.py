@@ -74,10 +74,19 @@ def test_detector_end_to_end_vs_oracle(prec, size, shape):
         assert rep["blocks"]["identical"] == rep["blocks"]["ref"] == rep["blocks"]["ours"]
         assert rep["refined_mask_equal_frac"] > 0.9999
     else:
+        # another arithmetic than the reference's fp32: no IoU floor (a floor of 0.9 is met by a page that loses a line) but
+        # a statement about SETS -- every line / block of the reference that the engine does not reproduce identically, and
+        # every one it adds, is accounted for by the threshold band (fp16_band below; nothing unexplained), so
+        # identical = reference - explained; the identical ones are the clear majority on these pages
         assert rep["mask_u8_max_level_diff"] <= 2
         assert rep["mask_iou_at_127"] > 0.995
-        assert rep["lines"]["mean_iou"] > 0.9 and rep["blocks"]["mean_iou"] > 0.9
         assert rep["refined_mask_equal_frac"] > 0.995
+        band, geo = fp16_band(p, ck, det, page, size, got)
+        nl, nb = rep["lines"], rep["blocks"]
+        assert geo["lines_unexplained"] == 0 and geo["blocks_unexplained"] == 0
+        assert nl["identical"] >= nl["ref"] - geo["lines_differing"] and nb["identical"] >= nb["ref"] - geo["blocks_differing"]
+        assert nl["identical"] >= 0.5 * nl["ref"] and nb["identical"] >= 0.3 * nb["ref"]
+        assert band["bitmap_flips_out_of_band"] == 0 and band["mask127_flips_out_of_band"] == 0
 
 
 # The fp16 engine computes in another arithmetic than the reference's fp32, so it cannot be bit-identical; what CAN be
@@ -91,14 +100,9 @@ def test_detector_end_to_end_vs_oracle(prec, size, shape):
 #       explain_geometry) -- nothing is left unexplained.
 # `bench.py`'s `parity.fp16_band` prints the same numbers for the benchmark's page.
 
-@pytest.mark.parametrize("size,shape", [(512, (512, 512)), (1024, (1024, 1024)), (512, (700, 495))])
-def test_fp16_engine_deviation_is_confined_to_the_threshold_band(size, shape):
-    p = pkg()
-    ck = blob_ckpt()
-    page = p.synth.text_like_page(shape, 3, n_blocks=8)
+def fp16_band(p, ck, det, page, size, got):
+    """(band report, geometry explanation) of the fp16 detector `det` on `page` against the oracle."""
     ref, om, ol, (dw, dh), ref_dets, sbb, ref_cand = oracle_full(ck, page, size, (size, page.shape))
-    det = p.detector.TextDetector(ck, input_size=size, device="cuda", precision="fp16")
-    got = det(page, refine_mode=0, keep_undetected_mask=False)
     net = det.net
     blks, mask, lines = net.forward_u8(det._prepare([page])[0])
     torch.cuda.synchronize()
@@ -112,6 +116,17 @@ def test_fp16_engine_deviation_is_confined_to_the_threshold_band(size, shape):
     geo = accept.explain_geometry(got, ref, flips, ratio_xy=((size - dw) / im_w, (size - dh) / im_h),
                                   dets=dets[0, : int(counts[0])].cpu().numpy(), ref_dets=ref_dets, score_band_boxes=sbb,
                                   candidates=(extras["db_boxes"], ref_cand, 1000))
+    return rep, geo
+
+
+@pytest.mark.parametrize("size,shape", [(512, (512, 512)), (1024, (1024, 1024)), (512, (700, 495))])
+def test_fp16_engine_deviation_is_confined_to_the_threshold_band(size, shape):
+    p = pkg()
+    ck = blob_ckpt()
+    page = p.synth.text_like_page(shape, 3, n_blocks=8)
+    det = p.detector.TextDetector(ck, input_size=size, device="cuda", precision="fp16")
+    got = det(page, refine_mode=0, keep_undetected_mask=False)
+    rep, geo = fp16_band(p, ck, det, page, size, got)
     print(f"\nfp16 band size={size} page={shape}: {rep} {geo}")
     assert rep["prob_max_abs_delta"] < EPS_FP16 and rep["mask_max_abs_delta"] < EPS_FP16
     assert rep["bitmap_flips_out_of_band"] == 0 and rep["mask127_flips_out_of_band"] == 0

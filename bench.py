@@ -20,11 +20,13 @@ The tail of step k runs on worker threads (own HIP streams; one page-range work 
 step k+1.  Before the W warm-up steps the process runs `--spinup` untimed steps (board out of its low-power state, host
 buffers settled; `config.spinup_steps`); the timed region is exactly K steps between barriers + synchronisations.
 
-The same JSON line carries, from short sub-runs on rank 0 at N=1 (skipped with --no-extras):
+The same JSON line carries, from short sub-runs on rank 0 at N=1 (skipped with --no-extras; in this process, reusing the
+headline's native tails -- see `inproc_bench` -- except the mixed-size stream and the MIOpen baseline, which are children):
   parity_exact   the EXACT engine (fp32s: fp32 tensors, split-operand products; identical lines / blocks / refined mask
                  to the oracle) end to end at the same batch size -- the rate the parity claim refers to
   extra_configs  BASELINE configs[1] (fp32 bs=8, end to end) and configs[4] (mixed 640/1024/1536 stream, hipGraph per
-                 bucket, native tail)
+                 bucket, native tail); the headline on round 3's pages (16 lines per page), on the dense-block pages, on
+                 round 2's canned tail inputs, with eagerly built TextBlocks, and with the pages starting in host memory
   rocm_baseline  the reference's own torch network on this GPU through PyTorch-ROCm / MIOpen
   cpu_baseline   the oracle (CPU fp32 port of the reference forward + the oracle tail) on the host cores
 
@@ -502,6 +504,39 @@ def sub_bench(argv, steps: int, warmup: int = 3, spinup: int = 40, timeout: floa
     return out
 
 
+def inproc_bench(pkg, D, DET, TL, base_args, dev, steps: int, warmup: int = 3, spinup: int = 40, **over) -> dict:
+    """One more configuration of the end-to-end pipeline IN THIS PROCESS (rank 0, N = 1): its own checkpoint / pages /
+    detector / worker pool, closed again afterwards.  Worker threads take over the native tails (streams, buffers) of the
+    pools before them (tail._Lease) -- with FRESH tails per pool a later pipeline measured 12-18 % low once the process had
+    owned more tail streams than hardware queues (scripts/gpu_inprocess.py), which is why round 3 ran these as children."""
+    import copy
+    import gc
+    a = copy.copy(base_args)
+    for k, v in over.items():
+        setattr(a, k, v)
+    try:
+        ckpt, batches, canned, _ = make_workload(pkg, a, 0, a.batch, dev)
+        det = DET.TextDetector(ckpt, input_size=a.size, device=dev, precision=a.precision)
+        pipe = Pipeline(det, batches, canned, dev, 1, 0, a.batch, D, a.workers, a.depth, a.tail_split,
+                        host_input=a.host_input, loaders=a.loaders, engines=a.engines, keep_undetected=a.keep_undetected,
+                        lazy=not a.eager_blocks)
+        gc.unfreeze()
+        dt = timed(pipe.run, steps, warmup, spinup, 1, dev, pipe.stats)
+        st = dict(pipe.stats)
+        prof = det.net.profile(batches[0])
+        pipe.close()
+        out = {"value": round(a.batch * steps / dt, 2), "unit": "pages/s", "ms_per_step": round(dt / steps * 1e3, 3), "steps": steps,
+               "blocks_per_page": round(st["blocks"] / max(st["pages"], 1), 2), "lines_per_page": round(st["lines"] / max(st["pages"], 1), 2),
+               "net_ms_per_step": round(float(prof["ms"].sum()), 3), "host_cpu_cores_used": round(float(st.get("cpu_cores", 0.0)), 2),
+               "in_process": True, "overrides": {k: (v if isinstance(v, (int, float, str, bool)) else str(v)) for k, v in over.items()}}
+        del pipe, det, batches, canned, ckpt
+        gc.collect()
+        torch.cuda.empty_cache()
+        return out
+    except Exception as e:                                   # a sub-run must never take the bench line down
+        return {"error": repr(e)[:300], "overrides": {k: str(v) for k, v in over.items()}}
+
+
 # =====================================================================================================================
 # BASELINE configs[4]: mixed-size stream
 # =====================================================================================================================
@@ -858,17 +893,22 @@ def main() -> None:
     stats = dict(pipe.stats)
 
     if rank == 0:
-        # ---- one un-pipelined step: where a batch's time goes
-        torch.cuda.synchronize()
-        ta = time.perf_counter()
-        job = pipe.forward_job(0)
-        torch.cuda.synchronize()
-        tb_ = time.perf_counter()
-        tail = TL.thread_tail(dev)
-        det._tail(job, 0, args.keep_undetected)
-        tc = time.perf_counter()
-        serial = {"forward_ms": round((tb_ - ta) * 1e3, 3), "tail_ms": round((tc - tb_) * 1e3, 3),
-                  "tail_ms_per_page": round((tc - tb_) * 1e3 / nloc, 4), "tail_stages_ms": tail.timings()}
+        # ---- one un-pipelined step: where a batch's time goes.  The tail runs on one of the pipeline's own worker threads
+        # (no extra native tail / stream for the measurement: see tail._Lease), second of two runs (the first one sizes the
+        # 32-page buffers, the pipelined steps used page-range work items)
+        def serial_tail(job_):
+            t0_ = time.perf_counter()
+            det._tail(job_, 0, args.keep_undetected, lazy=True)
+            return (time.perf_counter() - t0_) * 1e3, TL.thread_tail(dev).timings()
+        for _ in range(2):
+            torch.cuda.synchronize()
+            ta = time.perf_counter()
+            job = pipe.forward_job(0)
+            torch.cuda.synchronize()
+            tb_ = time.perf_counter()
+            tail_ms, stages = pipe.pool.submit(serial_tail, job).result()
+        serial = {"forward_ms": round((tb_ - ta) * 1e3, 3), "tail_ms": round(tail_ms, 3),
+                  "tail_ms_per_page": round(tail_ms / nloc, 4), "tail_stages_ms": stages}
         roof = roofline_block(be, batches[0], args.precision, B, S, args.dump_ops)
         page0 = batches[0][0].cpu().numpy()
         cpu = parity = exact = extra = rocm = None
@@ -884,27 +924,38 @@ def main() -> None:
             # Sub-runs as CHILD processes of this script (same pages, pipeline and arguments; `--no-extras`): inside this
             # process, after the headline run, the same pipelines measured 12-18 % low (fp32s 752 vs 897 pages/s, canned
             # inputs 1992 vs 2456) with or without the CPU legs before them -- a child is the stand-alone number.
-            common = ["--batch", str(B), "--size", str(S), "--batches", str(args.batches), "--workers", str(args.workers),
-                      "--depth", str(args.depth), "--tail-split", str(args.tail_split)]
             torch.cuda.synchronize()
+            pipe.close()                                     # the headline's workers end: their tails go to the next pools
+            TL.release_thread_tail()                         # ... and so does the one the parity leg used on this thread
+            sub = lambda steps_, **ov: inproc_bench(pkg, D, DET, TL, args, dev, steps_, **ov)      # noqa: E731
             ex = "fp32s" if args.precision != "fp32s" else "fp32"
-            c = sub_bench(["--precision", ex] + common + (["--tail-input", "canned"] if not real else []), 16)
-            exact = dict(c, engine=ex, batch=B, workload="the headline's (same pages, checkpoint, pipeline), in a child process",
+            c = sub(16, precision=ex)
+            exact = dict(c, engine=ex, batch=B, workload="the headline's (same pages, checkpoint, pipeline), in this process",
                          acceptance="lines / blocks / refined mask identical to the oracle on the acceptance pages "
                                     "(tests/test_gpu_accept.py; `parity.engines` here)")
             extra = {}
-            c = sub_bench(["--precision", "fp32", "--batch", "8", "--size", str(S), "--batches", str(args.batches)], 16)
+            c = sub(16, precision="fp32", batch=8, tail_input="forward")
             extra["fp32_bs8_e2e"] = dict(c, config="BASELINE configs[1]: bs=8 1024x1024, fp32 (f32-operand MFMA engine), end to end "
                                                    "with the native tail")
             c = sub_bench(["--mode", "mixed", "--precision", args.precision], 3, warmup=1, spinup=0, timeout=240, whole=True)
             extra["mixed_e2e"] = c
             if real and not args.dense_blocks:
-                c = sub_bench(["--precision", args.precision, "--dense-blocks"] + common, 16)
+                c = sub(16, dense_blocks=True)
                 extra["dense_blocks_e2e"] = dict(c, config="the headline's pages and pipeline on synth.make_blob_checkpoint(0) WITHOUT "
                                                            "sparse_det: every cell of one Detect anchor fires (random weights), NMS "
-                                                           "packs the page with boxes")
+                                                           "packs the page with boxes (65 blocks / 67 lines per page)")
+                c = sub(16, line_density="r3")
+                extra["r3_density_e2e"] = dict(c, config="round 3's headline pages (sparse_det without the line-density calibration: 16 "
+                                                         "blocks / 16 lines per page; round 3's driver line: 2586 pages/s)")
+                c = sub(16, eager_blocks=True)
+                extra["eager_textblocks_e2e"] = dict(c, config="the headline with the tail workers building every page's Python "
+                                                               "TextBlock objects (detect_batch's return type) instead of handing "
+                                                               "over lazily materialised BlockLists")
+                c = sub(16, host_input=True)
+                extra["host_input_e2e"] = dict(c, config="the headline with the pages starting in HOST memory (numpy arrays, as the "
+                                                         "reference's callers hand them over): PCIe-inclusive, never the headline")
             if real:
-                c = sub_bench(["--precision", args.precision, "--tail-input", "canned"] + common, 16)
+                c = sub(16, tail_input="canned")
                 extra["canned_tail_inputs_e2e"] = dict(c, config="round 2's workload (`--tail-input canned`): random checkpoint, ONE "
                                                                  "resident batch, the tail fed text-like maps of the same pages "
                                                                  "instead of the forward's outputs (round 2 measured 2502 pages/s)")
@@ -987,7 +1038,7 @@ def main() -> None:
             "rocm_baseline": rocm,
         }
         print(json.dumps(out), flush=True)
-    pipe.close()
+    pipe.close()                                             # (idempotent)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

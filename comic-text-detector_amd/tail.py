@@ -240,10 +240,34 @@ class Tail:
 
 
 _tls = threading.local()
+_free = {}                      # device index -> native tails whose threads have ended, ready for the next thread
+_free_lock = threading.Lock()
+
+
+class _Lease:
+    """A thread's hold on a `Tail`.  When the thread ends (its thread-local state is dropped) the tail goes back to the
+    module's free list instead of being destroyed, and the next worker thread takes it over: the process never owns more
+    tail STREAMS than it has had concurrent tail threads.  That matters on this stack: once a process has had more compute
+    streams alive than the runtime has hardware queues for them, every later stream shares a queue with another one --
+    measured (scripts/gpu_inprocess.py): a pipeline started while an earlier pipeline's three idle tails still existed ran
+    at 1970-2050 pages/s instead of 2510, and stayed there after the old tails were destroyed (GPU_MAX_HW_QUEUES = 8 made
+    no difference); pipelines that REUSE three tails run at 2450-2510 however often they are rebuilt.  (Round 3 had seen
+    this as "a second pipeline in one process is 12-18 % slower" and moved bench.py's sub-runs into child processes.)"""
+
+    def __init__(self, tail: Tail):
+        self.tail = tail
+
+    def __del__(self):
+        try:
+            with _free_lock:
+                _free.setdefault(self.tail.device.index or 0, []).append(self.tail)
+        except Exception:
+            pass
 
 
 def thread_tail(device) -> Tail:
-    """One `Tail` per (host thread, device): its stream and buffers are not shared."""
+    """One `Tail` per (host thread, device): its stream and buffers are not shared between live threads; tails of threads
+    that have ended are reused (`_Lease`)."""
     device = torch.device(device)
     if device.index is None:
         device = torch.device("cuda", torch.cuda.current_device())
@@ -251,5 +275,26 @@ def thread_tail(device) -> Tail:
     if pool is None:
         pool = _tls.pool = {}
     if device.index not in pool:
-        pool[device.index] = Tail(device)
-    return pool[device.index]
+        with _free_lock:
+            spare = _free.get(device.index)
+            t = spare.pop() if spare else None
+        if t is None:
+            t = Tail(device)
+        elif _host_threads is not None:
+            L.check(t._lib.ctd_tail_set_threads(t._h, _host_threads), "ctd_tail_set_threads")
+        pool[device.index] = _Lease(t)
+    return pool[device.index].tail
+
+
+def release_thread_tail() -> None:
+    """Hands the calling thread's tails back to the free list now (they return by themselves when the thread ends): a
+    long-lived thread that ran a tail once -- the main thread after a `detect_batch` -- otherwise keeps a stream of its own."""
+    pool = getattr(_tls, "pool", None)
+    if pool:
+        pool.clear()
+
+
+def live_tails() -> int:
+    """Native tails this process owns right now (in use by a thread or waiting in the free list) -- for tests."""
+    import gc
+    return sum(1 for o in gc.get_objects() if isinstance(o, Tail))

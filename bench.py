@@ -64,7 +64,7 @@ MFMA_F32_PEAK_TFLOPS = 157.3   # v_mfma_f32_32x32x2_f32
 # fp32s: every product costs three fp16 MFMAs -> a third of the fp16 peak for the ALGORITHMIC flops
 PEAK_TF = {"fp16": MFMA_F16_PEAK_TFLOPS, "fp32": MFMA_F32_PEAK_TFLOPS, "fp32s": MFMA_F16_PEAK_TFLOPS / 3}
 DTYPE = {"fp16": "f16", "fp32": "f32", "fp32s": "f32"}
-FAMILY = {"fp16": "conv_halo_kernel + conv_igemm_kernel + c3_fused_kernel (MFMA conv / convT family)",
+FAMILY = {"fp16": "conv_halo2_kernel + conv_halo_kernel + conv_igemm_kernel + c3_fused_kernel (MFMA conv / convT family)",
           "fp32": "conv_f32_mfma_kernel (f32-operand MFMA conv / convT family)",
           "fp32s": "conv_split_kernel + conv_split_halo_kernel + stem_split_kernel (split-operand conv / convT family: 3 fp16 MFMAs "
                    "per product; conv-to-conv tensors split-plane in HBM)"}
@@ -705,7 +705,7 @@ def roofline_block(be, x, precision: str, B: int, S: int, dump_ops: str = "") ->
     # --pmc passes: scripts/gpu_traffic.sh).  PMC cannot be collected inside this process; the committed measurement of
     # this engine at this shape is attached when it exists (and says which round it is from).
     traffic, tnote = None, None
-    for tname in {"fp16": ("r03_traffic_pmc.json", "r02_traffic_pmc.json"), "fp32s": ("r03_traffic_pmc_fp32s.json",)}.get(precision, ()):
+    for tname in {"fp16": ("r04_traffic_pmc.json", "r03_traffic_pmc.json"), "fp32s": ("r03_traffic_pmc_fp32s.json",)}.get(precision, ()):
         tpath = os.path.join(ROOT, "profiles", tname)
         if os.path.isfile(tpath) and (B, S) == (32, 1024):
             try:

@@ -85,6 +85,13 @@ bool conv_halo2_supported(const ConvArgs& a, bool dst_f32);
 void launch_conv_halo2(const ConvArgs& a, hipStream_t st);
 int halo2_tuning_set(const char* key, long long value);
 
+// ---- kernels_halo3.hip : the same K loop on 256-pixel x 128-column tiles, four waves per block, two blocks per CU ----
+extern long long g_halo3;              // 0 disables ("halo3")
+extern long long g_halo3_min_blocks;   // "halo3_min_blocks"
+bool conv_halo3_supported(const ConvArgs& a, bool dst_f32);
+void launch_conv_halo3(const ConvArgs& a, hipStream_t st);
+int halo3_tuning_set(const char* key, long long value);
+
 // ---- kernels_c3.hip : one-kernel C3 block (32 hidden channels, one bottleneck) -------------
 // Weights / biases are the packed arrays of the four unfused ops (tile-major, 32-channel K step):
 // w12 [Cin/32][64][32] (cv1 rows 0-31, cv2 rows 32-63), wm1 [32][32], wm2 [9 taps][32][32], wc3 [2][64][32].

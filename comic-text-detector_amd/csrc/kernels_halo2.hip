@@ -423,6 +423,6 @@ int halo2_tuning_set(const char* key, long long value) {
   const std::string k(key ? key : "");
   if (k == "halo2") g_halo2 = value;
   else if (k == "halo2_min_blocks") g_halo2_min_blocks = value;
-  else return -1;
+  else return halo3_tuning_set(key, value);
   return 0;
 }

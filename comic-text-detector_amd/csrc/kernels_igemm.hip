@@ -570,6 +570,10 @@ void launch_conv_igemm(const ConvArgs& a_in, bool dst_f32, hipStream_t st) {
   magic_div(a.Mw, a.mw_mul, a.mw_sh);
   magic_div(a.Mh, a.mh_mul, a.mh_sh);
   a.bk = pick_bk(a);
+  if (conv_halo3_supported(a, dst_f32)) {
+    launch_conv_halo3(a, st);
+    return;
+  }
   if (conv_halo2_supported(a, dst_f32)) {
     launch_conv_halo2(a, st);
     return;

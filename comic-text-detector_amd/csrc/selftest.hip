@@ -178,10 +178,10 @@ static void run_case(const Case& cs, int B, bool timing) {
   const double flops = cs.kind ? 2.0 * B * Hin * Win * 16.0 * cin * cs.N : 2.0 * (double)ig.M * cs.N * ig.K;
   const double bytes = 2.0 * ((double)n0 + n1 + (double)B * Ho * Wo * cs.N * (cs.res ? 2 : 1) + (double)cs.N * cin * k * k);
   std::printf("[case] %-32s B=%d out %dx%dx%d |", cs.name, B, Ho, Wo, cs.N);
-  struct Var { const char* name; int bk, tiled, rot, abl, h1 = 0; };   // h1: big-tile ConvT kernel (kernels_halo2.hip) off
+  struct Var { const char* name; int bk, tiled, rot, abl, h1 = 0; };   // h1: 1 = only kernels_halo.hip, 2 = kernels_halo2.hip, 0 = product dispatch
   // ST_ABL=1 appends ablations of the default kernel (wrong results by construction, timing only)
   // rot: 0 = default dispatch (halo kernel where it applies), 2 = implicit-GEMM kernel only, 1 = register staged
-  const Var vars[] = {{"default", 32, 1, 0, 0}, {"halo1", 32, 1, 0, 0, 1}, {"igemm", 32, 1, 2, 0}, {"bk32/reg", 32, 1, 1, 0}, {"bk64/glds", 64, 1, 2, 0},
+  const Var vars[] = {{"default", 32, 1, 0, 0}, {"halo2", 32, 1, 0, 0, 2}, {"halo1", 32, 1, 0, 0, 1}, {"igemm", 32, 1, 2, 0}, {"bk32/reg", 32, 1, 1, 0}, {"bk64/glds", 64, 1, 2, 0},
                       // ablations of the implicit-GEMM kernel (rot 2 keeps the halo kernel out of the way)
                       {"noload", 32, 1, 2, 1}, {"nomfma", 32, 1, 2, 2}, {"nostore", 32, 1, 2, 4},
                       {"loadonly", 32, 1, 2, 6}, {"mfmaonly", 32, 1, 2, 5}, {"phasemajor", 32, 1, 2, 8},
@@ -197,14 +197,14 @@ static void run_case(const Case& cs, int B, bool timing) {
     ig.bk = bk; ig.w_tiled = v.tiled; ig.k_rot = v.abl;
     g_igemm_occ_lo = v.rot == 1;   // staging mode: 0 = LDS-DMA, 1 = register staged
     g_conv_halo = v.rot == 0;
-    if (v.h1) {                                       // only where the default variant ran the big-tile kernel
+    if (v.h1) {                                       // only where the default variant ran one of the big-tile kernels
       ConvArgs q = ig;
       q.bk = 32, q.w_tiled = 1, q.k_rot = 0;
-      g_halo2 = 1;
-      g_conv_halo = 1;
-      if (!conv_halo2_supported(q, false) || !conv_halo_supported(q, false)) continue;   // (small grids go to the implicit GEMM)
+      g_halo2 = 1, g_halo3 = 1, g_conv_halo = 1;
+      if (!conv_halo3_supported(q, false) || !conv_halo2_supported(q, false) || !conv_halo_supported(q, false)) continue;
     }
-    g_halo2 = (v.rot == 0 && !v.h1) ? (std::getenv("ST_H2_NOPRIO") ? 2 : 1) : 0;
+    g_halo3 = (v.rot == 0 && !v.h1 && !std::getenv("ST_NO_H3")) ? 1 : 0;
+    g_halo2 = (v.rot == 0 && v.h1 != 1) ? (std::getenv("ST_H2_NOPRIO") ? 2 : 1) : 0;
     if (g_halo2 && std::getenv("ST_H2_ABL")) g_halo2 = 1 + 16 * std::atoi(std::getenv("ST_H2_ABL"));   // timing-only ablation of the big-tile kernel
     {
       std::vector<half_t> wig;
@@ -226,7 +226,7 @@ static void run_case(const Case& cs, int B, bool timing) {
     if (bad && !v.abl) ++g_fail;
     static std::vector<half_t> o_default;             // the big-tile kernel must reproduce the 256 x 128 kernel bit for bit
     if (&v == vars) o_default = o;
-    if (&v == vars && g_halo2 == 1 && conv_halo2_supported(ig, false)) {
+    if (&v == vars && ((g_halo2 == 1 && conv_halo2_supported(ig, false)) || conv_halo3_supported(ig, false))) {
       // its LDS hand-offs are ordered by counted waits and barriers only: repeat the launch and demand identical bits
       // (a race shows as a run-to-run difference long before it shows as an error beyond the tolerance)
       size_t racy = 0;
@@ -238,14 +238,14 @@ static void run_case(const Case& cs, int B, bool timing) {
         CK(hipMemcpy(o2.data(), dOut, nout * 2, hipMemcpyDeviceToHost));
         if (std::memcmp(o2.data(), o.data(), nout * 2) != 0) ++racy;
       }
-      std::printf("  [halo2 x6 repeat: %s]", racy ? "DIFFERS RUN TO RUN" : "stable");
+      std::printf("  [x6 repeat: %s]", racy ? "DIFFERS RUN TO RUN" : "stable");
       if (racy) ++g_fail;
     }
     if (v.h1) {
       size_t diff = 0;
       for (size_t i = 0; i < nout; ++i)
         if ((int)(i % pitchD) < cs.N && std::memcmp(&o[i], &o_default[i], 2) != 0) ++diff;
-      std::printf("  [halo2 vs halo1: %s]", diff ? "DIFFERENT" : "bit-identical");
+      std::printf("  [default vs %s: %s]", v.name, diff ? "DIFFERENT" : "bit-identical");
       if (diff) { std::printf(" %zu values", diff); ++g_fail; }
     }
     double ms = 0;

@@ -146,6 +146,7 @@ class Pipeline:
         self.engines, self.keep_undetected, self.lazy = max(1, engines), keep_undetected, lazy
         self.nloc = batches[0].shape[0]
         self.pool = ThreadPoolExecutor(max_workers=self.workers, thread_name_prefix="ctd-tail")
+        det.warm_tails(self.pool, self.workers)               # the tails' streams before any loader stream (detector._copy_stream)
         self.host_batches = [[p for p in b.cpu().numpy()] for b in batches] if host_input else None
         self.lpool = ThreadPoolExecutor(max_workers=max(1, loaders), thread_name_prefix="ctd-load") if host_input else None
         self.comm_stream = torch.cuda.Stream(dev) if world > 1 else None
@@ -894,19 +895,20 @@ def main() -> None:
 
     if rank == 0:
         # ---- one un-pipelined step: where a batch's time goes.  The tail runs on one of the pipeline's own worker threads
-        # (no extra native tail / stream for the measurement: see tail._Lease), second of two runs (the first one sizes the
-        # 32-page buffers, the pipelined steps used page-range work items)
-        def serial_tail(job_):
-            t0_ = time.perf_counter()
-            det._tail(job_, 0, args.keep_undetected, lazy=True)
-            return (time.perf_counter() - t0_) * 1e3, TL.thread_tail(dev).timings()
-        for _ in range(2):
-            torch.cuda.synchronize()
-            ta = time.perf_counter()
-            job = pipe.forward_job(0)
-            torch.cuda.synchronize()
-            tb_ = time.perf_counter()
-            tail_ms, stages = pipe.pool.submit(serial_tail, job).result()
+        # (no extra native tail / stream for the measurement: see tail._Lease), the second of two runs on that thread (the
+        # first one sizes its 32-page buffers: the pipelined steps used page-range work items)
+        def serial_tail(job_):                               # twice on ONE worker thread: the first run sizes its tail's buffers
+            for _ in range(2):
+                t0_ = time.perf_counter()
+                det._tail(job_, 0, args.keep_undetected, lazy=True)
+                ms_ = (time.perf_counter() - t0_) * 1e3
+            return ms_, TL.thread_tail(dev).timings()
+        torch.cuda.synchronize()
+        ta = time.perf_counter()
+        job = pipe.forward_job(0)
+        torch.cuda.synchronize()
+        tb_ = time.perf_counter()
+        tail_ms, stages = pipe.pool.submit(serial_tail, job).result()
         serial = {"forward_ms": round((tb_ - ta) * 1e3, 3), "tail_ms": round(tail_ms, 3),
                   "tail_ms_per_page": round(tail_ms / nloc, 4), "tail_stages_ms": stages}
         roof = roofline_block(be, batches[0], args.precision, B, S, args.dump_ops)

@@ -30,7 +30,12 @@
 #include "tail.h"
 
 int ctd_fail_msg(int code, const std::string& msg);   // engine.hip: sets the thread-local error text
-int g_tail_priority = 0;                               // stream priority of tails created from now on (engine.hip: tuning)
+// Stream priority of tails created from now on ("tail_priority"): 1 = the device's default priority (the default since
+// round 4), 0 = highest, 2 = lowest.  Rounds 2-3 created the tails' streams at the HIGHEST priority; the runtime has fewer
+// hardware queues for that class than a pipeline with a 4th worker, a loader stream or a second pool needs, and a stream
+// beyond them shares a queue: 4 workers 1994 pages/s at priority 0 against 2554 at priority 1 (3 workers: 2545 either way),
+// pages from host memory 2025-2380 against 2500, the dense-block pages 1828 against 1926-1993.
+int g_tail_priority = 1;
 
 #define T_TRY(expr)                                                                                  \
   do {                                                                                               \
@@ -801,8 +806,7 @@ int ctd_tail_create(ctd_tail** out, int32_t device) {
   t->device = device;
   int lo = 0, hi = 0;
   (void)hipDeviceGetStreamPriorityRange(&lo, &hi);   // hi = numerically lowest = highest priority
-  // ctd_tuning_set("tail_priority"): 0 = highest (default: a batch's tail finishes early and frees its pipeline slot),
-  // 1 = the device's default priority, 2 = lowest (the forward's kernels go first, the tail fills the gaps)
+  // ctd_tuning_set("tail_priority"): 1 = the device's default priority (default), 0 = highest, 2 = lowest (measured: -13 %)
   const int prio = g_tail_priority == 2 ? lo : (g_tail_priority == 1 ? (lo + hi) / 2 : hi);
   if (hipStreamCreateWithPriority(&t->st, hipStreamNonBlocking, prio) != hipSuccess) {
     delete t;

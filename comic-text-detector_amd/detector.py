@@ -183,10 +183,11 @@ class TextDetector:
 
     def _copy_stream(self):
         """ONE upload stream per detector, shared by its loader threads (uploads are serial on the link anyway), created on
-        first use -- which `warm_tails` arranges to be AFTER the tail workers' streams exist.  Stream count and creation
-        order matter on this stack: compute streams beyond the runtime's hardware queues share a queue with an earlier one,
-        and a tail stream that lands on the forward's queue costs 20 % end to end (tail._Lease; bench `--host-input` as a
-        fresh process: 2025 pages/s with loader streams created before the tails' against 2380 the other way round)."""
+        first use -- which `warm_tails` arranges to be AFTER the tail workers' streams exist.  Stream count, priority class
+        and creation order matter on this stack: streams beyond the runtime's hardware queues of their class share a queue
+        with an earlier one (tail._Lease; with the tails at the highest priority, bench `--host-input` as a fresh process
+        ran at 2025 pages/s with two loader streams created before the tails' and 2380 this way round; with the tails at
+        the default priority it runs at 2500, 2 % under device-resident pages)."""
         with self._copy_lock:
             if self._copy_st is None:
                 self._copy_st = torch.cuda.Stream(self.net.device)
@@ -243,7 +244,7 @@ class TextDetector:
 
     @torch.no_grad()
     def detect_stream(self, batches: Iterable[Sequence[Page]], refine_mode=REFINEMASK_INPAINT,
-                      keep_undetected_mask=False, workers: int = 2, depth: int = 3, engines: int = 1,
+                      keep_undetected_mask=False, workers: int = 3, depth: int = 4, engines: int = 1,
                       loaders: int = 2, tail_split: int = 0, lazy: bool = True) -> Iterator[list]:
         """Yields `detect_batch(batch)` for every batch, in order, with up to `depth` batches in flight:
         the forward of the next batches is launched while `workers` threads run the tails of earlier ones.

@@ -247,12 +247,14 @@ _free_lock = threading.Lock()
 class _Lease:
     """A thread's hold on a `Tail`.  When the thread ends (its thread-local state is dropped) the tail goes back to the
     module's free list instead of being destroyed, and the next worker thread takes it over: the process never owns more
-    tail STREAMS than it has had concurrent tail threads.  That matters on this stack: once a process has had more compute
-    streams alive than the runtime has hardware queues for them, every later stream shares a queue with another one --
-    measured (scripts/gpu_inprocess.py): a pipeline started while an earlier pipeline's three idle tails still existed ran
-    at 1970-2050 pages/s instead of 2510, and stayed there after the old tails were destroyed (GPU_MAX_HW_QUEUES = 8 made
-    no difference); pipelines that REUSE three tails run at 2450-2510 however often they are rebuilt.  (Round 3 had seen
-    this as "a second pipeline in one process is 12-18 % slower" and moved bench.py's sub-runs into child processes.)"""
+    tail STREAMS than it has had concurrent tail threads.  That matters on this stack: a process that has had more compute
+    streams of one priority class alive than the runtime has hardware queues for them makes later streams share a queue,
+    and it does not recover when the old streams are destroyed -- measured (scripts/gpu_inprocess.py) with the tails'
+    streams at the highest priority (rounds 2-3): a pipeline started while an earlier pipeline's three idle tails still
+    existed ran at 1970-2050 pages/s instead of 2510, and so did every pipeline after it; with the default priority
+    (round 4) the cliff comes at the third kept-alive pool instead of the second.  Pipelines that REUSE their tails run at
+    2450-2550 however often they are rebuilt.  (Round 3 had seen this as "a second pipeline in one process is 12-18 %
+    slower" and moved bench.py's sub-runs into child processes.)"""
 
     def __init__(self, tail: Tail):
         self.tail = tail

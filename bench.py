@@ -153,6 +153,7 @@ class Pipeline:
         self.stats = {"blocks": 0, "lines": 0, "pages": 0, "cpu_cores": 0.0}
         self.k = 0                                           # batches rotate across calls too
         self.fixed_job = None
+        self.fwd_stream = None
         # N > 1: the tail builds every page's gather record natively (dist.pack_results then only stacks them)
         self.records = (D.CAP_BLK, D.CAP_LINE) if world > 1 else None
 
@@ -189,6 +190,12 @@ class Pipeline:
         self.stats["lines"] += sum(r[2].n_lines if hasattr(r[2], "n_lines") else sum(len(b.lines) for b in r[2]) for r in res)
 
     def run(self, n):
+        if self.fwd_stream is not None:                      # --fwd-stream high: the forwards on a high-priority stream
+            with torch.cuda.stream(self.fwd_stream):
+                return self._run(n)
+        return self._run(n)
+
+    def _run(self, n):
         det, pending, ahead, issued = self.det, deque(), deque(), 0
         main = torch.cuda.current_stream(self.dev)
         collect = lambda futs: [r for f in futs for r in f.result()]          # noqa: E731
@@ -796,6 +803,9 @@ def main() -> None:
     ap.add_argument("--loaders", type=int, default=2, help="loader threads of --host-input")
     ap.add_argument("--engines", type=int, default=1, help="engine copies on their own streams (e2e)")
     ap.add_argument("--keep-undetected", action="store_true", help="also run refine_undetected_mask in the tail")
+    ap.add_argument("--fwd-stream", default="default", choices=["default", "high"],
+                    help="e2e: the forwards on torch's current stream (default) or on a stream of the highest priority (ONE such "
+                         "stream: the class has few hardware queues, DESIGN 4.4)")
     ap.add_argument("--tail-only", action="store_true",
                     help="e2e pipeline WITHOUT the forward: one forward at set-up, then every step runs the native tail on those "
                          "outputs (workers, work items, record gather as in e2e).  With --gpus N on one device (rehearsal) this "
@@ -868,6 +878,8 @@ def main() -> None:
                     host_input=args.host_input and e2e, loaders=args.loaders, engines=args.engines,
                     keep_undetected=args.keep_undetected, lazy=not args.eager_blocks)
 
+    if args.fwd_stream == "high" and e2e:
+        pipe.fwd_stream = torch.cuda.Stream(dev, priority=-1)
     if args.tail_only and e2e:
         fj = pipe.forward_job(0)
         torch.cuda.synchronize()

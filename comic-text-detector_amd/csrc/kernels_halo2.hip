@@ -32,10 +32,23 @@
 
 #include "kernels.h"
 
+// The PRODUCT library ships kernels_halo3.hip for these layers; this kernel -- the investigation's first structure, with its
+// cycle stamps and ablations -- is compiled into the selftest build only (-DCTD_AB_VARIANTS), like the other A/B variants.
 long long g_halo2 = 1;                 // "halo2": 0 sends the ConvT layers back to kernels_halo.hip
 long long g_halo2_min_blocks = 1024;   // "halo2_min_blocks": fewer 256x256 tiles than 4 per CU -> the smaller-tile kernels fill the chip
                                        // better (B = 5: 0.114 vs 0.107 ms on 256 -> 128, 0.134 vs 0.121 on 128 -> 64)
 
+#ifndef CTD_AB_VARIANTS
+bool conv_halo2_supported(const ConvArgs&, bool) { return false; }
+void launch_conv_halo2(const ConvArgs&, hipStream_t) {}
+int halo2_tuning_set(const char* key, long long value) {
+  const std::string k(key ? key : "");
+  if (k == "halo2") g_halo2 = value;
+  else if (k == "halo2_min_blocks") g_halo2_min_blocks = value;
+  else return halo3_tuning_set(key, value);
+  return 0;
+}
+#else
 namespace {
 
 constexpr int TWP = 16, THP = 16;      // pixel patch
@@ -426,3 +439,4 @@ int halo2_tuning_set(const char* key, long long value) {
   else return halo3_tuning_set(key, value);
   return 0;
 }
+#endif  // CTD_AB_VARIANTS

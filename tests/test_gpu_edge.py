@@ -160,3 +160,30 @@ def test_fused_blocks_equal_the_layer_per_launch_program_bit_for_bit(shape, u8):
         for i, (g, r) in enumerate(zip(got, ref)):
             assert torch.equal(g, r), f"fuse mask {mask}: output {i} differs from the unfused program " \
                                       f"(max |d| {float((g.float() - r.float()).abs().max()):.3g})"
+
+
+@pytest.mark.parametrize("shape", [(2, 512, 512), (1, 1024, 768), (3, 256, 512)])
+def test_big_tile_convt_kernels_reproduce_the_256x128_kernel_bit_for_bit(shape):
+    """The ConvTranspose layers on kernels_halo3.hip (256 x 128 tiles, four waves, two blocks per CU) and on
+    kernels_halo2.hip (selftest build only) walk K and issue their MFMAs per accumulator in the order of kernels_halo.hip:
+    with the grid threshold lifted (`halo3_min_blocks` = 1: also maps whose ConvT inputs are 16x16 ... 64x48, i.e. every
+    tile at an image border) every output of the network equals the output without it, bit for bit."""
+    ck = checkpoint(0)
+    x = gen_golden.make_input(51, shape).cuda()
+    be = pkg().backend.HipTextDetBackend(ck, device="cuda", precision="fp16")
+    _tune(b"halo3", 0)
+    _tune(b"halo_min_patches", 1)                       # the reference side: the 256 x 128 halo kernel on every ConvT layer
+    try:
+        ref = [t.clone() for t in be(x)]
+        ref_side = (be.mask_u8.clone(), be.bitmap.clone())
+        _tune(b"halo3", 1)
+        _tune(b"halo3_min_blocks", 1)
+        got = [t.clone() for t in be(x)]
+        got_side = (be.mask_u8.clone(), be.bitmap.clone())
+        torch.cuda.synchronize()
+    finally:
+        _tune(b"halo3", 1)
+        _tune(b"halo3_min_blocks", 1024)
+        _tune(b"halo_min_patches", 1024)
+    for g, r in zip(got + list(got_side), ref + list(ref_side)):
+        assert torch.equal(g, r)

@@ -44,3 +44,19 @@ def test_selftest_of_the_split_operand_kernels():
     assert sum("f32->planes ok, planes->f32 ok" in ln for ln in sp) >= 8
     st = [ln for ln in lines if ln.startswith("[stem-split]")]
     assert len(st) == 2 and all(ln.count(": ok") == 3 for ln in st), "\n".join(st)
+
+
+def test_selftest_of_the_big_tile_convt_kernels():
+    """ConvTranspose 512 -> 256, 256 -> 128, 128 -> 64 at B = 16 (1024 ... 8192 tiles): the product dispatch (kernels_halo3.hip)
+    against the exact direct kernel, bit for bit against kernels_halo2.hip and kernels_halo.hip, and six repeated launches
+    with identical bits (the LDS hand-offs of both big-tile kernels are ordered by counted waits and barriers only)."""
+    L = pkg()._lib
+    r = subprocess.run([L.SELFTEST_PATH, "16"], env={**os.environ, "ST_CASES": "16,17,18", "ST_NO_C3": "1"}, capture_output=True,
+                       text=True, timeout=600)
+    out = r.stdout
+    assert r.returncode == 0 and "selftest: PASSED (0 failures)" in out, out[-4000:]
+    cases = [ln for ln in out.splitlines() if ln.startswith("[case] convT4")]
+    assert len(cases) == 3
+    for ln in cases:
+        assert "[x6 repeat: stable]" in ln and "default: ok" in ln, ln
+        assert "[default vs halo2: bit-identical]" in ln and "[default vs halo1: bit-identical]" in ln, ln

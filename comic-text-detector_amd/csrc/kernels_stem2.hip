@@ -12,6 +12,12 @@
 // the packed weights, sums x 1/128), layer 1 as the implicit-GEMM kernel (K = tap * 32 + channel in 32-channel steps,
 // fp32 accumulation) -- so the result is bit-identical to the two launches; the selftest checks exactly that.
 //
+// Round 4: 512 threads per block instead of 256.  LDS (74 KB) allows two blocks per CU whatever their size, and the kernel is
+// a chain of dependent phases (page loads -> fp16 patch -> stem MFMAs + SiLU -> layer-1 MFMAs -> store) with one other block
+// to hide behind: eight waves per block = four per SIMD double what is in flight under every wait.  The arithmetic per
+// accumulator is unchanged (a wave now owns ONE of layer 1's two N fragments for its two output rows; stem fragments are
+// dealt over eight waves), so the result is still bit-identical to the two launches.
+//
 // LDS (73.9 KB, two blocks per CU): the nine 64x32 weight tiles of layer 1 (36.9 KB; tiles 5-8 share their space with
 // the fp16 input patch, which is dead when they are needed) and the stem patch (576 rows x 64 B, XOR-swizzled 16-B
 // chunks; later the staged output tile).  Stem pixels outside the stem map are ZERO (layer 1's padding pads the
@@ -38,12 +44,13 @@ constexpr int S2_U = S2_W5 + (S2_INH > 4 * S2_WTILE ? S2_INH : 4 * S2_WTILE);   
 constexpr int S2_S = (S2_U + 7) / 8 * 8;                 // stem patch [576][32]; later the output tile [128][72]
 constexpr int S2_LDS = S2_S + S2_SROWS * 32;
 constexpr int S2_OP = 72;
+constexpr int S2_NT = 512;                               // threads per block (8 waves)
 static_assert(S2_TW * S2_TH * S2_OP <= S2_SROWS * 32, "output tile fits the stem patch");
 
 // ACT0 is a compile-time constant evaluated by the stem kernel's own `ctd_act` (same arithmetic, no per-element
 // switch on a run-time value)
 template <int ACT0, int ACT1>
-__global__ __launch_bounds__(256, 2) void stem_conv2_kernel(Stem2Args a) {
+__global__ __launch_bounds__(S2_NT, 4) void stem_conv2_kernel(Stem2Args a) {   // 2 blocks / CU = 4 waves / SIMD
   if (a.prio) __builtin_amdgcn_s_setprio(3);   // ahead of a co-running tail's waves in the issue arbiter
   __shared__ __attribute__((aligned(16))) half_t lds[S2_LDS + 2 * 96];
   float* bias_s = (float*)(lds + S2_LDS);     // [0,32) stem, [32,96) layer 1
@@ -79,13 +86,16 @@ __global__ __launch_bounds__(256, 2) void stem_conv2_kernel(Stem2Args a) {
   auto swz = [](int row) { return (row >> 2) & 3; };
   const int pos = t & 3;
   // layer-1 weight tiles [tap][64][32] -> LDS by LDS-DMA, swizzle on the source chunk
-  auto dma_w = [&](int pass, half_t* dst_base) {        // pass = 256 chunks = 64 rows = one tap tile
-    const int row = (pass * 256 + t) >> 2;
+  const int wg = w >> 2, w4 = w & 3, t4 = t & 255;      // wave group (0 / 1), wave and thread inside it
+  auto dma_w = [&](int pass, half_t* dst_base) {        // pass = 256 chunks = 64 rows = one tap tile, by ONE wave group
+    const int row = (pass * 256 + t4) >> 2;
     __builtin_amdgcn_global_load_lds((gptr_t)(a.w1 + row * 32 + ((pos ^ swz(row)) * 8)),
-                                     (lptr_t)(dst_base + (w * 64) * 8), 16, 0, 0);
+                                     (lptr_t)(dst_base + (w4 * 64) * 8), 16, 0, 0);
   };
+  // tiles 0-4: group 0 fetches 0, 2, 4, group 1 fetches 1, 3
 #pragma unroll
-  for (int i = 0; i < 5; ++i) dma_w(i, lds + S2_W0 + i * S2_WTILE);
+  for (int i = 0; i < 5; ++i)
+    if ((i & 1) == wg) dma_w(i, lds + S2_W0 + i * S2_WTILE);
 
   // stem A fragments: 9 k-steps x (32 channels x 16 k), one 16-B load each
   half8_t wf[9];
@@ -99,19 +109,19 @@ __global__ __launch_bounds__(256, 2) void stem_conv2_kernel(Stem2Args a) {
   if (u8in && interior) {
     // rows are 210 B at a 4-B aligned address: 53 dword loads per row (the last one runs 2 B into column 70, which
     // exists: ix0 + 72 <= W), all issued before the first use
-    constexpr int DPR = 53, NDW = S2_IH * DPR, NIT = (NDW + 255) / 256;   // 2014 dwords, 8 per thread
+    constexpr int DPR = 53, NDW = S2_IH * DPR, NIT = (NDW + S2_NT - 1) / S2_NT;   // 2014 dwords, 4 per thread
     const uint8_t* src = (const uint8_t*)a.in + ((size_t)b * H * W + (size_t)iy0 * W + ix0) * 3;
     uint32_t vv[NIT];
 #pragma unroll
     for (int k = 0; k < NIT; ++k) {
-      const int i = t + 256 * k;
+      const int i = t + S2_NT * k;
       const int ii = i < NDW ? i : 0;                      // clamped address instead of a branch around the load
       const int r = ii / DPR, d = ii - r * DPR;
       vv[k] = *(const uint32_t*)(src + (size_t)r * W * 3 + d * 4);
     }
 #pragma unroll
     for (int k = 0; k < NIT; ++k) {
-      const int i = t + 256 * k;
+      const int i = t + S2_NT * k;
       const int r = i / DPR, d = i - r * DPR;
       if (i < NDW) {
         half_t* p = patch + r * S2_PITCH + d * 4;
@@ -129,7 +139,7 @@ __global__ __launch_bounds__(256, 2) void stem_conv2_kernel(Stem2Args a) {
     auto stage = [&](auto u8tag) {
       constexpr bool U8 = decltype(u8tag)::value;
       constexpr int NEL = 3 * S2_IH * S2_IW;            // 7980
-      constexpr int RND = 16, NR = (NEL + 256 * RND - 1) / (256 * RND);   // two rounds of 16 loads per thread
+      constexpr int RND = 16, NR = (NEL + S2_NT * RND - 1) / (S2_NT * RND);   // one round of 16 loads per thread
       const uint8_t* src8 = (const uint8_t*)a.in + (size_t)b * H * W * 3;
       const float* src32 = (const float*)a.in + (size_t)b * 3 * H * W;
 #pragma unroll 1
@@ -138,7 +148,7 @@ __global__ __launch_bounds__(256, 2) void stem_conv2_kernel(Stem2Args a) {
         int dsti[RND];
 #pragma unroll
         for (int k = 0; k < RND; ++k) {
-          const int i = t + 256 * (rd * RND + k);
+          const int i = t + S2_NT * (rd * RND + k);
           int r, q, c;
           if (U8) { r = i / (S2_IW * 3); const int j = i - r * (S2_IW * 3); q = j / 3; c = j - 3 * q; }
           else { c = i / (S2_IH * S2_IW); const int j = i - c * (S2_IH * S2_IW); r = j / S2_IW; q = j - r * S2_IW; }
@@ -158,7 +168,7 @@ __global__ __launch_bounds__(256, 2) void stem_conv2_kernel(Stem2Args a) {
     else stage(std::false_type{});
   }
   // pad columns 70, 71 (zero weights meet them: they must be finite) and the slack behind the last row
-  for (int i = t; i < S2_IH * 6; i += 256) patch[(i / 6) * S2_PITCH + S2_IW * 3 + i % 6] = (half_t)0.f;
+  for (int i = t; i < S2_IH * 6; i += S2_NT) patch[(i / 6) * S2_PITCH + S2_IW * 3 + i % 6] = (half_t)0.f;
   if (t < 16) patch[S2_IH * S2_PITCH + t] = (half_t)0.f;
   __syncthreads();
 
@@ -166,7 +176,7 @@ __global__ __launch_bounds__(256, 2) void stem_conv2_kernel(Stem2Args a) {
   const float oscale = u8in ? 1.0f / 128.0f : 1.0f;
   half_t* S = lds + S2_S;
 #pragma unroll 1
-  for (int f = w; f < S2_SFRAG; f += 4) {
+  for (int f = w; f < S2_SFRAG; f += S2_NT / 64) {
     const int p = 32 * f + l31;
     const int pc = p < S2_SPX ? p : S2_SPX - 1;
     const int py = pc / S2_SW, px = pc - py * S2_SW;
@@ -196,15 +206,17 @@ __global__ __launch_bounds__(256, 2) void stem_conv2_kernel(Stem2Args a) {
     }
   }
   __syncthreads();   // the stem patch is complete; the input patch is dead
+  // tiles 5-8: group 0 fetches 5, 7, group 1 fetches 6, 8
 #pragma unroll
-  for (int i = 0; i < 4; ++i) dma_w(5 + i, lds + S2_W5 + i * S2_WTILE);
+  for (int i = 0; i < 4; ++i)
+    if ((i & 1) == wg) dma_w(5 + i, lds + S2_W5 + i * S2_WTILE);
 
-  // ---- layer 1: 3x3 / s2 over the stem patch; wave w = output rows 2w, 2w+1; two N fragments ---------------------
-  const int prow1 = 2 * w + (l31 >> 4), pcol1 = l31 & 15;
+  // ---- layer 1: 3x3 / s2 over the stem patch; wave (w4, wg) = output rows 2 w4, 2 w4 + 1, N fragment wg -----------
+  const int prow1 = 2 * w4 + (l31 >> 4), pcol1 = l31 & 15;
   const int pl = prow1 * S2_TW + pcol1;
-  float16_t acc0, acc1;
+  float16_t acc;
 #pragma unroll
-  for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
   auto ld = [&](const half_t* base, int row, int kc) {
     return *(const half8_t*)(base + row * 32 + ((kc ^ swz(row)) * 8));
   };
@@ -217,11 +229,9 @@ __global__ __launch_bounds__(256, 2) void stem_conv2_kernel(Stem2Args a) {
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk) {
         const int kc = kk * 2 + khalf;
-        const half8_t fw0 = ld(Wb, l31, kc);
-        const half8_t fw1 = ld(Wb, 32 + l31, kc);
+        const half8_t fw = ld(Wb, 32 * wg + l31, kc);
         const half8_t fx = ld(S, row, kc);
-        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(fw0, fx, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(fw1, fx, acc1, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fw, fx, acc, 0, 0, 0);
       }
     }
   };
@@ -231,22 +241,18 @@ __global__ __launch_bounds__(256, 2) void stem_conv2_kernel(Stem2Args a) {
   __syncthreads();   // every wave is done reading the stem patch: the output tile may overwrite it
   half_t* Os = S;
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const float16_t& acc = i ? acc1 : acc0;
+  for (int g = 0; g < 4; ++g) {
+    const float4_t bv = *(const float4_t*)(bias_s + 32 + 32 * wg + 8 * g + 4 * khalf);
+    half4_t o;
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const float4_t bv = *(const float4_t*)(bias_s + 32 + 32 * i + 8 * g + 4 * khalf);
-      half4_t o;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) o[e] = (half_t)ctd_act_fast<ACT1>(acc[4 * g + e] + bv[e]);
-      *(half4_t*)(Os + pl * S2_OP + 32 * i + 8 * g + 4 * khalf) = o;
-    }
+    for (int e = 0; e < 4; ++e) o[e] = (half_t)ctd_act_fast<ACT1>(acc[4 * g + e] + bv[e]);
+    *(half4_t*)(Os + pl * S2_OP + 32 * wg + 8 * g + 4 * khalf) = o;
   }
   __syncthreads();
   const int cch = t & 7;
 #pragma unroll
-  for (int it = 0; it < S2_TW * S2_TH / 32; ++it) {
-    const int p = it * 32 + (t >> 3);
+  for (int it = 0; it < S2_TW * S2_TH / (S2_NT / 8); ++it) {
+    const int p = it * (S2_NT / 8) + (t >> 3);
     const int oy = oy0 + (p >> 4), ox = ox0 + (p & 15);
     if (oy < Ho && ox < Wo)
       *(half8_t*)(a.dst + (((size_t)b * Ho + oy) * Wo + ox) * a.pitchD + cch * 8) = *(const half8_t*)(Os + p * S2_OP + cch * 8);
@@ -267,8 +273,8 @@ void launch_stem_conv2(const Stem2Args& a, hipStream_t st) {
   const int Ho = a.H / 4, Wo = a.W / 4;
   const dim3 grid((unsigned)(((Wo + S2_TW - 1) / S2_TW) * ((Ho + S2_TH - 1) / S2_TH) * a.B), 1, 1);
   switch (a.act1) {
-    case CTD_ACT_SILU: hipLaunchKernelGGL((stem_conv2_kernel<CTD_ACT_SILU, CTD_ACT_SILU>), grid, dim3(256), 0, st, a); break;
-    case CTD_ACT_LEAKY: hipLaunchKernelGGL((stem_conv2_kernel<CTD_ACT_SILU, CTD_ACT_LEAKY>), grid, dim3(256), 0, st, a); break;
-    default: hipLaunchKernelGGL((stem_conv2_kernel<CTD_ACT_SILU, CTD_ACT_RELU>), grid, dim3(256), 0, st, a); break;
+    case CTD_ACT_SILU: hipLaunchKernelGGL((stem_conv2_kernel<CTD_ACT_SILU, CTD_ACT_SILU>), grid, dim3(S2_NT), 0, st, a); break;
+    case CTD_ACT_LEAKY: hipLaunchKernelGGL((stem_conv2_kernel<CTD_ACT_SILU, CTD_ACT_LEAKY>), grid, dim3(S2_NT), 0, st, a); break;
+    default: hipLaunchKernelGGL((stem_conv2_kernel<CTD_ACT_SILU, CTD_ACT_RELU>), grid, dim3(S2_NT), 0, st, a); break;
   }
 }

@@ -14,7 +14,7 @@ run sq1 SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_A
 run sq2 SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_VMEM SQ_INST_LEVEL_VMEM
 run grbm GRBM_GUI_ACTIVE GRBM_COUNT
 python3 "$ROOT/scripts/pmc_summary.py" "$O" > "$O/summary_all.txt" 2>&1
-grep -A22 "conv_halo2_kernel\|conv_split_halo_kernel\|conv_halo_kernel<" "$O/summary_all.txt" > "$O/summary.txt"
+grep -A22 "conv_halo3_kernel\|conv_halo2_kernel\|conv_split_halo_kernel\|conv_halo_kernel<" "$O/summary_all.txt" > "$O/summary.txt"
 grep "\[case\]" "$O/sq1.log" | cut -c1-200 >> "$O/summary.txt"
 rm -rf "$O/sq1" "$O/sq2" "$O/grbm" "$O/summary_all.txt"
 cat "$O/summary.txt" | cut -c1-160 | head -150

@@ -64,7 +64,7 @@ MFMA_F32_PEAK_TFLOPS = 157.3   # v_mfma_f32_32x32x2_f32
 # fp32s: every product costs three fp16 MFMAs -> a third of the fp16 peak for the ALGORITHMIC flops
 PEAK_TF = {"fp16": MFMA_F16_PEAK_TFLOPS, "fp32": MFMA_F32_PEAK_TFLOPS, "fp32s": MFMA_F16_PEAK_TFLOPS / 3}
 DTYPE = {"fp16": "f16", "fp32": "f32", "fp32s": "f32"}
-FAMILY = {"fp16": "conv_halo2_kernel + conv_halo_kernel + conv_igemm_kernel + c3_fused_kernel (MFMA conv / convT family)",
+FAMILY = {"fp16": "conv_halo3_kernel + conv_halo_kernel + conv_igemm_kernel + c3_fused_kernel (MFMA conv / convT family)",
           "fp32": "conv_f32_mfma_kernel (f32-operand MFMA conv / convT family)",
           "fp32s": "conv_split_kernel + conv_split_halo_kernel + stem_split_kernel (split-operand conv / convT family: 3 fp16 MFMAs "
                    "per product; conv-to-conv tensors split-plane in HBM)"}

@@ -12,5 +12,5 @@ for C in FETCH_SIZE WRITE_SIZE; do
      python $ROOT/bench.py --precision $PREC --mode net --steps 1 --warmup 1 --spinup 0 --no-cpu-baseline --no-extras > $OUT/$C.log 2>&1
   echo "$C rc=$?"
 done
-find $OUT -name "*kernel_trace.csv" -delete
+find $OUT -name "*kernel_trace.csv" -delete; find $OUT -name "*agent_info.csv" -delete
 python3 $ROOT/scripts/traffic_summary.py $OUT $PREC

@@ -935,9 +935,10 @@ def main() -> None:
                 parity = {"error": repr(e)[:400]}
         real = canned is None
         if solo and e2e and not args.no_extras:
-            # Sub-runs as CHILD processes of this script (same pages, pipeline and arguments; `--no-extras`): inside this
-            # process, after the headline run, the same pipelines measured 12-18 % low (fp32s 752 vs 897 pages/s, canned
-            # inputs 1992 vs 2456) with or without the CPU legs before them -- a child is the stand-alone number.
+            # Sub-runs IN THIS PROCESS (`inproc_bench`: fresh checkpoint / pages / detector / worker pool each; the native
+            # tails are leased from the pool before).  Round 3 ran them as child processes because a second pipeline in one
+            # process measured 12-18 % low; the cause -- a second set of tail streams at the highest priority sharing
+            # hardware queues with the first -- is gone.  Only the mixed-size stream and MIOpen are children.
             torch.cuda.synchronize()
             pipe.close()                                     # the headline's workers end: their tails go to the next pools
             TL.release_thread_tail()                         # ... and so does the one the parity leg used on this thread

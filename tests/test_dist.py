@@ -212,3 +212,26 @@ def test_bench_four_ranks_tail_only_on_one_device():
     assert out["n_gpus"] == 4 and out["config"]["global_batch"] == 16 and out["config"]["tail_only"] is True
     assert out["config"]["host_threads"]["per_rank"] * 4 <= max(16, out["config"]["host_threads"]["usable_cpus"])
     assert out["value"] > 0 and out["config"]["blocks_per_page"] > 0 and out["config"]["host_cpu_cores_used"] > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two devices in one process")
+def test_one_process_drives_detectors_on_two_devices():
+    """`TextDetector(device='cuda:1')` next to one on `cuda:0` in ONE process -- the native tails' stage-1 chain
+    (mutex, last event, ring of 16 events) is per device, so more than 16 batches on each device, interleaved, must neither
+    fail on an event / stream device mismatch nor change a result."""
+    import numpy as np
+    p = pkg()
+    ck = p.synth.make_blob_checkpoint(0, sparse_det=True)
+    pages = [p.synth.text_like_page((512, 512), s, n_blocks=6) for s in (3, 4)]
+    dets = [p.detector.TextDetector(ck, input_size=512, device=f"cuda:{d}", precision="fp16") for d in (0, 1)]
+    ref = None
+    for it in range(20):                                                        # the ring wraps after 16
+        for det in dets:
+            res = det.detect_batch(pages)
+            sig = [(np.asarray(r[1]).tobytes(), [tuple(int(v) for v in b.xyxy) for b in r[2]]) for r in res]
+            if ref is None:
+                ref = sig
+            assert sig == ref, f"iteration {it} on {det.device}"
+    for det in dets:
+        det.close()

@@ -31,7 +31,7 @@ import torch
 from . import _lib as L
 from . import backend as BK
 from . import postproc as PP
-from .tail import thread_tail
+from .tail import bind_thread, thread_tail
 from .textblock import TextBlock
 from .textmask import (REFINEMASK_ANNOTATION, REFINEMASK_INPAINT, refine_mask, refine_mask_batch,   # noqa: F401
                        refine_undetected_mask)
@@ -144,6 +144,7 @@ class TextDetector:
         dev = self.net.device
         if all(isinstance(p, torch.Tensor) and p.is_cuda for p in pages):
             return list(pages), None
+        bind_thread(dev)
         tl = self._stage_tl                                   # per loader thread: pinned ring + copy stream
         if not hasattr(tl, "ring"):
             tl.ring, tl.k, tl.stream = [], 0, self._copy_stream()

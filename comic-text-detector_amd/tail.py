@@ -138,6 +138,7 @@ class Tail:
         for tns in (blks, mask_u8, lines_map, bitmap):
             if not tns.is_cuda:
                 raise L.CtdError("Tail.run: the network outputs must live on the GPU")
+        bind_thread(self.device)
         Hn, Wn = mask_u8.shape[-2:]
         # The native tail reads these buffers on ITS stream and waits for `ready_event` only.  A layout / dtype
         # conversion here runs on torch's current stream AFTER that event: order the tail behind it with a fresh event.
@@ -267,12 +268,22 @@ class _Lease:
             pass
 
 
+def bind_thread(device) -> None:
+    """Makes `device` the calling thread's current device.  A new host thread starts on device 0: on a multi-GPU node a
+    worker or loader thread of rank r would otherwise create a context on GPU 0 with its first device-less torch call
+    (pinned allocations, events) -- 7 foreign contexts on rank 0's GPU in an 8-rank launch."""
+    device = torch.device(device)
+    if device.index is not None and torch.cuda.current_device() != device.index:
+        torch.cuda.set_device(device)
+
+
 def thread_tail(device) -> Tail:
     """One `Tail` per (host thread, device): its stream and buffers are not shared between live threads; tails of threads
     that have ended are reused (`_Lease`)."""
     device = torch.device(device)
     if device.index is None:
         device = torch.device("cuda", torch.cuda.current_device())
+    bind_thread(device)
     pool = getattr(_tls, "pool", None)
     if pool is None:
         pool = _tls.pool = {}

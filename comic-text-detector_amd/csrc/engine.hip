@@ -63,8 +63,16 @@ struct OpState {
   bool sppf_head = false; // first of SPPF's three chained max pools: one launch does all three
   bool stem2_head = false; // STEM op that also computes the following 3x3/s2 conv (which is `skip`)
   bool stemsp_head = false; // fp32s: first conv reads the network input itself (kernels_split_stem.hip); its INPUT op is `skip`
+  bool c3b_head = false;  // m.cv1 of a 64 / 128-channel bottleneck: launches kernels_c3b.hip for [m.cv1, m.cv2 (+ cv3)]
+  int c3b_conv3 = -1;     // ... index of that bottleneck's 3x3 op (its dispatch decides the K walk, at launch time)
   Stem2Args st2{};
   C3Args c3{};
+  C3bArgs c3b{};
+};
+
+// A C3 block in the op list: [cv1+cv2 -> Y] ([m.j.cv1: Y[0:c] -> Tj] [m.j.cv2: Tj -> Y[0:c] (+ Y[0:c])]) x n [cv3: Y -> out]
+struct C3Chain {
+  int a = -1, d = -1, n = 0, c = 0;   // op indices of cv1+cv2 and cv3, bottlenecks, hidden channels
 };
 
 struct TensorState {
@@ -443,6 +451,60 @@ int plan(ctd_engine* e, int B, int H, int W, hipStream_t cap_stream = nullptr) {
     if (e->tensors[t].last_use >= 0 && e->tensors[t].first_def < 0)
       return fail(CTD_ERR_INVALID, "tensor " + std::to_string(t) + " is read but never written");
 
+  // ---- C3 blocks with 64 / 128 hidden channels (kernels_c3b.hip): found here, BEFORE the arena is laid out, because the
+  // fused launches change what is alive when.  Bottleneck j < n - 1 becomes one launch at m.j.cv1's position that reads the
+  // block's running tensor and writes Tj (NOT Y[0:c] in place: neighbouring patches still read its halo), so Tj lives until
+  // the next bottleneck's launch has read it; the last bottleneck + cv3 become one launch at m.(n-1).cv1's position, so
+  // cv3's output exists from there on.  Both changes only lengthen lifetimes: a chain the kernel then declines (grid too
+  // small) runs layer per launch on the same arena.
+  std::vector<C3Chain> chains;
+  for (int i = 0; e->prec == CTD_PREC_F16 && i + 3 < nO; ++i) {
+    const OpState& A = e->ops[i];
+    const ctd_op& a = A.op;
+    auto mfma16 = [&](const OpState& s) { return s.op.kind == CTD_OP_CONV && s.impl == IMPL_IGEMM && s.bk == 32 && e->w_tiled; };
+    if (!mfma16(A) || a.k != 1 || a.stride != 1 || a.res >= 0 || a.dst_coff != 0) continue;
+    const int Y = a.dst, c = a.cout / 2;
+    if (a.cout % 2 || !(c == 64 || c == 128) || e->tensors[Y].t.channels != 2 * c || e->tensors[Y].first_def != i) continue;
+    int j = i + 1, n = 0;
+    bool ok = true;
+    while (ok && j + 1 < nO) {
+      const OpState &Bo = e->ops[j], &C = e->ops[j + 1];
+      const ctd_op &b = Bo.op, &cc = C.op;
+      if (!mfma16(Bo) || !mfma16(C)) break;
+      const int T = b.dst;
+      if (b.k != 1 || b.stride != 1 || b.src0 != Y || b.src0_coff != 0 || b.src0_c != c || b.src0_up || b.src1 >= 0 ||
+          b.cout != c || b.res >= 0 || b.dst_coff != 0 || T == Y || e->tensors[T].t.channels != c || b.act != a.act)
+        break;
+      if (cc.k != 3 || cc.stride != 1 || cc.pad != 1 || cc.src0 != T || cc.src0_coff != 0 || cc.src0_c != c || cc.src0_up ||
+          cc.src1 >= 0 || cc.cout != c || cc.dst != Y || cc.dst_coff != 0 || cc.act != a.act ||
+          !(cc.res < 0 || (cc.res == Y && cc.res_coff == 0)))
+        break;
+      if (e->tensors[T].first_def != j || e->tensors[T].last_use != j + 1 || e->tensors[T].esize != 2) break;
+      ++n;
+      j += 2;
+    }
+    if (!n || j >= nO) continue;
+    const OpState& D = e->ops[j];
+    const ctd_op& d = D.op;
+    if (!mfma16(D) || d.k != 1 || d.stride != 1 || d.src0 != Y || d.src0_coff != 0 || d.src0_c != 2 * c || d.src0_up ||
+        d.src1 >= 0 || d.cout != 2 * c || d.res >= 0 || d.dst == Y || d.act != a.act)
+      continue;
+    if (e->tensors[Y].last_use != j || e->tensors[Y].esize != 2 || e->tensors[d.dst].esize != 2) continue;
+    bool t_is_dst = false;
+    for (int q = 0; q < n; ++q) t_is_dst = t_is_dst || e->ops[i + 1 + 2 * q].op.dst == d.dst;
+    if (t_is_dst) continue;
+    C3Chain ch;
+    ch.a = i; ch.d = j; ch.n = n; ch.c = c;
+    chains.push_back(ch);
+    for (int q = 0; q + 1 < n; ++q) {   // Tq is read by the launch of bottleneck q + 1
+      TensorState& tq = e->tensors[e->ops[i + 1 + 2 * q].op.dst];
+      tq.last_use = std::max(tq.last_use, i + 1 + 2 * (q + 1));
+    }
+    TensorState& td = e->tensors[d.dst];   // written by the launch at the last bottleneck's m.cv1
+    td.first_def = std::min(td.first_def, i + 1 + 2 * (n - 1));
+    i = j;
+  }
+
   // first-fit allocation over a free list, in op order
   struct Blk { size_t off, size; };
   std::vector<Blk> freel;
@@ -640,7 +702,8 @@ int plan(ctd_engine* e, int B, int H, int W, hipStream_t cap_stream = nullptr) {
                 (double)a.N * o.k * o.k * cin * es;
     }
     s.args = a;
-    s.c3_head = s.skip = s.sppf_head = s.stem2_head = s.stemsp_head = false;
+    s.c3_head = s.skip = s.sppf_head = s.stem2_head = s.stemsp_head = s.c3b_head = false;
+    s.c3b_conv3 = -1;
   }
   // ---- fp32s: INPUT (page -> fp32 NHWC, zero 4th channel) + the 6x6/s2 first conv -> one launch that reads the page itself
   for (int i = 0; e->prec == CTD_PREC_F32S && g_split_stem && i + 1 < nO; ++i) {
@@ -743,6 +806,59 @@ int plan(ctd_engine* e, int B, int H, int W, hipStream_t cap_stream = nullptr) {
     Bo.bytes = C.bytes = D.bytes = 0;
     i += 3;
   }
+  // ---- the wider C3 blocks found above: one launch per bottleneck, the last one with cv3 (kernels_c3b.hip)
+  for (const C3Chain& ch : chains) {
+    if (!(g_fuse & 8)) break;
+    OpState &A = e->ops[ch.a], &D = e->ops[ch.d];
+    const ctd_op& d = D.op;
+    std::vector<C3bArgs> fs(ch.n);
+    bool ok = true;
+    for (int q = 0; q < ch.n && ok; ++q) {
+      OpState &Bo = e->ops[ch.a + 1 + 2 * q], &C = e->ops[ch.a + 2 + 2 * q];
+      const bool last = q + 1 == ch.n;
+      C3bArgs f{};
+      f.prio = g_fwd_prio;
+      f.B = B; f.H = A.args.oH; f.W = A.args.oW;
+      f.ch = ch.c;
+      f.y1 = q == 0 ? Bo.args.s0 : SrcView{e->ops[ch.a + 1 + 2 * (q - 1)].args.dst, ch.c, ch.c, 0, f.H, f.W};
+      f.wm1 = (const half_t*)Bo.w_dev; f.bm1 = Bo.b_dev;
+      f.wm2 = (const half_t*)C.w_dev; f.bm2 = C.b_dev;
+      f.add = C.op.res >= 0;
+      f.act = Bo.op.act;
+      f.zeros = e->zeros;
+      if (last) {
+        f.cv3 = 1;
+        f.y2 = D.args.s0;
+        f.y2.ptr = (const char*)D.args.s0.ptr + (size_t)ch.c * 2;
+        f.y2.c = ch.c;
+        f.wc3 = (const half_t*)D.w_dev; f.bc3 = D.b_dev;
+        f.dst = D.args.dst; f.pitchD = D.args.pitchD;
+        ok = D.args.oH == f.H && D.args.oW == f.W && D.npad == 2 * ch.c;
+      } else {
+        f.cv3 = 0;
+        f.dst = Bo.args.dst; f.pitchD = Bo.args.pitchD;
+      }
+      ok = ok && Bo.npad == ch.c && C.npad == ch.c && Bo.args.oH == f.H && Bo.args.oW == f.W && c3b_supported(f);
+      fs[q] = f;
+    }
+    if (!ok) continue;
+    for (int q = 0; q < ch.n; ++q) {
+      OpState &Bo = e->ops[ch.a + 1 + 2 * q], &C = e->ops[ch.a + 2 + 2 * q];
+      Bo.c3b_head = true;
+      Bo.c3b = fs[q];
+      Bo.c3b_conv3 = ch.a + 2 + 2 * q;
+      C.skip = true;
+      // the launch's work is booked on its first op (the algorithmic bytes of the layers stay the yardstick)
+      Bo.flops += C.flops; Bo.bytes += C.bytes;
+      C.flops = C.bytes = 0;
+      if (q + 1 == ch.n) {
+        D.skip = true;
+        Bo.flops += D.flops; Bo.bytes += D.bytes;
+        D.flops = D.bytes = 0;
+      }
+    }
+    (void)d;
+  }
   e->p_fuse = g_fuse + 16 * g_fuse_epoch;
   e->pB = B; e->pH = H; e->pW = W;
   return CTD_OK;
@@ -788,6 +904,12 @@ int launch_op(ctd_engine* e, int i, const Outs& x, hipStream_t st) {
     case CTD_OP_CONV:
       if (s.skip) break;
       if (s.c3_head) { launch_c3_fused(s.c3, st); break; }
+      if (s.c3b_head) {   // the 3x3's K walk is the one its own dispatch would take NOW (a tuning key may have moved it)
+        C3bArgs f = s.c3b;
+        f.tap_major = conv_halo_supported(e->ops[s.c3b_conv3].args, false) ? 0 : 1;
+        launch_c3b(f, st);
+        break;
+      }
       if (s.stemsp_head) { launch_stem_split(s.args, x.input, x.in_fmt, st); break; }
       if (s.impl == IMPL_IGEMM && s.split) launch_conv_split(s.args, st);
       else if (s.impl == IMPL_IGEMM && !f16) launch_conv_f32_mfma(s.args, st);
@@ -1053,6 +1175,8 @@ int ctd_tuning_set(const char* key, int64_t value) {
   if (key && std::string(key) == "db_up_mfma") { g_db_up_mfma = (int)value; return CTD_OK; }
   if (key && std::string(key) == "seg_final_mfma") { g_seg_final_mfma = (int)value; return CTD_OK; }
   if (key && std::string(key) == "c3_min_patches") { g_c3_min_patches = value; g_fuse_epoch++; return CTD_OK; }
+  if (key && std::string(key) == "c3b_min_patches") { g_c3b_min_patches = value; g_fuse_epoch++; return CTD_OK; }
+  if (key && std::string(key) == "c3b_max_ch") { g_c3b_max_ch = (int)value; g_fuse_epoch++; return CTD_OK; }
   if (conv_tuning_set(key, (long long)value) != 0) return fail(CTD_ERR_INVALID, "unknown tuning key");
   return CTD_OK;
 }

@@ -107,10 +107,34 @@ struct C3Args {
   int prio;                // as ConvArgs::prio
   half_t* dbg;             // selftest only: three (B,H,W,32) planes receiving y2, t, b of every patch pixel; null in the product
 };
-extern int g_fuse;         // fusion bit mask (CTD_FUSE / ctd_tuning_set("fuse")): 1 C3 block, 2 SPPF pools, 4 stem + model.1
+extern int g_fuse;         // fusion bit mask (CTD_FUSE / ctd_tuning_set("fuse")): 1 C3 block, 2 SPPF pools, 4 stem + model.1, 8 C3 bottleneck + cv3 (kernels_c3b.hip)
 extern long long g_c3_min_patches;
 bool c3_fused_supported(const C3Args& a);
 void launch_c3_fused(const C3Args& a, hipStream_t st);
+
+// ---- kernels_c3b.hip : bottleneck (m.cv1 1x1 + m.cv2 3x3 + shortcut) [+ cv3] of a C3 block with 64 / 128 hidden channels ----
+// Weights / biases are the packed arrays of the unfused ops (tile-major, 32-channel K step, N tile = igemm_ntile):
+// wm1 [ch/32][ch][32], wm2 [9 ch/32][ch][32] (K step = tap * ch/32 + chunk), wc3 [2ch/128][2ch/32][128][32].
+struct C3bArgs {
+  SrcView y1;              // the bottleneck's input (ch channels), read with a one-pixel halo
+  SrcView y2;              // cv3 only: the C3's second branch (ch channels), cv3's K rows ch .. 2ch-1
+  int B, H, W;
+  int ch;                  // hidden channels: 64 or 128
+  const half_t *wm1, *wm2, *wc3;
+  const float *bm1, *bm2, *bc3;
+  void* dst;               // (B,H,W,pitchD) fp16: 2 ch channels (cv3) or ch channels (the bottleneck's output), already offset
+  int pitchD;
+  int act;
+  int add;                 // the bottleneck has a shortcut
+  int cv3;                 // 1: cv3 follows in the same launch
+  int tap_major;           // K walk of the 3x3: 1 = K-linear (kernels_igemm.hip), 0 = channel chunk outer (kernels_halo.hip)
+  const void* zeros;       // >= 16 B of zeros in HBM (source of out-of-image rows)
+  int prio;                // as ConvArgs::prio
+};
+extern long long g_c3b_min_patches;   // "c3b_min_patches"
+extern int g_c3b_max_ch;              // "c3b_max_ch"
+bool c3b_supported(const C3bArgs& a);
+void launch_c3b(const C3bArgs& a, hipStream_t st);
 
 // ---- kernels_stem2.hip : stem (6x6/s2, 3 -> 32) + layer 1 (3x3/s2, 32 -> 64) in one kernel -----------
 struct Stem2Args {

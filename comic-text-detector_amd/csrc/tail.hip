@@ -189,6 +189,8 @@ struct GpuChain {
 long long g_tail_dma_min = 256 << 10;   // device -> host copies of at least this many bytes use the copy engines ("tail_dma_min"; huge = never)
 namespace {
 
+inline void* device_view(const void* host);
+
 // A stage's copies and fills as segments of one kernel launch (launch_multi_copy, kernels_tail.hip).
 struct Batch {
   MSegs m;
@@ -214,6 +216,20 @@ struct Batch {
   // first: the stream order is the call order.
   hipError_t d2h(void* host, const void* dev, size_t bytes) {
     if (bytes < (size_t)g_tail_dma_min) { copy(host, dev, bytes); return hipSuccess; }
+    flush();
+    return hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, st);
+  }
+  // Device -> a CALLER's host array, which `ctd_hip.h` only promises to be host memory: a copy-kernel segment may store to
+  // it only through its device-visible address, i.e. when it is page-locked; a pageable array (a C caller's malloc, an
+  // unpinned numpy array) always goes through hipMemcpyAsync, whatever its size (a kernel store into pageable memory is a
+  // memory fault without XNACK).
+  hipError_t d2h_user(void* host, const void* dev, size_t bytes) {
+    if (bytes && bytes < (size_t)g_tail_dma_min) {
+      void* dv = device_view(host);
+      // both ends page-locked and mapped contiguously (several arrays handed over as one back-to-back range)
+      void* de = dv ? device_view((const char*)host + bytes - 1) : nullptr;
+      if (dv && de == (char*)dv + bytes - 1) { copy(dv, dev, bytes); return hipSuccess; }
+    }
     flush();
     return hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, st);
   }
@@ -901,9 +917,9 @@ static int tail_run_impl(ctd_tail* t, int32_t B, int32_t Hn, int32_t Wn, const f
   if (plain) {   // device and host copy of the page masks both read the network's u8 mask: same launch, no ordering needed
     const size_t stride = B > 1 ? t->poff[1] - t->poff[0] : hw;
     post.copy2d(pmask, stride, mask_u8_dev, hw, hw, B);
-    if (dense) T_TRY(post.d2h(mask_out[0], mask_u8_dev, hw * (size_t)B));
+    if (dense) T_TRY(post.d2h_user(mask_out[0], mask_u8_dev, hw * (size_t)B));
     else if (direct)
-      for (int b = 0; b < B; ++b) T_TRY(post.d2h(mask_out[b], mask_u8_dev + (size_t)b * hw, hw));
+      for (int b = 0; b < B; ++b) T_TRY(post.d2h_user(mask_out[b], mask_u8_dev + (size_t)b * hw, hw));
     else T_TRY(post.d2h2d(hpmask, stride, mask_u8_dev, hw, hw, B));
   }
   for (int b = 0; b < B && !plain; ++b) {
@@ -923,7 +939,7 @@ static int tail_run_impl(ctd_tail* t, int32_t B, int32_t Hn, int32_t Wn, const f
   if (!plain) {
     if (!direct) T_TRY(post.d2h(hpmask, pmask, t->ptotal));
     else
-      for (int b = 0; b < B; ++b) T_TRY(post.d2h(mask_out[b], pmask + t->poff[b], (size_t)pages[b].im_h * pages[b].im_w));
+      for (int b = 0; b < B; ++b) T_TRY(post.d2h_user(mask_out[b], pmask + t->poff[b], (size_t)pages[b].im_h * pages[b].im_w));
   }
   post.flush();
   T_TRY(hipGetLastError());

@@ -64,7 +64,7 @@ MFMA_F32_PEAK_TFLOPS = 157.3   # v_mfma_f32_32x32x2_f32
 # fp32s: every product costs three fp16 MFMAs -> a third of the fp16 peak for the ALGORITHMIC flops
 PEAK_TF = {"fp16": MFMA_F16_PEAK_TFLOPS, "fp32": MFMA_F32_PEAK_TFLOPS, "fp32s": MFMA_F16_PEAK_TFLOPS / 3}
 DTYPE = {"fp16": "f16", "fp32": "f32", "fp32s": "f32"}
-FAMILY = {"fp16": "conv_halo3_kernel + conv_halo_kernel + conv_igemm_kernel + c3_fused_kernel (MFMA conv / convT family)",
+FAMILY = {"fp16": "conv_halo3_kernel + conv_halo_kernel + conv_igemm_kernel + c3_fused_kernel + c3b_kernel (MFMA conv / convT family)",
           "fp32": "conv_f32_mfma_kernel (f32-operand MFMA conv / convT family)",
           "fp32s": "conv_split_kernel + conv_split_halo_kernel + stem_split_kernel (split-operand conv / convT family: 3 fp16 MFMAs "
                    "per product; conv-to-conv tensors split-plane in HBM)"}
@@ -87,11 +87,12 @@ def host_info() -> dict:
     return {"cpu_model": model, "logical_cpus": os.cpu_count(), "usable_cpus": avail}
 
 
-def thread_budget(world: int) -> dict:
+def thread_budget(world: int, pinned: bool = False) -> dict:
     """Host threads one rank may use: the usable cores divided by the ranks on this host (an 8-rank node runs 8 of these
-    processes).  Tail workers x native geometry threads + loaders + the launching thread must fit."""
+    processes) -- or, once the rank is bound to its own CPUs (`affinity.apply`, N > 1), simply the CPUs it is bound to.
+    Tail workers x native geometry threads + loaders + the launching thread must fit."""
     avail = host_info()["usable_cpus"]
-    per_rank = max(4, avail // max(1, world))
+    per_rank = max(4, avail if pinned else avail // max(1, world))
     workers = 4 if per_rank >= 16 else (3 if per_rank >= 8 else 2)     # a 4th worker is free since the tails' streams have the
     native = max(1, min(8, (per_rank - 2) // workers))                  # default priority (tail.hip g_tail_priority); dense pages gain 4 %
     return {"usable_cpus": avail, "per_rank": per_rank, "tail_workers": workers, "native_threads_per_worker": native}
@@ -139,7 +140,7 @@ class Pipeline:
     while worker threads run the tail work items of step k; (N>1) the record gather on its own stream."""
 
     def __init__(self, det, batches, canned, dev, world, rank, total_pages, D, workers, depth, tail_split,
-                 host_input=False, loaders=2, engines=1, keep_undetected=False, lazy=True):
+                 host_input=False, loaders=2, engines=1, keep_undetected=False, lazy=False):
         self.det, self.batches, self.canned, self.dev = det, batches, canned, dev
         self.world, self.rank, self.total_pages, self.D = world, rank, total_pages, D
         self.workers, self.depth, self.tail_split = max(1, workers), max(1, depth), max(1, tail_split)
@@ -228,6 +229,10 @@ def timed(run, steps, warmup, spinup, world, dev, stats=None):
     import gc
     gc.collect()
     gc.freeze()
+    # ... and this: the result objects of a batch (32 pages x 30 TextBlocks, each a dict, a few lists and numpy values) are
+    # ~10 k tracked containers; at the default threshold of 700 allocations the youngest generation is collected a dozen
+    # times per batch, on the tail workers, under the interpreter lock.  Nothing on this path creates reference cycles.
+    gc.set_threshold(50000, 20, 20)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -341,16 +346,19 @@ def cpu_baseline(pkg, ckpt, size: int, pages, canned_sample=None, budget_s: floa
 FP16_BAND_EPS = 4e-3            # = tests/test_gpu_accept.py EPS_FP16
 
 
-def parity_block(pkg, ckpt, det, page: np.ndarray, size: int) -> dict:
-    """The second half of BASELINE's metric on ONE page of the benchmark input (checkpoint and page as benchmarked):
+def parity_block(pkg, ckpt, det, batch: torch.Tensor, idx: int, size: int) -> dict:
+    """The second half of BASELINE's metric on ONE page of the benchmark input (checkpoint and page as benchmarked), taken
+    from a forward of the WHOLE benchmark batch -- the dispatch that is timed (at B = 32 the grid thresholds select
+    `conv_halo3_kernel`, `c3_fused_kernel`, `c3b_kernel`; a B = 1 re-run of the page would go through other kernels):
     (1) every engine's maps against the oracle forward; (2) for the fp16 engine the BOUND on its deviation (every
     thresholded pixel that differs lies within eps of the threshold in the oracle's map; every differing line / block
-    touches such a pixel); (3) end to end -- lines / blocks / masks of every engine against oracle forward + oracle
-    tail (= the reference's TextDetector.__call__ restated)."""
+    touches such a pixel); (3) end to end -- lines / blocks / masks of every engine (`detect_batch` of the batch) against
+    oracle forward + oracle tail (= the reference's TextDetector.__call__ restated)."""
     from oracle import accept
     from oracle import postproc_ref as R
     from oracle.net_ref import OracleNet
     DET = importlib.import_module("comic-text-detector_amd.detector")
+    page = batch[idx].cpu().numpy()
     x = torch.from_numpy(np.ascontiguousarray(page.transpose(2, 0, 1)[None])).float() / 255
     torch.set_num_threads(min(32, host_info()["usable_cpus"]))
     ob, om, ol = OracleNet(ckpt)(x)
@@ -360,34 +368,47 @@ def parity_block(pkg, ckpt, det, page: np.ndarray, size: int) -> dict:
     sbb = accept.score_band_boxes(ol.numpy(), (size, size), FP16_BAND_EPS)
     ref_cand = np.asarray(R.seg_rep((size, size), ol.numpy())[0][0])
     BKm = importlib.import_module("comic-text-detector_amd.backend")
-    out = {"page": f"first page of the benchmark input ({size}x{size}), benchmark checkpoint; oracle = CPU fp32 restatement "
-                   "of the reference net + restated tail", "engines": {}}
+    nB = int(batch.shape[0])
+    out = {"page": f"page {idx} of the benchmark's first batch ({size}x{size}), benchmark checkpoint; oracle = CPU fp32 restatement "
+                   "of the reference net + restated tail",
+           "dispatch": f"as timed: every engine's outputs come from ONE forward / `detect_batch` of the {nB}-page benchmark batch "
+                       "at the default grid thresholds",
+           "engines": {}}
     dev = det.net.device
     for prec in ("fp16", "fp32s", "fp32"):
         d = det if det.precision == prec else DET.TextDetector(ckpt, input_size=size, device=dev, precision=prec)
-        got = d(page, refine_mode=0, keep_undetected_mask=False)
+        # the fp32 engine is benchmarked at bs = 8 (BASELINE configs[1]): its batch here is the first 8 pages
+        xb = batch[: max(8, idx + 1)] if prec == "fp32" else batch
+        got = d.detect_batch([xb[i] for i in range(int(xb.shape[0]))], refine_mode=0, keep_undetected_mask=False)[idx]
         rep = accept.compare(got, ref)
-        pages = torch.from_numpy(page)[None].to(dev)
-        blks, mask, lines = d.net.forward_u8(pages)
+        rep["batch"] = int(xb.shape[0])
+        blks, mask, lines = d.net.forward_u8(xb)
         torch.cuda.synchronize()
-        band = accept.band_report(ol[0, 0].numpy(), om[0, 0].numpy(), d.net.bitmap[0].cpu().numpy(),
-                                  d.net.mask_u8[0].cpu().numpy(), FP16_BAND_EPS, prob=lines[0, 0].cpu().numpy(),
+        kern = d.net.op_kernels()
+        rep["kernels"] = sorted({k for _, k in kern if k != "(fused)"})
+        blks, mask, lines = blks[idx: idx + 1], mask[idx: idx + 1], lines[idx: idx + 1]
+        mu8, bmp = d.net.mask_u8[idx: idx + 1], d.net.bitmap[idx: idx + 1]
+        band = accept.band_report(ol[0, 0].numpy(), om[0, 0].numpy(), bmp[0].cpu().numpy(),
+                                  mu8[0].cpu().numpy(), FP16_BAND_EPS, prob=lines[0, 0].cpu().numpy(),
                                   mask=mask[0, 0].cpu().numpy())
         flips = band.pop("_flips")
-        dets, counts = BKm.nms(blks, 0.4, 0.35)
-        extras = d.tail_batch([page], blks, d.net.mask_u8, lines[:, 0].contiguous(), d.net.bitmap, want_extras=True)[0][3]
+        dets, counts = BKm.nms(blks.contiguous(), 0.4, 0.35)
+        extras = d.tail_batch([page], blks.contiguous(), mu8.contiguous(), lines[:, 0].contiguous(), bmp.contiguous(),
+                              want_extras=True)[0][3]
         band.update(accept.explain_geometry(got, ref, flips, dets=dets[0, : int(counts[0])].cpu().numpy(), ref_dets=ref_dets,
                                             score_band_boxes=sbb, candidates=(extras["db_boxes"], ref_cand, 1000)))
         rep["band"] = band
         out["engines"][prec] = rep
         if d is not det:
             del d
+            torch.cuda.empty_cache()
     b16 = out["engines"]["fp16"]["band"]
     out["fp16_band"] = {"eps": FP16_BAND_EPS,
                         "claim": "the fp16 engine's maps stay within eps of the oracle's; every DB-bitmap (0.3) / mask@127 pixel "
                                  "that differs lies within eps of the threshold in the ORACLE's map; every differing line / "
                                  "block is attributed to such a pixel, to an int32 truncation of coordinates < 1 px apart, or "
-                                 "to a detection NMS kept differently (tests/test_gpu_accept.py, oracle/accept.py)",
+                                 "to a detection NMS kept differently (tests/test_gpu_accept.py, tests/test_gpu_dispatch.py, "
+                                 "oracle/accept.py)",
                         "holds": bool(b16["bitmap_flips_out_of_band"] == 0 and b16["mask127_flips_out_of_band"] == 0 and
                                       b16["prob_max_abs_delta"] < FP16_BAND_EPS and b16["mask_max_abs_delta"] < FP16_BAND_EPS and
                                       b16["lines_unexplained"] == 0 and b16["blocks_unexplained"] == 0),
@@ -527,7 +548,7 @@ def inproc_bench(pkg, D, DET, TL, base_args, dev, steps: int, warmup: int = 3, s
         det = DET.TextDetector(ckpt, input_size=a.size, device=dev, precision=a.precision)
         pipe = Pipeline(det, batches, canned, dev, 1, 0, a.batch, D, a.workers, a.depth, a.tail_split,
                         host_input=a.host_input, loaders=a.loaders, engines=a.engines, keep_undetected=a.keep_undetected,
-                        lazy=not a.eager_blocks)
+                        lazy=bool(a.lazy_blocks))
         gc.unfreeze()
         dt = timed(pipe.run, steps, warmup, spinup, 1, dev, pipe.stats)
         st = dict(pipe.stats)
@@ -811,9 +832,10 @@ def main() -> None:
                          "outputs (workers, work items, record gather as in e2e).  With --gpus N on one device (rehearsal) this "
                          "measures what N ranks' HOST sides -- interpreter pipelines, tail workers x geometry threads, pinned "
                          "buffers, the gather -- cost each other; not a detector rate")
-    ap.add_argument("--eager-blocks", action="store_true",
-                    help="e2e: the tail workers build the Python TextBlock objects of every page (detect_batch's return type) "
-                         "instead of handing over the native records as lazily materialised BlockLists (detect_stream's default)")
+    ap.add_argument("--lazy-blocks", action="store_true",
+                    help="e2e: the tail workers hand over every page's native records as a lazily materialised BlockList "
+                         "(`detect_stream(lazy=True)`) instead of building the reference's return type, a list of Python TextBlock "
+                         "objects (the default, and what the headline times since round 5)")
     ap.add_argument("--spinup", type=int, default=int(os.environ.get("BENCH_SPINUP", "100")),
                     help="untimed steps before the warm-up steps (clock / host-side spin-up of a fresh process)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -822,6 +844,8 @@ def main() -> None:
                     help="wall-clock limit of the rocm_baseline child process (s); 0 skips it")
     ap.add_argument("--rocm-budget", type=float, default=240.0, help="(rocm-baseline mode) stop starting new cases after this many s")
     ap.add_argument("--dump-ops", default="", help="write the per-op profile table to this file")
+    ap.add_argument("--no-pin", action="store_true",
+                    help="N > 1: do NOT bind the rank's threads to the CPUs of its GPU's NUMA node (affinity.py; A/B knob)")
     args = ap.parse_args()
 
     if args.mode == "rocm-baseline":
@@ -843,7 +867,16 @@ def main() -> None:
     one_device = bool(os.environ.get("CTD_BENCH_ONE_DEVICE"))
     dev = torch.device("cuda", 0 if one_device else local_rank)
     torch.cuda.set_device(dev)
-    tb = thread_budget(world)
+    # N > 1: bind this rank's host side (launcher, tail workers and their native threads, loaders -- all created below
+    # and inheriting the mask) to CPUs of ITS GPU's NUMA node, disjoint from the other ranks' (affinity.py)
+    AFF = importlib.import_module("comic-text-detector_amd.affinity")
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", world))
+    pin = AFF.rank_cpus(local_rank % max(1, local_world), local_world,
+                        gpu_of_rank=[0] * local_world if one_device else list(range(local_world)))
+    pinned = bool(world > 1 and not args.no_pin and AFF.apply(pin["cpus"]))
+    cpu_affinity = {"pinned": pinned, "numa_node": pin["node"], "source": pin["source"], "n_cpus": len(pin["cpus"]),
+                    "cpus": f"{pin['cpus'][0]}..{pin['cpus'][-1]}" if pin["cpus"] else ""}
+    tb = thread_budget(world, pinned)
     if args.workers <= 0:
         args.workers = tb["tail_workers"]
     if args.tail_split <= 0:
@@ -876,7 +909,7 @@ def main() -> None:
     e2e = args.mode == "e2e"
     pipe = Pipeline(det, batches, canned, dev, world, rank, total_pages, D, args.workers, args.depth, args.tail_split,
                     host_input=args.host_input and e2e, loaders=args.loaders, engines=args.engines,
-                    keep_undetected=args.keep_undetected, lazy=not args.eager_blocks)
+                    keep_undetected=args.keep_undetected, lazy=bool(args.lazy_blocks))
 
     if args.fwd_stream == "high" and e2e:
         pipe.fwd_stream = torch.cuda.Stream(dev, priority=-1)
@@ -930,7 +963,7 @@ def main() -> None:
         if solo and not args.no_cpu_baseline:
             cpu = cpu_baseline(pkg, ckpt, S, batches[0][:16].cpu().numpy(), canned_sample)
             try:
-                parity = parity_block(pkg, ckpt, det, page0, S)
+                parity = parity_block(pkg, ckpt, det, batches[0], 0, S)
             except Exception as e:                      # never lose the bench line to the extra check
                 parity = {"error": repr(e)[:400]}
         real = canned is None
@@ -962,10 +995,13 @@ def main() -> None:
                 c = sub(16, line_density="r3")
                 extra["r3_density_e2e"] = dict(c, config="round 3's headline pages (sparse_det without the line-density calibration: 16 "
                                                          "blocks / 16 lines per page; round 3's driver line: 2586 pages/s)")
-                c = sub(16, eager_blocks=True)
-                extra["eager_textblocks_e2e"] = dict(c, config="the headline with the tail workers building every page's Python "
-                                                               "TextBlock objects (detect_batch's return type) instead of handing "
-                                                               "over lazily materialised BlockLists")
+                c = sub(16, lazy_blocks=True)
+                extra["lazy_blocklists_e2e"] = dict(c, config="the headline with the tail workers handing over lazily materialised "
+                                                              "BlockLists (`detect_stream(lazy=True)`: the native records, "
+                                                              "TextBlock objects built when a consumer looks at them) instead "
+                                                              "of the reference's return type, a list of TextBlock objects per "
+                                                              "page, which the headline builds (rounds 3-4 timed this variant "
+                                                              "as the headline)")
                 c = sub(16, host_input=True)
                 extra["host_input_e2e"] = dict(c, config="the headline with the pages starting in HOST memory (numpy arrays, as the "
                                                          "reference's callers hand them over): PCIe-inclusive, never the headline")
@@ -1034,7 +1070,7 @@ def main() -> None:
                        "tail_workers": args.workers if e2e else 0, "batches_in_flight": args.depth if e2e else 1,
                        "engines": args.engines if e2e else 1,
                        "spinup_steps": args.spinup, "tail_split": args.tail_split if e2e else 1,
-                       "host_threads": tb,
+                       "host_threads": tb, "cpu_affinity": cpu_affinity,
                        "pages_start_in": "host memory (pinned staging + async H2D on %d loader threads)" % args.loaders
                                          if (e2e and args.host_input) else "HBM",
                        "blocks_per_page": round(stats["blocks"] / max(stats["pages"], 1), 2) if e2e else None,
@@ -1043,6 +1079,7 @@ def main() -> None:
                        "one_device_rehearsal": one_device, "tail_only": bool(args.tail_only and e2e),
                        "parallelism": f"dp{n_gpus} (pages sharded, no data-path collective except the final record "
                                       f"gather; ranks={world}, backend={dist.get_backend() if world > 1 else 'none'}"
+                                      + (f", each rank bound to {cpu_affinity['n_cpus']} CPUs of its GPU's NUMA node" if pinned else "")
                                       + (", ALL RANKS ON ONE DEVICE: rehearsal, not a measurement" if one_device else "") + ")"},
             "serial_step": serial,
             "roofline": roof,

@@ -14,7 +14,7 @@ __all__ = ["arch", "synth", "graph", "backend", "HipTextDetBackend"]
 
 def __getattr__(name):
     # lazy: these need torch + ctypes
-    if name in ("graph", "backend", "_lib", "detector", "postproc", "dist", "textblock", "textmask", "tail", "annotations"):
+    if name in ("graph", "backend", "_lib", "detector", "postproc", "dist", "textblock", "textmask", "tail", "annotations", "affinity"):
         import importlib
         return importlib.import_module(f"{__name__}.{name}")
     if name == "HipTextDetBackend":

@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, "libctd_hip.so")
 SELFTEST_PATH = os.path.join(_HERE, "ctd_selftest")
 
 # ---- constants mirrored from include/ctd_hip.h -------------------------------
-ABI_VERSION = 4
+ABI_VERSION = 5
 OK = 0
 PREC_F32, PREC_F16, PREC_F32S = 0, 1, 2
 ACT = {"none": 0, "silu": 1, "leaky": 2, "relu": 3, "sigmoid": 4}
@@ -71,6 +71,7 @@ SYMBOLS = {
     "ctd_engine_forward": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ctd_engine_n_ops": (_i32, [_vp]),
     "ctd_engine_op_work": (_i32, [_vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(_i32)]),
+    "ctd_engine_op_kernel": (_i32, [_vp, _i32, C.c_char_p, _i32]),
     "ctd_engine_profile": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp,
                                   C.POINTER(C.c_float)]),
     "ctd_engine_read_tensor": (_i32, [_vp, _i32, C.POINTER(C.c_float), _i64]),

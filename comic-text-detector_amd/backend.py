@@ -196,6 +196,17 @@ class HipTextDetBackend:
         return dict(ms=self.last_op_ms, flops=np.array(fl[:]), bytes=np.array(by[:]), cls=np.array(cl[:]),
                     names=[o["name"] for o in self.program.ops])
 
+    def op_kernels(self) -> list:
+        """[(op name, kernel it launches under the current plan and tuning)] in program order, for the shape of the last
+        forward (`ctd_engine_op_kernel`); "(fused)" = another op's launch does this op's work.  (The two heads' inner
+        layers share names -- `upconv4.conv.1` exists in the UNet and in the DB head -- hence a list, not a dict.)"""
+        n = self._lib.ctd_engine_n_ops(self._h)
+        out, buf = [], C.create_string_buffer(64)
+        for i in range(n):
+            L.check(self._lib.ctd_engine_op_kernel(self._h, i, buf, 64), "ctd_engine_op_kernel")
+            out.append((self.program.ops[i]["name"] or f"op{i}", buf.value.decode()))
+        return out
+
     def read_tensor(self, name_or_id) -> np.ndarray:
         """Debug: activation tensor of the last forward as f32 (B,H,W,C).  Only
         meaningful with CTD_NO_REUSE=1 (otherwise the arena slot may have been reused)."""

@@ -1102,6 +1102,49 @@ int ctd_engine_op_work(const ctd_engine* e, double* flops, double* bytes, int32_
   return CTD_OK;
 }
 
+int ctd_engine_op_kernel(const ctd_engine* e, int32_t i, char* name, int32_t cap) {
+  if (!e || !name || cap < 2) return fail(CTD_ERR_INVALID, "null argument");
+  if (i < 0 || i >= (int)e->ops.size()) return fail(CTD_ERR_INVALID, "op index out of range");
+  if (!e->pB) return fail(CTD_ERR_INVALID, "no plan yet: run a forward of the shape first");
+  const OpState& s = e->ops[i];
+  const ctd_op& o = s.op;
+  const bool f16 = e->prec == CTD_PREC_F16;
+  const char* k = "?";
+  auto conv_kernel = [&]() -> const char* {   // mirrors launch_op / launch_conv_igemm / launch_conv_split
+    if (s.skip) return "(fused)";
+    if (s.c3_head) return "c3_fused_kernel";
+    if (s.c3b_head) return "c3b_kernel";
+    if (s.stemsp_head) return "stem_split_kernel";
+    const bool mfma = s.impl == IMPL_IGEMM || s.impl == IMPL_IGEMM_T;
+    if (mfma && s.split) return conv_split_halo_supported(s.args) ? "conv_split_halo_kernel" : "conv_split_kernel";
+    if (mfma && !f16) return "conv_f32_mfma_kernel";
+    if (mfma) {
+      ConvArgs a = s.args;
+      if (!a.bk) a.bk = igemm_pick_bk(a.s0.c, a.s1.c, a.K, a.N, 0);
+      const bool d32 = o.kind == CTD_OP_CONV && e->tensors[o.dst].esize == 4;
+      if (conv_halo3_supported(a, d32)) return "conv_halo3_kernel";
+      if (conv_halo2_supported(a, d32)) return "conv_halo2_kernel";
+      if (conv_halo_supported(a, d32)) return "conv_halo_kernel";
+      return "conv_igemm_kernel";
+    }
+    return o.kind == CTD_OP_CONV ? "conv_direct_kernel" : "convt_direct_kernel";
+  };
+  switch (o.kind) {
+    case CTD_OP_INPUT: k = s.skip ? "(fused)" : "input_kernel"; break;
+    case CTD_OP_STEM: k = s.stem2_head ? "stem_conv2_kernel" : "stem_mfma_kernel"; break;
+    case CTD_OP_CONV:
+    case CTD_OP_CONVT: k = conv_kernel(); break;
+    case CTD_OP_MAXPOOL: k = s.skip ? "(fused)" : s.sppf_head ? "sppf_pool3_kernel" : "maxpool_kernel"; break;
+    case CTD_OP_AVGPOOL2: k = "avgpool2_kernel"; break;
+    case CTD_OP_DETECT: k = "detect_decode_kernel"; break;
+    case CTD_OP_EXPORT: k = "export_plane_kernel"; break;
+    case CTD_OP_SEG_FINAL: k = e->tensors[o.src0].esize == 4 ? "seg_final_f32_kernel" : (g_seg_final_mfma ? "seg_final_mfma_kernel" : "seg_final_kernel"); break;
+    case CTD_OP_DB_UP: k = (e->tensors[o.src0].esize == 2 && g_db_up_mfma) ? "db_up_mfma_kernel" : "db_up_kernel"; break;
+  }
+  std::snprintf(name, (size_t)cap, "%s", k);
+  return CTD_OK;
+}
+
 int ctd_engine_profile(ctd_engine* e, const void* input_dev, int32_t input_fmt, int32_t B, int32_t H, int32_t W,
                        float* blks_dev, float* mask_dev, float* lines_dev, uint8_t* mask_u8_dev, uint8_t* bitmap_dev,
                        void* stream, float* op_ms) {
@@ -1177,6 +1220,8 @@ int ctd_tuning_set(const char* key, int64_t value) {
   if (key && std::string(key) == "c3_min_patches") { g_c3_min_patches = value; g_fuse_epoch++; return CTD_OK; }
   if (key && std::string(key) == "c3b_min_patches") { g_c3b_min_patches = value; g_fuse_epoch++; return CTD_OK; }
   if (key && std::string(key) == "c3b_max_ch") { g_c3b_max_ch = (int)value; g_fuse_epoch++; return CTD_OK; }
+  if (key && std::string(key) == "c3b_cfg64") { g_c3b_cfg64 = (int)value; g_fuse_epoch++; return CTD_OK; }
+  if (key && std::string(key) == "c3b_cfg128") { g_c3b_cfg128 = (int)value; g_fuse_epoch++; return CTD_OK; }
   if (conv_tuning_set(key, (long long)value) != 0) return fail(CTD_ERR_INVALID, "unknown tuning key");
   return CTD_OK;
 }

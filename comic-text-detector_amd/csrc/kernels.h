@@ -133,6 +133,7 @@ struct C3bArgs {
 };
 extern long long g_c3b_min_patches;   // "c3b_min_patches"
 extern int g_c3b_max_ch;              // "c3b_max_ch"
+extern int g_c3b_cfg64, g_c3b_cfg128; // tiling variants per hidden width ("c3b_cfg64" 0 / 1 / 2, "c3b_cfg128" 0 / 1)
 bool c3b_supported(const C3bArgs& a);
 void launch_c3b(const C3bArgs& a, hipStream_t st);
 

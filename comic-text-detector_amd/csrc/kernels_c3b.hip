@@ -36,22 +36,23 @@
 
 #include "kernels.h"
 
-long long g_c3b_min_patches = 1024;   // fewer 128-pixel patches: the per-layer kernels ("c3b_min_patches")
+long long g_c3b_min_patches = 1024;   // fewer patches (blocks) than this: the per-layer kernels ("c3b_min_patches")
 int g_c3b_max_ch = 128;               // widest hidden width the kernel takes ("c3b_max_ch": 0 / 64 / 128)
+// Tiling per hidden width (A/B knobs, "c3b_cfg64" / "c3b_cfg128"): 0 = 16x8 patch, wave tile 64 channels x 32 pixels (16
+// waves per CU); 1 = wave tile 64 channels x 64 pixels on a 16x16 patch (64 channels) / on the 16x8 patch with four waves
+// (128 channels): 8 waves per CU, a third fewer LDS reads per MFMA; 2 (64 channels only) = 16x8 patch, two waves of 64 x 64
+int g_c3b_cfg64 = 0, g_c3b_cfg128 = 0;
 
 namespace {
 
-constexpr int BW = 16, BH = 8;                     // pixel patch
-constexpr int HW = BW + 2, HH = BH + 2;            // haloed patch 18 x 10
-constexpr int HROWS = HW * HH;                     // 180
-constexpr int NROW = 192;                          // padded to 6 MFMA pixel fragments
-constexpr int PX = BW * BH;                        // 128
-constexpr int PLANE = NROW * 32;                   // halves of one 32-channel plane of the haloed image
+constexpr int BW = 16;                             // patch width; the patch height BH is a template parameter
+constexpr int HW = BW + 2;                         // haloed patch width
 
 template <int N> __device__ __forceinline__ void wait_vm_lgkm0() {
-  static_assert(N == 0 || N == 1, "LDS-DMA instructions of one step");
+  static_assert(N >= 0 && N <= 2, "LDS-DMA instructions of one step");
   if (N == 0) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-  else asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)" ::: "memory");
+  else if (N == 1) asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
 }
 
 template <int I, int N, class F> __device__ __forceinline__ void static_for(F&& f) {
@@ -61,26 +62,47 @@ template <int I, int N, class F> __device__ __forceinline__ void static_for(F&& 
   }
 }
 
-template <int CH, int ACT, bool CV3>
-__global__ __launch_bounds__(CH * 4, 4) void c3b_kernel(C3bArgs a) {
+// Geometry of one instantiation.  CH hidden channels, BH patch rows, PXF pixel fragments (of 32) per wave in S3 / S4.
+template <int CH, int BH, int PXF> struct Geo {
+  static constexpr int HH = BH + 2, HROWS = HW * HH;             // haloed patch: 18 x 10 = 180 or 18 x 18 = 324 rows
+  static constexpr int NFH = (HROWS + 31) / 32;                  // haloed MFMA pixel fragments: 6 / 11
+  static constexpr int NROW = NFH * 32;                          // padded rows of a plane: 192 / 352
+  static constexpr int PX = BW * BH, NPF = PX / 32;              // patch pixels, patch fragments: 4 / 8
+  static constexpr int WN = CH / 64, WM = NPF / PXF, NW = WN * WM, NTHR = 64 * NW;
+  static constexpr int NCH = CH / 32;
+  static constexpr int PLANE = NROW * 32;                        // halves of one 32-channel plane of the haloed image
+  static constexpr int SLOT = CH * 32;                           // halves of one ring slot: CH weight rows x 32 channels
+  static constexpr int RING = NCH * PLANE, LDS_MAIN = RING + 3 * SLOT;
+  static constexpr int NDW = CH * 4 / NTHR;                      // LDS-DMA instructions per thread and weight step
+  static constexpr int NDY = NCH * NROW * 4 / NTHR;              // ... for the haloed patch
+  static constexpr int MAXF = (NFH + NW - 1) / NW;               // haloed fragments a wave owns in S2
+  static constexpr int LDS_BYTES = (LDS_MAIN + 8 * CH) * 2;
+  static constexpr int BLOCKS = (160 * 1024) / LDS_BYTES;        // blocks per CU the LDS allows
+  static constexpr int OCC = BLOCKS * NW / 4 < 1 ? 1 : (BLOCKS * NW / 4 > 4 ? 4 : BLOCKS * NW / 4);   // waves per SIMD
+  static_assert(CH * 4 % NTHR == 0 && (NCH * NROW * 4) % NTHR == 0 && NPF % PXF == 0, "pieces divide evenly");
+};
+
+template <int CH, int BH, int PXF, int ACT, bool CV3>
+__global__ __launch_bounds__((Geo<CH, BH, PXF>::NTHR), (Geo<CH, BH, PXF>::OCC)) void c3b_kernel(C3bArgs a) {
   if (a.prio) __builtin_amdgcn_s_setprio(3);
-  constexpr int NTHR = CH * 4, NW = CH / 16, NCH = CH / 32;
-  constexpr int SLOT = CH * 32;                    // halves of one ring slot: CH weight rows x 32 channels
-  constexpr int RING = NCH * PLANE;
-  constexpr int LDS_MAIN = RING + 3 * SLOT;
+  using G = Geo<CH, BH, PXF>;
+  constexpr int NTHR = G::NTHR, NW = G::NW, WM = G::WM, NCH = G::NCH, NFH = G::NFH, NROW = G::NROW, HROWS = G::HROWS;
+  constexpr int PX = G::PX, NPF = G::NPF, PLANE = G::PLANE, SLOT = G::SLOT, RING = G::RING, LDS_MAIN = G::LDS_MAIN;
+  constexpr int NDW = G::NDW, NDY = G::NDY, MAXF = G::MAXF;
   constexpr int OC = CV3 ? 2 * CH : CH;            // channels this block stores
   constexpr int OP = OC + 8;                       // pitch of the staged output tile
-  static_assert(PX * OP <= LDS_MAIN, "output tile fits the staging buffers");
+  constexpr int NOS = PX * OP <= LDS_MAIN ? 1 : 2; // the output tile is staged in this many passes of PX / NOS pixels
+  constexpr int PXH = PX / NOS;
+  static_assert(PXH * OP <= LDS_MAIN && (NPF / NOS) % PXF == 0, "output tile fits the staging buffers");
   constexpr int N2 = NCH, N3 = 9 * NCH, N4 = CV3 ? 4 * NCH : 0;   // weight steps of the three stages
   constexpr int NSTEP = N2 + N3 + N4;
-  constexpr int MAXF = NW == 4 ? 2 : 1;            // haloed pixel fragments a wave owns in S2 (6 fragments over NW waves)
   __shared__ __attribute__((aligned(16))) half_t lds[LDS_MAIN + 8 * CH];
   float* bias_s = (float*)(lds + LDS_MAIN);        // [0,CH) m.cv1, [CH,2CH) m.cv2, [2CH,4CH) cv3
 
   const int t = threadIdx.x;
   const int lane = t & 63;
   const int w = __builtin_amdgcn_readfirstlane(t >> 6);
-  const int wn = w >> 2, wm = w & 3;
+  const int wn = w / WM, wm = w % WM;
   const int l31 = lane & 31, khalf = lane >> 5;
 
   // ---- block -> (page, patch); XCD-aware: each XCD gets a contiguous run of patches (shared halos share an L2)
@@ -98,7 +120,9 @@ __global__ __launch_bounds__(CH * 4, 4) void c3b_kernel(C3bArgs a) {
   const int b = v / tilesY;
   const int y0 = tpy * BH, x0 = tpx * BW;
 
-  bias_s[t] = t < CH ? a.bm1[t] : t < 2 * CH ? a.bm2[t - CH] : (CV3 ? a.bc3[t - 2 * CH] : 0.f);
+#pragma unroll
+  for (int i = t; i < 4 * CH; i += NTHR)
+    bias_s[i] = i < CH ? a.bm1[i] : i < 2 * CH ? a.bm2[i - CH] : (CV3 ? a.bc3[i - 2 * CH] : 0.f);
 
   using gptr_t = const __attribute__((address_space(1))) void*;
   using lptr_t = __attribute__((address_space(3))) void*;
@@ -110,10 +134,14 @@ __global__ __launch_bounds__(CH * 4, 4) void c3b_kernel(C3bArgs a) {
     return r < HROWS && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
   };
 
-  // ---- weights: one 16-B piece per thread and step; steps run m.cv1's K chunks, the 3x3's (chunk, tap) tiles in the
+  // ---- weights: NDW 16-B pieces per thread and step; steps run m.cv1's K chunks, the 3x3's (chunk, tap) tiles in the
   // order of the unfused dispatch, then cv3's tiles -- all CH-row pieces of the implicit-GEMM packing
-  const int wrow = t >> 2, wpos = t & 3;
-  const int woff = wrow * 32 + ((wpos ^ swz(wrow)) * 8);
+  int woff[NDW];
+#pragma unroll
+  for (int d = 0; d < NDW; ++d) {
+    const int piece = d * NTHR + t, wrow = piece >> 2, wpos = piece & 3;
+    woff[d] = wrow * 32 + ((wpos ^ swz(wrow)) * 8);
+  }
   half_t* const ring = lds + RING;
   auto dma_w = [&](auto g_tag) {
     constexpr int g = decltype(g_tag)::value;
@@ -124,12 +152,13 @@ __global__ __launch_bounds__(CH * 4, 4) void c3b_kernel(C3bArgs a) {
       const int tile = a.tap_major ? s : (s % 9) * NCH + s / 9;
       src = a.wm2 + (size_t)tile * SLOT;
     } else src = a.wc3 + (size_t)(g - N2 - N3) * SLOT;
-    dma(src + woff, ring + (g % 3) * SLOT + w * 64 * 8);
+#pragma unroll
+    for (int d = 0; d < NDW; ++d) dma(src + woff[d], ring + (g % 3) * SLOT + (d * NTHR + w * 64) * 8);
   };
 
-  // ---- prologue: the haloed patch of y1 (6 pieces per thread), the first two weight tiles
+  // ---- prologue: the haloed patch of y1 (NDY pieces per thread), the first two weight tiles
 #pragma unroll
-  for (int j = 0; j < 6; ++j) {
+  for (int j = 0; j < NDY; ++j) {
     const int Q = j * NTHR + t;
     const int plane = Q / (NROW * 4), q = Q - plane * (NROW * 4);
     const int r = q >> 2, pos = q & 3;
@@ -147,12 +176,16 @@ __global__ __launch_bounds__(CH * 4, 4) void c3b_kernel(C3bArgs a) {
   __syncthreads();   // waits for the LDS-DMAs (vmcnt 0) first
 
   // ---- fragment addressing
-  // patch fragment of this wave = patch rows 2 wm, 2 wm + 1; the second row's lanes are rotated by HW - 16 columns so the
-  // 16-lane ds_read_b128 groups meet 16 distinct bank slots (kernels_halo.hip)
-  const int prow = 2 * wm + (l31 >> 4);
+  // patch fragment j of this wave = patch rows 2 (wm PXF + j), + 1; the second row's lanes are rotated by HW - 16 columns
+  // so the 16-lane ds_read_b128 groups meet 16 distinct bank slots (kernels_halo.hip)
   const int pcol = (l31 < 16) ? l31 : ((l31 - (HW - 16)) & 15);
-  const int pl = prow * BW + pcol;                          // pixel index in the patch
-  const int rowIn = (prow + 1) * HW + pcol + 1;             // its row in haloed coordinates (centre tap)
+  int prow[PXF], pl[PXF], rowIn[PXF];
+#pragma unroll
+  for (int j = 0; j < PXF; ++j) {
+    prow[j] = 2 * (wm * PXF + j) + (l31 >> 4);
+    pl[j] = prow[j] * BW + pcol;                          // pixel index in the patch
+    rowIn[j] = (prow[j] + 1) * HW + pcol + 1;             // its row in haloed coordinates (centre tap)
+  }
   auto ld = [&](const half_t* base, int row, int kc) { return *(const half8_t*)(base + row * 32 + ((kc ^ swz(row)) * 8)); };
   auto zero16 = [](float16_t& x) {
 #pragma unroll
@@ -167,7 +200,7 @@ __global__ __launch_bounds__(CH * 4, 4) void c3b_kernel(C3bArgs a) {
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (g + 2 < NSTEP) {
       dma_w(std::integral_constant<int, g + 2>{});
-      wait_vm_lgkm0<1>();
+      wait_vm_lgkm0<NDW>();
     } else {
       wait_vm_lgkm0<0>();
     }
@@ -183,17 +216,23 @@ __global__ __launch_bounds__(CH * 4, 4) void c3b_kernel(C3bArgs a) {
 
   // ================= S2: t = act(Wm1 y1) on the haloed patch, in place, zero outside the image =====================
   // the shortcut first: y1 at this wave's S3 pixels in accumulator layout (4 consecutive channels per lane and group)
-  half4_t sc[2][4];
+  half4_t sc[2][PXF][4];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int g = 0; g < 4; ++g)
-      sc[i][g] = *(const half4_t*)(lds + (wn * 2 + i) * PLANE + rowIn * 32 + ((g ^ swz(rowIn)) * 8) + 4 * khalf);
+    for (int j = 0; j < PXF; ++j)
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        sc[i][j][g] = *(const half4_t*)(lds + (wn * 2 + i) * PLANE + rowIn[j] * 32 + ((g ^ swz(rowIn[j])) * 8) + 4 * khalf);
 
-  const int f0 = w, f1 = w + NW;                           // haloed fragments of this wave (6 in all)
-  const bool has0 = f0 < 6, has1 = MAXF == 2 && f1 < 6;    // wave-uniform
-  const int rowA[2] = {32 * f0 + l31, 32 * f1 + l31};
   {
+    bool has[MAXF];                                          // wave-uniform: haloed fragments w, w + NW, ... of NFH
+    int rowA[MAXF];
+#pragma unroll
+    for (int f = 0; f < MAXF; ++f) {
+      has[f] = w + f * NW < NFH;
+      rowA[f] = 32 * (w + f * NW) + l31;
+    }
     float16_t acc[MAXF][NCH];
 #pragma unroll
     for (int f = 0; f < MAXF; ++f)
@@ -207,23 +246,23 @@ __global__ __launch_bounds__(CH * 4, 4) void c3b_kernel(C3bArgs a) {
       for (int kk = 0; kk < 2; ++kk) {
 #pragma unroll
         for (int n = 0; n < NCH; ++n) fw[n][kk] = ld(Wb, n * 32 + l31, kk * 2 + khalf);
-        if (has0) fx[0][kk] = ld(lds + kc * PLANE, rowA[0], kk * 2 + khalf);
-        if (MAXF == 2 && has1) fx[MAXF - 1][kk] = ld(lds + kc * PLANE, rowA[1], kk * 2 + khalf);
+#pragma unroll
+        for (int f = 0; f < MAXF; ++f)
+          if (has[f]) fx[f][kk] = ld(lds + kc * PLANE, rowA[f], kk * 2 + khalf);
       }
       step_sync(kc_tag);
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
-        for (int n = 0; n < NCH; ++n) {
-          if (has0) acc[0][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fw[n][kk], fx[0][kk], acc[0][n], 0, 0, 0);
-          if (MAXF == 2 && has1)
-            acc[MAXF - 1][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fw[n][kk], fx[MAXF - 1][kk], acc[MAXF - 1][n], 0, 0, 0);
-        }
+        for (int n = 0; n < NCH; ++n)
+#pragma unroll
+          for (int f = 0; f < MAXF; ++f)
+            if (has[f]) acc[f][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fw[n][kk], fx[f][kk], acc[f][n], 0, 0, 0);
     });
     // every wave's shortcut reads completed before the barrier of step 0; the rows written here are this wave's own
 #pragma unroll
     for (int f = 0; f < MAXF; ++f) {
-      if (f == 0 ? !has0 : !has1) continue;
+      if (!has[f]) continue;
       const int row = rowA[f];
       const bool keep = inside(row);   // the 3x3's zero padding pads t, not y1
 #pragma unroll
@@ -242,18 +281,23 @@ __global__ __launch_bounds__(CH * 4, 4) void c3b_kernel(C3bArgs a) {
 
   // ================= S3: b = [y1 +] act(Wm2 * t)  (3x3 over the haloed t) ==========================================
   // y2 (cv3's second K half) straight into registers: B-operand layout, 16 B per lane and K step of 16
-  half8_t y2r[CV3 ? NCH : 1][2];
+  half8_t y2r[CV3 ? NCH : 1][2][PXF];
   if constexpr (CV3) {
-    const int oy = min(y0 + prow, a.H - 1), ox = min(x0 + pcol, a.W - 1);
-    const half_t* p = (const half_t*)a.y2.ptr + ((size_t)(b * a.H + oy) * a.W + ox) * a.y2.pitch + khalf * 8;
 #pragma unroll
-    for (int kc = 0; kc < NCH; ++kc)
+    for (int j = 0; j < PXF; ++j) {
+      const int oy = min(y0 + prow[j], a.H - 1), ox = min(x0 + pcol, a.W - 1);
+      const half_t* p = (const half_t*)a.y2.ptr + ((size_t)(b * a.H + oy) * a.W + ox) * a.y2.pitch + khalf * 8;
 #pragma unroll
-      for (int kk = 0; kk < 2; ++kk) y2r[kc][kk] = *(const half8_t*)(p + kc * 32 + kk * 16);
+      for (int kc = 0; kc < NCH; ++kc)
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) y2r[kc][kk][j] = *(const half8_t*)(p + kc * 32 + kk * 16);
+    }
   }
-  float16_t acc3[2];
-  zero16(acc3[0]);
-  zero16(acc3[1]);
+  float16_t acc3[2][PXF];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < PXF; ++j) zero16(acc3[i][j]);
   static_for<0, N3>([&](auto s_tag) {
     constexpr int s = decltype(s_tag)::value;
     constexpr int g = N2 + s;
@@ -261,48 +305,69 @@ __global__ __launch_bounds__(CH * 4, 4) void c3b_kernel(C3bArgs a) {
     const int c = a.tap_major ? s % NCH : s / 9;
     const int tap = a.tap_major ? s / NCH : s % 9;
     const int ty = tap / 3, tx = tap - 3 * ty;
-    const int row = (prow + ty) * HW + pcol + tx;
     const half_t* Wb = ring + (g % 3) * SLOT + wn * 64 * 32;
-    half8_t fw[2][2], fx[2];
+    half8_t fw[2][2], fx[PXF][2];
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
 #pragma unroll
       for (int i = 0; i < 2; ++i) fw[i][kk] = ld(Wb, i * 32 + l31, kk * 2 + khalf);
-      fx[kk] = ld(lds + c * PLANE, row, kk * 2 + khalf);
+#pragma unroll
+      for (int j = 0; j < PXF; ++j) fx[j][kk] = ld(lds + c * PLANE, (prow[j] + ty) * HW + pcol + tx, kk * 2 + khalf);
     }
     step_sync(std::integral_constant<int, g>{});
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
-      for (int i = 0; i < 2; ++i) acc3[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fw[i][kk], fx[kk], acc3[i], 0, 0, 0);
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < PXF; ++j)
+          acc3[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fw[i][kk], fx[j][kk], acc3[i][j], 0, 0, 0);
   });
   // Every wave's reads of t completed before the last barrier: the image may be overwritten.  Shortcut: conv output
   // rounded to fp16, then added to y1 and rounded (the reference's half-precision `x + cv2(cv1(x))`, kernels_halo.hip).
-  half_t* const Os = lds;   // [128][OP]
+  half_t* const Os = lds;   // [PX / NOS][OP]
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const int n = (wn * 2 + i) * 32 + 8 * g + 4 * khalf;
-      const float4_t bv = *(const float4_t*)(bias_s + CH + n);
-      half4_t o;
+    for (int j = 0; j < PXF; ++j)
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const half_t u = (half_t)ctd_act_fast<ACT>(acc3[i][4 * g + e] + bv[e]);
-        o[e] = a.add ? (half_t)((float)u + (float)sc[i][g][e]) : u;
+      for (int g = 0; g < 4; ++g) {
+        const int n = (wn * 2 + i) * 32 + 8 * g + 4 * khalf;
+        const float4_t bv = *(const float4_t*)(bias_s + CH + n);
+        half4_t o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const half_t u = (half_t)ctd_act_fast<ACT>(acc3[i][j][4 * g + e] + bv[e]);
+          o[e] = a.add ? (half_t)((float)u + (float)sc[i][j][g][e]) : u;
+        }
+        if constexpr (CV3) *(half4_t*)(lds + (wn * 2 + i) * PLANE + pl[j] * 32 + ((g ^ swz(pl[j])) * 8) + 4 * khalf) = o;
+        else *(half4_t*)(Os + pl[j] * OP + n) = o;
       }
-      if constexpr (CV3) *(half4_t*)(lds + (wn * 2 + i) * PLANE + pl * 32 + ((g ^ swz(pl)) * 8) + 4 * khalf) = o;
-      else *(half4_t*)(Os + pl * OP + n) = o;
+
+  // 16-B channel-row stores of staged pixels [p0, p0 + PXH): OC / 8 lanes per pixel
+  auto store_tile = [&](int p0) {
+    constexpr int CPP = OC / 8, PPI = NTHR / CPP;
+    const int cch = t % CPP;
+#pragma unroll
+    for (int it = 0; it < PXH / PPI; ++it) {
+      const int p = it * PPI + t / CPP;
+      const int oy = y0 + ((p0 + p) >> 4), ox = x0 + ((p0 + p) & 15);
+      if (oy < a.H && ox < a.W)
+        *(half8_t*)((half_t*)a.dst + ((size_t)(b * a.H + oy) * a.W + ox) * a.pitchD + cch * 8) =
+            *(const half8_t*)(Os + p * OP + cch * 8);
     }
+  };
 
   // ================= S4: out = act(Wc3 [b ; y2]) ==================================================================
   if constexpr (CV3) {
     lds_fence();
-    float16_t acc4[2][2];
+    float16_t acc4[2][2][PXF];
 #pragma unroll
     for (int p = 0; p < 2; ++p)
 #pragma unroll
-      for (int i = 0; i < 2; ++i) zero16(acc4[p][i]);
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < PXF; ++j) zero16(acc4[p][i][j]);
     static_for<0, N4>([&](auto s_tag) {
       constexpr int s = decltype(s_tag)::value;
       constexpr int g = N2 + N3 + s;
@@ -310,58 +375,77 @@ __global__ __launch_bounds__(CH * 4, 4) void c3b_kernel(C3bArgs a) {
       constexpr int kc = CH == 64 ? s >> 1 : s & 7;
       constexpr int p = CH == 64 ? s & 1 : s >> 3;
       const half_t* Wb = ring + (g % 3) * SLOT + wn * 64 * 32;
-      half8_t fw[2][2], fx[2];
+      half8_t fw[2][2], fx[PXF][2];
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) fw[i][kk] = ld(Wb, i * 32 + l31, kk * 2 + khalf);
-        if constexpr (kc < NCH) fx[kk] = ld(lds + kc * PLANE, pl, kk * 2 + khalf);
-        else fx[kk] = y2r[kc - NCH][kk];
+#pragma unroll
+        for (int j = 0; j < PXF; ++j) {
+          if constexpr (kc < NCH) fx[j][kk] = ld(lds + kc * PLANE, pl[j], kk * 2 + khalf);
+          else fx[j][kk] = y2r[kc - NCH][kk][j];
+        }
       }
       step_sync(std::integral_constant<int, g>{});
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
         for (int i = 0; i < 2; ++i)
-          acc4[p][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fw[i][kk], fx[kk], acc4[p][i], 0, 0, 0);
+#pragma unroll
+          for (int j = 0; j < PXF; ++j)
+            acc4[p][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fw[i][kk], fx[j][kk], acc4[p][i][j], 0, 0, 0);
     });
     // every wave's reads of b and of the ring completed before the last barrier: the output tile may take their place
+    // (in NOS passes of PXH pixels when the whole patch does not fit)
 #pragma unroll
-    for (int p = 0; p < 2; ++p)
+    for (int h = 0; h < NOS; ++h) {
+      if (h > 0) __syncthreads();
+      if ((wm * PXF) / (NPF / NOS) == h) {              // wave-uniform: this wave's pixel fragments lie in pass h
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+        for (int p = 0; p < 2; ++p)
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const int n = (CH == 64 ? (p * 2 + i) * 32 : p * 128 + wn * 64 + i * 32) + 8 * g + 4 * khalf;
-          const float4_t bv = *(const float4_t*)(bias_s + 2 * CH + n);
-          half4_t o;
+          for (int i = 0; i < 2; ++i)
 #pragma unroll
-          for (int e = 0; e < 4; ++e) o[e] = (half_t)ctd_act_fast<ACT>(acc4[p][i][4 * g + e] + bv[e]);
-          *(half4_t*)(Os + pl * OP + n) = o;
-        }
-  }
-  __syncthreads();
-  // 16-B channel-row stores: OC / 8 lanes per pixel
-  constexpr int CPP = OC / 8, PPI = NTHR / CPP;
-  const int cch = t % CPP;
+            for (int j = 0; j < PXF; ++j)
 #pragma unroll
-  for (int it = 0; it < PX / PPI; ++it) {
-    const int p = it * PPI + t / CPP;
-    const int oy = y0 + (p >> 4), ox = x0 + (p & 15);
-    if (oy < a.H && ox < a.W)
-      *(half8_t*)((half_t*)a.dst + ((size_t)(b * a.H + oy) * a.W + ox) * a.pitchD + cch * 8) =
-          *(const half8_t*)(Os + p * OP + cch * 8);
+              for (int g = 0; g < 4; ++g) {
+                const int n = (CH == 64 ? (p * 2 + i) * 32 : p * 128 + wn * 64 + i * 32) + 8 * g + 4 * khalf;
+                const float4_t bv = *(const float4_t*)(bias_s + 2 * CH + n);
+                half4_t o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = (half_t)ctd_act_fast<ACT>(acc4[p][i][j][4 * g + e] + bv[e]);
+                *(half4_t*)(Os + (pl[j] - h * PXH) * OP + n) = o;
+              }
+      }
+      __syncthreads();
+      store_tile(h * PXH);
+    }
+  } else {
+    static_assert(CV3 || NOS == 1, "the bottleneck's own output is staged in one pass");
+    __syncthreads();
+    store_tile(0);
   }
 }
 
-template <int CH, bool CV3>
-void launch_act(const C3bArgs& a, dim3 grid, hipStream_t st) {
+template <int CH, int BH, int PXF, bool CV3>
+void launch_act(const C3bArgs& a, hipStream_t st) {
+  using G = Geo<CH, BH, PXF>;
+  const int tilesX = (a.W + BW - 1) / BW, tilesY = (a.H + BH - 1) / BH;
+  const dim3 grid((unsigned)(tilesX * tilesY * a.B), 1, 1), blk(G::NTHR);
   switch (a.act) {
-    case CTD_ACT_SILU: hipLaunchKernelGGL((c3b_kernel<CH, CTD_ACT_SILU, CV3>), grid, dim3(CH * 4), 0, st, a); break;
-    case CTD_ACT_LEAKY: hipLaunchKernelGGL((c3b_kernel<CH, CTD_ACT_LEAKY, CV3>), grid, dim3(CH * 4), 0, st, a); break;
-    default: hipLaunchKernelGGL((c3b_kernel<CH, CTD_ACT_RELU, CV3>), grid, dim3(CH * 4), 0, st, a); break;
+    case CTD_ACT_SILU: hipLaunchKernelGGL((c3b_kernel<CH, BH, PXF, CTD_ACT_SILU, CV3>), grid, blk, 0, st, a); break;
+    case CTD_ACT_LEAKY: hipLaunchKernelGGL((c3b_kernel<CH, BH, PXF, CTD_ACT_LEAKY, CV3>), grid, blk, 0, st, a); break;
+    default: hipLaunchKernelGGL((c3b_kernel<CH, BH, PXF, CTD_ACT_RELU, CV3>), grid, blk, 0, st, a); break;
   }
 }
+
+template <int CH, int BH, int PXF>
+void launch_cv3(const C3bArgs& a, hipStream_t st) {
+  if (a.cv3) launch_act<CH, BH, PXF, true>(a, st);
+  else launch_act<CH, BH, PXF, false>(a, st);
+}
+
+int patch_rows(const C3bArgs& a) { return a.ch == 64 && g_c3b_cfg64 == 1 ? 16 : 8; }
 
 }  // namespace
 
@@ -372,18 +456,18 @@ bool c3b_supported(const C3bArgs& a) {
   if (a.y1.H != a.H || a.y1.W != a.W) return false;
   if (a.cv3 && (a.y2.c != a.ch || a.y2.up || a.y2.pitch % 8 || a.y2.H != a.H || a.y2.W != a.W)) return false;
   if (a.act != CTD_ACT_SILU && a.act != CTD_ACT_LEAKY && a.act != CTD_ACT_RELU) return false;
-  const long long patches = (long long)a.B * ((a.H + BH - 1) / BH) * ((a.W + BW - 1) / BW);
-  return patches >= g_c3b_min_patches;
+  const int bh = patch_rows(a);
+  const long long patches = (long long)a.B * ((a.H + bh - 1) / bh) * ((a.W + BW - 1) / BW);
+  return patches >= g_c3b_min_patches * 8 / bh;   // the threshold counts 128-pixel patches
 }
 
 void launch_c3b(const C3bArgs& a, hipStream_t st) {
-  const int tilesX = (a.W + BW - 1) / BW, tilesY = (a.H + BH - 1) / BH;
-  const dim3 grid((unsigned)(tilesX * tilesY * a.B), 1, 1);
   if (a.ch == 64) {
-    if (a.cv3) launch_act<64, true>(a, grid, st);
-    else launch_act<64, false>(a, grid, st);
+    if (g_c3b_cfg64 == 1) launch_cv3<64, 16, 2>(a, st);
+    else if (g_c3b_cfg64 == 2) launch_cv3<64, 8, 2>(a, st);
+    else launch_cv3<64, 8, 1>(a, st);
   } else {
-    if (a.cv3) launch_act<128, true>(a, grid, st);
-    else launch_act<128, false>(a, grid, st);
+    if (g_c3b_cfg128 == 1) launch_cv3<128, 8, 2>(a, st);
+    else launch_cv3<128, 8, 1>(a, st);
   }
 }

@@ -74,6 +74,7 @@ class TextDetector:
         self._stage_tl = threading.local()
         self._copy_st, self._copy_lock = None, threading.Lock()
         self._pools = {}                                      # detect_stream's worker / loader pools, kept between calls
+        self._warmed = None                                   # the tail pool whose threads already hold their native tails
         self.backend = "hip"
         self.seg_rep = PP.SegRepresenter(thresh=0.3)          # inference.py:139
 
@@ -246,7 +247,7 @@ class TextDetector:
     @torch.no_grad()
     def detect_stream(self, batches: Iterable[Sequence[Page]], refine_mode=REFINEMASK_INPAINT,
                       keep_undetected_mask=False, workers: int = 3, depth: int = 4, engines: int = 1,
-                      loaders: int = 2, tail_split: int = 0, lazy: bool = True) -> Iterator[list]:
+                      loaders: int = 2, tail_split: int = 0, lazy: bool = False) -> Iterator[list]:
         """Yields `detect_batch(batch)` for every batch, in order, with up to `depth` batches in flight:
         the forward of the next batches is launched while `workers` threads run the tails of earlier ones.
         Host (numpy) pages are staged to the GPU by `loaders` threads up to `depth` batches ahead (`_stage`).
@@ -254,17 +255,20 @@ class TextDetector:
         `tail_split` cuts every batch's tail into that many page ranges, each a work item of its own for the workers
         (0 = one per worker): lower latency per batch and a shorter drain when the stream ends, for more, smaller
         native calls -- measured +6 % end to end at 32 pages per batch (2311 -> 2456 pages/s, 3 workers).
-        `lazy` (default): every page's blk_list is a `textblock.BlockList` -- the native records, complete on the host,
-        which builds the `TextBlock` objects when first iterated / indexed, on the consumer's thread; `lazy=False` builds
-        plain lists on the worker threads as `detect_batch` does (the workers then spend most of their time holding the
-        interpreter lock: 0.37 ms of Python per page against 0.3 ms of native work).
+        `lazy=False` (default): every page's blk_list is the reference's return type, a plain list of `TextBlock`s, built
+        on the worker threads as `detect_batch` does.  `lazy=True`: a `textblock.BlockList` instead -- the native records,
+        complete on the host, which builds the `TextBlock` objects when first iterated / indexed, on the consumer's thread
+        (not a `list`: no `append` / `sort` / `json.dumps`); for consumers that read the columnar records or only a few
+        pages' blocks it saves the workers ~0.1 ms of interpreter-lock time per page (+2 % end to end at 30 blocks a page).
         The pools stay alive between calls (`close()` stops them): each worker thread keeps a native tail object with a
         HIP stream and ~250 MB of device tables at 32 pages per batch."""
         # The pools live on the detector: their threads own the native `Tail` objects (a HIP stream, ~250 MB of
         # fixed-capacity device tables at 32 pages, pinned buffers) and the pinned staging rings, which a pool per call
         # would create and destroy every time.
         pool = self._pool("tail", workers)
-        self.warm_tails(pool, workers)                        # tail streams first, the upload stream after them
+        if self._warmed is not pool:                          # once per pool: its threads then hold their leases
+            self.warm_tails(pool, workers)                    # tail streams first, the upload stream after them
+            self._warmed = pool
         lpool = self._pool("load", loaders)
         pending = deque()
         engines = max(1, int(engines))
@@ -312,11 +316,21 @@ class TextDetector:
             self._pools[kind] = cur
         return cur[0]
 
-    def close(self) -> None:
-        """Stops `detect_stream`'s worker threads (their native tails and staging buffers go with them)."""
+    def close(self, drain: bool = False) -> None:
+        """Stops `detect_stream`'s worker threads.  Their pinned staging rings go with them; their native tails (a HIP
+        stream, ~250 MB of device tables at 32 pages per batch, pinned result buffers each) go back to the module's free
+        list for the next pipeline of this process to take over (`tail._Lease`: reuse keeps the process's stream count
+        inside the hardware queues) -- they are NOT freed unless `drain=True` (`tail.drain_free_tails`: for a process
+        that is done detecting on this device)."""
         for ex, _ in self._pools.values():
             ex.shutdown(wait=True)
         self._pools = {}
+        self._warmed = None
+        if drain:
+            from .tail import drain_free_tails
+            import gc
+            gc.collect()                                      # ended threads' thread-local leases return their tails
+            drain_free_tails(self.net.device)
 
     def __del__(self):
         try:

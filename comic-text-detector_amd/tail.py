@@ -16,7 +16,7 @@ import numpy as np
 import torch
 
 from . import _lib as L
-from .textblock import BLK_DTYPE, BlockList, TextBlock, blocks_from_records
+from .textblock import BLK_DTYPE, BlockList, TextBlock, blocks_from_batch, blocks_from_records
 
 
 def _pinned_u8(h: int, w: int) -> np.ndarray:
@@ -106,9 +106,10 @@ class Tail:
         extras = {"db_boxes": boxes, "db_scores": scores, "yolo": (yx, yc, np.round(yf, 3))}
         return blocks_from_records(recs, lines, dist, nb.value), extras
 
-    def _block_lists(self, B: int) -> List[BlockList]:
-        """The grouped blocks of every page of the last run: two native calls and three arrays for the batch, per-page
-        views of them wrapped as `BlockList`s (no per-block Python here)."""
+    def _block_lists(self, B: int, lazy: bool = True):
+        """The grouped blocks of every page of the last run: two native calls and three arrays for the batch; `lazy`:
+        per-page views of them wrapped as `BlockList`s (no per-block Python here), else the reference's lists of
+        `TextBlock`s, built for the whole batch in one conversion (`textblock.blocks_from_batch`)."""
         lib = self._lib
         cnt = np.empty((B, 5), np.int32)
         L.check(lib.ctd_tail_batch_counts(self._h, cnt.ctypes.data), "ctd_tail_batch_counts")
@@ -117,6 +118,8 @@ class Tail:
         lines = np.empty((max(nl, 1), 8), np.int32)
         dist = np.empty((max(nd, 1), 3), np.float64)
         L.check(lib.ctd_tail_batch_fetch(self._h, recs.ctypes.data, lines.ctypes.data, dist.ctypes.data), "ctd_tail_batch_fetch")
+        if not lazy:
+            return blocks_from_batch(recs, lines, dist, cnt[:, :3])
         ob = np.concatenate(([0], np.cumsum(cnt[:, 0]))).tolist()
         ol = np.concatenate(([0], np.cumsum(cnt[:, 1]))).tolist()
         od = np.concatenate(([0], np.cumsum(cnt[:, 2]))).tolist()
@@ -127,13 +130,16 @@ class Tail:
             lines_map: torch.Tensor, bitmap: torch.Tensor, conf_thresh=0.4, nms_thresh=0.35, box_thresh=0.6,
             refine: bool = True, refine_mode: int = 0, keep_undetected_mask: bool = False,
             ready_event: Optional[torch.cuda.Event] = None, want_extras: bool = False, records=None,
-            lazy: bool = False):
+            lazy: bool = False, pinned: bool = True):
         """metas[b] = (im_h, im_w, dw, dh); blks (B,rows,no) f32, mask_u8 (B,Hn,Wn) u8, lines_map (B,2,Hn,Wn) f32
         or its plane 0 (B,Hn,Wn), bitmap (B,Hn,Wn) u8 -- all on the GPU.  Returns per page
         (mask, mask_refined, blk_list[, extras]) as the reference's `TextDetector.__call__` does.
         records=(cap_blk, cap_line): every page's tuple is a `PageResult` whose `.record` is its gather record.
         lazy: blk_list is a `BlockList` (the native records; `TextBlock` objects are built when first accessed, by whoever
-        accesses them) instead of a list built here -- what `detect_stream`'s workers return."""
+        accesses them) instead of a list built here -- what `detect_stream`'s workers return.
+        pinned=False: the result arrays are ordinary (pageable) numpy arrays, as a C caller's malloc'ed buffers would be --
+        `ctd_hip.h` only asks for host memory; the native side then downloads with hipMemcpyAsync instead of the copy
+        kernel / DMA into page-locked memory (slower; exists so that the contract is tested)."""
         B = len(metas)
         for tns in (blks, mask_u8, lines_map, bitmap):
             if not tns.is_cuda:
@@ -163,8 +169,12 @@ class Tail:
         prm = L.CtdTailParams(conf_thresh, nms_thresh, box_thresh, 1000, 1.5, int(bool(refine)), int(refine_mode),
                               int(bool(keep_undetected_mask)), 0)
         # page-locked result arrays (torch's caching host allocator): the tail DMAs straight into them
-        masks = _pinned_pages([(m[0], m[1]) for m in metas])
-        refined = _pinned_pages([(m[0], m[1]) for m in metas]) if refine else [None] * B
+        if pinned:
+            masks = _pinned_pages([(m[0], m[1]) for m in metas])
+            refined = _pinned_pages([(m[0], m[1]) for m in metas]) if refine else [None] * B
+        else:
+            masks = [np.empty((m[0], m[1]), np.uint8) for m in metas]
+            refined = [np.empty((m[0], m[1]), np.uint8) for m in metas] if refine else [None] * B
         mptr = (C.c_void_p * B)(*[m.ctypes.data for m in masks])
         rptr = (C.c_void_p * B)(*[r.ctypes.data for r in refined]) if refine else None
         ev = C.c_void_p(ready_event.cuda_event) if ready_event is not None else None
@@ -177,13 +187,13 @@ class Tail:
             rec = np.empty((B, 4 + 12 * cb + 8 * cl), np.float64)
             L.check(self._lib.ctd_tail_pack_records(self._h, cb, cl, rec.ctypes.data), "ctd_tail_pack_records")
         out = []
-        lists = self._block_lists(B) if not want_extras else None
+        lists = self._block_lists(B, lazy) if not want_extras else None
         for b in range(B):
             if want_extras:
                 blk_list, extras = self._blocks(b, True)
                 r = (masks[b], refined[b], blk_list, extras)
             else:
-                r = (masks[b], refined[b], lists[b] if lazy else lists[b].to_list())
+                r = (masks[b], refined[b], lists[b])
             if rec is not None:
                 r = PageResult(r)
                 r.record = rec[b]
@@ -305,6 +315,25 @@ def release_thread_tail() -> None:
     pool = getattr(_tls, "pool", None)
     if pool:
         pool.clear()
+
+
+def drain_free_tails(device=None) -> int:
+    """Destroys the native tails waiting in the free list (those of `device`, or all): each holds a HIP stream, ~250 MB of
+    device tables at 32 pages per batch and its pinned buffers.  Tails leased to live threads are not touched.  A process
+    that is done with detection for good (or about to hand the GPU to something else) calls this after
+    `TextDetector.close()`; a process that will build another pipeline should NOT -- reused tails are what keeps the
+    stream count of the process inside the hardware queues (`_Lease`).  Returns how many were destroyed."""
+    with _free_lock:
+        if device is None:
+            gone = [t for ts in _free.values() for t in ts]
+            _free.clear()
+        else:
+            idx = torch.device(device).index or 0
+            gone = _free.pop(idx, [])
+    n = len(gone)
+    for t in gone:
+        t.__del__()
+    return n
 
 
 def live_tails() -> int:

@@ -208,6 +208,15 @@ class TextBlock:
 
 _TAIL_DEFAULTS = tuple((attr, default) for attr, _, default in _RECORD_TAIL)
 _TAIL_DICT = {attr: default for attr, default in _TAIL_DEFAULTS}          # "text" gets a fresh list per block
+# every attribute in the reference's creation order (the key order of `to_dict()`): the C builder copies this and fills in
+_TEMPLATE = dict.fromkeys(("xyxy", "lines", "vertical", "language", "font_size", "distance", "angle", "vec", "norm", "merged",
+                           "weight"))
+_TEMPLATE.update(_TAIL_DICT)
+
+try:                                   # csrc/pyblocks.c, built by csrc/Makefile next to libctd_hip.so
+    from . import _ctd_pyblocks as _PYB
+except ImportError:                    # not built (a source checkout before `make`): the Python loop below does the same
+    _PYB = None
 
 
 def _fast_block(xyxy, lines, language, vertical, font_size, distance, angle, vec, norm, merged, weight) -> TextBlock:
@@ -229,13 +238,14 @@ BLK_DTYPE = _BLK_DT = np.dtype([("xyxy", "<i4", (4,)), ("language", "<i4"), ("ve
 assert _BLK_DT.itemsize == C.sizeof(L.CtdBlk)
 
 
-def blocks_from_records(recs, lines: np.ndarray, dist: np.ndarray, n: Optional[int] = None) -> List[TextBlock]:
+def blocks_from_records(recs, lines: np.ndarray, dist: np.ndarray, n: Optional[int] = None, native: bool = True) -> List[TextBlock]:
     """Native records (`ctd_blk` array + line / distance pools) -> the reference's Python objects.
     `TextBlock.distance` is re-evaluated from its two operands with numpy's own arccos / sin
     (reference utils/textblock.py:327-328), so the record carries the bits the reference's numpy
     expression gives on this machine (csrc/host_group.cpp decided with libm's).
     Column-wise: the per-block Python work is one dict (the interpreter lock is what the tail workers of
-    `detect_stream` share, and a crowded page has 60+ blocks)."""
+    `detect_stream` share, and a crowded page has 60+ blocks) -- and with csrc/pyblocks.c built, one C loop
+    (`native=False` forces the Python loop: the two are compared in tests/test_textblock_helpers.py)."""
     if isinstance(recs, list):                       # a slice of a ctypes array is a list of struct copies
         n = len(recs)
         recs = (L.CtdBlk * max(n, 1))(*recs)
@@ -249,6 +259,13 @@ def blocks_from_records(recs, lines: np.ndarray, dist: np.ndarray, n: Optional[i
     else:
         dval = np.zeros((0,), np.float64)
     all_lines = lines.reshape(-1, 4, 2).tolist()
+    if _PYB is not None and native:
+        # one C loop over the columns (csrc/pyblocks.c): ~1 us per block instead of 3.7
+        return _PYB.build_blocks(TextBlock, _TEMPLATE, n, a["xyxy"].tolist(), all_lines, a["line_off"].tolist(),
+                                 a["n_lines"].tolist(), a["vertical"].tolist(), a["language"].tolist(), LANG_LIST,
+                                 a["font_size"].tolist(), a["font_is_float"].tolist(), dval, a["dist_off"].tolist(),
+                                 a["n_dist"].tolist(), a["angle"].tolist(), list(a["vec"].copy()), list(a["norm"]),
+                                 a["merged"].tolist(), list(a["weight"]))
     tail, new = _TAIL_DICT, TextBlock.__new__
     out = []
     # one row per block: plain Python values from .tolist() (C loops), np.float64 / (2,) float64 arrays where the
@@ -266,6 +283,43 @@ def blocks_from_records(recs, lines: np.ndarray, dist: np.ndarray, n: Optional[i
         t.__dict__ = d
         out.append(t)
     return out
+
+
+def blocks_from_batch(recs: np.ndarray, lines: np.ndarray, dist: np.ndarray, counts: np.ndarray) -> List[List[TextBlock]]:
+    """The `blk_list`s of EVERY page of a native tail run in one conversion: `recs` / `lines` / `dist` are the batch-wide
+    arrays of `ctd_tail_batch_fetch` (pages back to back, per-page offsets inside the records), `counts[b] = (blocks, lines,
+    distances)` of page b.  One pass over the columns and one C loop for the whole work item instead of one per page: the
+    fixed cost of a conversion (a dozen column extractions, the `distance` expression) is paid once.  Same objects as
+    `blocks_from_records` page by page (tests/test_textblock_helpers.py)."""
+    counts = np.asarray(counts).reshape(-1, 3)
+    B = len(counts)
+    nb = int(counts[:, 0].sum())
+    if nb == 0:
+        return [[] for _ in range(B)]
+    if _PYB is None:
+        ob = np.concatenate(([0], np.cumsum(counts[:, 0]))).tolist()
+        ol = np.concatenate(([0], np.cumsum(counts[:, 1]))).tolist()
+        od = np.concatenate(([0], np.cumsum(counts[:, 2]))).tolist()
+        return [blocks_from_records(recs[ob[b]: ob[b + 1]], lines[ol[b]: ol[b + 1]], dist[od[b]: od[b + 1]]) for b in range(B)]
+    a = recs[:nb]
+    nblk = counts[:, 0].astype(np.int64)
+    # the records' line / distance offsets are page-relative: shift them to the batch-wide pools
+    lbase = np.repeat(np.concatenate(([0], np.cumsum(counts[:-1, 1]))), nblk)
+    dbase = np.repeat(np.concatenate(([0], np.cumsum(counts[:-1, 2]))), nblk)
+    nd = int(counts[:, 2].sum())
+    if nd:
+        with np.errstate(divide="ignore", invalid="ignore"):
+            dval = np.abs(np.sin(np.arccos(np.ascontiguousarray(dist[:nd, 1]))) * np.ascontiguousarray(dist[:nd, 2]))
+    else:
+        dval = np.zeros((0,), np.float64)
+    nl = int(counts[:, 1].sum())
+    flat = _PYB.build_blocks(TextBlock, _TEMPLATE, nb, a["xyxy"].tolist(), lines[:nl].reshape(-1, 4, 2).tolist(),
+                             (a["line_off"] + lbase).tolist(), a["n_lines"].tolist(), a["vertical"].tolist(),
+                             a["language"].tolist(), LANG_LIST, a["font_size"].tolist(), a["font_is_float"].tolist(), dval,
+                             (a["dist_off"] + dbase).tolist(), a["n_dist"].tolist(), a["angle"].tolist(),
+                             list(a["vec"].copy()), list(a["norm"]), a["merged"].tolist(), list(a["weight"]))
+    ob = np.concatenate(([0], np.cumsum(nblk))).tolist()
+    return [flat[ob[b]: ob[b + 1]] for b in range(B)]
 
 
 class BlockList:

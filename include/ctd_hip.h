@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define CTD_ABI_VERSION 4
+#define CTD_ABI_VERSION 5
 
 /* ---- error codes ------------------------------------------------------ */
 #define CTD_OK 0
@@ -154,6 +154,12 @@ int32_t ctd_engine_n_ops(const ctd_engine* e);
 int ctd_engine_op_work(const ctd_engine* e, double* flops, double* bytes, int32_t* kernel_class);
 /* kernel_class: 0 = pointwise/pool/export, 1 = MFMA implicit-GEMM conv, 2 = MFMA convT,
  *               3 = direct (VALU) conv, 4 = fused stem / seg-final / db-up */
+
+/* ABI v5.  Name of the kernel op `op_index` launches under the CURRENT plan and tuning ("conv_halo3_kernel",
+ * "conv_igemm_kernel", "c3b_kernel", ...; "(fused)" for an op whose work another op's launch does): lets a test assert
+ * WHICH dispatch a parity comparison ran through (grid thresholds pick different kernels at B = 1 and B = 32).  `name` gets
+ * at most cap - 1 characters and a terminator.  Valid after a forward / profile of the shape in question. */
+int ctd_engine_op_kernel(const ctd_engine* e, int32_t op_index, char* name, int32_t cap);
 
 /* Runs one forward with a hipEvent pair around every op on `stream` and
  * returns the per-op milliseconds (synchronous). */

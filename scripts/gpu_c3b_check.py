@@ -34,11 +34,16 @@ def check():
         if o["dst"] >= 0:
             writer.setdefault(o["dst"], o["name"])
     bad = 0
-    for shape, halo_min in (((2, 256, 256), 1024), ((2, 256, 256), 1), ((1, 320, 448), 1), ((3, 128, 192), 1024)):
+    cases = [((2, 256, 256), 1024, 0, 0), ((2, 256, 256), 1, 0, 0), ((1, 320, 448), 1, 0, 0), ((3, 128, 192), 1024, 0, 0)]
+    for c64, c128 in ((1, 1), (2, 1)):                   # the other tilings of the kernel
+        cases += [((2, 256, 256), 1024, c64, c128), ((1, 320, 448), 1, c64, c128), ((3, 128, 192), 1, c64, c128)]
+    for shape, halo_min, c64, c128 in cases:
         g = torch.Generator().manual_seed(7)
         x = torch.rand((shape[0], 3, shape[1], shape[2]), generator=g).cuda()
         tune("c3b_min_patches", 1)
         tune("halo_min_patches", halo_min)
+        tune("c3b_cfg64", c64)
+        tune("c3b_cfg128", c128)
         res = {}
         for fuse in (7, 15):
             tune("fuse", fuse)
@@ -54,6 +59,8 @@ def check():
         tune("fuse", 15)
         tune("c3b_min_patches", 1024)
         tune("halo_min_patches", 1024)
+        tune("c3b_cfg64", 0)
+        tune("c3b_cfg128", 0)
         nd = 0
         for tid in sorted(res[7][1]):
             a, b = res[7][1][tid], res[15][1][tid]
@@ -61,11 +68,13 @@ def check():
                 d = np.abs(a.astype(np.float64) - b.astype(np.float64))
                 w = writer.get(tid, "?")
                 # tensors the fused program never writes (t of a fused bottleneck, y1 overwritten in place) differ by design
-                print(f"  shape {shape} halo_min {halo_min}: tensor {tid} ({names.get(tid, '')}, written by {w}) differs: "
-                      f"{int((d > 0).sum())} of {d.size} values, max |d| {np.nanmax(d):.4g}")
+                if os.environ.get("C3B_VERBOSE"):
+                    print(f"  shape {shape} halo_min {halo_min}: tensor {tid} ({names.get(tid, '')}, written by {w}) differs: "
+                          f"{int((d > 0).sum())} of {d.size} values, max |d| {np.nanmax(d):.4g}")
                 nd += 1
         same = all(torch.equal(u, v) for u, v in zip(res[7][0], res[15][0]))
-        print(f"shape {shape} halo_min_patches {halo_min}: network outputs identical: {same}; {nd} tensors differ")
+        print(f"shape {shape} halo_min_patches {halo_min} cfg64 {c64} cfg128 {c128}: network outputs identical: {same}; "
+              f"{nd} intermediate tensors differ (by design: y1 / t of fused bottlenecks)")
         bad += 0 if same else 1
     print("C3B CHECK", "PASS" if bad == 0 else "FAIL")
     return bad
@@ -75,10 +84,13 @@ def time_chains():
     ck = pkg.synth.make_checkpoint(0)
     be = pkg.backend.HipTextDetBackend(ck, device="cuda", precision="fp16")
     x = torch.randint(0, 256, (32, 1024, 1024, 3), dtype=torch.uint8, generator=torch.Generator().manual_seed(1)).cuda()
+    variants = [("unfused", 7, 0, 0), ("c3b 0/0", 15, 0, 0), ("c3b 1/0", 15, 1, 0), ("c3b 2/0", 15, 2, 0), ("c3b 0/1", 15, 0, 1),
+                ("c3b 1/1", 15, 1, 1)]
     rows = {}
-    for fuse, maxch in ((7, 128), (15, 64), (15, 128)):
+    for name, fuse, c64, c128 in variants:
         tune("fuse", fuse)
-        tune("c3b_max_ch", maxch)
+        tune("c3b_cfg64", c64)
+        tune("c3b_cfg128", c128)
         for _ in range(3):
             be.forward_u8(x)
         torch.cuda.synchronize()
@@ -86,38 +98,33 @@ def time_chains():
         for _ in range(5):
             p = be.profile(x)
             acc = p["ms"] if acc is None else acc + p["ms"]
-        rows[(fuse, maxch)] = (acc / 5, p["names"])
-    tune("fuse", 15)
-    tune("c3b_max_ch", 128)
-    names = rows[(7, 128)][1]
-    print(f"{'op':44s} {'unfused':>9s} {'c3b<=64':>9s} {'c3b<=128':>9s}")
-    tot = np.zeros(3)
-    chain = np.zeros(3)
-    for i, n in enumerate(names):
-        v = np.array([rows[k][0][i] for k in ((7, 128), (15, 64), (15, 128))])
-        tot += v
-        if ".m." in n or n.endswith("cv3.conv") or n.endswith(".cv3"):
-            chain += v
-        if v.max() > 0.02 and (abs(v[0] - v[2]) > 0.004 or abs(v[0] - v[1]) > 0.004):
-            print(f"{n:44s} {v[0]:9.4f} {v[1]:9.4f} {v[2]:9.4f}")
-    print(f"{'bottleneck + cv3 ops':44s} {chain[0]:9.4f} {chain[1]:9.4f} {chain[2]:9.4f}")
-    print(f"{'all ops (sum of per-op events)':44s} {tot[0]:9.4f} {tot[1]:9.4f} {tot[2]:9.4f}")
-    # back-to-back forwards (no per-op events)
-    for fuse, maxch in ((7, 128), (15, 64), (15, 128)):
-        tune("fuse", fuse)
-        tune("c3b_max_ch", maxch)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         for _ in range(5):
             be.forward_u8(x)
         torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(40):
             be.forward_u8(x)
         e1.record()
         torch.cuda.synchronize()
-        print(f"forward fuse={fuse} c3b_max_ch={maxch}: {e0.elapsed_time(e1) / 40:.3f} ms per 32 pages")
+        rows[name] = (acc / 5, p["names"], e0.elapsed_time(e1) / 40)
     tune("fuse", 15)
-    tune("c3b_max_ch", 128)
+    tune("c3b_cfg64", 0)
+    tune("c3b_cfg128", 0)
+    names = rows["unfused"][1]
+    print(f"{'op (ms per 32 pages)':44s} " + " ".join(f"{n:>9s}" for n, *_ in variants))
+    tot = np.zeros(len(variants))
+    chain = np.zeros(len(variants))
+    for i, n in enumerate(names):
+        v = np.array([rows[k][0][i] for k, *_ in variants])
+        tot += v
+        if ".m." in n or n.endswith("cv3.conv") or n.endswith(".cv3"):
+            chain += v
+        if ".m." in n and "cv1" in n and v.max() > 0.05:
+            print(f"{n:44s} " + " ".join(f"{q:9.4f}" for q in v))
+    print(f"{'bottleneck + cv3 ops':44s} " + " ".join(f"{q:9.4f}" for q in chain))
+    print(f"{'all ops (sum of per-op events)':44s} " + " ".join(f"{q:9.4f}" for q in tot))
+    print(f"{'forward, 40 back to back':44s} " + " ".join(f"{rows[k][2]:9.4f}" for k, *_ in variants))
 
 
 if __name__ == "__main__":

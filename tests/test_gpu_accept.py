@@ -86,6 +86,9 @@ def test_detector_end_to_end_vs_oracle(prec, size, shape):
         assert geo["lines_unexplained"] == 0 and geo["blocks_unexplained"] == 0
         assert nl["identical"] >= nl["ref"] - geo["lines_differing"] and nb["identical"] >= nb["ref"] - geo["blocks_differing"]
         assert nl["identical"] >= 0.5 * nl["ref"] and nb["identical"] >= 0.3 * nb["ref"]
+        # ... and an IoU floor NEXT TO the set statement: a regression that shifted most boxes while staying
+        # inside the band would keep "nothing unexplained" true; matched boxes must still sit where the reference's do
+        assert nl["mean_iou"] > 0.9 and nb["mean_iou"] > 0.9, (nl, nb)
         assert band["bitmap_flips_out_of_band"] == 0 and band["mask127_flips_out_of_band"] == 0
 
 

@@ -323,3 +323,77 @@ def test_host_pages_are_staged_through_pinned_memory():
                 np.testing.assert_array_equal(m, m1)
                 np.testing.assert_array_equal(r, r1)
                 blocks_equal(bl, bl1)
+
+
+@pytest.mark.parametrize("keep", [False, True])
+def test_pageable_result_arrays_of_small_pages(keep):
+    """`ctd_tail_run` promises to fill "host arrays": a C caller's malloc'ed masks are PAGEABLE.  Pages under 256 KB
+    (`tail_dma_min`) are downloaded by segments of the stage's copy kernel when the arrays are page-locked -- a kernel
+    store into pageable memory would be a memory fault, so such arrays must take the hipMemcpyAsync path.
+    Small pages, not back to back (separate numpy arrays), B = 3, both the same-size and the letterboxed (resized) form."""
+    p = pkg()
+    size = 256
+    det = detector(size)
+    for shapes in ([(size, size)] * 3, [(200, 180), (256, 256), (300, 212)]):
+        pages = [p.synth.text_like_page(sh, 40 + i, n_blocks=4) for i, sh in enumerate(shapes)]
+        job = det._forward(pages)
+        torch.cuda.synchronize()
+        tl = p.tail.thread_tail(det.net.device)
+        args = (job["gpu"], job["metas"], job["blks"], job["mask_u8"], job["lines_map"], job["bitmap"], det.conf_thresh,
+                det.nms_thresh, 0.6, True, 1 if keep else 0, keep, job["ev"])
+        ref = tl.run(*args)
+        got = tl.run(*args, pinned=False)
+        for (m0, r0, b0), (m1, r1, b1) in zip(ref, got):
+            np.testing.assert_array_equal(m0, m1)
+            np.testing.assert_array_equal(r0, r1)
+            blocks_equal(b0, b1)
+        assert any((r > 0).any() for _, r, _ in got)
+
+
+def _speckle_page(H, W, seed):
+    """7x7 dark squares on an 8-pixel grid (60 % of the cells): thousands of separate components per window that the merge
+    stage ACCEPTS (a square survives the 3x3 erosion as 5x5 > half of it); the raw mask misses 15 % of them."""
+    rng = np.random.RandomState(seed)
+    on = rng.rand(H // 8, W // 8) < 0.6
+    dark = np.zeros((H, W), bool)
+    for dy in range(7):
+        for dx in range(7):
+            dark[dy::8, dx::8][: on.shape[0], : on.shape[1]] |= on
+    page = np.full((H, W, 3), 235, np.uint8)
+    page[dark] = 20
+    page = (page.astype(int) + rng.randint(-12, 13, (H, W, 3))).clip(0, 255).astype(np.uint8)
+    mask = np.where(dark, 220, 0).astype(np.uint8)
+    drop = rng.rand(H // 8, W // 8) < 0.15
+    for dy in range(8):
+        for dx in range(8):
+            mask[dy::8, dx::8][: on.shape[0], : on.shape[1]][drop] = 0
+    return page, mask
+
+
+def test_fused_merge_rounds_equal_the_per_round_launches():
+    """`tw_accept_all_kernel` / `tw_holes_all_kernel` (one block per window for every merge round / every hole pass,
+    `tail_fused_rounds` = 1, the default) against the per-round launches they replaced (`tail_fused_rounds` = 0) on pages
+    built to overflow the fused kernels' LDS tables: page-sized windows over a speckle of 7x7 squares give every candidate
+    mask thousands of components (> 2048 keys per band, probe failures), i.e. the global-memory fallback inside the kernels
+    -- a branch the text-like pages of the other tests never reach.  Byte-identical refined masks, and equal to
+    the oracle on the smaller page."""
+    p = pkg()
+    L = p._lib
+    for (H, W), check_oracle in (((320, 448), True), ((960, 1024), False)):
+        page, mask = _speckle_page(H, W, 5)
+        boxes = [[2, 2, W - 2, H - 2], [0, 0, W // 2, H // 2], [W // 3, H // 4, W - 5, H - 9], [5, H // 2, W // 2, H - 1]]
+        blks = [p.textblock.TextBlock(b) for b in boxes]
+        out = {}
+        try:
+            for fused in (1, 0):
+                L.check(L.lib().ctd_tuning_set(b"tail_fused_rounds", fused), "ctd_tuning_set")
+                out[fused] = [p.textmask.refine_mask(page, mask, blks, mode, "cuda") for mode in (0, 1)]
+        finally:
+            L.check(L.lib().ctd_tuning_set(b"tail_fused_rounds", 1), "ctd_tuning_set")
+        for a, b in zip(out[1], out[0]):
+            np.testing.assert_array_equal(a, b)
+        assert (out[1][0] > 0).mean() > 0.2
+        if check_oracle:
+            rblks = [R.TextBlock(b) for b in boxes]
+            for mode in (0, 1):
+                np.testing.assert_array_equal(out[1][mode], R.refine_mask(page, mask, rblks, mode))

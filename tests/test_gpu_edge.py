@@ -88,9 +88,11 @@ def test_halo_kernel_forced_onto_small_maps_matches_oracle(shape):
     finally:
         L.check(L.lib().ctd_tuning_set(b"halo_min_patches", 1024), "ctd_tuning_set")
     assert not all(torch.equal(g, r) for g, r in zip(got, ref)), "the forced dispatch did not change any kernel"
-    assert float((got[1].cpu() - om).abs().max()) < 3e-2
-    assert float((got[2].cpu() - ol).abs().max()) < 3e-2
-    assert float((got[0].cpu()[..., 4:] - ob[..., 4:]).abs().max()) < 3e-2
+    # the fp16 golden tolerances of tests/test_gpu_net.py (2e-2 max, 2e-3 mean), not a looser bar for the forced dispatch
+    for g, o in ((got[1].cpu(), om), (got[2].cpu(), ol)):
+        d = (g - o).abs()
+        assert float(d.max()) < 2e-2 and float(d.mean()) < 2e-3, (float(d.max()), float(d.mean()))
+    assert float((got[0].cpu()[..., 4:] - ob[..., 4:]).abs().max()) < 2e-2
     # same arithmetic up to the summation order of the K walk
     assert float((got[1] - ref[1]).abs().max()) < 5e-3 and float((got[2] - ref[2]).abs().max()) < 5e-3
 
@@ -131,11 +133,14 @@ def _tune(key, value):
 @pytest.mark.parametrize("shape,u8", [((1, 64, 64), False), ((3, 128, 64), True), ((2, 320, 448), False),
                                       ((2, 1024, 1024), True), ((1, 1536, 1536), True)])
 def test_fused_blocks_equal_the_layer_per_launch_program_bit_for_bit(shape, u8):
-    """The multi-layer kernels of the fp16 engine (stem + layer 1, the 32-channel C3 block, SPPF's three pools;
+    """The multi-layer kernels of the fp16 engine (stem + layer 1, the 32-channel C3 block, SPPF's three pools, bit 8:
+    bottleneck + cv3 of the 64 / 128-channel C3 blocks of backbone, neck and heads -- kernels_c3b.hip;
     `ctd_tuning_set("fuse", mask)`) do the arithmetic of the launches they replace in the same order: every output
     of the network must be IDENTICAL with and without them -- interior and border patches, float and uint8 input,
-    maps smaller than one patch (the C3 kernel is forced onto them with c3_min_patches = 1).  (This test is what
-    found that the compiler rounded SiLU outputs once or twice depending on the kernel: ctd_common.h ctd_act_fast.)"""
+    maps smaller than one patch (the C3 kernels are forced onto them with c3_min_patches = c3b_min_patches = 1), and
+    for bit 8 both K walks of the 3x3 it absorbs (the halo kernel's, forced onto every map by halo_min_patches = 1,
+    and the implicit GEMM's).  (This test is what found that the compiler rounded SiLU outputs once or twice depending
+    on the kernel: ctd_common.h ctd_act_fast.)"""
     be = pkg().backend.HipTextDetBackend(checkpoint(0), device="cuda", precision="fp16")
     if u8:
         x = torch.randint(0, 256, (shape[0], shape[1], shape[2], 3), dtype=torch.uint8,
@@ -148,16 +153,27 @@ def test_fused_blocks_equal_the_layer_per_launch_program_bit_for_bit(shape, u8):
         _tune(b"fuse", 0)
         ref = run()
         _tune(b"c3_min_patches", 1)
+        _tune(b"c3b_min_patches", 1)
         outs = {}
-        for mask in (1, 2, 4, 6, 7):
+        for mask in (1, 2, 4, 6, 7, 8, 15):
             _tune(b"fuse", mask)
             outs[mask] = run()
+        _tune(b"halo_min_patches", 1)                   # the 3x3s (and ConvT phases) on the halo kernel everywhere
+        _tune(b"fuse", 0)
+        ref_h = run()
+        _tune(b"fuse", 8)
+        outs["8 + halo"] = run()
+        _tune(b"c3b_max_ch", 64)
+        outs["8 + halo, 64 only"] = run()
         torch.cuda.synchronize()
     finally:
-        _tune(b"fuse", 7)
+        _tune(b"fuse", 15)
         _tune(b"c3_min_patches", 1024)
+        _tune(b"c3b_min_patches", 1024)
+        _tune(b"c3b_max_ch", 128)
+        _tune(b"halo_min_patches", 1024)
     for mask, got in outs.items():
-        for i, (g, r) in enumerate(zip(got, ref)):
+        for i, (g, r) in enumerate(zip(got, ref_h if isinstance(mask, str) else ref)):
             assert torch.equal(g, r), f"fuse mask {mask}: output {i} differs from the unfused program " \
                                       f"(max |d| {float((g.float() - r.float()).abs().max()):.3g})"
 

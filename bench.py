@@ -87,12 +87,14 @@ def host_info() -> dict:
     return {"cpu_model": model, "logical_cpus": os.cpu_count(), "usable_cpus": avail}
 
 
-def thread_budget(world: int, pinned: bool = False) -> dict:
+def thread_budget(world: int, pinned: bool = False, host_cpus: int = 0) -> dict:
     """Host threads one rank may use: the usable cores divided by the ranks on this host (an 8-rank node runs 8 of these
     processes) -- or, once the rank is bound to its own CPUs (`affinity.apply`, N > 1), simply the CPUs it is bound to.
     Tail workers x native geometry threads + loaders + the launching thread must fit."""
     avail = host_info()["usable_cpus"]
     per_rank = max(4, avail if pinned else avail // max(1, world))
+    if pinned and host_cpus:
+        avail = host_cpus                                     # what the host offered before this rank bound itself
     workers = 4 if per_rank >= 16 else (3 if per_rank >= 8 else 2)     # a 4th worker is free since the tails' streams have the
     native = max(1, min(8, (per_rank - 2) // workers))                  # default priority (tail.hip g_tail_priority); dense pages gain 4 %
     return {"usable_cpus": avail, "per_rank": per_rank, "tail_workers": workers, "native_threads_per_worker": native}
@@ -873,10 +875,11 @@ def main() -> None:
     local_world = int(os.environ.get("LOCAL_WORLD_SIZE", world))
     pin = AFF.rank_cpus(local_rank % max(1, local_world), local_world,
                         gpu_of_rank=[0] * local_world if one_device else list(range(local_world)))
+    host_cpus = host_info()["usable_cpus"]
     pinned = bool(world > 1 and not args.no_pin and AFF.apply(pin["cpus"]))
     cpu_affinity = {"pinned": pinned, "numa_node": pin["node"], "source": pin["source"], "n_cpus": len(pin["cpus"]),
                     "cpus": f"{pin['cpus'][0]}..{pin['cpus'][-1]}" if pin["cpus"] else ""}
-    tb = thread_budget(world, pinned)
+    tb = thread_budget(world, pinned, host_cpus)
     if args.workers <= 0:
         args.workers = tb["tail_workers"]
     if args.tail_split <= 0:

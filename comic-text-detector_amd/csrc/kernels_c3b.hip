@@ -41,7 +41,7 @@ int g_c3b_max_ch = 128;               // widest hidden width the kernel takes ("
 // Tiling per hidden width (A/B knobs, "c3b_cfg64" / "c3b_cfg128"): 0 = 16x8 patch, wave tile 64 channels x 32 pixels (16
 // waves per CU); 1 = wave tile 64 channels x 64 pixels on a 16x16 patch (64 channels) / on the 16x8 patch with four waves
 // (128 channels): 8 waves per CU, a third fewer LDS reads per MFMA; 2 (64 channels only) = 16x8 patch, two waves of 64 x 64
-int g_c3b_cfg64 = 0, g_c3b_cfg128 = 0;
+int g_c3b_cfg64 = 0, g_c3b_cfg128 = 1;
 
 namespace {
 
@@ -53,6 +53,14 @@ template <int N> __device__ __forceinline__ void wait_vm_lgkm0() {
   if (N == 0) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   else if (N == 1) asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)" ::: "memory");
   else asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
+}
+
+// the activations of ctd_act_fast (same values for every input), written without a compare + select: leaky / relu as one
+// v_max -- the epilogues below are VALU-bound (PMC: 13 VALU instructions per MFMA before this)
+template <int ACT> __device__ __forceinline__ float act_c3b(float v) {
+  if (ACT == CTD_ACT_LEAKY) return fmaxf(v, 0.1f * v);
+  if (ACT == CTD_ACT_RELU) return fmaxf(v, 0.f);
+  return ctd_act_fast<ACT>(v);
 }
 
 template <int I, int N, class F> __device__ __forceinline__ void static_for(F&& f) {
@@ -128,9 +136,15 @@ __global__ __launch_bounds__((Geo<CH, BH, PXF>::NTHR), (Geo<CH, BH, PXF>::OCC)) 
   using lptr_t = __attribute__((address_space(3))) void*;
   auto swz = [](int row) { return (row >> 2) & 3; };
   auto dma = [&](const void* g, half_t* dst) { __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)dst, 16, 0, 0); };
-  auto inside = [&](int r) {   // haloed row r (18 per patch row) lies inside the image
-    const int hy = r / HW, hx = r - hy * HW;
-    const int iy = y0 - 1 + hy, ix = x0 - 1 + hx;
+  // haloed row r (18 per patch row): r / 18 == (r * 3641) >> 16 for r < 4096 (no integer division: ~40 VALU each)
+  auto row_yx = [&](int r, int& iy, int& ix) {
+    const int hy = (r * 3641) >> 16, hx = r - hy * HW;
+    iy = y0 - 1 + hy;
+    ix = x0 - 1 + hx;
+  };
+  auto inside = [&](int r) {   // ... lies inside the image
+    int iy, ix;
+    row_yx(r, iy, ix);
     return r < HROWS && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
   };
 
@@ -157,19 +171,36 @@ __global__ __launch_bounds__((Geo<CH, BH, PXF>::NTHR), (Geo<CH, BH, PXF>::OCC)) 
   };
 
   // ---- prologue: the haloed patch of y1 (NDY pieces per thread), the first two weight tiles
+  if constexpr ((NROW * 4) % NTHR == 0) {
+    // a plane is a whole number of passes of the block: a thread fetches the SAME rows of every plane -- row / validity /
+    // address once per pass, the planes 64 B apart
+    constexpr int PPP = NROW * 4 / NTHR;
 #pragma unroll
-  for (int j = 0; j < NDY; ++j) {
-    const int Q = j * NTHR + t;
-    const int plane = Q / (NROW * 4), q = Q - plane * (NROW * 4);
-    const int r = q >> 2, pos = q & 3;
-    const int hy = r / HW, hx = r - hy * HW;
-    const int iy = y0 - 1 + hy, ix = x0 - 1 + hx;
-    const void* g = inside(r) ? (const void*)((const half_t*)a.y1.ptr + ((size_t)(b * a.H + iy) * a.W + ix) * a.y1.pitch +
-                                               plane * 32 + ((pos ^ swz(r)) * 8))
-                              : a.zeros;
-    const int Q0 = j * NTHR + w * 64;             // the wave's first piece: a whole wave lies inside one plane
-    const int plane0 = Q0 / (NROW * 4), q0 = Q0 - plane0 * (NROW * 4);
-    dma(g, lds + plane0 * PLANE + q0 * 8);
+    for (int i = 0; i < PPP; ++i) {
+      const int q = i * NTHR + t, r = q >> 2, pos = q & 3;
+      int iy, ix;
+      row_yx(r, iy, ix);
+      const bool ok = r < HROWS && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+      const half_t* g0 = (const half_t*)a.y1.ptr + ((size_t)(b * a.H + iy) * a.W + ix) * a.y1.pitch + ((pos ^ swz(r)) * 8);
+#pragma unroll
+      for (int pn = 0; pn < NCH; ++pn)
+        dma(ok ? (const void*)(g0 + pn * 32) : a.zeros, lds + pn * PLANE + (i * NTHR + w * 64) * 8);
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < NDY; ++j) {
+      const int Q = j * NTHR + t;
+      const int plane = Q / (NROW * 4), q = Q - plane * (NROW * 4);
+      const int r = q >> 2, pos = q & 3;
+      int iy, ix;
+      row_yx(r, iy, ix);
+      const void* g = inside(r) ? (const void*)((const half_t*)a.y1.ptr + ((size_t)(b * a.H + iy) * a.W + ix) * a.y1.pitch +
+                                                 plane * 32 + ((pos ^ swz(r)) * 8))
+                                : a.zeros;
+      const int Q0 = j * NTHR + w * 64;             // the wave's first piece: a whole wave lies inside one plane
+      const int plane0 = Q0 / (NROW * 4), q0 = Q0 - plane0 * (NROW * 4);
+      dma(g, lds + plane0 * PLANE + q0 * 8);
+    }
   }
   dma_w(std::integral_constant<int, 0>{});
   dma_w(std::integral_constant<int, 1>{});
@@ -259,22 +290,31 @@ __global__ __launch_bounds__((Geo<CH, BH, PXF>::NTHR), (Geo<CH, BH, PXF>::OCC)) 
           for (int f = 0; f < MAXF; ++f)
             if (has[f]) acc[f][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fw[n][kk], fx[f][kk], acc[f][n], 0, 0, 0);
     });
-    // every wave's shortcut reads completed before the barrier of step 0; the rows written here are this wave's own
+    // every wave's shortcut reads completed before the barrier of step 0; the rows written here are this wave's own.
+    // Straight-line code: out-of-image rows are zeroed by a mask on the packed halves (a `keep ? x : 0` per value became an
+    // exec-mask branch per value)
 #pragma unroll
     for (int f = 0; f < MAXF; ++f) {
       if (!has[f]) continue;
       const int row = rowA[f];
-      const bool keep = inside(row);   // the 3x3's zero padding pads t, not y1
+      const unsigned km = inside(row) ? 0xffffffffu : 0u;   // the 3x3's zero padding pads t, not y1
+      const int sw = swz(row);
 #pragma unroll
-      for (int n = 0; n < NCH; ++n)
+      for (int n = 0; n < NCH; ++n) {
+        float4_t bv[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) bv[g] = *(const float4_t*)(bias_s + n * 32 + 8 * g + 4 * khalf);
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-          const float4_t bv = *(const float4_t*)(bias_s + n * 32 + 8 * g + 4 * khalf);
           half4_t o;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) o[e] = keep ? (half_t)ctd_act_fast<ACT>(acc[f][n][4 * g + e] + bv[e]) : (half_t)0.f;
-          *(half4_t*)(lds + n * PLANE + row * 32 + ((g ^ swz(row)) * 8) + 4 * khalf) = o;
+          for (int e = 0; e < 4; ++e) o[e] = (half_t)act_c3b<ACT>(acc[f][n][4 * g + e] + bv[g][e]);
+          uint2 u = __builtin_bit_cast(uint2, o);
+          u.x &= km;
+          u.y &= km;
+          *(uint2*)(lds + n * PLANE + row * 32 + ((g ^ sw) * 8) + 4 * khalf) = u;
         }
+      }
     }
   }
   lds_fence();
@@ -337,7 +377,7 @@ __global__ __launch_bounds__((Geo<CH, BH, PXF>::NTHR), (Geo<CH, BH, PXF>::OCC)) 
         half4_t o;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const half_t u = (half_t)ctd_act_fast<ACT>(acc3[i][j][4 * g + e] + bv[e]);
+          const half_t u = (half_t)act_c3b<ACT>(acc3[i][j][4 * g + e] + bv[e]);
           o[e] = a.add ? (half_t)((float)u + (float)sc[i][j][g][e]) : u;
         }
         if constexpr (CV3) *(half4_t*)(lds + (wn * 2 + i) * PLANE + pl[j] * 32 + ((g ^ swz(pl[j])) * 8) + 4 * khalf) = o;
@@ -413,7 +453,7 @@ __global__ __launch_bounds__((Geo<CH, BH, PXF>::NTHR), (Geo<CH, BH, PXF>::OCC)) 
                 const float4_t bv = *(const float4_t*)(bias_s + 2 * CH + n);
                 half4_t o;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) o[e] = (half_t)ctd_act_fast<ACT>(acc4[p][i][j][4 * g + e] + bv[e]);
+                for (int e = 0; e < 4; ++e) o[e] = (half_t)act_c3b<ACT>(acc4[p][i][j][4 * g + e] + bv[e]);
                 *(half4_t*)(Os + (pl[j] - h * PXH) * OP + n) = o;
               }
       }

@@ -211,6 +211,8 @@ def test_bench_four_ranks_tail_only_on_one_device():
     out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     assert out["n_gpus"] == 4 and out["config"]["global_batch"] == 16 and out["config"]["tail_only"] is True
     assert out["config"]["host_threads"]["per_rank"] * 4 <= max(16, out["config"]["host_threads"]["usable_cpus"])
+    aff = out["config"]["cpu_affinity"]                  # every rank bound to its own CPUs of the GPU's NUMA node (affinity.py)
+    assert aff["pinned"] is True and aff["n_cpus"] >= 1 and aff["n_cpus"] * 4 <= max(4, out["config"]["host_threads"]["usable_cpus"])
     assert out["value"] > 0 and out["config"]["blocks_per_page"] > 0 and out["config"]["host_cpu_cores_used"] > 0
 
 

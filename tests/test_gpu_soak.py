@@ -34,7 +34,7 @@ def one_pass(p, ck, batches, other):
     del det
     gc.collect()
     assert n_blocks > 0
-    return STEPS * B / dt
+    return STEPS * B / dt, p.tail.live_tails()
 
 
 def test_rate_survives_repeated_create_stream_close_with_two_detectors():
@@ -53,14 +53,16 @@ def test_rate_survives_repeated_create_stream_close_with_two_detectors():
     gc.collect()
     gc.freeze()
     try:
-        rates = [one_pass(p, ck, batches, other) for _ in range(5)]
+        passes = [one_pass(p, ck, batches, other) for _ in range(5)]
     finally:
         gc.unfreeze()
-    tails = p.tail.live_tails()
-    print(f"\nsoak: pages/s per pass {[round(r) for r in rates]}; live native tails {tails}")
+    rates, tails = [r for r, _ in passes], [n for _, n in passes]
+    print(f"\nsoak: pages/s per pass {[round(r) for r in rates]}; live native tails after each pass {tails}")
     # one-sided: the failure mode is a process that got slower.  5 % is the round's stated bar; passes of 0.6 s each on a
     # shared box scatter by 2-3 %
     assert rates[-1] >= 0.95 * rates[0], rates
     assert min(rates[1:]) >= 0.93 * rates[0], rates
-    assert tails <= WORKERS + 2, tails                    # reused, not accumulated (workers + the main thread's + slack)
+    # reused, not accumulated: the count stops growing once a pool's worth exists (a pass may start before the previous
+    # pool's thread-local leases have been returned, so the plateau can be up to two pools + the main thread's)
+    assert tails[-1] <= tails[1] and tails[-1] <= 2 * WORKERS + 2, tails
     other.close(drain=True)

@@ -58,6 +58,14 @@ struct ConvArgs {
   const void* w2;          // split kernel (kernels_split.hip): the lo plane of the weights (`w` is the hi plane)
   const float* oscale;     // split kernel: per output channel 1 / (power of two its weights were scaled by), padded to Npad
   int prio;                // 1: the kernel raises its waves' issue priority (s_setprio): the forward's kernels against a co-running tail
+  // kernels_halo3.hip, 128-channel ConvTranspose phases only: a pointwise (1x1) conv that is this layer's ONLY consumer runs on
+  // the block's output tile before it leaves the CU (post_w != null); this layer's own output is then never stored.
+  //   out2 = act2(W2 . [x ; this layer's output] + b2),  x = post_x: an optional second source AHEAD of it in the concat
+  const void* post_w;      // W2 in the implicit-GEMM packing [1][(post_x.c + 128) / 32][post_n][32] (post_n = 64 or 128)
+  const float* post_bias;  // padded to post_n
+  void* post_dst;          // (B, oH, oW, post_pitch) fp16, post_n channels written, already offset by the channel offset
+  int post_pitch, post_n, post_act;
+  SrcView post_x;          // c == 0 when unused; at the OUTPUT resolution of this layer, not upsampled
   int x_sp, d_sp, r_sp;    // split kernel: sources / destination / residual are SPLIT-PLANE tensors (kernels_split.hip): per pixel
                            // and 32-channel group 32 hi halves then 32 lo halves, in the 128 B the 32 floats would occupy
 };

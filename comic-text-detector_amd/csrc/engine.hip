@@ -63,6 +63,8 @@ struct OpState {
   bool sppf_head = false; // first of SPPF's three chained max pools: one launch does all three
   bool stem2_head = false; // STEM op that also computes the following 3x3/s2 conv (which is `skip`)
   bool stemsp_head = false; // fp32s: first conv reads the network input itself (kernels_split_stem.hip); its INPUT op is `skip`
+  bool post_head = false; // 128-channel ConvTranspose whose single consumer, the next op (a 1x1 conv), runs on its output tile
+  ConvArgs post_args{};   // ... its arguments with post_* filled (kernels_halo3.hip)
   bool c3b_head = false;  // m.cv1 of a 64 / 128-channel bottleneck: launches kernels_c3b.hip for [m.cv1, m.cv2 (+ cv3)]
   int c3b_conv3 = -1;     // ... index of that bottleneck's 3x3 op (its dispatch decides the K walk, at launch time)
   Stem2Args st2{};
@@ -504,6 +506,29 @@ int plan(ctd_engine* e, int B, int H, int W, hipStream_t cap_stream = nullptr) {
     td.first_def = std::min(td.first_def, i + 1 + 2 * (n - 1));
     i = j;
   }
+  // (after the C3 chains: their match wants the 1x1's output still defined by the 1x1)
+  // ---- a 128-channel ConvTranspose followed by its ONLY consumer, a 1x1 conv over it (or over [x ; it], x <= 64 channels):
+  // one launch of kernels_halo3.hip writes the 1x1's output, at the ConvTranspose's position -- so that tensor is alive
+  // from there on.  (UNet: upconv4.conv.1 -> upconv5.conv.0.cv1+cv2 over [f160 ; u160]; DB head: upconv4.conv.1 -> conv.0.)
+  std::vector<int> posts;
+  for (int i = 0; e->prec == CTD_PREC_F16 && i + 1 < nO; ++i) {
+    const OpState &T = e->ops[i], &P = e->ops[i + 1];
+    const ctd_op &t = T.op, &p = P.op;
+    if (t.kind != CTD_OP_CONVT || T.impl != IMPL_IGEMM_T || t.cout != 128 || t.dst_coff != 0 || T.bk != 32 || !e->w_tiled) continue;
+    const int U = t.dst;
+    if (e->tensors[U].t.channels != 128 || e->tensors[U].first_def != i || e->tensors[U].last_use != i + 1 || e->tensors[U].esize != 2)
+      continue;
+    if (p.kind != CTD_OP_CONV || P.impl != IMPL_IGEMM || P.bk != 32 || p.k != 1 || p.stride != 1 || p.res >= 0) continue;
+    if (!(p.cout == 64 || p.cout == 128) || P.npad != p.cout || e->tensors[p.dst].esize != 2 || p.dst == U) continue;
+    const bool alone = p.src0 == U && p.src0_coff == 0 && p.src0_c == 128 && !p.src0_up && p.src1 < 0;
+    const bool second = p.src1 == U && p.src1_coff == 0 && p.src1_c == 128 && !p.src1_up && p.src0 != U && !p.src0_up &&
+                        p.src0_c % 32 == 0 && p.src0_c <= 64 && e->tensors[p.src0].esize == 2 &&
+                        e->tensors[p.src0].first_def >= 0 && e->tensors[p.src0].first_def < i;
+    if (!alone && !second) continue;
+    posts.push_back(i);
+    TensorState& td = e->tensors[p.dst];
+    td.first_def = std::min(td.first_def, i);
+  }
 
   // first-fit allocation over a free list, in op order
   struct Blk { size_t off, size; };
@@ -702,7 +727,7 @@ int plan(ctd_engine* e, int B, int H, int W, hipStream_t cap_stream = nullptr) {
                 (double)a.N * o.k * o.k * cin * es;
     }
     s.args = a;
-    s.c3_head = s.skip = s.sppf_head = s.stem2_head = s.stemsp_head = s.c3b_head = false;
+    s.c3_head = s.skip = s.sppf_head = s.stem2_head = s.stemsp_head = s.c3b_head = s.post_head = false;
     s.c3b_conv3 = -1;
   }
   // ---- fp32s: INPUT (page -> fp32 NHWC, zero 4th channel) + the 6x6/s2 first conv -> one launch that reads the page itself
@@ -806,6 +831,26 @@ int plan(ctd_engine* e, int B, int H, int W, hipStream_t cap_stream = nullptr) {
     Bo.bytes = C.bytes = D.bytes = 0;
     i += 3;
   }
+  // ---- ConvTranspose + its 1x1 consumer (found above)
+  for (int i : posts) {
+    if (!(g_fuse & 16)) break;
+    OpState &T = e->ops[i], &P = e->ops[i + 1];
+    ConvArgs a = T.args;
+    a.post_w = P.w_dev;
+    a.post_bias = P.b_dev;
+    a.post_dst = P.args.dst;
+    a.post_pitch = P.args.pitchD;
+    a.post_n = P.op.cout;
+    a.post_act = P.op.act;
+    a.post_x = SrcView{};
+    if (P.op.src1 >= 0) a.post_x = P.args.s0;
+    if (P.args.oH != T.args.oH || P.args.oW != T.args.oW || !conv_halo3_post_supported(a)) continue;
+    T.post_head = true;
+    T.post_args = a;
+    P.skip = true;
+    T.flops += P.flops; T.bytes += P.bytes;
+    P.flops = P.bytes = 0;
+  }
   // ---- the wider C3 blocks found above: one launch per bottleneck, the last one with cv3 (kernels_c3b.hip)
   for (const C3Chain& ch : chains) {
     if (!(g_fuse & 8)) break;
@@ -859,7 +904,7 @@ int plan(ctd_engine* e, int B, int H, int W, hipStream_t cap_stream = nullptr) {
     }
     (void)d;
   }
-  e->p_fuse = g_fuse + 16 * g_fuse_epoch;
+  e->p_fuse = g_fuse + 64 * g_fuse_epoch;
   e->pB = B; e->pH = H; e->pW = W;
   return CTD_OK;
 }
@@ -917,6 +962,13 @@ int launch_op(ctd_engine* e, int i, const Outs& x, hipStream_t st) {
       else launch_conv_direct(s.args, f16, st);
       break;
     case CTD_OP_CONVT:
+      if (s.post_head) {
+        if (conv_halo3_post_supported(s.post_args)) { launch_conv_igemm(s.post_args, false, st); break; }
+        // a tuning key has taken the big-tile kernel away since the plan was made: the two layers, one launch each
+        launch_conv_igemm(s.args, false, st);
+        launch_conv_igemm(e->ops[i + 1].args, false, st);
+        break;
+      }
       if (s.impl == IMPL_IGEMM_T && s.split) launch_conv_split(s.args, st);
       else if (s.impl == IMPL_IGEMM_T && !f16) launch_conv_f32_mfma(s.args, st);
       else if (s.impl == IMPL_IGEMM_T) launch_conv_igemm(s.args, false, st);
@@ -988,7 +1040,7 @@ int launch_op(ctd_engine* e, int i, const Outs& x, hipStream_t st) {
 
 int prepare(ctd_engine* e, int B, int H, int W, hipStream_t st = nullptr) {
   HIP_TRY(hipSetDevice(e->device));
-  if (B != e->pB || H != e->pH || W != e->pW || e->p_fuse != g_fuse + 16 * g_fuse_epoch) return plan(e, B, H, W, st);
+  if (B != e->pB || H != e->pH || W != e->pW || e->p_fuse != g_fuse + 64 * g_fuse_epoch) return plan(e, B, H, W, st);
   return CTD_OK;
 }
 
@@ -1114,6 +1166,7 @@ int ctd_engine_op_kernel(const ctd_engine* e, int32_t i, char* name, int32_t cap
     if (s.skip) return "(fused)";
     if (s.c3_head) return "c3_fused_kernel";
     if (s.c3b_head) return "c3b_kernel";
+    if (s.post_head && conv_halo3_post_supported(s.post_args)) return "conv_halo3_kernel+1x1";
     if (s.stemsp_head) return "stem_split_kernel";
     const bool mfma = s.impl == IMPL_IGEMM || s.impl == IMPL_IGEMM_T;
     if (mfma && s.split) return conv_split_halo_supported(s.args) ? "conv_split_halo_kernel" : "conv_split_kernel";

@@ -89,6 +89,7 @@ int halo2_tuning_set(const char* key, long long value);
 extern long long g_halo3;              // 0 disables ("halo3")
 extern long long g_halo3_min_blocks;   // "halo3_min_blocks"
 bool conv_halo3_supported(const ConvArgs& a, bool dst_f32);
+bool conv_halo3_post_supported(const ConvArgs& a);   // `a` carries post_*: the layer + its single 1x1 consumer in one launch
 void launch_conv_halo3(const ConvArgs& a, hipStream_t st);
 int halo3_tuning_set(const char* key, long long value);
 

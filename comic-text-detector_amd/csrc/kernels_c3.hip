@@ -321,9 +321,9 @@ __global__ __launch_bounds__(256, 2) void c3_fused_kernel(C3Args a) {
 }  // namespace
 
 // Multi-layer fusions of the fp16 engine, one bit each: 1 = C3 block (this file), 2 = SPPF's three pools
-// (kernels_basic.hip), 4 = stem + model.1 (kernels_fused.hip), 8 = bottleneck + cv3 of the wider C3 blocks (kernels_c3b.hip).  ctd_tuning_set("fuse", 0) runs the layer-per-launch
+// (kernels_basic.hip), 4 = stem + model.1 (kernels_fused.hip), 8 = bottleneck + cv3 of the wider C3 blocks (kernels_c3b.hip), 16 = a 128-channel ConvTranspose + its single 1x1 consumer (kernels_halo3.hip).  ctd_tuning_set("fuse", 0) runs the layer-per-launch
 // program (the bit-identity tests and A/B runs use it).
-int g_fuse = 15;
+int g_fuse = 31;
 
 long long g_c3_min_patches = 1024;   // fewer 128-pixel patches: the per-layer kernels (ctd_tuning_set("c3_min_patches"))
 

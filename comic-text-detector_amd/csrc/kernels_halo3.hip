@@ -49,7 +49,12 @@ template <int N> __device__ __forceinline__ void wait_vm_lgkm0() {
 }
 
 // NPH: phases per block (2: N = 64, the px pair; 1: N >= 128).  NT: 128-column tiles per phase (2: N = 256).
-template <int NPH, int NT>
+// POST (NPH = 1, NT = 1 only): the layer's single consumer, a 1x1 conv with N2 = 64 or 128 output channels (optionally over
+// the concat [x ; this layer's output]), runs on the block's staged output tile: the tile is the B operand of a second
+// GEMM whose A fragments come straight from HBM / L2 (the weight matrix is 16-48 KB and every block reads all of it), and
+// only out2 leaves the CU.  K order and epilogue arithmetic are the implicit-GEMM kernel's: bit-identical to the two
+// launches (tests/test_gpu_edge.py).
+template <int NPH, int NT, int N2 = 0>
 __global__ __launch_bounds__(NTHR, 2) void conv_halo3_kernel(ConvArgs a) {   // 2 blocks / CU = 2 waves / SIMD
   if (a.prio) __builtin_amdgcn_s_setprio(3);
   constexpr int CP = BN3 / NPH;                       // channels of a phase inside this block's columns (64 or 128)
@@ -274,6 +279,114 @@ __global__ __launch_bounds__(NTHR, 2) void conv_halo3_kernel(ConvArgs a) {   // 
     default: epilogue(std::integral_constant<int, CTD_ACT_NONE>{}); break;
   }
   __syncthreads();
+  if constexpr (N2 > 0) {
+    static_assert(NPH == 1 && NT == 1, "the post conv needs every channel of the layer in one block");
+    constexpr int NF2 = N2 / 32;
+    constexpr int OP2 = N2 + 8;
+    static_assert(BMH * OP2 <= LDS_MAIN, "out2 tile fits the staging region");
+    // wave w: tile rows (= patch pixels) 64 w .. 64 w + 63, every output channel
+    const int K0 = a.post_x.c;                              // channels of the concat ahead of this layer's: 0 or a multiple of 32
+    const int nk0 = K0 / BKH, nk = nk0 + BN3 / BKH;
+    const half_t* W2 = (const half_t*)a.post_w;
+    int r2[2];
+    size_t opx[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      r2[j] = (wave_u * 2 + j) * 32 + l31;
+      const int oy = (y0 + (r2[j] >> 4)) * 2 + py_b, ox = (x0 + (r2[j] & 15)) * 2 + (pg & 1);
+      opx[j] = ((size_t)b * a.oH + oy) * a.oW + ox;
+    }
+    auto load_a = [&](int kc, half8_t (&fa)[NF2][2]) {
+#pragma unroll
+      for (int i = 0; i < NF2; ++i)
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+          fa[i][kk] = *(const half8_t*)(W2 + ((size_t)kc * N2 + i * 32 + l31) * BKH + (kk * 2 + khalf) * 8);
+    };
+    auto load_b = [&](int kc, half8_t (&fb)[2][2]) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+          if (kc < nk0)   // the concat's first source, straight from HBM (wave-uniform branch)
+            fb[j][kk] = *(const half8_t*)((const half_t*)a.post_x.ptr + opx[j] * a.post_x.pitch + kc * BKH + (kk * 2 + khalf) * 8);
+          else
+            fb[j][kk] = *(const half8_t*)(Os + (size_t)r2[j] * OP + (kc - nk0) * BKH + (kk * 2 + khalf) * 8);
+        }
+    };
+    float16_t acc2[NF2][2];
+#pragma unroll
+    for (int i = 0; i < NF2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc2[i][j][r] = 0.f;
+    half8_t fa[2][NF2][2], fb[2][2][2];
+    load_a(0, fa[0]);
+    load_b(0, fb[0]);
+    for (int kc = 0; kc < nk; kc += 2) {                   // two chunks per trip: the double buffers keep static indices
+      if (kc + 1 < nk) {
+        load_a(kc + 1, fa[1]);
+        load_b(kc + 1, fb[1]);
+      }
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+        for (int i = 0; i < NF2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            acc2[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[0][i][kk], fb[0][j][kk], acc2[i][j], 0, 0, 0);
+      if (kc + 1 < nk) {
+        if (kc + 2 < nk) {
+          load_a(kc + 2, fa[0]);
+          load_b(kc + 2, fb[0]);
+        }
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+          for (int i = 0; i < NF2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+              acc2[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[1][i][kk], fb[1][j][kk], acc2[i][j], 0, 0, 0);
+      }
+    }
+    __syncthreads();                                        // every wave has read its rows of the layer's tile
+    half_t* Os2 = lds;                                      // [256][OP2]
+    auto epilogue2 = [&](auto act_tag) {
+      constexpr int ACT = decltype(act_tag)::value;
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int i = 0; i < NF2; ++i)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const int nl = i * 32 + 4 * hi + 8 * g;
+            const float4_t bv = *(const float4_t*)(a.post_bias + nl);
+            float vv[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) vv[e] = ctd_act_fast<ACT>(acc2[i][j][4 * g + e] + bv[e]);
+            half4_t o = {(half_t)vv[0], (half_t)vv[1], (half_t)vv[2], (half_t)vv[3]};
+            *(half4_t*)(Os2 + (size_t)r2[j] * OP2 + nl) = o;
+          }
+    };
+    switch (a.post_act) {
+      case CTD_ACT_SILU: epilogue2(std::integral_constant<int, CTD_ACT_SILU>{}); break;
+      case CTD_ACT_LEAKY: epilogue2(std::integral_constant<int, CTD_ACT_LEAKY>{}); break;
+      case CTD_ACT_RELU: epilogue2(std::integral_constant<int, CTD_ACT_RELU>{}); break;
+      default: epilogue2(std::integral_constant<int, CTD_ACT_NONE>{}); break;
+    }
+    __syncthreads();
+    constexpr int CPP2 = N2 / 8, PPI2 = NTHR / CPP2;        // 16-B chunks per pixel row; pixels per pass
+    const int c2 = t % CPP2;
+#pragma unroll
+    for (int it = 0; it < BMH / PPI2; ++it) {
+      const int r = it * PPI2 + t / CPP2;
+      const int oy = (y0 + (r >> 4)) * 2 + py_b, ox = (x0 + (r & 15)) * 2 + (pg & 1);
+      *(half8_t*)((half_t*)a.post_dst + (((size_t)b * a.oH + oy) * a.oW + ox) * a.post_pitch + c2 * 8) =
+          *(const half8_t*)(Os2 + (size_t)r * OP2 + c2 * 8);
+    }
+    return;
+  }
   constexpr int CPP = BN3 / 8;         // 16 chunks of 16 B per pixel row of the tile
   constexpr int PPI = NTHR / CPP;      // 16 pixels per pass = one patch row
   const int cch = t % CPP;
@@ -293,11 +406,11 @@ __global__ __launch_bounds__(NTHR, 2) void conv_halo3_kernel(ConvArgs a) {   // 
   }
 }
 
-template <int NPH, int NT>
+template <int NPH, int NT, int N2 = 0>
 void launch_cfg(const ConvArgs& a, hipStream_t st) {
   const int tilesX = (a.Mw + TWP - 1) / TWP, tilesY = (a.Mh + THP - 1) / THP;
   dim3 grid((unsigned)((4 / NPH) * NT * tilesX * tilesY * a.B), 1, 1);
-  hipLaunchKernelGGL((conv_halo3_kernel<NPH, NT>), grid, dim3(NTHR), 0, st, a);
+  hipLaunchKernelGGL((conv_halo3_kernel<NPH, NT, N2>), grid, dim3(NTHR), 0, st, a);
 }
 
 }  // namespace
@@ -317,7 +430,20 @@ bool conv_halo3_supported(const ConvArgs& a, bool dst_f32) {
   return blocks >= g_halo3_min_blocks;
 }
 
+// the fused form of (ConvTranspose with 128 output channels, its single 1x1 consumer): `a` carries post_*
+bool conv_halo3_post_supported(const ConvArgs& a) {
+  if (!a.post_w || a.N != 128 || !(a.post_n == 64 || a.post_n == 128)) return false;
+  if (a.post_pitch % 8 || a.post_x.c % BKH || a.post_x.c > 64 || a.post_x.up) return false;
+  if (a.post_x.c && (a.post_x.pitch % 8 || a.post_x.H != a.oH || a.post_x.W != a.oW)) return false;
+  return conv_halo3_supported(a, false);
+}
+
 void launch_conv_halo3(const ConvArgs& a, hipStream_t st) {
+  if (a.post_w && a.N == 128) {
+    if (a.post_n == 64) launch_cfg<1, 1, 64>(a, st);
+    else launch_cfg<1, 1, 128>(a, st);
+    return;
+  }
   if (a.N == 64) launch_cfg<2, 1>(a, st);
   else if (a.N == 128) launch_cfg<1, 1>(a, st);
   else launch_cfg<1, 2>(a, st);

@@ -134,7 +134,8 @@ def _tune(key, value):
                                       ((2, 1024, 1024), True), ((1, 1536, 1536), True)])
 def test_fused_blocks_equal_the_layer_per_launch_program_bit_for_bit(shape, u8):
     """The multi-layer kernels of the fp16 engine (stem + layer 1, the 32-channel C3 block, SPPF's three pools, bit 8:
-    bottleneck + cv3 of the 64 / 128-channel C3 blocks of backbone, neck and heads -- kernels_c3b.hip;
+    bottleneck + cv3 of the 64 / 128-channel C3 blocks of backbone, neck and heads -- kernels_c3b.hip; bit 16: a 128-channel
+    ConvTranspose and the 1x1 conv that is its only consumer -- kernels_halo3.hip;
     `ctd_tuning_set("fuse", mask)`) do the arithmetic of the launches they replace in the same order: every output
     of the network must be IDENTICAL with and without them -- interior and border patches, float and uint8 input,
     maps smaller than one patch (the C3 kernels are forced onto them with c3_min_patches = c3b_min_patches = 1), and
@@ -155,7 +156,7 @@ def test_fused_blocks_equal_the_layer_per_launch_program_bit_for_bit(shape, u8):
         _tune(b"c3_min_patches", 1)
         _tune(b"c3b_min_patches", 1)
         outs = {}
-        for mask in (1, 2, 4, 6, 7, 8, 15):
+        for mask in (1, 2, 4, 6, 7, 8, 15, 16, 31):
             _tune(b"fuse", mask)
             outs[mask] = run()
         _tune(b"halo_min_patches", 1)                   # the 3x3s (and ConvT phases) on the halo kernel everywhere
@@ -165,15 +166,26 @@ def test_fused_blocks_equal_the_layer_per_launch_program_bit_for_bit(shape, u8):
         outs["8 + halo"] = run()
         _tune(b"c3b_max_ch", 64)
         outs["8 + halo, 64 only"] = run()
+        # bit 16 (a 128-channel ConvTranspose + its single 1x1 consumer in one launch of the big-tile kernel) needs that
+        # kernel: lift its grid threshold so that also the small shapes go through it (maps that are multiples of 16)
+        _tune(b"c3b_max_ch", 128)
+        _tune(b"halo3_min_blocks", 1)
+        _tune(b"fuse", 0)
+        ref_3 = run()
+        for mask in (16, 31):
+            _tune(b"fuse", mask)
+            outs[f"{mask} + halo3"] = run()
         torch.cuda.synchronize()
     finally:
-        _tune(b"fuse", 15)
+        _tune(b"fuse", 31)
+        _tune(b"halo3_min_blocks", 1024)
         _tune(b"c3_min_patches", 1024)
         _tune(b"c3b_min_patches", 1024)
         _tune(b"c3b_max_ch", 128)
         _tune(b"halo_min_patches", 1024)
     for mask, got in outs.items():
-        for i, (g, r) in enumerate(zip(got, ref_h if isinstance(mask, str) else ref)):
+        base = ref if not isinstance(mask, str) else (ref_3 if "halo3" in mask else ref_h)
+        for i, (g, r) in enumerate(zip(got, base)):
             assert torch.equal(g, r), f"fuse mask {mask}: output {i} differs from the unfused program " \
                                       f"(max |d| {float((g.float() - r.float()).abs().max()):.3g})"
 

@@ -95,8 +95,10 @@ def thread_budget(world: int, pinned: bool = False, host_cpus: int = 0) -> dict:
     per_rank = max(4, avail if pinned else avail // max(1, world))
     if pinned and host_cpus:
         avail = host_cpus                                     # what the host offered before this rank bound itself
-    workers = 4 if per_rank >= 16 else (3 if per_rank >= 8 else 2)     # a 4th worker is free since the tails' streams have the
-    native = max(1, min(8, (per_rank - 2) // workers))                  # default priority (tail.hip g_tail_priority); dense pages gain 4 %
+    # round 5 (forward 9.2 ms): 3 workers = 4 workers on the headline / dense / host-input pages and +6 % on the canned ones,
+    # for one core less per rank (scripts/experiments/e2e_workers_r5.sh); round 4 (forward 10.1 ms) had 4 ahead on dense pages
+    workers = 3 if per_rank >= 8 else 2
+    native = max(1, min(8, (per_rank - 2) // workers))
     return {"usable_cpus": avail, "per_rank": per_rank, "tail_workers": workers, "native_threads_per_worker": native}
 
 

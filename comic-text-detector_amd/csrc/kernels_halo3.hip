@@ -271,18 +271,12 @@ __global__ __launch_bounds__(NTHR, 2) void conv_halo3_kernel(ConvArgs a) {   // 
       }
     }
   };
-  switch (a.act) {
-    case CTD_ACT_SILU: epilogue(std::integral_constant<int, CTD_ACT_SILU>{}); break;
-    case CTD_ACT_LEAKY: epilogue(std::integral_constant<int, CTD_ACT_LEAKY>{}); break;
-    case CTD_ACT_RELU: epilogue(std::integral_constant<int, CTD_ACT_RELU>{}); break;
-    case CTD_ACT_SIGMOID: epilogue(std::integral_constant<int, CTD_ACT_SIGMOID>{}); break;
-    default: epilogue(std::integral_constant<int, CTD_ACT_NONE>{}); break;
-  }
-  __syncthreads();
-  if constexpr (N2 > 0) {
-    static_assert(NPH == 1 && NT == 1, "the post conv needs every channel of the layer in one block");
-    constexpr int NF2 = N2 / 32;
-    constexpr int OP2 = N2 + 8;
+  // POST: everything the second GEMM needs that does not depend on the staged tile is set up -- and its first fragments
+  // requested -- BEFORE the tile is written, so that their round trip hides under the epilogue and its barrier
+  static_assert(N2 == 0 || (NPH == 1 && NT == 1), "the post conv needs every channel of the layer in one block");
+  constexpr int N2S = N2 > 0 ? N2 : 32;               // (stand-in sizes keep the declarations legal when N2 == 0)
+    constexpr int NF2 = N2S / 32;
+    constexpr int OP2 = N2S + 8;
     static_assert(BMH * OP2 <= LDS_MAIN, "out2 tile fits the staging region");
     // wave w: tile rows (= patch pixels) 64 w .. 64 w + 63, every output channel
     const int K0 = a.post_x.c;                              // channels of the concat ahead of this layer's: 0 or a multiple of 32
@@ -301,7 +295,7 @@ __global__ __launch_bounds__(NTHR, 2) void conv_halo3_kernel(ConvArgs a) {   // 
       for (int i = 0; i < NF2; ++i)
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk)
-          fa[i][kk] = *(const half8_t*)(W2 + ((size_t)kc * N2 + i * 32 + l31) * BKH + (kk * 2 + khalf) * 8);
+          fa[i][kk] = *(const half8_t*)(W2 + ((size_t)kc * N2S + i * 32 + l31) * BKH + (kk * 2 + khalf) * 8);
     };
     auto load_b = [&](int kc, half8_t (&fb)[2][2]) {
 #pragma unroll
@@ -314,6 +308,20 @@ __global__ __launch_bounds__(NTHR, 2) void conv_halo3_kernel(ConvArgs a) {   // 
             fb[j][kk] = *(const half8_t*)(Os + (size_t)r2[j] * OP + (kc - nk0) * BKH + (kk * 2 + khalf) * 8);
         }
     };
+  half8_t fa[2][NF2][2], fb[2][2][2];
+  if constexpr (N2 > 0) {
+    load_a(0, fa[0]);
+    if (nk0 > 0) load_b(0, fb[0]);                    // the concat's first source does not wait for the tile either
+  }
+  switch (a.act) {
+    case CTD_ACT_SILU: epilogue(std::integral_constant<int, CTD_ACT_SILU>{}); break;
+    case CTD_ACT_LEAKY: epilogue(std::integral_constant<int, CTD_ACT_LEAKY>{}); break;
+    case CTD_ACT_RELU: epilogue(std::integral_constant<int, CTD_ACT_RELU>{}); break;
+    case CTD_ACT_SIGMOID: epilogue(std::integral_constant<int, CTD_ACT_SIGMOID>{}); break;
+    default: epilogue(std::integral_constant<int, CTD_ACT_NONE>{}); break;
+  }
+  __syncthreads();
+  if constexpr (N2 > 0) {
     float16_t acc2[NF2][2];
 #pragma unroll
     for (int i = 0; i < NF2; ++i)
@@ -321,9 +329,7 @@ __global__ __launch_bounds__(NTHR, 2) void conv_halo3_kernel(ConvArgs a) {   // 
       for (int j = 0; j < 2; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc2[i][j][r] = 0.f;
-    half8_t fa[2][NF2][2], fb[2][2][2];
-    load_a(0, fa[0]);
-    load_b(0, fb[0]);
+    if (nk0 == 0) load_b(0, fb[0]);
     for (int kc = 0; kc < nk; kc += 2) {                   // two chunks per trip: the double buffers keep static indices
       if (kc + 1 < nk) {
         load_a(kc + 1, fa[1]);

@@ -7,7 +7,7 @@ import csv
 import gzip
 import sys
 
-FWD = ("conv_", "stem_", "c3_fused", "seg_final", "db_up", "sppf", "avgpool", "detect_decode", "export", "input_", "maxpool")
+FWD = ("conv_", "stem_", "c3_fused", "c3b_", "seg_final", "db_up", "sppf", "avgpool", "detect_decode", "export", "input_", "maxpool")
 
 
 def load(f):

@@ -10,7 +10,7 @@ import sys
 
 out = sys.argv[1]
 # kernel family by engine: fp16 (default) | fp32s | fp32
-FAMILY = {"fp16": ("conv_igemm_kernel", "conv_halo_kernel", "conv_halo2_kernel", "conv_halo3_kernel", "c3_fused_kernel"), "fp32s": ("conv_split_kernel", "conv_split_halo_kernel", "stem_split_kernel", "conv_f32_mfma_kernel"),
+FAMILY = {"fp16": ("conv_igemm_kernel", "conv_halo_kernel", "conv_halo2_kernel", "conv_halo3_kernel", "c3_fused_kernel", "c3b_kernel"), "fp32s": ("conv_split_kernel", "conv_split_halo_kernel", "stem_split_kernel", "conv_f32_mfma_kernel"),
           "fp32": ("conv_f32_mfma_kernel",)}[sys.argv[2] if len(sys.argv) > 2 else "fp16"]
 tot = collections.defaultdict(lambda: [0.0, 0])
 stems = collections.defaultdict(int)

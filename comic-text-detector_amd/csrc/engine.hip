@@ -63,6 +63,8 @@ struct OpState {
   bool sppf_head = false; // first of SPPF's three chained max pools: one launch does all three
   bool stem2_head = false; // STEM op that also computes the following 3x3/s2 conv (which is `skip`)
   bool stemsp_head = false; // fp32s: first conv reads the network input itself (kernels_split_stem.hip); its INPUT op is `skip`
+  bool segp_head = false; // 64-channel ConvTranspose feeding only SEG_FINAL: stores the 16 tap products per pixel instead (halo3 SEGP)
+  bool segp_ran = false;  // (on the SEG_FINAL op, set per launch) its source holds P (B,H,W,16) f32, not the 64-channel map
   bool post_head = false; // 128-channel ConvTranspose whose single consumer, the next op (a 1x1 conv), runs on its output tile
   ConvArgs post_args{};   // ... its arguments with post_* filled (kernels_halo3.hip)
   bool c3b_head = false;  // m.cv1 of a 64 / 128-channel bottleneck: launches kernels_c3b.hip for [m.cv1, m.cv2 (+ cv3)]
@@ -727,7 +729,7 @@ int plan(ctd_engine* e, int B, int H, int W, hipStream_t cap_stream = nullptr) {
                 (double)a.N * o.k * o.k * cin * es;
     }
     s.args = a;
-    s.c3_head = s.skip = s.sppf_head = s.stem2_head = s.stemsp_head = s.c3b_head = s.post_head = false;
+    s.c3_head = s.skip = s.sppf_head = s.stem2_head = s.stemsp_head = s.c3b_head = s.post_head = s.segp_head = s.segp_ran = false;
     s.c3b_conv3 = -1;
   }
   // ---- fp32s: INPUT (page -> fp32 NHWC, zero 4th channel) + the 6x6/s2 first conv -> one launch that reads the page itself
@@ -851,6 +853,24 @@ int plan(ctd_engine* e, int B, int H, int W, hipStream_t cap_stream = nullptr) {
     T.flops += P.flops; T.bytes += P.bytes;
     P.flops = P.bytes = 0;
   }
+  // ---- the UNet's last pair: ConvTranspose 128 -> 64 (+BN+ReLU) whose only reader is the 64 -> 1 ConvTranspose + sigmoid
+  // (SEG_FINAL): the first one's launch also forms the second one's 16 tap products per pixel and stores THOSE (64 B per
+  // pixel, in the 64-channel tensor's own arena slot, which is 128 B per pixel) -- kernels_halo3.hip SEGP
+  for (int i = 0; f16 && (g_fuse & 32) && i + 1 < nO; ++i) {
+    OpState &T = e->ops[i], &F = e->ops[i + 1];
+    const ctd_op &t = T.op, &fo = F.op;
+    if (t.kind != CTD_OP_CONVT || T.impl != IMPL_IGEMM_T || t.cout != 64 || t.dst_coff != 0 || T.bk != 32 || !e->w_tiled) continue;
+    if (fo.kind != CTD_OP_SEG_FINAL || fo.src0 != t.dst || fo.src0_coff != 0 || fo.src0_c != 64 || !g_seg_final_mfma) continue;
+    const TensorState& tu = e->tensors[t.dst];
+    if (tu.t.channels != 64 || tu.esize != 2 || tu.first_def != i || tu.last_use != i + 1) continue;
+    ConvArgs a = T.args;
+    a.post_w = F.w_dev;
+    a.post_dst = T.args.dst;             // P takes the place of the map it replaces
+    a.post_n = -16;
+    if (!conv_halo3_segp_supported(a)) continue;
+    T.segp_head = true;
+    T.post_args = a;
+  }
   // ---- the wider C3 blocks found above: one launch per bottleneck, the last one with cv3 (kernels_c3b.hip)
   for (const C3Chain& ch : chains) {
     if (!(g_fuse & 8)) break;
@@ -962,6 +982,12 @@ int launch_op(ctd_engine* e, int i, const Outs& x, hipStream_t st) {
       else launch_conv_direct(s.args, f16, st);
       break;
     case CTD_OP_CONVT:
+      if (s.segp_head) {   // decided per launch (a tuning key may have taken the big-tile kernel away): SEG_FINAL is told
+        const bool fused = conv_halo3_segp_supported(s.post_args) && (x.mask || x.mask_u8);
+        e->ops[i + 1].segp_ran = fused;
+        launch_conv_igemm(fused ? s.post_args : s.args, false, st);
+        break;
+      }
       if (s.post_head) {
         if (conv_halo3_post_supported(s.post_args)) { launch_conv_igemm(s.post_args, false, st); break; }
         // a tuning key has taken the big-tile kernel away since the plan was made: the two layers, one launch each
@@ -1019,7 +1045,9 @@ int launch_op(ctd_engine* e, int i, const Outs& x, hipStream_t st) {
     case CTD_OP_SEG_FINAL: {
       const TensorState& ts = e->tensors[o.src0];
       if (!x.mask && !x.mask_u8) break;
-      if (ts.esize == 4)
+      if (s.segp_ran)      // the producer stored the tap products: col2im + sigmoid + u8 from them
+        launch_seg_final_gather((const float*)tptr(o.src0, o.src0_coff), B, ts.H, ts.W, 0.f, x.mask, x.mask_u8, st);
+      else if (ts.esize == 4)
         launch_seg_final_f32((const float*)tptr(o.src0, o.src0_coff), ts.t.channels, o.src0_c, B, ts.H, ts.W,
                              (const float*)s.w_dev, x.mask, x.mask_u8, st);
       else
@@ -1167,6 +1195,7 @@ int ctd_engine_op_kernel(const ctd_engine* e, int32_t i, char* name, int32_t cap
     if (s.c3_head) return "c3_fused_kernel";
     if (s.c3b_head) return "c3b_kernel";
     if (s.post_head && conv_halo3_post_supported(s.post_args)) return "conv_halo3_kernel+1x1";
+    if (s.segp_head && conv_halo3_segp_supported(s.post_args)) return "conv_halo3_kernel+taps";
     if (s.stemsp_head) return "stem_split_kernel";
     const bool mfma = s.impl == IMPL_IGEMM || s.impl == IMPL_IGEMM_T;
     if (mfma && s.split) return conv_split_halo_supported(s.args) ? "conv_split_halo_kernel" : "conv_split_kernel";
@@ -1191,7 +1220,7 @@ int ctd_engine_op_kernel(const ctd_engine* e, int32_t i, char* name, int32_t cap
     case CTD_OP_AVGPOOL2: k = "avgpool2_kernel"; break;
     case CTD_OP_DETECT: k = "detect_decode_kernel"; break;
     case CTD_OP_EXPORT: k = "export_plane_kernel"; break;
-    case CTD_OP_SEG_FINAL: k = e->tensors[o.src0].esize == 4 ? "seg_final_f32_kernel" : (g_seg_final_mfma ? "seg_final_mfma_kernel" : "seg_final_kernel"); break;
+    case CTD_OP_SEG_FINAL: k = (i > 0 && e->ops[i - 1].segp_head && conv_halo3_segp_supported(e->ops[i - 1].post_args)) ? "seg_final_gather_kernel" : e->tensors[o.src0].esize == 4 ? "seg_final_f32_kernel" : (g_seg_final_mfma ? "seg_final_mfma_kernel" : "seg_final_kernel"); break;
     case CTD_OP_DB_UP: k = (e->tensors[o.src0].esize == 2 && g_db_up_mfma) ? "db_up_mfma_kernel" : "db_up_kernel"; break;
   }
   std::snprintf(name, (size_t)cap, "%s", k);

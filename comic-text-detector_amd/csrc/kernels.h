@@ -89,7 +89,8 @@ int halo2_tuning_set(const char* key, long long value);
 extern long long g_halo3;              // 0 disables ("halo3")
 extern long long g_halo3_min_blocks;   // "halo3_min_blocks"
 bool conv_halo3_supported(const ConvArgs& a, bool dst_f32);
-bool conv_halo3_post_supported(const ConvArgs& a);   // `a` carries post_*: the layer + its single 1x1 consumer in one launch
+bool conv_halo3_post_supported(const ConvArgs& a);
+bool conv_halo3_segp_supported(const ConvArgs& a);   // `a` carries post_w = seg-final taps, post_dst = P, post_n = -16   // `a` carries post_*: the layer + its single 1x1 consumer in one launch
 void launch_conv_halo3(const ConvArgs& a, hipStream_t st);
 int halo3_tuning_set(const char* key, long long value);
 
@@ -163,6 +164,8 @@ void launch_seg_final(const half_t* src, int pitch, int C, int B, int H, int W, 
 // params f32 per branch: W1[q][q][2][2] (cin,cout,ky,kx) b1[q] W2[q][1][2][2] b2[1]
 void launch_seg_final_f32(const float* src, int pitch, int C, int B, int H, int W, const float* w, float* mask,
                           uint8_t* mask_u8, hipStream_t st);
+// the same layer from the per-tap products P (B,H,W,16) f32 its producer left (kernels_halo3.hip SEGP): col2im + sigmoid + u8
+void launch_seg_final_gather(const float* P, int B, int H, int W, float bias, float* mask, uint8_t* mask_u8, hipStream_t st);
 extern int g_seg_final_mfma;   // fp16 engine: seg-final's channel reduction on the MFMA (CTD_SEGFINAL_MFMA / "seg_final_mfma")
 extern int g_db_up_mfma;   // fp16 engine: DB tail's first stage on the MFMA (CTD_DBUP_MFMA / ctd_tuning_set("db_up_mfma"))
 void launch_db_up(const void* src, bool f32in, int pitch, int q, int nbr, int B, int H, int W, const float* params, float* lines,

@@ -145,14 +145,22 @@ __global__ __launch_bounds__(256, 2) void c3_fused_kernel(C3Args a) {
   };
   // bias + activation of one 32-channel accumulator tile -> fp16 row `row` of an LDS image (swizzled chunks);
   // keep = false writes zeros (t outside the image: the 3x3's zero padding applies to t, not to x)
+  // (`keep` as a MASK on the packed halves: `keep ? act(..) : 0` per value compiles to an exec-mask branch around every
+  // activation, kernels_c3b.hip / DESIGN 4.11)
   auto store_frag = [&](half_t* base, int row, const float16_t& acc, const float* bias, bool keep) {
+    const unsigned km = keep ? 0xffffffffu : 0u;
+    float4_t bv[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) bv[g] = *(const float4_t*)(bias + 8 * g + 4 * khalf);
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-      const float4_t bv = *(const float4_t*)(bias + 8 * g + 4 * khalf);
       half4_t o;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) o[e] = keep ? (half_t)ctd_act_fast<ACT>(acc[4 * g + e] + bv[e]) : (half_t)0.f;
-      *(half4_t*)(base + row * 32 + ((g ^ swz(row)) * 8) + 4 * khalf) = o;
+      for (int e = 0; e < 4; ++e) o[e] = (half_t)ctd_act_fast<ACT>(acc[4 * g + e] + bv[g][e]);
+      uint2 u = __builtin_bit_cast(uint2, o);
+      u.x &= km;
+      u.y &= km;
+      *(uint2*)(base + row * 32 + ((g ^ swz(row)) * 8) + 4 * khalf) = u;
     }
   };
 
@@ -321,9 +329,9 @@ __global__ __launch_bounds__(256, 2) void c3_fused_kernel(C3Args a) {
 }  // namespace
 
 // Multi-layer fusions of the fp16 engine, one bit each: 1 = C3 block (this file), 2 = SPPF's three pools
-// (kernels_basic.hip), 4 = stem + model.1 (kernels_fused.hip), 8 = bottleneck + cv3 of the wider C3 blocks (kernels_c3b.hip), 16 = a 128-channel ConvTranspose + its single 1x1 consumer (kernels_halo3.hip).  ctd_tuning_set("fuse", 0) runs the layer-per-launch
+// (kernels_basic.hip), 4 = stem + model.1 (kernels_fused.hip), 8 = bottleneck + cv3 of the wider C3 blocks (kernels_c3b.hip), 16 = a 128-channel ConvTranspose + its single 1x1 consumer, 32 = the last 64-channel ConvTranspose + the tap products of the 64 -> 1 one behind it (kernels_halo3.hip).  ctd_tuning_set("fuse", 0) runs the layer-per-launch
 // program (the bit-identity tests and A/B runs use it).
-int g_fuse = 31;
+int g_fuse = 63;
 
 long long g_c3_min_patches = 1024;   // fewer 128-pixel patches: the per-layer kernels (ctd_tuning_set("c3_min_patches"))
 

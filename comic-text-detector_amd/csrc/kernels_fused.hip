@@ -539,6 +539,50 @@ __global__ __launch_bounds__(256) void db_up_mfma_kernel(const half_t* __restric
   }
 }
 
+// The col2im + sigmoid + u8 quantiser of the 64 -> 1 ConvTranspose from the per-tap products of the haloed 18x18 tile in LDS
+// (Ps[pixel][tap], out-of-image pixels zero): shared by seg_final_mfma_kernel (which computes the products itself) and
+// seg_final_gather_kernel (which reads them from the producing ConvTranspose's launch) -- ONE summation order.
+__device__ __forceinline__ void seg_final_gather(const float* Ps, int x0, int y0, long long b, int H, int W, float bias,
+                                                 float* __restrict__ mask, uint8_t* __restrict__ mask_u8) {
+  constexpr int TP = SF_T + 2;
+  const int lx = threadIdx.x % SF_T, ly = threadIdx.x / SF_T;
+  const int x = x0 + lx, y = y0 + ly;
+  if (x >= W || y >= H) return;
+  float o[2][2] = {{bias, bias}, {bias, bias}};
+#pragma unroll
+  for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+    for (int dx = -1; dx <= 1; ++dx) {
+      const float* Pn = Ps + ((ly + 1 + dy) * TP + (lx + 1 + dx)) * 16;
+#pragma unroll
+      for (int py = 0; py < 2; ++py) {
+        const int ky = py + 1 - 2 * dy;
+        if (ky < 0 || ky > 3) continue;
+#pragma unroll
+        for (int px2 = 0; px2 < 2; ++px2) {
+          const int kx = px2 + 1 - 2 * dx;
+          if (kx < 0 || kx > 3) continue;
+          o[py][px2] += Pn[ky * 4 + kx];
+        }
+      }
+    }
+  const int Wo = 2 * W;
+  const long long Ho = 2LL * H;
+#pragma unroll
+  for (int py = 0; py < 2; ++py) {
+    const float s0 = 1.0f / (1.0f + expf(-o[py][0]));
+    const float s1 = 1.0f / (1.0f + expf(-o[py][1]));
+    const long long off = (b * Ho + (2 * y + py)) * Wo + 2 * x;
+    if (mask) *(float2*)(mask + off) = make_float2(s0, s1);
+    if (mask_u8) {
+      uchar2 q;
+      q.x = (uint8_t)(s0 * 255.0f);
+      q.y = (uint8_t)(s1 * 255.0f);
+      *(uchar2*)(mask_u8 + off) = q;
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------
 // Seg final on the matrix cores (fp16 engine).  seg_final_kernel above spends 1024 FMAs per input pixel on a
 // 64 -> 1 transposed convolution (0.36 ms per 32 pages against 0.23 ms of bytes).  Per input pixel the layer is a
@@ -591,45 +635,42 @@ __global__ __launch_bounds__(256) void seg_final_mfma_kernel(const half_t* __res
     *(float4_t*)(Ps + p * 16 + 8 + 4 * hi) = hi4;
   }
   __syncthreads();
-  const int lx = threadIdx.x % SF_T, ly = threadIdx.x / SF_T;
-  const int x = x0 + lx, y = y0 + ly;
-  if (x >= W || y >= H) return;
-  float o[2][2] = {{bias, bias}, {bias, bias}};
-#pragma unroll
-  for (int dy = -1; dy <= 1; ++dy)
-#pragma unroll
-    for (int dx = -1; dx <= 1; ++dx) {
-      const float* Pn = Ps + ((ly + 1 + dy) * TP + (lx + 1 + dx)) * 16;
-#pragma unroll
-      for (int py = 0; py < 2; ++py) {
-        const int ky = py + 1 - 2 * dy;
-        if (ky < 0 || ky > 3) continue;
-#pragma unroll
-        for (int px2 = 0; px2 < 2; ++px2) {
-          const int kx = px2 + 1 - 2 * dx;
-          if (kx < 0 || kx > 3) continue;
-          o[py][px2] += Pn[ky * 4 + kx];
-        }
-      }
-    }
-  const int Wo = 2 * W;
-  const long long Ho = 2LL * H;
-#pragma unroll
-  for (int py = 0; py < 2; ++py) {
-    const float s0 = 1.0f / (1.0f + expf(-o[py][0]));
-    const float s1 = 1.0f / (1.0f + expf(-o[py][1]));
-    const long long off = (b * Ho + (2 * y + py)) * Wo + 2 * x;
-    if (mask) *(float2*)(mask + off) = make_float2(s0, s1);
-    if (mask_u8) {
-      uchar2 q;
-      q.x = (uint8_t)(s0 * 255.0f);
-      q.y = (uint8_t)(s1 * 255.0f);
-      *(uchar2*)(mask_u8 + off) = q;
-    }
+  seg_final_gather(Ps, x0, y0, b, H, W, bias, mask, mask_u8);
+}
+
+// The same layer when the producing ConvTranspose (128 -> 64, kernels_halo3.hip SEGP) has already multiplied its output
+// tile by the 16 taps: P (B, H, W, 16) fp32 holds, per pixel of the 64-channel map that is never stored, the per-tap
+// products seg_final_mfma_kernel computes for itself -- by the same MFMA sequence on the same fp16 values, so the mask is
+// bit-identical -- at half the bytes of the map (64 B instead of 128 B per pixel, written once, read once).
+__global__ __launch_bounds__(256) void seg_final_gather_kernel(const float* __restrict__ P, int B, int H, int W, float bias,
+                                                               float* __restrict__ mask, uint8_t* __restrict__ mask_u8) {
+  constexpr int TP = SF_T + 2, NPX = TP * TP;
+  __shared__ __attribute__((aligned(16))) float Ps[NPX * 16];
+  const int tiles_x = (W + SF_T - 1) / SF_T, tiles_y = (H + SF_T - 1) / SF_T;
+  int bid = blockIdx.x;
+  const int x0 = (bid % tiles_x) * SF_T;
+  bid /= tiles_x;
+  const int y0 = (bid % tiles_y) * SF_T;
+  const long long b = bid / tiles_y;
+  for (int i = threadIdx.x; i < NPX * 4; i += 256) {
+    const int p = i >> 2, q = i & 3;
+    const int ty = p / TP, tx = p - ty * TP;
+    const int yy = y0 + ty - 1, xx = x0 + tx - 1;
+    const bool ok = yy >= 0 && yy < H && xx >= 0 && xx < W;
+    float4_t v = {0.f, 0.f, 0.f, 0.f};
+    if (ok) v = *(const float4_t*)(P + (((size_t)b * H + yy) * W + xx) * 16 + q * 4);
+    *(float4_t*)(Ps + p * 16 + q * 4) = v;
   }
+  __syncthreads();
+  seg_final_gather(Ps, x0, y0, b, H, W, bias, mask, mask_u8);
 }
 
 }  // namespace
+
+void launch_seg_final_gather(const float* P, int B, int H, int W, float bias, float* mask, uint8_t* mask_u8, hipStream_t st) {
+  const int g = ((W + SF_T - 1) / SF_T) * ((H + SF_T - 1) / SF_T) * B;
+  hipLaunchKernelGGL(seg_final_gather_kernel, dim3(g), dim3(256), 0, st, P, B, H, W, bias, mask, mask_u8);
+}
 
 void launch_stem(const void* in, int in_fmt, half_t* dst, int pitchD, int B, int H, int W, int N, const half_t* wfrag,
                  const float* bias, int act, hipStream_t st) {

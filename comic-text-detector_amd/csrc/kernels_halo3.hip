@@ -54,7 +54,13 @@ template <int N> __device__ __forceinline__ void wait_vm_lgkm0() {
 // GEMM whose A fragments come straight from HBM / L2 (the weight matrix is 16-48 KB and every block reads all of it), and
 // only out2 leaves the CU.  K order and epilogue arithmetic are the implicit-GEMM kernel's: bit-identical to the two
 // launches (tests/test_gpu_edge.py).
-template <int NPH, int NT, int N2 = 0>
+// SEGP (NPH = 2, NT = 1: the 64-channel layer whose block holds both px phases): the layer's single consumer is the network's
+// LAST layer, ConvTranspose 4x4/s2 64 -> 1 + sigmoid (kernels_fused.hip seg_final_mfma_kernel), which starts by multiplying every
+// pixel's 64 channels with the 16 taps.  That product is a GEMM on this block's output tile: it runs here (the MFMA sequence of
+// seg_final_mfma_kernel on the same fp16 values: bit-identical products), and the block stores P (16 fp32 per pixel = 64 B)
+// instead of the 64-channel map (128 B); seg_final_gather_kernel does the col2im + sigmoid from P.  1.07 GB less written and
+// 1.07 GB less read per 32 pages.
+template <int NPH, int NT, int N2 = 0, bool SEGP = false>
 __global__ __launch_bounds__(NTHR, 2) void conv_halo3_kernel(ConvArgs a) {   // 2 blocks / CU = 2 waves / SIMD
   if (a.prio) __builtin_amdgcn_s_setprio(3);
   constexpr int CP = BN3 / NPH;                       // channels of a phase inside this block's columns (64 or 128)
@@ -308,6 +314,16 @@ __global__ __launch_bounds__(NTHR, 2) void conv_halo3_kernel(ConvArgs a) {   // 
             fb[j][kk] = *(const half8_t*)(Os + (size_t)r2[j] * OP + (kc - nk0) * BKH + (kk * 2 + khalf) * 8);
         }
     };
+  half8_t wseg[4];                                    // SEGP: A fragments = the 16 taps (rows 16-31 zero) x 16 channels per k step
+  if constexpr (SEGP) {
+    static_assert(NPH == 2 && NT == 1 && N2 == 0, "SEGP is the 64-channel layer's variant");
+    const half_t* w6 = (const half_t*)a.post_w;       // [64 / 8][16 taps][8 channels] (engine.hip, the seg-final packing)
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const half8_t z = {0, 0, 0, 0, 0, 0, 0, 0};
+      wseg[ks] = l31 < 16 ? *(const half8_t*)(w6 + ((size_t)(2 * ks + hi) * 16 + l31) * 8) : z;
+    }
+  }
   half8_t fa[2][NF2][2], fb[2][2][2];
   if constexpr (N2 > 0) {
     load_a(0, fa[0]);
@@ -321,6 +337,47 @@ __global__ __launch_bounds__(NTHR, 2) void conv_halo3_kernel(ConvArgs a) {   // 
     default: epilogue(std::integral_constant<int, CTD_ACT_NONE>{}); break;
   }
   __syncthreads();
+  if constexpr (SEGP) {
+    // wave w: tile rows (= patch pixels) 64 w .. 64 w + 63, both px phases (columns 0-63 / 64-127 of the tile)
+    half8_t xb[2][2][4];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int ps = 0; ps < 2; ++ps)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+          xb[j][ps][ks] = *(const half8_t*)(Os + (size_t)((wave_u * 2 + j) * 32 + l31) * OP + ps * 64 + 16 * ks + 8 * hi);
+    __syncthreads();                                  // every wave holds its operands: the tile's space is free
+    float* Pst = (float*)lds;                         // [16 patch rows][32 output columns][16 taps] fp32 = 32 KB
+    static_assert(16 * 32 * 16 * 4 <= LDS_MAIN * 2, "P tile fits the staging region");
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int ps = 0; ps < 2; ++ps) {
+        float16_t pa;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) pa[r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) pa = __builtin_amdgcn_mfma_f32_32x32x16_f16(wseg[ks], xb[j][ps][ks], pa, 0, 0, 0);
+        // rows n = (r & 3) + 8 (r >> 2) + 4 hi: r = 0..3 -> taps 4 hi .. 4 hi + 3, r = 4..7 -> taps 8 + 4 hi .. (r >= 8: unused rows)
+        const int r = (wave_u * 2 + j) * 32 + l31;
+        float* d = Pst + (size_t)(((r >> 4) * 32 + 2 * (r & 15) + ps) * 16);
+        const float4_t lo = {pa[0], pa[1], pa[2], pa[3]}, hi4 = {pa[4], pa[5], pa[6], pa[7]};
+        *(float4_t*)(d + 4 * hi) = lo;
+        *(float4_t*)(d + 8 + 4 * hi) = hi4;
+      }
+    __syncthreads();
+    // 512 pixels x 64 B: a patch row's 32 output columns are 2 KB contiguous in P
+    float* Pg = (float*)a.post_dst;
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int idx = it * NTHR + t, up = idx >> 2, q = idx & 3;
+      const int row = up >> 5, col = up & 31;
+      const size_t opx = ((size_t)b * a.oH + (y0 + row) * 2 + py_b) * a.oW + x0 * 2 + col;
+      *(float4_t*)(Pg + opx * 16 + q * 4) = *(const float4_t*)(Pst + (size_t)up * 16 + q * 4);
+    }
+    return;
+  }
   if constexpr (N2 > 0) {
     float16_t acc2[NF2][2];
 #pragma unroll
@@ -412,11 +469,11 @@ __global__ __launch_bounds__(NTHR, 2) void conv_halo3_kernel(ConvArgs a) {   // 
   }
 }
 
-template <int NPH, int NT, int N2 = 0>
+template <int NPH, int NT, int N2 = 0, bool SEGP = false>
 void launch_cfg(const ConvArgs& a, hipStream_t st) {
   const int tilesX = (a.Mw + TWP - 1) / TWP, tilesY = (a.Mh + THP - 1) / THP;
   dim3 grid((unsigned)((4 / NPH) * NT * tilesX * tilesY * a.B), 1, 1);
-  hipLaunchKernelGGL((conv_halo3_kernel<NPH, NT, N2>), grid, dim3(NTHR), 0, st, a);
+  hipLaunchKernelGGL((conv_halo3_kernel<NPH, NT, N2, SEGP>), grid, dim3(NTHR), 0, st, a);
 }
 
 }  // namespace
@@ -444,7 +501,15 @@ bool conv_halo3_post_supported(const ConvArgs& a) {
   return conv_halo3_supported(a, false);
 }
 
+// the fused form of (ConvTranspose with 64 output channels, the 64 -> 1 seg-final ConvTranspose's tap products): post_n == -16
+bool conv_halo3_segp_supported(const ConvArgs& a) {
+  if (!a.post_w || !a.post_dst || a.N != 64 || a.post_n != -16) return false;
+  if ((((uintptr_t)a.post_w | (uintptr_t)a.post_dst) & 15) != 0) return false;
+  return conv_halo3_supported(a, false);
+}
+
 void launch_conv_halo3(const ConvArgs& a, hipStream_t st) {
+  if (a.post_w && a.N == 64 && a.post_n == -16) return launch_cfg<2, 1, 0, true>(a, st);
   if (a.post_w && a.N == 128) {
     if (a.post_n == 64) launch_cfg<1, 1, 64>(a, st);
     else launch_cfg<1, 1, 128>(a, st);

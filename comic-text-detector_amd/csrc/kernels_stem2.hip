@@ -195,14 +195,22 @@ __global__ __launch_bounds__(S2_NT, 4) void stem_conv2_kernel(Stem2Args a) {   /
       acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[s], fx.h, acc, 0, 0, 0);
     }
     const int sy = sy0 + py, sx = sx0 + px;
-    const bool keep = p < S2_SPX && sy >= 0 && sy < Hs && sx >= 0 && sx < Ws;
+    // Stem pixels outside the stem map are zero: a MASK on the packed halves, not `keep ? act(..) : 0` per value -- that
+    // form compiled to an exec-mask branch around every single SiLU (v_exp / v_rcp with their s_nops, no two of the 16
+    // values of a fragment in flight together), and this kernel is bound by exactly that VALU work (round 5)
+    const unsigned km = (p < S2_SPX && sy >= 0 && sy < Hs && sx >= 0 && sx < Ws) ? 0xffffffffu : 0u;
+    float4_t bv[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) bv[g] = *(const float4_t*)(bias_s + 8 * g + 4 * khalf);
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-      const float4_t bv = *(const float4_t*)(bias_s + 8 * g + 4 * khalf);
       half4_t o;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) o[e] = keep ? (half_t)ctd_act_fast_rt(acc[4 * g + e] * oscale + bv[e], ACT0) : (half_t)0.f;
-      *(half4_t*)(S + p * 32 + ((g ^ swz(p)) * 8) + 4 * khalf) = o;
+      for (int e = 0; e < 4; ++e) o[e] = (half_t)ctd_act_fast_rt(acc[4 * g + e] * oscale + bv[g][e], ACT0);
+      uint2 u = __builtin_bit_cast(uint2, o);
+      u.x &= km;
+      u.y &= km;
+      *(uint2*)(S + p * 32 + ((g ^ swz(p)) * 8) + 4 * khalf) = u;
     }
   }
   __syncthreads();   // the stem patch is complete; the input patch is dead

@@ -46,7 +46,7 @@ def check():
         tune("c3b_cfg128", c128)
         tune("halo3_min_blocks", 1)
         res = {}
-        for fuse in (7, 31):
+        for fuse in (7, 63):
             tune("fuse", fuse)
             outs = [t.clone() for t in be(x)] + [be.mask_u8.clone(), be.bitmap.clone()]
             torch.cuda.synchronize()
@@ -57,7 +57,7 @@ def check():
                 except Exception:
                     pass
             res[fuse] = (outs, tens)
-        tune("fuse", 31)
+        tune("fuse", 63)
         tune("c3b_min_patches", 1024)
         tune("halo_min_patches", 1024)
         tune("halo3_min_blocks", 1024)
@@ -65,7 +65,7 @@ def check():
         tune("c3b_cfg128", 1)
         nd = 0
         for tid in sorted(res[7][1]):
-            a, b = res[7][1][tid], res[31][1][tid]
+            a, b = res[7][1][tid], res[63][1][tid]
             if not np.array_equal(a, b, equal_nan=True):
                 d = np.abs(a.astype(np.float64) - b.astype(np.float64))
                 w = writer.get(tid, "?")
@@ -74,7 +74,7 @@ def check():
                     print(f"  shape {shape} halo_min {halo_min}: tensor {tid} ({names.get(tid, '')}, written by {w}) differs: "
                           f"{int((d > 0).sum())} of {d.size} values, max |d| {np.nanmax(d):.4g}")
                 nd += 1
-        same = all(torch.equal(u, v) for u, v in zip(res[7][0], res[31][0]))
+        same = all(torch.equal(u, v) for u, v in zip(res[7][0], res[63][0]))
         print(f"shape {shape} halo_min_patches {halo_min} cfg64 {c64} cfg128 {c128}: network outputs identical: {same}; "
               f"{nd} intermediate tensors differ (by design: y1 / t of fused bottlenecks)")
         bad += 0 if same else 1
@@ -86,7 +86,7 @@ def time_chains():
     ck = pkg.synth.make_checkpoint(0)
     be = pkg.backend.HipTextDetBackend(ck, device="cuda", precision="fp16")
     x = torch.randint(0, 256, (32, 1024, 1024, 3), dtype=torch.uint8, generator=torch.Generator().manual_seed(1)).cuda()
-    variants = [("unfused", 7, 0, 0), ("c3b 0/0", 15, 0, 0), ("c3b 0/1", 15, 0, 1), ("+post1x1", 31, 0, 1)]
+    variants = [("unfused", 7, 0, 0), ("c3b 0/0", 15, 0, 0), ("c3b 0/1", 15, 0, 1), ("+post1x1", 31, 0, 1), ("+segtaps", 63, 0, 1)]
     rows = {}
     for name, fuse, c64, c128 in variants:
         tune("fuse", fuse)
@@ -109,7 +109,7 @@ def time_chains():
         e1.record()
         torch.cuda.synchronize()
         rows[name] = (acc / 5, p["names"], e0.elapsed_time(e1) / 40)
-    tune("fuse", 31)
+    tune("fuse", 63)
     tune("c3b_cfg64", 0)
     tune("c3b_cfg128", 1)
     names = rows["unfused"][1]
@@ -121,7 +121,7 @@ def time_chains():
         tot += v
         if ".m." in n or n.endswith("cv3.conv") or n.endswith(".cv3"):
             chain += v
-        if ((".m." in n and "cv1" in n) or n.endswith("conv.1") or "upconv5.conv.0.cv1+cv2" in n or n == "db.conv.0") and v.max() > 0.05:
+        if ((".m." in n and "cv1" in n) or n.endswith("conv.1") or "upconv5.conv.0.cv1+cv2" in n or n == "db.conv.0" or n == "seg.upconv6") and v.max() > 0.05:
             print(f"{n:44s} " + " ".join(f"{q:9.4f}" for q in v))
     print(f"{'bottleneck + cv3 ops':44s} " + " ".join(f"{q:9.4f}" for q in chain))
     print(f"{'all ops (sum of per-op events)':44s} " + " ".join(f"{q:9.4f}" for q in tot))

@@ -95,13 +95,13 @@ def test_the_timed_dispatch_ran(prec):
         convt = [kern for n, kern in k if n.endswith("conv.1")]
         # the ConvTranspose 4x4/s2 layers from 64^2 maps up; two of them with their 1x1 consumer folded in
         assert len(convt) == 7 and sum(c.startswith("conv_halo3_kernel") for c in convt) >= 5, convt
-        assert convt.count("conv_halo3_kernel+1x1") == 2, convt
+        assert convt.count("conv_halo3_kernel+1x1") == 2 and convt.count("conv_halo3_kernel+taps") == 1, convt
+        assert dict(k)["seg.upconv6"] == "seg_final_gather_kernel"
         assert dict(k)["model.2.cv1+cv2"] == "c3_fused_kernel"
         c3b = [n for n, kern in k if kern == "c3b_kernel"]
         # model.4 (x2), model.6 (x3), model.13 / 17 / 20, seg.upconv4 / 5.conv.0, db.upconv4.conv.0
         assert len(c3b) == 11 and "upconv5.conv.0.m.0.cv1.conv" in c3b, c3b
-        assert {"stem_conv2_kernel", "conv_halo_kernel", "conv_igemm_kernel", "sppf_pool3_kernel", "seg_final_mfma_kernel",
-                "db_up_mfma_kernel"} <= names, names
+        assert {"stem_conv2_kernel", "conv_halo_kernel", "conv_igemm_kernel", "sppf_pool3_kernel", "db_up_mfma_kernel"} <= names, names
     else:
         assert {"conv_split_halo_kernel", "conv_split_kernel", "stem_split_kernel"} <= names, names
 

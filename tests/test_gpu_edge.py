@@ -135,7 +135,8 @@ def _tune(key, value):
 def test_fused_blocks_equal_the_layer_per_launch_program_bit_for_bit(shape, u8):
     """The multi-layer kernels of the fp16 engine (stem + layer 1, the 32-channel C3 block, SPPF's three pools, bit 8:
     bottleneck + cv3 of the 64 / 128-channel C3 blocks of backbone, neck and heads -- kernels_c3b.hip; bit 16: a 128-channel
-    ConvTranspose and the 1x1 conv that is its only consumer -- kernels_halo3.hip;
+    ConvTranspose and the 1x1 conv that is its only consumer, bit 32: the last 64-channel ConvTranspose and the tap
+    products of the 64 -> 1 one behind it -- kernels_halo3.hip;
     `ctd_tuning_set("fuse", mask)`) do the arithmetic of the launches they replace in the same order: every output
     of the network must be IDENTICAL with and without them -- interior and border patches, float and uint8 input,
     maps smaller than one patch (the C3 kernels are forced onto them with c3_min_patches = c3b_min_patches = 1), and
@@ -156,7 +157,7 @@ def test_fused_blocks_equal_the_layer_per_launch_program_bit_for_bit(shape, u8):
         _tune(b"c3_min_patches", 1)
         _tune(b"c3b_min_patches", 1)
         outs = {}
-        for mask in (1, 2, 4, 6, 7, 8, 15, 16, 31):
+        for mask in (1, 2, 4, 6, 7, 8, 15, 16, 31, 32, 63):
             _tune(b"fuse", mask)
             outs[mask] = run()
         _tune(b"halo_min_patches", 1)                   # the 3x3s (and ConvT phases) on the halo kernel everywhere
@@ -172,12 +173,12 @@ def test_fused_blocks_equal_the_layer_per_launch_program_bit_for_bit(shape, u8):
         _tune(b"halo3_min_blocks", 1)
         _tune(b"fuse", 0)
         ref_3 = run()
-        for mask in (16, 31):
+        for mask in (16, 31, 32, 63):
             _tune(b"fuse", mask)
             outs[f"{mask} + halo3"] = run()
         torch.cuda.synchronize()
     finally:
-        _tune(b"fuse", 31)
+        _tune(b"fuse", 63)
         _tune(b"halo3_min_blocks", 1024)
         _tune(b"c3_min_patches", 1024)
         _tune(b"c3b_min_patches", 1024)

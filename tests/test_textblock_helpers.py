@@ -101,3 +101,78 @@ if __name__ == "__main__" and "--regen" in sys.argv:
     assert R is not None, "needs /root/reference"
     json.dump([evaluate(R, c) for c in cases()], open(GOLD, "w"), indent=0)
     print("wrote", GOLD)
+
+
+def _random_records(rng, n_pages, max_blocks):
+    """Batch-wide native records as `ctd_tail_batch_fetch` lays them out: pages back to back, per-page offsets inside."""
+    TB = pkg().textblock
+    counts, recs, lines, dist = [], [], [], []
+    for _ in range(n_pages):
+        nb = int(rng.randint(0, max_blocks + 1))
+        r = np.zeros((nb,), TB.BLK_DTYPE)
+        nl = rng.randint(0, 4, nb)
+        nd = nl.copy()
+        r["xyxy"] = rng.randint(0, 2000, (nb, 4))
+        r["language"] = rng.randint(0, 3, nb)
+        r["vertical"] = rng.randint(0, 2, nb)
+        r["angle"] = rng.randint(-90, 91, nb)
+        r["font_is_float"] = rng.randint(0, 2, nb)
+        r["font_size"] = rng.rand(nb) * 60 - 5                       # int(font_size) truncates toward zero, also below 0
+        r["vec"] = rng.randn(nb, 2)
+        r["norm"] = rng.rand(nb) * 100
+        r["weight"] = rng.rand(nb)
+        r["merged"] = rng.randint(0, 2, nb)
+        r["n_lines"], r["n_dist"] = nl, nd
+        r["line_off"] = np.concatenate(([0], np.cumsum(nl)))[:-1] if nb else 0
+        r["dist_off"] = np.concatenate(([0], np.cumsum(nd)))[:-1] if nb else 0
+        counts.append((nb, int(nl.sum()), int(nd.sum())))
+        recs.append(r)
+        lines.append(rng.randint(-5, 3000, (int(nl.sum()), 8)).astype(np.int32))
+        d = rng.rand(int(nd.sum()), 3) * 2.4 - 1.2                   # cosines beyond [-1, 1]: arccos gives nan, like numpy's
+        dist.append(d)
+    cat = lambda xs, shape, dt: np.concatenate(xs) if sum(len(x) for x in xs) else np.zeros(shape, dt)   # noqa: E731
+    return (np.concatenate(recs) if sum(len(r) for r in recs) else np.zeros((0,), TB.BLK_DTYPE),
+            cat(lines, (0, 8), np.int32), cat(dist, (0, 3), np.float64), np.array(counts, np.int64).reshape(-1, 3))
+
+
+def _same_objects(a, b):
+    assert len(a) == len(b)
+    for x, y in zip(a, b):
+        dx, dy = vars(x), vars(y)
+        assert list(dx) == list(dy)                                  # attribute order = the key order of to_dict()
+        for k in dx:
+            assert type(dx[k]) is type(dy[k]), (k, type(dx[k]), type(dy[k]))
+            if isinstance(dx[k], np.ndarray):
+                assert dx[k].dtype == dy[k].dtype and np.array_equal(dx[k], dy[k], equal_nan=True), k
+            else:
+                assert dx[k] == dy[k] or (dx[k] != dx[k] and dy[k] != dy[k]), k
+
+
+def test_textblocks_built_in_c_equal_the_python_loop():
+    """csrc/pyblocks.c (`_ctd_pyblocks.build_blocks`: one C loop over the native records' columns) against the Python loop it
+    replaces on the tail workers -- same attribute order, same Python types (bool / int / float / list / np.float64 /
+    ndarray), same values incl. `int(font_size)`, the nan distances and fresh `text` lists; and the batch-wide conversion
+    (`blocks_from_batch`: page-relative offsets shifted into the batch's pools) against page-by-page conversion."""
+    TB = pkg().textblock
+    if TB._PYB is None:                                              # a checkout that has not been built yet
+        pkg()._lib.build()
+        TB = importlib.reload(TB)
+    assert TB._PYB is not None, "csrc/pyblocks.c was not built (make -C comic-text-detector_amd/csrc)"
+    rng = np.random.RandomState(3)
+    for n_pages, max_blocks in ((1, 0), (1, 7), (5, 40), (9, 3)):
+        recs, lines, dist, counts = _random_records(rng, n_pages, max_blocks)
+        ob = np.concatenate(([0], np.cumsum(counts[:, 0])))
+        ol = np.concatenate(([0], np.cumsum(counts[:, 1])))
+        od = np.concatenate(([0], np.cumsum(counts[:, 2])))
+        per_page = [(recs[ob[b]: ob[b + 1]], lines[ol[b]: ol[b + 1]], dist[od[b]: od[b + 1]]) for b in range(n_pages)]
+        py = [TB.blocks_from_records(*p, native=False) for p in per_page]
+        cc = [TB.blocks_from_records(*p, native=True) for p in per_page]
+        batch = TB.blocks_from_batch(recs, lines, dist, counts)
+        assert len(batch) == n_pages
+        for b in range(n_pages):
+            _same_objects(cc[b], py[b])
+            _same_objects(batch[b], py[b])
+            assert all(t.text == [] for t in batch[b]) and len({id(t.text) for t in batch[b]}) == len(batch[b])
+            assert isinstance(batch[b], list)
+        for blk in (x for pg in batch for x in pg):                  # the objects are ordinary TextBlocks
+            assert isinstance(blk, TB.TextBlock) and isinstance(blk.to_dict(), dict)

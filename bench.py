@@ -848,6 +848,9 @@ def main() -> None:
                     help="wall-clock limit of the rocm_baseline child process (s); 0 skips it")
     ap.add_argument("--rocm-budget", type=float, default=240.0, help="(rocm-baseline mode) stop starting new cases after this many s")
     ap.add_argument("--dump-ops", default="", help="write the per-op profile table to this file")
+    ap.add_argument("--cu-split", type=int, default=0,
+                    help="e2e experiment: confine the tails' streams to this many CUs (mask bits 0..T-1, the same share of every "
+                         "XCD) and run the forwards on a stream masked to the REST of the chip (hipExtStreamCreateWithCUMask)")
     ap.add_argument("--no-pin", action="store_true",
                     help="N > 1: do NOT bind the rank's threads to the CPUs of its GPU's NUMA node (affinity.py; A/B knob)")
     args = ap.parse_args()
@@ -906,6 +909,25 @@ def main() -> None:
             dist.destroy_process_group()
         return
 
+    masked_stream = None
+    if args.cu_split > 0:
+        # before any tail exists: their streams get the first T CUs; the forwards' stream the others
+        Lb = importlib.import_module("comic-text-detector_amd._lib")
+        TL.drain_free_tails()
+        Lb.check(Lb.lib().ctd_tuning_set(b"tail_cus", int(args.cu_split)), "ctd_tuning_set tail_cus")
+        import ctypes
+        hip = ctypes.CDLL("libamdhip64.so")
+        ncu = torch.cuda.get_device_properties(dev).multi_processor_count
+        words = (ncu + 31) // 32
+        bits = [0] * words
+        for c in range(args.cu_split, ncu):
+            bits[c >> 5] |= 1 << (c & 31)
+        arr = (ctypes.c_uint32 * words)(*bits)
+        sp = ctypes.c_void_p()
+        rc = hip.hipExtStreamCreateWithCUMask(ctypes.byref(sp), ctypes.c_uint32(words), arr)
+        if rc != 0:
+            raise RuntimeError(f"hipExtStreamCreateWithCUMask failed: {rc}")
+        masked_stream = torch.cuda.ExternalStream(sp.value, device=dev)
     ckpt, batches, canned, canned_sample = make_workload(pkg, args, rank, nloc, dev)
     det = DET.TextDetector(ckpt, input_size=S, device=dev, precision=args.precision)
     # every mode times the WHOLE network (the seam's full contract: blks, mask f32, lines_map with both planes), as the
@@ -918,6 +940,8 @@ def main() -> None:
 
     if args.fwd_stream == "high" and e2e:
         pipe.fwd_stream = torch.cuda.Stream(dev, priority=-1)
+    if masked_stream is not None:
+        pipe.fwd_stream = masked_stream
     if args.tail_only and e2e:
         fj = pipe.forward_job(0)
         torch.cuda.synchronize()

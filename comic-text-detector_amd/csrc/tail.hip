@@ -36,6 +36,10 @@ int ctd_fail_msg(int code, const std::string& msg);   // engine.hip: sets the th
 // beyond them shares a queue: 4 workers 1994 pages/s at priority 0 against 2554 at priority 1 (3 workers: 2545 either way),
 // pages from host memory 2025-2380 against 2500, the dense-block pages 1828 against 1926-1993.
 int g_tail_priority = 1;
+// > 0: the tails' streams may only use this many CUs, mask bits [g_tail_cu_first, + g_tail_cus) (hipExtStreamCreateWithCUMask; the
+// driver deals mask bits round-robin over the XCDs, so a contiguous run is the same share of every XCD); the caller gives the
+// network's stream the complementary mask ("tail_cus", "tail_cu_first"; bench.py --cu-split)
+int g_tail_cus = 0, g_tail_cu_first = 0;
 
 #define T_TRY(expr)                                                                                  \
   do {                                                                                               \
@@ -824,7 +828,17 @@ int ctd_tail_create(ctd_tail** out, int32_t device) {
   (void)hipDeviceGetStreamPriorityRange(&lo, &hi);   // hi = numerically lowest = highest priority
   // ctd_tuning_set("tail_priority"): 1 = the device's default priority (default), 0 = highest, 2 = lowest (measured: -13 %)
   const int prio = g_tail_priority == 2 ? lo : (g_tail_priority == 1 ? (lo + hi) / 2 : hi);
-  if (hipStreamCreateWithPriority(&t->st, hipStreamNonBlocking, prio) != hipSuccess) {
+  if (g_tail_cus > 0) {
+    hipDeviceProp_t p;
+    T_TRY(hipGetDeviceProperties(&p, device));
+    const int ncu = p.multiProcessorCount, words = (ncu + 31) / 32;
+    std::vector<uint32_t> mask((size_t)words, 0u);
+    for (int c = g_tail_cu_first; c < g_tail_cu_first + g_tail_cus && c < ncu; ++c) mask[c >> 5] |= 1u << (c & 31);
+    if (hipExtStreamCreateWithCUMask(&t->st, (uint32_t)words, mask.data()) != hipSuccess) {
+      delete t;
+      return ctd_fail_msg(CTD_ERR_HIP, "hipExtStreamCreateWithCUMask failed");
+    }
+  } else if (hipStreamCreateWithPriority(&t->st, hipStreamNonBlocking, prio) != hipSuccess) {
     delete t;
     return ctd_fail_msg(CTD_ERR_HIP, "hipStreamCreateWithPriority failed");
   }

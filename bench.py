@@ -95,9 +95,10 @@ def thread_budget(world: int, pinned: bool = False, host_cpus: int = 0) -> dict:
     per_rank = max(4, avail if pinned else avail // max(1, world))
     if pinned and host_cpus:
         avail = host_cpus                                     # what the host offered before this rank bound itself
-    # round 5 (forward 9.2 ms): 3 workers = 4 workers on the headline / dense / host-input pages and +6 % on the canned ones,
-    # for one core less per rank (scripts/experiments/e2e_workers_r5.sh); round 4 (forward 10.1 ms) had 4 ahead on dense pages
-    workers = 3 if per_rank >= 8 else 2
+    # 4 workers where a rank has 16 CPUs or more: round 5 re-measured it after the forward got shorter -- on one box 3 = 4 on the
+    # headline and +6 % on the canned pages, on another 4 is +2 % on the headline and +6 % on dense pages (three interleaved
+    # repetitions each, profiles/r05_e2e_workers_3_vs_4.txt); the dense pages decide
+    workers = 4 if per_rank >= 16 else (3 if per_rank >= 8 else 2)
     native = max(1, min(8, (per_rank - 2) // workers))
     return {"usable_cpus": avail, "per_rank": per_rank, "tail_workers": workers, "native_threads_per_worker": native}
 

@@ -61,7 +61,7 @@ def test_pooled_oracle_tail_equals_the_oracle_tail(tmp_path):
 
 def test_thread_budget_divides_the_host_between_ranks(monkeypatch):
     import bench
-    for cpus, world, want_workers in ((256, 1, 3), (256, 8, 3), (64, 8, 3), (16, 8, 2), (8, 1, 3)):   # round 5: 3 workers suffice
+    for cpus, world, want_workers in ((256, 1, 4), (256, 8, 4), (64, 8, 3), (16, 8, 2), (8, 1, 3)):
         monkeypatch.setattr(bench, "host_info", lambda c=cpus: {"cpu_model": "x", "logical_cpus": c, "usable_cpus": c})
         tb = bench.thread_budget(world)
         assert tb["tail_workers"] == want_workers, (cpus, world, tb)

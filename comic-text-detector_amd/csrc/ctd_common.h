@@ -91,8 +91,10 @@ template <int ACT> __device__ __forceinline__ float ctd_act_fast(float v) {
     asm("" : "+v"(r));
     return r;
   }
-  if (ACT == CTD_ACT_LEAKY) return v > 0.f ? v : 0.1f * v;
-  if (ACT == CTD_ACT_RELU) return v > 0.f ? v : 0.f;
+  // leaky / relu as ONE v_max (same value for every input, NaN and -0 included: 0.1 v > v exactly when v < 0) instead of a
+  // compare + select: the select's vcc hazard costs an s_nop per value and the pair does not fold into packed code (round 5)
+  if (ACT == CTD_ACT_LEAKY) return fmaxf(v, 0.1f * v);
+  if (ACT == CTD_ACT_RELU) return fmaxf(v, 0.f);
   if (ACT == CTD_ACT_SIGMOID) return __builtin_amdgcn_rcpf(1.0f + __expf(-v));
   return v;
 }

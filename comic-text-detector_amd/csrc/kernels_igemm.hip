@@ -358,6 +358,32 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_kernel(ConvArgs a) {
   };
   auto epilogue = [&](auto act_tag) {
     constexpr int ACT = decltype(act_tag)::value;
+    if (staged) {
+      // The common case (fp16 destination with 16-B channel rows) as STRAIGHT-LINE code: a tile's biases first, then bias +
+      // activation + rounding of its 16 values, then four 8-B LDS writes -- no branch, no wait between the groups.  The
+      // general path below tests `staged`, the residual and the channel tail per group of four values: 3-4 scalar branches
+      // and an `s_waitcnt lgkmcnt(0)` per group, 16 groups per wave tile in series -- ~3 k cycles per wave where a short-K 1x1
+      // layer's whole K loop is ~1 k (round 5, found in the ISA after the same defect in kernels_c3b.hip / kernels_stem2.hip)
+#pragma unroll
+      for (int j = 0; j < TM; ++j) {
+        const int pl = (wm * TM + j) * 32 + l31;
+#pragma unroll
+        for (int i = 0; i < TN; ++i) {
+          const int nl = (wn * TN + i) * 32 + 4 * hi;
+          float4_t bv[4];
+#pragma unroll
+          for (int g = 0; g < 4; ++g) bv[g] = *(const float4_t*)(bias_s + nl + 8 * g);
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            half4_t o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = (half_t)ctd_act_fast<ACT>(acc[i][j][4 * g + e] + bv[g][e]);
+            *(half4_t*)(Os + (size_t)pl * OP + nl + 8 * g) = o;
+          }
+        }
+      }
+      return;
+    }
 #pragma unroll
     for (int j = 0; j < TM; ++j) {
       const int pl = (wm * TM + j) * 32 + l31;   // pixel inside the tile

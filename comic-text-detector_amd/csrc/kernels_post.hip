@@ -162,11 +162,16 @@ __global__ __launch_bounds__(1024) void nms_greedy_kernel(Cand* __restrict__ can
 // raster order), then roots are ranked in raster order so label ids follow the
 // first-pixel order (OpenCV SAUF numbering for 4-connectivity).
 // ===========================================================================
+// (agent scope: every thread that links or flattens a parent array runs on this GPU; the default system scope made each
+// hop a load that bypasses the caches)
+__device__ __forceinline__ int uf_load(const int* parent, int x) {
+  return __hip_atomic_load(parent + x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 __device__ __forceinline__ int uf_find(int* parent, int x) {
-  int p = __atomic_load_n(parent + x, __ATOMIC_RELAXED);
+  int p = uf_load(parent, x);
   while (p != x) {
     x = p;
-    p = __atomic_load_n(parent + x, __ATOMIC_RELAXED);
+    p = uf_load(parent, x);
   }
   return x;
 }
@@ -232,12 +237,20 @@ __device__ __forceinline__ void ccl_local_body(int vb, const uint8_t* __restrict
   const int x0 = tx * CT, y0 = ty * CT;
   const int lane = threadIdx.x & 63;
   const int lx = threadIdx.x & 31;
+  // the tile's four rows of this thread first, then the ballots: a ballot consumes its load, and interleaved the four
+  // were four memory round trips in a row (pixels outside the image read the image's first byte and are masked)
+  int pix[CT * CT / 256];
+#pragma unroll
+  for (int k = 0; k < CT * CT / 256; ++k) {
+    const int gx = x0 + lx, gy = y0 + ((threadIdx.x + 256 * k) >> 5);
+    pix[k] = img[base + (gx < W && gy < H ? (size_t)gy * W + gx : (size_t)0)];
+  }
 #pragma unroll
   for (int k = 0; k < CT * CT / 256; ++k) {
     const int li = threadIdx.x + 256 * k;
     const int ly = li >> 5;
     const int gx = x0 + lx, gy = y0 + ly;
-    const bool fg = gx < W && gy < H && (((int)img[base + (size_t)gy * W + gx] > thresh) != (invert != 0));
+    const bool fg = gx < W && gy < H && ((pix[k] > thresh) != (invert != 0));
     const unsigned long long bal = __ballot(fg);
     const unsigned m = (unsigned)(lane < 32 ? bal : bal >> 32);          // this row's 32 pixels
     // first pixel of my run: one past the highest clear bit below me
@@ -371,16 +384,27 @@ __device__ __forceinline__ void ccl_flatten_count_body(int vb, int* __restrict__
   int* parent = parent_all + (size_t)b * hw;
   const int p0 = ch * RK_CHUNK + threadIdx.x;
   int local = 0;
-#pragma unroll 4
-  for (int j = 0; j < RK_PER_T; ++j) {
-    const int p = p0 + 256 * j;                 // coalesced: consecutive threads, consecutive pixels
-    if (p < hw) {
-      const int v = parent[p];
-      if (v >= 0) {
-        const int r = uf_find(parent, p);
-        if (r != v) parent[p] = r;              // most pixels already point at their root (tile-local labelling)
-        local += r == p;
-      }
+  // Four pixels per thread at a time, hop by hop: the parents of all four, then the parents' parents of all four -- after
+  // the tile-local labelling nearly every pixel is a root or points at one, i.e. done after these two loads -- and only
+  // what is left walks its chain alone.  One pixel at a time was a chain of 2-3 dependent loads, 16 times in a row.
+  constexpr int FU = 4;
+  static_assert(RK_PER_T % FU == 0, "whole batches");
+  for (int j0 = 0; j0 < RK_PER_T; j0 += FU) {
+    int v[FU], g[FU];
+#pragma unroll
+    for (int j = 0; j < FU; ++j) {
+      const int p = p0 + 256 * (j0 + j);        // coalesced: consecutive threads, consecutive pixels
+      v[j] = p < hw ? uf_load(parent, p) : -1;
+    }
+#pragma unroll
+    for (int j = 0; j < FU; ++j) g[j] = v[j] >= 0 ? uf_load(parent, v[j]) : -1;
+#pragma unroll
+    for (int j = 0; j < FU; ++j) {
+      const int p = p0 + 256 * (j0 + j);
+      if (v[j] < 0) continue;
+      const int r = g[j] == v[j] ? v[j] : uf_find(parent, g[j]);
+      if (r != v[j]) parent[p] = r;             // most pixels already point at their root (tile-local labelling)
+      local += r == p;
     }
   }
   int total;
@@ -428,10 +452,13 @@ __device__ __forceinline__ void ccl_rank_body(int vb, const int* __restrict__ pa
   const int base = ch * RK_CHUNK + w * 1024 + lane;
   unsigned long long m[16];
   int cnt = 0;
+  int pv[16];                                   // all 16 loads, then the ballots (each ballot consumes its load)
+#pragma unroll
+  for (int j = 0; j < 16; ++j) pv[j] = parent[min(base + 64 * j, hw - 1)];
 #pragma unroll
   for (int j = 0; j < 16; ++j) {
     const int p = base + 64 * j;
-    m[j] = __ballot(p < hw && parent[p] == p);
+    m[j] = __ballot(p < hw && pv[j] == p);
     cnt += __popcll(m[j]);
   }
   if (lane == 0) sh[w] = cnt;
@@ -516,16 +543,31 @@ __device__ __forceinline__ void ccl_label_body(int vb, int* __restrict__ labels_
     __syncthreads();
   }
   const int lane = threadIdx.x & 63;
-  for (int p0 = p_begin; p0 < p_end; p0 += 256) {
-    const int p = p0 + threadIdx.x;
-    const bool live = p < p_end;
-    int id = 0;
-    if (live) {
-      const int root = labels_all[base + p];
-      if (root >= 0) id = ids_all[base + root];
-      labels_all[base + p] = id;
+  // Four 256-pixel steps at a time: their roots, then their ids (a dependent gather), then the statistics step by step.
+  // One step at a time was two memory round trips per step, 32 steps in a row.
+  constexpr int LU = 4;
+  for (int pb = p_begin; pb < p_end; pb += 256 * LU) {
+    int root[LU], idv[LU];
+#pragma unroll
+    for (int u = 0; u < LU; ++u) {
+      const int p = pb + 256 * u + threadIdx.x;
+      root[u] = p < p_end ? labels_all[base + p] : -1;
+    }
+#pragma unroll
+    for (int u = 0; u < LU; ++u) idv[u] = root[u] >= 0 ? ids_all[base + root[u]] : 0;
+#pragma unroll
+    for (int u = 0; u < LU; ++u) {
+      const int p = pb + 256 * u + threadIdx.x;
+      if (p < p_end) labels_all[base + p] = idv[u];
     }
     if (!stats) continue;
+#pragma unroll
+    for (int u = 0; u < LU; ++u) {
+    const int p0 = pb + 256 * u;
+    if (p0 >= p_end) break;
+    const int p = p0 + threadIdx.x;
+    const bool live = p < p_end;
+    const int id = idv[u];
     const int x = live ? p % W : 0, y = live ? p / W : 0;
     const int key = live ? id : -1;                         // dead lanes end a run
     const int prev = __shfl_up(key, 1);
@@ -550,6 +592,7 @@ __device__ __forceinline__ void ccl_label_body(int vb, int* __restrict__ labels_
       atomicMax(s + 2, x + len - 1);
       atomicMax(s + 3, y);
       atomicAdd(s + 4, len);
+    }
     }
   }
   if (stats) {
@@ -608,13 +651,19 @@ __device__ __forceinline__ void ccl2_local_body(int vb, const uint8_t* __restric
   const int x0 = tx * CT, y0 = ty * CT;
   const int lane = threadIdx.x & 63;
   const int lx = threadIdx.x & 31;
+  int pix[CT * CT / 256];                                   // loads first, ballots second (see ccl_local_body)
+#pragma unroll
+  for (int k = 0; k < CT * CT / 256; ++k) {
+    const int gx = x0 + lx, gy = y0 + ((threadIdx.x + 256 * k) >> 5);
+    pix[k] = img[base + (gx < W && gy < H ? (size_t)gy * W + gx : (size_t)0)];
+  }
 #pragma unroll
   for (int k = 0; k < CT * CT / 256; ++k) {
     const int li = threadIdx.x + 256 * k;
     const int ly = li >> 5;
     const int gx = x0 + lx, gy = y0 + ly;
     const bool valid = gx < W && gy < H;
-    const bool fg = valid && (int)img[base + (size_t)gy * W + gx] > thresh;
+    const bool fg = valid && pix[k] > thresh;
     const unsigned long long balf = __ballot(fg), balv = __ballot(valid);
     const unsigned mf = (unsigned)(lane < 32 ? balf : balf >> 32);
     const unsigned mv = (unsigned)(lane < 32 ? balv : balv >> 32);
@@ -740,15 +789,26 @@ __device__ __forceinline__ void ccl2_flatten_count_body(int vb, int* __restrict_
   const uint8_t* img = img_all + (size_t)b * hw;
   const int p0 = ch * RK_CHUNK + threadIdx.x;
   int lf = 0, lb = 0;
-#pragma unroll 4
-  for (int j = 0; j < RK_PER_T; ++j) {
-    const int p = p0 + 256 * j;
-    if (p < hw) {
-      const int v = parent[p];
-      const int r = uf_find(parent, p);
-      if (r != v) parent[p] = r;
+  constexpr int FU = 4;                         // hop by hop over four pixels (see ccl_flatten_count_body)
+  static_assert(RK_PER_T % FU == 0, "whole batches");
+  for (int j0 = 0; j0 < RK_PER_T; j0 += FU) {
+    int v[FU], g[FU], px[FU];
+#pragma unroll
+    for (int j = 0; j < FU; ++j) {
+      const int p = p0 + 256 * (j0 + j);
+      v[j] = p < hw ? uf_load(parent, p) : -1;  // every pixel of the image has a class: parents are never negative
+      px[j] = img[min(p, hw - 1)];
+    }
+#pragma unroll
+    for (int j = 0; j < FU; ++j) g[j] = v[j] >= 0 ? uf_load(parent, v[j]) : -1;
+#pragma unroll
+    for (int j = 0; j < FU; ++j) {
+      const int p = p0 + 256 * (j0 + j);
+      if (v[j] < 0) continue;
+      const int r = g[j] == v[j] ? v[j] : uf_find(parent, g[j]);
+      if (r != v[j]) parent[p] = r;
       if (r == p) {
-        if ((int)img[p] > thresh) ++lf; else ++lb;
+        if (px[j] > thresh) ++lf; else ++lb;
       }
     }
   }
@@ -801,11 +861,18 @@ __device__ __forceinline__ void ccl2_rank_body(int vb, const int* __restrict__ p
   const int base = ch * RK_CHUNK + w * 1024 + lane;
   unsigned long long mf[16], mb[16];
   int cf = 0, cb = 0;
+  int pv[16], px[16];                           // all loads, then the ballots (each ballot consumes its loads)
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    const int q = min(base + 64 * j, hw - 1);
+    pv[j] = parent[q];
+    px[j] = img[q];
+  }
 #pragma unroll
   for (int j = 0; j < 16; ++j) {
     const int p = base + 64 * j;
-    const bool root = p < hw && parent[p] == p;
-    const bool fg = root && (int)img[p] > thresh;
+    const bool root = p < hw && pv[j] == p;
+    const bool fg = root && px[j] > thresh;
     mf[j] = __ballot(fg);
     mb[j] = __ballot(root && !fg);
     cf += __popcll(mf[j]);
@@ -863,14 +930,28 @@ __device__ __forceinline__ void ccl2_label_body(int vb, int* __restrict__ labels
   __syncthreads();
   const int lane = threadIdx.x & 63;
   auto row_of = [&](int id) { return (id > 0 ? st_f : st_b) + ((size_t)b * max_labels + ((id > 0 ? id : -id) - 1)) * 5; };
-  for (int p0 = p_begin; p0 < p_end; p0 += 256) {
+  constexpr int LU = 4;                                     // four steps' roots, then their ids (see ccl_label_body)
+  for (int pb = p_begin; pb < p_end; pb += 256 * LU) {
+    int root[LU], idv[LU];
+#pragma unroll
+    for (int u = 0; u < LU; ++u) {
+      const int p = pb + 256 * u + threadIdx.x;
+      root[u] = p < p_end ? labels_all[base + p] : -1;
+    }
+#pragma unroll
+    for (int u = 0; u < LU; ++u) idv[u] = root[u] >= 0 ? ids_all[base + root[u]] : 0;
+#pragma unroll
+    for (int u = 0; u < LU; ++u) {
+      const int p = pb + 256 * u + threadIdx.x;
+      if (p < p_end) labels_all[base + p] = idv[u];
+    }
+#pragma unroll
+    for (int u = 0; u < LU; ++u) {
+    const int p0 = pb + 256 * u;
+    if (p0 >= p_end) break;
     const int p = p0 + threadIdx.x;
     const bool live = p < p_end;
-    int id = 0;                                             // 0 = dead lane (every pixel has a class, so no real id is 0)
-    if (live) {
-      id = ids_all[base + labels_all[base + p]];
-      labels_all[base + p] = id;
-    }
+    const int id = idv[u];                                  // 0 = dead lane (every pixel has a class, so no real id is 0)
     const int x = live ? p % W : 0, y = live ? p / W : 0;
     const int prev = __shfl_up(id, 1);
     const bool head = lane == 0 || prev != id || x == 0;
@@ -895,6 +976,7 @@ __device__ __forceinline__ void ccl2_label_body(int vb, int* __restrict__ labels
       atomicMax(s + 2, x + len - 1);
       atomicMax(s + 3, y);
       atomicAdd(s + 4, len);
+    }
     }
   }
   __syncthreads();

@@ -508,16 +508,85 @@ __global__ __launch_bounds__(256) void tw_accept_apply_kernel(const TWin* __rest
 // addressing; keys that do not fit go to the global counters, which stay zero otherwise), so the decision of a component
 // = LDS entry + global entry.  Only this block touches the window's pixels of `merged`: __syncthreads orders its rounds.
 constexpr int TWB_THREADS = 512, TWB_HN = 2048;
-__global__ __launch_bounds__(TWB_THREADS) void tw_accept_all_kernel(const TWin* __restrict__ wins, const TBand* __restrict__ bands,
-                                                                    const int* __restrict__ labels, int canvas_w,
-                                                                    const int* __restrict__ stats, int max_labels, int min_box,
-                                                                    uint8_t* __restrict__ merged, int merged_w,
-                                                                    unsigned* __restrict__ counters) {
-  const TWin w = wins[blockIdx.x];
+// Groups a thread has in flight per sweep step.  A window is one block's work, so its time is a chain of dependent loads
+// (labels -> prediction rows -> table, labels -> stats -> counters) times the steps of the sweep: one group per thread and
+// step made the largest window of a work item take 0.6 ms (rocprofv3, round 5: the biggest entry of the tail's GPU time,
+// and a block that holds 16 KB of LDS on its CU for all of it).  Every sweep below first issues the loads of TWB_U groups,
+// then uses them.  Sums, maxima and ORs: the order of the additions does not change a counter.
+constexpr int TWB_U = 4;
+
+// A group cut by the window's right edge takes a byte path in `load_lab4` / `pred_on4`: a branch whose loads are consumed
+// inside it, i.e. a memory round trip in the middle of every wave that spans a row end (most do) -- with it the groups of a
+// step wait for each other again.  In windows at least 8 pixels wide (`FAST`: the kernels pick the instantiation per
+// window) the last group of a row is the row's LAST four pixels instead: it overlaps its left neighbour, and its first `lo`
+// pixels -- the neighbour's -- are skipped.  Every group is then four whole pixels inside the window: one 16-B / 4-B / 8-B
+// load each, no edge branch.  The sweeps only add, take maxima and set bytes per pixel, and every pixel is still taken
+// exactly once.
+template <bool FAST>
+__device__ __forceinline__ Grp win_group_lo(const TWin& w, int gi, int& lo) {
+  Grp g = win_group(w, gi);
+  lo = 0;
+  if (FAST) {
+    lo = 4 - g.nv;
+    g.x -= lo;
+    g.nv = 4;
+  }
+  return g;
+}
+// four bytes of a row from column g.x on, little-endian in one word; 255 beyond the window's right edge
+__device__ __forceinline__ unsigned bytes4(const uint8_t* row0, const Grp& g) {
+  uint8_t b[4];
+  if (g.nv == 4) {
+    __builtin_memcpy(b, row0 + g.x, 4);
+  } else {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) b[k] = k < g.nv ? row0[g.x + k] : (uint8_t)255;
+  }
+  unsigned v;
+  __builtin_memcpy(&v, b, 4);
+  return v;
+}
+// pred_on4 of a whole group in a window at least 8 wide, without a byte path and in two halves: the loads of several
+// groups are issued before the first is used
+struct PredRaw {
+  unsigned long long mid;   // 8 bytes of the group's row from column clamp(x - 1, 0, w - 8) on
+  unsigned up, dn;          // columns x .. x+3 of the rows above / below (the group's own row where there is none)
+};
+__device__ __forceinline__ PredRaw pred_load_wide(const TWin& w, const Grp& g) {
+  const uint8_t* base = w.mask + (size_t)(w.y1 + g.y) * w.mask_w + w.x1;
+  PredRaw r;
+  __builtin_memcpy(&r.mid, base + min(max(g.x - 1, 0), w.w - 8), 8);
+  __builtin_memcpy(&r.up, base + (g.y > 0 ? -(long long)w.mask_w : 0ll) + g.x, 4);
+  __builtin_memcpy(&r.dn, base + (g.y + 1 < w.h ? (long long)w.mask_w : 0ll) + g.x, 4);
+  return r;
+}
+__device__ __forceinline__ unsigned pred_bits_wide(const TWin& w, const Grp& g, const PredRaw& r) {
+  // columns x-1 .. x+4 as bytes 0..5; 255 outside the window
+  const int d = g.x - 1 - min(max(g.x - 1, 0), w.w - 8);       // -1 (the first group of a row) .. 3
+  unsigned long long v = d < 0 ? ((r.mid << 8) | 0xffull) : (r.mid >> (8 * (d & 7)));
+  const int nvalid = w.w - (g.x - 1);                          // bytes from byte 0 on that are window columns (>= 5)
+  v |= nvalid < 8 ? ~0ull << (8 * (nvalid & 7)) : 0ull;
+  int c[6], m[4];
+#pragma unroll
+  for (int j = 0; j < 6; ++j) c[j] = (int)((v >> (8 * j)) & 0xffull);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) m[k] = min(c[k + 1], min(c[k], c[k + 2]));
+  // a row outside the window is ignored: its stand-in is the group's own row, already in the minimum
+#pragma unroll
+  for (int k = 0; k < 4; ++k) m[k] = min(m[k], min((int)((r.up >> (8 * k)) & 0xffu), (int)((r.dn >> (8 * k)) & 0xffu)));
+  unsigned bits = 0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) bits |= (m[k] > 60 ? 1u : 0u) << k;
+  return bits;
+}
+
+template <bool FAST>
+__device__ __forceinline__ void tw_accept_all_body(const TWin& w, const TBand* __restrict__ bands, const int* __restrict__ labels,
+                                                   int canvas_w, const int* __restrict__ stats, int max_labels, int min_box,
+                                                   uint8_t* __restrict__ merged, int merged_w, unsigned* __restrict__ counters,
+                                                   int* hkey, unsigned* hcnt) {
   const int ng = win_groups(w);
   const int lane = threadIdx.x & 63;
-  __shared__ int hkey[TWB_HN];
-  __shared__ unsigned hcnt[TWB_HN];
   auto add = [&](int key, unsigned n) {
     unsigned h = ((unsigned)key * 2654435761u) >> 21;          // 11 bits
 #pragma unroll
@@ -530,107 +599,172 @@ __global__ __launch_bounds__(TWB_THREADS) void tw_accept_all_kernel(const TWin* 
     }
     atomicAdd(counters + (size_t)key, n);
   };
-  auto total = [&](int key) -> unsigned {                     // LDS entry (if any) + what overflowed to the global table
-    unsigned v = __hip_atomic_load(counters + (size_t)key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  auto in_lds = [&](int key) -> unsigned {                    // the LDS entry of a key (0: none)
     unsigned h = ((unsigned)key * 2654435761u) >> 21;
 #pragma unroll
     for (int probe = 0; probe < 4; ++probe, h = (h + 1) & (TWB_HN - 1)) {
       const int k = hkey[h];
-      if (k == key) return v + hcnt[h];
+      if (k == key) return hcnt[h];
       if (k == 0) break;
     }
-    return v;
+    return 0u;
+  };
+  auto in_hbm = [&](int key) -> unsigned {                    // what overflowed to the global table
+    return __hip_atomic_load(counters + (size_t)key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   };
   for (int r = 0; r < w.nband; ++r) {
     const TBand bd = bands[w.band0 + r];
     for (int i = threadIdx.x; i < TWB_HN; i += TWB_THREADS) hkey[i] = 0, hcnt[i] = 0;
     __syncthreads();                                           // also: the previous round's writes to `merged` are visible
     // ---- count: pixels of every component of this band not merged yet, split by the prediction (as tw_accept_count)
-    for (int g0 = 0; g0 < ng; g0 += TWB_THREADS) {
-      const int gi = g0 + threadIdx.x;
-      int ukey = 0, ulen = 0;
-      if (gi < ng) {
-        const Grp g = win_group(w, gi);
-        int l[4];
-        load_lab4(labels + (size_t)(bd.cy + g.y) * canvas_w + bd.cx + g.x, g, l);
-        const uint8_t* mr = merged + (size_t)(w.my + g.y) * merged_w + w.mx + g.x;
-        uint8_t mg[4];
-        if (g.nv == 4) {
-          __builtin_memcpy(mg, mr, 4);
-        } else {
+    for (int g0 = 0; g0 < ng; g0 += TWB_THREADS * TWB_U) {
+      Grp g[TWB_U];
+      int lo[TWB_U];                                           // pixels lo .. nv-1 of the group are this thread's
+      int l[TWB_U][4];
+      unsigned mg[TWB_U];                                      // four bytes of `merged`, 255 beyond the window's right edge
 #pragma unroll
-          for (int k = 0; k < 4; ++k) mg[k] = k < g.nv ? mr[k] : 255;
-        }
-        bool any = false;
+      for (int u = 0; u < TWB_U; ++u) {
+        const int gi = g0 + u * TWB_THREADS + threadIdx.x;
+        g[u] = win_group_lo<FAST>(w, min(gi, ng - 1), lo[u]);
+        load_lab4(labels + (size_t)(bd.cy + g[u].y) * canvas_w + bd.cx + g[u].x, g[u], l[u]);
+        mg[u] = bytes4(merged + (size_t)(w.my + g[u].y) * merged_w + w.mx, g[u]);
+        if (gi >= ng) lo[u] = 4;                               // a group beyond the window counts nothing
+      }
+      unsigned pred[TWB_U];
+      PredRaw raw[TWB_U];
+      bool any[TWB_U];
+#pragma unroll
+      for (int u = 0; u < TWB_U; ++u) {
+        any[u] = false;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-          if (!(k < g.nv && l[k] > 0 && l[k] <= max_labels && mg[k] == 0)) l[k] = 0;
-          any |= l[k] != 0;
+          // (`&`, not `&&`: one mask per pixel instead of a chain of exec-mask branches; k >= nv: the byte is 255)
+          const bool keep = (k >= lo[u]) & (l[u][k] > 0) & (l[u][k] <= max_labels) & (((mg[u] >> (8 * k)) & 0xffu) == 0);
+          l[u][k] = keep ? l[u][k] : 0;
+          any[u] |= keep;
         }
-        if (any) {
-          const unsigned pred = pred_on4(w, g);
+      }
+      // the prediction around the groups that have a pixel to count: again every group's loads before the first use
+#pragma unroll
+      for (int u = 0; u < TWB_U; ++u) {
+        pred[u] = 0;
+        raw[u].mid = 0, raw[u].up = raw[u].dn = 0;
+        if (any[u]) {
+          if (FAST) raw[u] = pred_load_wide(w, g[u]);
+          else pred[u] = pred_on4(w, g[u]);
+        }
+      }
+      if (FAST) {
+#pragma unroll
+        for (int u = 0; u < TWB_U; ++u) pred[u] = pred_bits_wide(w, g[u], raw[u]);   // unused where the group has no key
+      }
+#pragma unroll
+      for (int u = 0; u < TWB_U; ++u) {
+        int ukey = 0, ulen = 0;                                // this thread's contribution to a wave-level run
+        if (l[u][0] | l[u][1] | l[u][2] | l[u][3]) {
           int key[4];
 #pragma unroll
-          for (int k = 0; k < 4; ++k) key[k] = l[k] ? 2 * l[k] + (((pred >> k) & 1u) ? 0 : 1) : 0;
+          for (int k = 0; k < 4; ++k) key[k] = l[u][k] ? 2 * l[u][k] + (((pred[u] >> k) & 1u) ? 0 : 1) : 0;
+          const int last = g[u].nv - 1;                        // the group's last pixel is always this thread's
+          const int kl = last == 3 ? key[3] : (last == 2 ? key[2] : (last == 1 ? key[1] : key[0]));
           bool same = true;
 #pragma unroll
-          for (int k = 1; k < 4; ++k) same &= k >= g.nv || key[k] == key[0];
+          for (int k = 0; k < 4; ++k) same &= k < lo[u] || k >= g[u].nv || key[k] == kl;
           if (same) {
-            ukey = key[0], ulen = g.nv;
+            ukey = kl, ulen = g[u].nv - lo[u];
           } else {
 #pragma unroll
             for (int k = 0; k < 4; ++k)
               if (key[k]) add(key[k], 1u);
           }
         }
+        if (!__ballot(ukey != 0)) continue;
+        const int prev = __shfl_up(ukey, 1);
+        const bool head = lane == 0 || prev != ukey;
+        const unsigned long long heads = __ballot(head);
+        int ps = ulen;
+        for (int off = 1; off < 64; off <<= 1) {
+          const int v = __shfl_up(ps, off);
+          if (lane >= off) ps += v;
+        }
+        const unsigned long long later = lane == 63 ? 0ull : (heads >> (lane + 1));
+        const int lanes = later ? __ffsll((long long)later) : 64 - lane;
+        const int tail = __shfl(ps, lane + lanes - 1);
+        if (head && ukey) add(ukey, (unsigned)(tail - ps + ulen));
       }
-      if (!__ballot(ukey != 0)) continue;
-      const int prev = __shfl_up(ukey, 1);
-      const bool head = lane == 0 || prev != ukey;
-      const unsigned long long heads = __ballot(head);
-      int ps = ulen;
-      for (int off = 1; off < 64; off <<= 1) {
-        const int u = __shfl_up(ps, off);
-        if (lane >= off) ps += u;
-      }
-      const unsigned long long later = lane == 63 ? 0ull : (heads >> (lane + 1));
-      const int lanes = later ? __ffsll((long long)later) : 64 - lane;
-      const int tail = __shfl(ps, lane + lanes - 1);
-      if (head && ukey) add(ukey, (unsigned)(tail - ps + ulen));
     }
     __syncthreads();
     // ---- apply: OR a component in iff its bbox has >= min_box pixels and it lowers the xor distance (as tw_accept_apply)
-    for (int gi = threadIdx.x; gi < ng; gi += TWB_THREADS) {
-      const Grp g = win_group(w, gi);
-      int l[4];
-      load_lab4(labels + (size_t)(bd.cy + g.y) * canvas_w + bd.cx + g.x, g, l);
-      int lprev = 0;
-      bool okprev = false;
+    for (int g0 = 0; g0 < ng; g0 += TWB_THREADS * TWB_U) {
+      Grp g[TWB_U];
+      int lo[TWB_U];
+      int l[TWB_U][4];
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const int lk = l[k];
-        if (lk <= 0 || lk > max_labels) continue;
-        if (lk != lprev) {                                     // neighbours mostly share their component: decide once
-          lprev = lk;
-          okprev = stats[(size_t)(lk - 1) * 5 + 2] * stats[(size_t)(lk - 1) * 5 + 3] >= min_box &&
-                   total(2 * lk) > total(2 * lk + 1);
+      for (int u = 0; u < TWB_U; ++u) {
+        const int gi = g0 + u * TWB_THREADS + threadIdx.x;
+        g[u] = win_group_lo<FAST>(w, min(gi, ng - 1), lo[u]);
+        load_lab4(labels + (size_t)(bd.cy + g[u].y) * canvas_w + bd.cx + g[u].x, g[u], l[u]);
+        if (gi >= ng) lo[u] = 4;
+      }
+#pragma unroll
+      for (int u = 0; u < TWB_U; ++u)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) l[u][k] = ((k >= lo[u]) & (l[u][k] > 0) & (l[u][k] <= max_labels)) ? l[u][k] : 0;
+      // the first component of every group (neighbours mostly share theirs) and what decides it, fetched for all groups
+      // before any is used (component 1's entries stand in where a group has none)
+      int l0[TWB_U], bw[TWB_U], bh[TWB_U];
+      unsigned on[TWB_U], off[TWB_U];
+#pragma unroll
+      for (int u = 0; u < TWB_U; ++u) {
+        l0[u] = 0;
+#pragma unroll
+        for (int k = 3; k >= 0; --k)
+          if (l[u][k]) l0[u] = l[u][k];
+        const int li = max(l0[u], 1);
+        bw[u] = stats[(size_t)(li - 1) * 5 + 2], bh[u] = stats[(size_t)(li - 1) * 5 + 3];
+        on[u] = in_hbm(2 * li), off[u] = in_hbm(2 * li + 1);
+      }
+#pragma unroll
+      for (int u = 0; u < TWB_U; ++u) {
+        if (!l0[u]) continue;
+        int lprev = l0[u];
+        bool okprev = bw[u] * bh[u] >= min_box && on[u] + in_lds(2 * lprev) > off[u] + in_lds(2 * lprev + 1);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int lk = l[u][k];
+          if (!lk) continue;
+          if (lk != lprev) {                                   // a second component in one group: decide it here
+            lprev = lk;
+            okprev = stats[(size_t)(lk - 1) * 5 + 2] * stats[(size_t)(lk - 1) * 5 + 3] >= min_box &&
+                     in_hbm(2 * lk) + in_lds(2 * lk) > in_hbm(2 * lk + 1) + in_lds(2 * lk + 1);
+          }
+          if (okprev) merged[(size_t)(w.my + g[u].y) * merged_w + w.mx + g[u].x + k] = 255;
         }
-        if (okprev) merged[(size_t)(w.my + g.y) * merged_w + w.mx + g.x + k] = 255;
       }
     }
     __syncthreads();                                           // before the table is cleared for the next band
   }
 }
 
-// ---- one block per window: the four passes of the hole filling (reference utils/textmask.py:113-131) ---------------------
-__global__ __launch_bounds__(TWB_THREADS) void tw_holes_all_kernel(const TWin* __restrict__ wins, const int* __restrict__ labels2,
-                                                                   const int* __restrict__ stats2, const int* __restrict__ first2,
-                                                                   int max_labels, const unsigned* __restrict__ count255,
-                                                                   uint8_t* __restrict__ merged, int merged_w,
-                                                                   unsigned* __restrict__ counters2) {
+__global__ __launch_bounds__(TWB_THREADS) void tw_accept_all_kernel(const TWin* __restrict__ wins, const TBand* __restrict__ bands,
+                                                                    const int* __restrict__ labels, int canvas_w,
+                                                                    const int* __restrict__ stats, int max_labels, int min_box,
+                                                                    uint8_t* __restrict__ merged, int merged_w,
+                                                                    unsigned* __restrict__ counters) {
+  __shared__ int hkey[TWB_HN];
+  __shared__ unsigned hcnt[TWB_HN];
   const TWin w = wins[blockIdx.x];
+  if (w.w >= 8) tw_accept_all_body<true>(w, bands, labels, canvas_w, stats, max_labels, min_box, merged, merged_w, counters, hkey, hcnt);
+  else tw_accept_all_body<false>(w, bands, labels, canvas_w, stats, max_labels, min_box, merged, merged_w, counters, hkey, hcnt);
+}
+
+// ---- one block per window: the four passes of the hole filling (reference utils/textmask.py:113-131) ---------------------
+template <bool FAST>
+__device__ __forceinline__ void tw_holes_all_body(const TWin& w, const int* __restrict__ labels2, const int* __restrict__ stats2,
+                                                  const int* __restrict__ first2, int max_labels,
+                                                  const unsigned* __restrict__ count255, uint8_t* __restrict__ merged,
+                                                  int merged_w, unsigned* __restrict__ counters2, int* tp) {
   const int ng = win_groups(w);
-  __shared__ int tp[3];                                        // [maximum, multiplicity - 1, runner-up]
   if (threadIdx.x < 3) tp[threadIdx.x] = -1;
   __syncthreads();
   const int a0 = (int)count255[blockIdx.x];                    // the background entry: pixels already set
@@ -643,34 +777,69 @@ __global__ __launch_bounds__(TWB_THREADS) void tw_holes_all_kernel(const TWin* _
     const int m1 = pass >= 1 ? tp[0] : 0;
     const int thr = pass >= 2 ? (tp[1] >= 1 ? tp[0] : tp[2]) : 0;
     if (pass >= 2 && thr < 0) break;                           // block-uniform: nothing can be filled
-    for (int gi = threadIdx.x; gi < ng; gi += TWB_THREADS) {
-      const Grp g = win_group(w, gi);
-      const size_t c0 = (size_t)(w.my + g.y) * merged_w + w.mx + g.x;
-      int lab[4];
-      load_lab4(labels2 + c0, g, lab);
+    for (int g0 = 0; g0 < ng; g0 += TWB_THREADS * TWB_U) {
+      Grp g[TWB_U];
+      int lo[TWB_U];
+      int lab[TWB_U][4];
+      size_t c0[TWB_U];
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const int l = lab[k];
-        if (l <= 0 || l > max_labels) continue;
-        const size_t ci = c0 + k;
-        const int area = stats2[(size_t)(l - 1) * 5 + 4];
-        if (pass <= 1) {
-          if (first2[l - 1] != (int)ci) continue;              // one representative pixel per component
-          if (pass == 0) atomicMax(&tp[0], area);
-          else if (area == m1) atomicAdd(&tp[1], 1);
-          else atomicMax(&tp[2], area);
-        } else if (pass == 2) {
-          if (area < thr && merged[ci] == 0) atomicAdd(counters2 + 2 * (size_t)l + (pred_on(w, g.x + k, g.y) ? 0 : 1), 1u);
-        } else {
-          if (area < thr &&
-              __hip_atomic_load(counters2 + 2 * (size_t)l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >
-                  __hip_atomic_load(counters2 + 2 * (size_t)l + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
-            merged[ci] = 255;
-        }
+      for (int u = 0; u < TWB_U; ++u) {
+        const int gi = g0 + u * TWB_THREADS + threadIdx.x;
+        g[u] = win_group_lo<FAST>(w, min(gi, ng - 1), lo[u]);
+        c0[u] = (size_t)(w.my + g[u].y) * merged_w + w.mx + g[u].x;
+        load_lab4(labels2 + c0[u], g[u], lab[u]);
+        if (gi >= ng) lo[u] = 4;
       }
+#pragma unroll
+      for (int u = 0; u < TWB_U; ++u)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) lab[u][k] = ((k >= lo[u]) & (lab[u][k] > 0) & (lab[u][k] <= max_labels)) ? lab[u][k] : 0;
+      // per pixel: the component's area and (passes 0, 1) its representative pixel -- all of them fetched before the first use
+      int area[TWB_U][4], rep[TWB_U][4];
+#pragma unroll
+      for (int u = 0; u < TWB_U; ++u)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int l = lab[u][k];
+          area[u][k] = l ? stats2[(size_t)(l - 1) * 5 + 4] : 0;
+          rep[u][k] = l && pass <= 1 ? first2[l - 1] : -1;
+        }
+#pragma unroll
+      for (int u = 0; u < TWB_U; ++u)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int l = lab[u][k];
+          if (!l) continue;
+          const size_t ci = c0[u] + k;
+          const int ar = area[u][k];
+          if (pass <= 1) {
+            if (rep[u][k] != (int)ci) continue;                // one representative pixel per component
+            if (pass == 0) atomicMax(&tp[0], ar);
+            else if (ar == m1) atomicAdd(&tp[1], 1);
+            else atomicMax(&tp[2], ar);
+          } else if (pass == 2) {
+            if (ar < thr && merged[ci] == 0) atomicAdd(counters2 + 2 * (size_t)l + (pred_on(w, g[u].x + k, g[u].y) ? 0 : 1), 1u);
+          } else {
+            if (ar < thr &&
+                __hip_atomic_load(counters2 + 2 * (size_t)l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >
+                    __hip_atomic_load(counters2 + 2 * (size_t)l + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+              merged[ci] = 255;
+          }
+        }
     }
     __syncthreads();
   }
+}
+
+__global__ __launch_bounds__(TWB_THREADS) void tw_holes_all_kernel(const TWin* __restrict__ wins, const int* __restrict__ labels2,
+                                                                   const int* __restrict__ stats2, const int* __restrict__ first2,
+                                                                   int max_labels, const unsigned* __restrict__ count255,
+                                                                   uint8_t* __restrict__ merged, int merged_w,
+                                                                   unsigned* __restrict__ counters2) {
+  __shared__ int tp[3];                                        // [maximum, multiplicity - 1, runner-up]
+  const TWin w = wins[blockIdx.x];
+  if (w.w >= 8) tw_holes_all_body<true>(w, labels2, stats2, first2, max_labels, count255, merged, merged_w, counters2, tp);
+  else tw_holes_all_body<false>(w, labels2, stats2, first2, max_labels, count255, merged, merged_w, counters2, tp);
 }
 
 // 3x3 rect dilation inside the window (REFINEMASK_INPAINT, textmask.py:110-111) or a copy; also the

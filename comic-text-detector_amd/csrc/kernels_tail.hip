@@ -100,17 +100,33 @@ __global__ __launch_bounds__(256) void dbc_accum_kernel(DbcTables t) {
   const int span = gridDim.x * 256;
   const int lane = threadIdx.x & 63;
   const int b = blockIdx.y;                            // one page per grid row: 32-bit index arithmetic only
-  for (int p0 = blockIdx.x * 256; p0 < hw; p0 += span) {
+  const size_t cb = (size_t)b * t.cap, rb = (size_t)b * t.rcap;
+  // Four steps of the sweep at a time: their labels, then (background pixels) the ring of their component -- two dependent
+  // loads that nearly every wave needs only to find out that it has nothing to add.  One step at a time a thread spent
+  // its ~44 steps waiting for one load after the other.
+  constexpr int DU = 4;
+  for (long long pb = (long long)blockIdx.x * 256; pb < hw; pb += (long long)span * DU) {
+    int keys[DU], pars[DU];
+#pragma unroll
+    for (int u = 0; u < DU; ++u) {
+      const long long q = pb + (long long)u * span + (int)threadIdx.x;
+      keys[u] = q < hw ? t.lab[(long long)b * hw + q] : 0;   // +foreground id / -background id
+    }
+#pragma unroll
+    for (int u = 0; u < DU; ++u) pars[u] = (keys[u] < 0 && -keys[u] <= t.cap) ? t.par_b[cb + (-keys[u]) - 1] : 0;
+#pragma unroll
+    for (int u = 0; u < DU; ++u) {
+    if (pb + (long long)u * span >= hw) break;
+    const int p0 = (int)(pb + (long long)u * span);
     const int p = min(p0 + (int)threadIdx.x, hw - 1);
     const bool live = p0 + (int)threadIdx.x < hw;
     const long long i = (long long)b * hw + p;
     const int x = p % t.W, y = p / t.W;
-    const int key = live ? t.lab[i] : 0;                  // +foreground id / -background id
+    const int key = keys[u];
     const int lf = max(key, 0), lb = max(-key, 0);
     // Most waves see only page background (a complement component that is no hole): nothing to add, and
     // the f64 scan below (14 cross-lane moves) is what this kernel's time goes into.
-    const size_t cb = (size_t)b * t.cap, rb = (size_t)b * t.rcap;
-    const bool hole = live && lf <= 0 && lb > 0 && lb <= t.cap && t.par_b[cb + lb - 1] > 0;
+    const bool hole = live && lf <= 0 && lb > 0 && lb <= t.cap && pars[u] > 0;
     if (!__ballot(live && (lf > 0 || hole))) continue;
     const double pr = live ? (double)t.prob[(long long)b * t.prob_stride + p] : 0.0;
     // horizontal runs of one label inside the wave: the first lane of a run acts for it
@@ -121,8 +137,8 @@ __global__ __launch_bounds__(256) void dbc_accum_kernel(DbcTables t) {
     const int len = later ? __ffsll((long long)later) : 64 - lane;
     double ps = pr;
     for (int off = 1; off < 64; off <<= 1) {
-      const double u = __shfl_up(ps, off);
-      if (lane >= off) ps += u;
+      const double up = __shfl_up(ps, off);
+      if (lane >= off) ps += up;
     }
     const double s_tail = __shfl(ps, lane + len - 1);
     const double s_prev = __shfl_up(ps, 1);
@@ -157,6 +173,7 @@ __global__ __launch_bounds__(256) void dbc_accum_kernel(DbcTables t) {
       }
     } else if (head && hole) {
       unsafeAtomicAdd(t.sum_b + cb + lb - 1, run);
+    }
     }
   }
 }

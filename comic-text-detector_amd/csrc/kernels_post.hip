@@ -436,8 +436,10 @@ __device__ __forceinline__ int block_exclusive_scan(int v, int* sh, int* total);
 
 // Path flattening fused with pass 1 of the ranking: a block owns one rank chunk, replaces every parent by
 // its root and counts the roots of the chunk (a pixel is a root iff it is its own parent).
+// ... and with the root bitmap of the chunk: bit (p % 64) of word (p / 64) of the image = pixel p is a root.  The ranking
+// kernel numbers the roots from these words (8 B per 64 pixels) instead of reading the parent plane again (256 B).
 __device__ __forceinline__ void ccl_flatten_count_body(int vb, int* __restrict__ parent_all, int hw, int nchunks,
-                                                                int* __restrict__ chunk_cnt) {
+                                                                int* __restrict__ chunk_cnt, unsigned long long* __restrict__ rootmask) {
   __shared__ int sh[4];
   const int b = vb / nchunks, ch = vb % nchunks;
   int* parent = parent_all + (size_t)b * hw;
@@ -460,10 +462,15 @@ __device__ __forceinline__ void ccl_flatten_count_body(int vb, int* __restrict__
 #pragma unroll
     for (int j = 0; j < FU; ++j) {
       const int p = p0 + 256 * (j0 + j);
-      if (v[j] < 0) continue;
-      const int r = g[j] == v[j] ? v[j] : uf_find(parent, g[j]);
-      if (r != v[j]) parent[p] = r;             // most pixels already point at their root (tile-local labelling)
-      local += r == p;
+      bool root = false;
+      if (v[j] >= 0) {
+        const int r = g[j] == v[j] ? v[j] : uf_find(parent, g[j]);
+        if (r != v[j]) parent[p] = r;           // most pixels already point at their root (tile-local labelling)
+        root = r == p;
+        local += root;
+      }
+      const unsigned long long m = __ballot(root);                 // this wave's 64 consecutive pixels
+      if ((threadIdx.x & 63) == 0) rootmask[((size_t)b * nchunks + ch) * 64 + 4 * (j0 + j) + (threadIdx.x >> 6)] = m;
     }
   }
   int total;
@@ -473,9 +480,10 @@ __device__ __forceinline__ void ccl_flatten_count_body(int vb, int* __restrict__
 // a block walks several tiles / chunks: the launcher caps the grid (tail_max_blocks) so that these kernels hold a few
 // waves per SIMD next to the network, not all of them
 __global__ __launch_bounds__(256) void ccl_flatten_count_kernel(int* __restrict__ parent_all, int hw, int nchunks,
-                                                                int* __restrict__ chunk_cnt, int nvb) {
+                                                                int* __restrict__ chunk_cnt, unsigned long long* __restrict__ rootmask,
+                                                                int nvb) {
   for (int vb = blockIdx.x; vb < nvb; vb += gridDim.x) {
-    ccl_flatten_count_body(vb, parent_all, hw, nchunks, chunk_cnt);
+    ccl_flatten_count_body(vb, parent_all, hw, nchunks, chunk_cnt, rootmask);
     __syncthreads();
   }
 }
@@ -498,7 +506,7 @@ __device__ __forceinline__ int block_exclusive_scan(int v, int* sh, int* total) 
 }
 
 // pass 3: assign raster-order ids to the roots (pass 1, the per-chunk count, is fused into the flattening).
-__device__ __forceinline__ void ccl_rank_body(int vb, const int* __restrict__ parent_all, int hw, int nchunks,
+__device__ __forceinline__ void ccl_rank_body(int vb, const unsigned long long* __restrict__ rootmask, int hw, int nchunks,
                                                        const int* __restrict__ chunk_cnt, int* __restrict__ ids_all,
                                                        int* __restrict__ first, int max_labels) {
   // A wave owns 1024 consecutive pixels of the chunk, 64 at a time (coalesced); the root masks of the 16
@@ -506,18 +514,15 @@ __device__ __forceinline__ void ccl_rank_body(int vb, const int* __restrict__ pa
   static_assert(RK_CHUNK == 4 * 16 * 64, "4 waves x 16 groups x 64 lanes");
   __shared__ int sh[4];
   const int b = vb / nchunks, ch = vb % nchunks;
-  const int* parent = parent_all + (size_t)b * hw;
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int base = ch * RK_CHUNK + w * 1024 + lane;
   unsigned long long m[16];
   int cnt = 0;
-  int pv[16];                                   // all 16 loads, then the ballots (each ballot consumes its load)
-#pragma unroll
-  for (int j = 0; j < 16; ++j) pv[j] = parent[min(base + 64 * j, hw - 1)];
+  // the root bitmap the flattening left: this wave's 16 words (pixels beyond the image are no roots there either)
+  const unsigned long long* words = rootmask + ((size_t)b * nchunks + ch) * 64 + w * 16;
 #pragma unroll
   for (int j = 0; j < 16; ++j) {
-    const int p = base + 64 * j;
-    m[j] = __ballot(p < hw && pv[j] == p);
+    m[j] = words[j];
     cnt += __popcll(m[j]);
   }
   if (lane == 0) sh[w] = cnt;
@@ -539,11 +544,11 @@ __device__ __forceinline__ void ccl_rank_body(int vb, const int* __restrict__ pa
 }
 // a block walks several tiles / chunks: the launcher caps the grid (tail_max_blocks) so that these kernels hold a few
 // waves per SIMD next to the network, not all of them
-__global__ __launch_bounds__(256) void ccl_rank_kernel(const int* __restrict__ parent_all, int hw, int nchunks,
+__global__ __launch_bounds__(256) void ccl_rank_kernel(const unsigned long long* __restrict__ rootmask, int hw, int nchunks,
                                                        const int* __restrict__ chunk_cnt, int* __restrict__ ids_all,
                                                        int* __restrict__ first, int max_labels, int nvb) {
   for (int vb = blockIdx.x; vb < nvb; vb += gridDim.x) {
-    ccl_rank_body(vb, parent_all, hw, nchunks, chunk_cnt, ids_all, first, max_labels);
+    ccl_rank_body(vb, rootmask, hw, nchunks, chunk_cnt, ids_all, first, max_labels);
     __syncthreads();
   }
 }
@@ -841,7 +846,8 @@ __global__ __launch_bounds__(256) void ccl2_border_v_kernel(int* __restrict__ pa
 
 // chunk_cnt: (B, 2, nchunks) -- class 0 = foreground roots, 1 = background roots
 __device__ __forceinline__ void ccl2_flatten_count_body(int vb, int* __restrict__ parent_all, const uint8_t* __restrict__ img_all,
-                                                                 int thresh, int hw, int nchunks, int* __restrict__ chunk_cnt) {
+                                                                 int thresh, int hw, int nchunks, int* __restrict__ chunk_cnt,
+                                                                 unsigned long long* __restrict__ rootmask) {
   __shared__ int sh[4];
   const int b = vb / nchunks, ch = vb % nchunks;
   int* parent = parent_all + (size_t)b * hw;
@@ -863,11 +869,20 @@ __device__ __forceinline__ void ccl2_flatten_count_body(int vb, int* __restrict_
 #pragma unroll
     for (int j = 0; j < FU; ++j) {
       const int p = p0 + 256 * (j0 + j);
-      if (v[j] < 0) continue;
-      const int r = g[j] == v[j] ? v[j] : uf_find(parent, g[j]);
-      if (r != v[j]) parent[p] = r;
-      if (r == p) {
-        if (px[j] > thresh) ++lf; else ++lb;
+      bool rf = false, rb = false;
+      if (v[j] >= 0) {
+        const int r = g[j] == v[j] ? v[j] : uf_find(parent, g[j]);
+        if (r != v[j]) parent[p] = r;
+        if (r == p) {
+          if (px[j] > thresh) ++lf, rf = true; else ++lb, rb = true;
+        }
+      }
+      // root bitmaps per class (see ccl_flatten_count_body): (B, 2, nchunks, 64) words
+      const unsigned long long mf = __ballot(rf), mb = __ballot(rb);
+      if ((threadIdx.x & 63) == 0) {
+        const size_t wi = (size_t)ch * 64 + 4 * (j0 + j) + (threadIdx.x >> 6);
+        rootmask[((size_t)b * 2 + 0) * nchunks * 64 + wi] = mf;
+        rootmask[((size_t)b * 2 + 1) * nchunks * 64 + wi] = mb;
       }
     }
   }
@@ -882,9 +897,10 @@ __device__ __forceinline__ void ccl2_flatten_count_body(int vb, int* __restrict_
 // a block walks several tiles / chunks: the launcher caps the grid (tail_max_blocks) so that these kernels hold a few
 // waves per SIMD next to the network, not all of them
 __global__ __launch_bounds__(256) void ccl2_flatten_count_kernel(int* __restrict__ parent_all, const uint8_t* __restrict__ img_all,
-                                                                 int thresh, int hw, int nchunks, int* __restrict__ chunk_cnt, int nvb) {
+                                                                 int thresh, int hw, int nchunks, int* __restrict__ chunk_cnt,
+                                                                 unsigned long long* __restrict__ rootmask, int nvb) {
   for (int vb = blockIdx.x; vb < nvb; vb += gridDim.x) {
-    ccl2_flatten_count_body(vb, parent_all, img_all, thresh, hw, nchunks, chunk_cnt);
+    ccl2_flatten_count_body(vb, parent_all, img_all, thresh, hw, nchunks, chunk_cnt, rootmask);
     __syncthreads();
   }
 }
@@ -908,32 +924,22 @@ __global__ __launch_bounds__(256) void ccl2_scan_chunks_kernel(int* __restrict__
 }
 
 // ids: +rank for a foreground root, -rank for a background root (ranks per class, raster order)
-__device__ __forceinline__ void ccl2_rank_body(int vb, const int* __restrict__ parent_all, const uint8_t* __restrict__ img_all,
-                                                        int thresh, int hw, int nchunks, const int* __restrict__ chunk_cnt,
+__device__ __forceinline__ void ccl2_rank_body(int vb, const unsigned long long* __restrict__ rootmask,
+                                                        int hw, int nchunks, const int* __restrict__ chunk_cnt,
                                                         int* __restrict__ ids_all, int* __restrict__ first_f,
                                                         int* __restrict__ first_b, int max_labels) {
   __shared__ int sh[2][4];
   const int b = vb / nchunks, ch = vb % nchunks;
-  const int* parent = parent_all + (size_t)b * hw;
-  const uint8_t* img = img_all + (size_t)b * hw;
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int base = ch * RK_CHUNK + w * 1024 + lane;
   unsigned long long mf[16], mb[16];
   int cf = 0, cb = 0;
-  int pv[16], px[16];                           // all loads, then the ballots (each ballot consumes its loads)
+  const unsigned long long* wf = rootmask + ((size_t)b * 2 + 0) * nchunks * 64 + (size_t)ch * 64 + w * 16;   // the flattening's root bitmaps
+  const unsigned long long* wb = rootmask + ((size_t)b * 2 + 1) * nchunks * 64 + (size_t)ch * 64 + w * 16;
 #pragma unroll
   for (int j = 0; j < 16; ++j) {
-    const int q = min(base + 64 * j, hw - 1);
-    pv[j] = parent[q];
-    px[j] = img[q];
-  }
-#pragma unroll
-  for (int j = 0; j < 16; ++j) {
-    const int p = base + 64 * j;
-    const bool root = p < hw && pv[j] == p;
-    const bool fg = root && px[j] > thresh;
-    mf[j] = __ballot(fg);
-    mb[j] = __ballot(root && !fg);
+    mf[j] = wf[j];
+    mb[j] = wb[j];
     cf += __popcll(mf[j]);
     cb += __popcll(mb[j]);
   }
@@ -961,12 +967,12 @@ __device__ __forceinline__ void ccl2_rank_body(int vb, const int* __restrict__ p
 }
 // a block walks several tiles / chunks: the launcher caps the grid (tail_max_blocks) so that these kernels hold a few
 // waves per SIMD next to the network, not all of them
-__global__ __launch_bounds__(256) void ccl2_rank_kernel(const int* __restrict__ parent_all, const uint8_t* __restrict__ img_all,
-                                                        int thresh, int hw, int nchunks, const int* __restrict__ chunk_cnt,
+__global__ __launch_bounds__(256) void ccl2_rank_kernel(const unsigned long long* __restrict__ rootmask,
+                                                        int hw, int nchunks, const int* __restrict__ chunk_cnt,
                                                         int* __restrict__ ids_all, int* __restrict__ first_f,
                                                         int* __restrict__ first_b, int max_labels, int nvb) {
   for (int vb = blockIdx.x; vb < nvb; vb += gridDim.x) {
-    ccl2_rank_body(vb, parent_all, img_all, thresh, hw, nchunks, chunk_cnt, ids_all, first_f, first_b, max_labels);
+    ccl2_rank_body(vb, rootmask, hw, nchunks, chunk_cnt, ids_all, first_f, first_b, max_labels);
     __syncthreads();
   }
 }
@@ -1098,7 +1104,8 @@ void launch_nms(const float* blks, int B, int rows, int no, float conf, float io
 size_t ccl_workspace_bytes(int B, int H, int W) {
   const size_t hw = (size_t)H * W;
   const size_t nchunks = (hw + RK_CHUNK - 1) / RK_CHUNK;
-  return (size_t)B * hw * sizeof(int) + 2 * (size_t)B * nchunks * sizeof(int) + 512;   // ids + chunk counts (two planes for launch_ccl_dual)
+  // ids + chunk counts + root bitmaps (64 words per chunk; two planes of each for launch_ccl_dual)
+  return (size_t)B * hw * sizeof(int) + 2 * (size_t)B * nchunks * sizeof(int) + 2 * (size_t)B * nchunks * 64 * 8 + 1024;
 }
 
 void launch_ccl(const uint8_t* img, int B, int H, int W, int thresh, int conn, int* labels, int* n_out, int* stats,
@@ -1108,6 +1115,7 @@ void launch_ccl(const uint8_t* img, int B, int H, int W, int thresh, int conn, i
   const int nchunks = (hw + RK_CHUNK - 1) / RK_CHUNK;
   int* ids = (int*)ws;
   int* chunk_cnt = (int*)((char*)ws + ((size_t)total * sizeof(int) + 255) / 256 * 256);
+  unsigned long long* rootmask = (unsigned long long*)((char*)chunk_cnt + ((size_t)B * nchunks * sizeof(int) + 255) / 256 * 256);
   const int tiles_x = (W + CT - 1) / CT, tiles_y = (H + CT - 1) / CT;
   if (conn == 8) {
     hipLaunchKernelGGL((ccl_local_kernel<8>), dim3(capped(B * tiles_x * tiles_y)), dim3(256), 0, st, img, labels, H, W, tiles_x,
@@ -1118,9 +1126,10 @@ void launch_ccl(const uint8_t* img, int B, int H, int W, int thresh, int conn, i
                        tiles_y, thresh, invert, B * tiles_x * tiles_y);
     launch_border<4>(labels, B, H, W, st);
   }
-  hipLaunchKernelGGL(ccl_flatten_count_kernel, dim3(capped(B * nchunks)), dim3(256), 0, st, labels, hw, nchunks, chunk_cnt, B * nchunks);
+  hipLaunchKernelGGL(ccl_flatten_count_kernel, dim3(capped(B * nchunks)), dim3(256), 0, st, labels, hw, nchunks, chunk_cnt, rootmask,
+                     B * nchunks);
   hipLaunchKernelGGL(ccl_scan_chunks_kernel, dim3(B), dim3(256), 0, st, chunk_cnt, nchunks, n_out);
-  hipLaunchKernelGGL(ccl_rank_kernel, dim3(capped(B * nchunks)), dim3(256), 0, st, labels, hw, nchunks, chunk_cnt, ids, first,
+  hipLaunchKernelGGL(ccl_rank_kernel, dim3(capped(B * nchunks)), dim3(256), 0, st, rootmask, hw, nchunks, chunk_cnt, ids, first,
                      max_labels, B * nchunks);
   const int sgrid = std::max(1, std::min(64, (max_labels + 255) / 256));
   if (stats) hipLaunchKernelGGL(ccl_stats_init_kernel, dim3(sgrid, B), dim3(256), 0, st, stats, n_out, max_labels, H, W);
@@ -1137,6 +1146,7 @@ void launch_ccl_dual(const uint8_t* img, int B, int H, int W, int thresh, int* l
   const int nchunks = (hw + RK_CHUNK - 1) / RK_CHUNK;
   int* ids = (int*)ws;
   int* chunk_cnt = (int*)((char*)ws + ((size_t)total * sizeof(int) + 255) / 256 * 256);   // (B, 2, nchunks)
+  unsigned long long* rootmask = (unsigned long long*)((char*)chunk_cnt + (2 * (size_t)B * nchunks * sizeof(int) + 255) / 256 * 256);
   const int tiles_x = (W + CT - 1) / CT, tiles_y = (H + CT - 1) / CT;
   hipLaunchKernelGGL(ccl2_local_kernel, dim3(capped(B * tiles_x * tiles_y)), dim3(256), 0, st, img, labels, H, W, tiles_x, tiles_y,
                      thresh, B * tiles_x * tiles_y);
@@ -1144,9 +1154,9 @@ void launch_ccl_dual(const uint8_t* img, int B, int H, int W, int thresh, int* l
   if (nh > 0) hipLaunchKernelGGL(ccl2_border_h_kernel, dim3((W + 255) / 256, nh, B), dim3(256), 0, st, labels, img, thresh, H, W);
   if (nv > 0) hipLaunchKernelGGL(ccl2_border_v_kernel, dim3((H + 255) / 256, nv, B), dim3(256), 0, st, labels, img, thresh, H, W);
   hipLaunchKernelGGL(ccl2_flatten_count_kernel, dim3(capped(B * nchunks)), dim3(256), 0, st, labels, img, thresh, hw, nchunks, chunk_cnt,
-                     B * nchunks);
+                     rootmask, B * nchunks);
   hipLaunchKernelGGL(ccl2_scan_chunks_kernel, dim3(2 * B), dim3(256), 0, st, chunk_cnt, nchunks, n_f, n_b);
-  hipLaunchKernelGGL(ccl2_rank_kernel, dim3(capped(B * nchunks)), dim3(256), 0, st, labels, img, thresh, hw, nchunks, chunk_cnt, ids,
+  hipLaunchKernelGGL(ccl2_rank_kernel, dim3(capped(B * nchunks)), dim3(256), 0, st, rootmask, hw, nchunks, chunk_cnt, ids,
                      first_f, first_b, max_labels, B * nchunks);
   const int sgrid = std::max(1, std::min(64, (max_labels + 255) / 256));
   hipLaunchKernelGGL(ccl_stats_init_kernel, dim3(sgrid, B), dim3(256), 0, st, st_f, n_f, max_labels, H, W);

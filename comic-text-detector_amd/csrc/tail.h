@@ -65,6 +65,8 @@ void launch_tw_accept(const TWin* wins, const TBand* bands, int nbands, int max_
                       unsigned* counters, hipStream_t st);
 // ALL merge rounds of every window in one launch: a block owns a window and walks its bands in merge order (count,
 // decide, apply, next band) -- the rounds of a window depend on each other, windows do not
+// zeroes the per-label counter pairs of the labels a labelling launch produced (their count is on the device)
+void launch_label_counters_zero(unsigned* counters, const int* n_labels, int cap, hipStream_t st);
 void launch_tw_accept_all(const TWin* wins, const TBand* bands, int n, const int* labels, int canvas_w, const int* stats,
                           int max_labels, int min_box, uint8_t* merged, int merged_w, unsigned* counters, hipStream_t st);
 void launch_tw_dilate(const TWin* wins, int n, int max_pix, const uint8_t* in, uint8_t* out, uint8_t* comp, int merged_w,

@@ -370,7 +370,8 @@ int refine_windows(ctd_tail* t, const std::vector<WinReq>& reqs, int refine_mode
   }
   GET(t->d_wins, sizeof(TWin) * n, TWin, dw);
   // ---- everything whose size depends on the windows only: one launch uploads the window table and zeroes the
-  // histograms, the xor sums, the merged canvases and the hole-filling counters
+  // histograms, the xor sums and the merged canvases (the per-label counters are cleared after the labelling, for the
+  // labels that exist: launch_label_counters_zero)
   GET(t->d_hist, (size_t)n * 1024 * 4, unsigned, dhist);
   GET(t->h_hist, (size_t)n * 1024 * 4, uint32_t, hhist);
   GET(t->d_sums, (size_t)n * 6 * 8, unsigned long long, dsums);
@@ -396,7 +397,6 @@ int refine_windows(ctd_tail* t, const std::vector<WinReq>& reqs, int refine_mode
   bt.fill(merged_a, 0, mpx * 3);
   bt.fill(count255, 0, (size_t)n * 4);
   bt.fill(top2, 0xFF, (size_t)n * 12);
-  bt.fill(counters2, 0, ((size_t)cap2 + 1) * 8);
   bt.flush();
   // ---- histograms -> rules
   launch_tw_hist(dw, n, max_pix, dhist, st);
@@ -459,12 +459,12 @@ int refine_windows(ctd_tail* t, const std::vector<WinReq>& reqs, int refine_mode
   T_TRY(bt.h2d(db, hb, sizeof(TBand) * nbands));
   T_TRY(bt.h2d(dw, hw, sizeof(TWin) * n));                   // again: with every window's band range (the stream is idle here)
   bt.fill(canvas, 0, cpx);
-  bt.fill(counters, 0, ((size_t)cap1 + 1) * 8);
   bt.flush();
   GpuChain chain(st, t->device, g_tail_chain >= 2);
   T_TRY(chain.begin());
   launch_tw_render(dw, db, nbands, max_pix, canvas, pc.W, st);
   launch_ccl(canvas, 1, pc.H, pc.W, 0, 8, clab, n_dev, cstats, cap1, ws, st);
+  launch_label_counters_zero(counters, n_dev, cap1, st);
   if (g_tail_fused_rounds) {
     launch_tw_accept_all(dw, db, n, clab, pc.W, cstats, cap1, 3, merged_a, pm.W, counters, st);
   } else {
@@ -477,6 +477,7 @@ int refine_windows(ctd_tail* t, const std::vector<WinReq>& reqs, int refine_mode
   GET(t->d_mstats, (size_t)cap2 * 6 * 4, int, mstats);
   int* mfirst = mstats + (size_t)cap2 * 5;
   launch_ccl(comp, 1, pm.H, pm.W, 0, 8, mlab, n_dev, mstats, cap2, ws, st, 0, mfirst);
+  launch_label_counters_zero(counters2, n_dev, cap2, st);
   if (g_tail_fused_rounds) launch_tw_holes_all(dw, n, mlab, mstats, mfirst, cap2, count255, merged_b, pm.W, counters2, st);
   else launch_tw_holes(dw, n, max_pix, mlab, mstats, mfirst, cap2, count255, top2, merged_b, pm.W, counters2, st);
   launch_tw_commit(dw, n, max_pix, merged_b, pm.W, st);

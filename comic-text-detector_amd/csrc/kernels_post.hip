@@ -284,7 +284,8 @@ constexpr int RK_PER_T = RK_CHUNK / 256;
 // complements (runs of 32) that was 30x the work (rocprofv3: 0.36 ms per 32 Mpixel launch before).
 template <int CONN>
 __device__ __forceinline__ void ccl_local_body(int vb, const uint8_t* __restrict__ img, int* __restrict__ parent_all,
-                                                        int H, int W, int tiles_x, int tiles_y, int thresh, int invert) {
+                                                        unsigned* __restrict__ colmask, int H, int W, int tiles_x, int tiles_y,
+                                                        int thresh, int invert) {
   __shared__ int lp[CT * CT];
   __shared__ unsigned rowmask[CT];
   int bid = vb;
@@ -319,6 +320,16 @@ __device__ __forceinline__ void ccl_local_body(int vb, const uint8_t* __restrict
     if (lx == 0) rowmask[ly] = m;
   }
   __syncthreads();
+  // the tile's first and last column as bit masks (bit ly = foreground): all the vertical-boundary kernel needs to know
+  // where a link is due -- read from the parent plane, a column is one 64-B line per PIXEL (0.5 GB per 32 pages)
+  if (threadIdx.x < 64) {
+    const unsigned rm = rowmask[threadIdx.x & 31];
+    const unsigned long long bl = __ballot(threadIdx.x < 32 && (rm & 1u)), br = __ballot(threadIdx.x < 32 && (rm >> 31));
+    if (threadIdx.x == 0) {
+      unsigned* cm = colmask + ((size_t)b * tiles_y * tiles_x + (size_t)ty * tiles_x + tx) * 2;
+      cm[0] = (unsigned)bl, cm[1] = (unsigned)br;
+    }
+  }
 #pragma unroll
   for (int k = 0; k < CT * CT / 256; ++k) {
     const int li = threadIdx.x + 256 * k;
@@ -361,9 +372,10 @@ __device__ __forceinline__ void ccl_local_body(int vb, const uint8_t* __restrict
 // waves per SIMD next to the network, not all of them
 template <int CONN>
 __global__ __launch_bounds__(256) void ccl_local_kernel(const uint8_t* __restrict__ img, int* __restrict__ parent_all,
-                                                        int H, int W, int tiles_x, int tiles_y, int thresh, int invert, int nvb) {
+                                                        unsigned* __restrict__ colmask, int H, int W, int tiles_x, int tiles_y,
+                                                        int thresh, int invert, int nvb) {
   for (int vb = blockIdx.x; vb < nvb; vb += gridDim.x) {
-    ccl_local_body<CONN>(vb, img, parent_all, H, W, tiles_x, tiles_y, thresh, invert);
+    ccl_local_body<CONN>(vb, img, parent_all, colmask, H, W, tiles_x, tiles_y, thresh, invert);
     __syncthreads();
   }
 }
@@ -403,19 +415,25 @@ __global__ __launch_bounds__(256) void ccl_border_h_kernel(int* __restrict__ par
 }
 
 template <int CONN>
-__global__ __launch_bounds__(256) void ccl_border_v_kernel(int* __restrict__ parent_all, int H, int W) {
+__global__ __launch_bounds__(256) void ccl_border_v_kernel(int* __restrict__ parent_all, const unsigned* __restrict__ colmask,
+                                                           int H, int W, int tiles_x, int tiles_y) {
   const int y = blockIdx.x * 256 + threadIdx.x;
-  const int x = CT * (blockIdx.y + 1);
+  const int k = blockIdx.y;                              // boundary between tile columns k and k + 1
+  const int x = CT * (k + 1);
   if (y >= H || x >= W) return;
   int* parent = parent_all + (size_t)blockIdx.z * H * W;
   const int p = y * W + x;
-  const bool me = parent[p] >= 0, left = parent[p - 1] >= 0;
+  // which of the four pixels around (x, y) are foreground: from the column masks the tile-local kernel left (bit = row of
+  // the tile; [0] first column, [1] last column), not from the parent plane
+  const unsigned* cm = colmask + (size_t)blockIdx.z * tiles_y * tiles_x * 2;
+  auto fg = [&](int yy, int tile_x, int side) { return ((cm[((size_t)(yy >> 5) * tiles_x + tile_x) * 2 + side] >> (yy & 31)) & 1u) != 0; };
+  const bool me = fg(y, k + 1, 0), left = fg(y, k, 1);
   if (!me && !left) return;
   // Rows y-1 and y of one tile: vertical neighbours are already one set, so the 2x2 block needs a link only
   // where the row above does not provide the connection.  On a horizontal tile boundary (y % CT == 0) nothing
   // is assumed about the row above (that is the other kernel's job) and every adjacent pair is linked.
   const bool ua = y > 0, same_tile = (y % CT) != 0;
-  const bool mu = ua && parent[p - W] >= 0, lu = ua && parent[p - W - 1] >= 0;
+  const bool mu = ua && fg(y - 1, k + 1, 0), lu = ua && fg(y - 1, k, 1);
   if (!same_tile) {
     if (me && left) uf_union(parent, p, p - 1);
     if (CONN == 8) {
@@ -1079,10 +1097,12 @@ inline int grid_for(long long total, int block = 256) {
 }
 
 template <int CONN>
-void launch_border(int* labels, int B, int H, int W, hipStream_t st) {
+void launch_border(int* labels, const unsigned* colmask, int B, int H, int W, hipStream_t st) {
   const int nh = (H - 1) / CT, nv = (W - 1) / CT;      // boundaries strictly inside the image
   if (nh > 0) hipLaunchKernelGGL((ccl_border_h_kernel<CONN>), dim3((W + 255) / 256, nh, B), dim3(256), 0, st, labels, H, W);
-  if (nv > 0) hipLaunchKernelGGL((ccl_border_v_kernel<CONN>), dim3((H + 255) / 256, nv, B), dim3(256), 0, st, labels, H, W);
+  if (nv > 0)
+    hipLaunchKernelGGL((ccl_border_v_kernel<CONN>), dim3((H + 255) / 256, nv, B), dim3(256), 0, st, labels, colmask, H, W,
+                       (W + CT - 1) / CT, (H + CT - 1) / CT);
 }
 
 }  // namespace
@@ -1104,8 +1124,11 @@ void launch_nms(const float* blks, int B, int rows, int no, float conf, float io
 size_t ccl_workspace_bytes(int B, int H, int W) {
   const size_t hw = (size_t)H * W;
   const size_t nchunks = (hw + RK_CHUNK - 1) / RK_CHUNK;
-  // ids + chunk counts + root bitmaps (64 words per chunk; two planes of each for launch_ccl_dual)
-  return (size_t)B * hw * sizeof(int) + 2 * (size_t)B * nchunks * sizeof(int) + 2 * (size_t)B * nchunks * 64 * 8 + 1024;
+  // ids + chunk counts + root bitmaps (64 words per chunk; two planes of each for launch_ccl_dual) + the tiles' column masks
+  // (two words per 32 x 32 tile; callers size for a pixel count and label any H x W within it: tiles <= hw / 1024 + (H + W) / 32 + 1)
+  const size_t tiles_max = hw / (CT * CT) + (hw + 1) / CT + 2;
+  return (size_t)B * hw * sizeof(int) + 2 * (size_t)B * nchunks * sizeof(int) + 2 * (size_t)B * nchunks * 64 * 8 +
+         (size_t)B * tiles_max * 2 * sizeof(unsigned) + 1280;
 }
 
 void launch_ccl(const uint8_t* img, int B, int H, int W, int thresh, int conn, int* labels, int* n_out, int* stats,
@@ -1116,15 +1139,16 @@ void launch_ccl(const uint8_t* img, int B, int H, int W, int thresh, int conn, i
   int* ids = (int*)ws;
   int* chunk_cnt = (int*)((char*)ws + ((size_t)total * sizeof(int) + 255) / 256 * 256);
   unsigned long long* rootmask = (unsigned long long*)((char*)chunk_cnt + ((size_t)B * nchunks * sizeof(int) + 255) / 256 * 256);
+  unsigned* colmask = (unsigned*)((char*)rootmask + ((size_t)B * nchunks * 64 * 8 + 255) / 256 * 256);
   const int tiles_x = (W + CT - 1) / CT, tiles_y = (H + CT - 1) / CT;
   if (conn == 8) {
-    hipLaunchKernelGGL((ccl_local_kernel<8>), dim3(capped(B * tiles_x * tiles_y)), dim3(256), 0, st, img, labels, H, W, tiles_x,
-                       tiles_y, thresh, invert, B * tiles_x * tiles_y);
-    launch_border<8>(labels, B, H, W, st);
+    hipLaunchKernelGGL((ccl_local_kernel<8>), dim3(capped(B * tiles_x * tiles_y)), dim3(256), 0, st, img, labels, colmask, H, W,
+                       tiles_x, tiles_y, thresh, invert, B * tiles_x * tiles_y);
+    launch_border<8>(labels, colmask, B, H, W, st);
   } else {
-    hipLaunchKernelGGL((ccl_local_kernel<4>), dim3(capped(B * tiles_x * tiles_y)), dim3(256), 0, st, img, labels, H, W, tiles_x,
-                       tiles_y, thresh, invert, B * tiles_x * tiles_y);
-    launch_border<4>(labels, B, H, W, st);
+    hipLaunchKernelGGL((ccl_local_kernel<4>), dim3(capped(B * tiles_x * tiles_y)), dim3(256), 0, st, img, labels, colmask, H, W,
+                       tiles_x, tiles_y, thresh, invert, B * tiles_x * tiles_y);
+    launch_border<4>(labels, colmask, B, H, W, st);
   }
   hipLaunchKernelGGL(ccl_flatten_count_kernel, dim3(capped(B * nchunks)), dim3(256), 0, st, labels, hw, nchunks, chunk_cnt, rootmask,
                      B * nchunks);

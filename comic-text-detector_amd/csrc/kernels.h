@@ -177,9 +177,10 @@ void launch_nms(const float* blks, int B, int rows, int no, float conf, float io
                 float max_wh, float* dets, int* counts, void* ws, hipStream_t st);
 size_t ccl_workspace_bytes(int B, int H, int W);
 // invert: foreground = !(img > thresh); first (B,max_labels): linear index of every component's first pixel
-// in raster order (= its union-find root), or null
+// in raster order (= its union-find root), or null; bg_negative: background pixels of `labels` keep the -1 the union-find
+// left there instead of being rewritten to 0 (callers that only test `label > 0`: 4 B less per background pixel)
 void launch_ccl(const uint8_t* img, int B, int H, int W, int thresh, int conn, int* labels, int* n_out,
-                int* stats, int max_labels, void* ws, hipStream_t st, int invert = 0, int* first = nullptr);
+                int* stats, int max_labels, void* ws, hipStream_t st, int invert = 0, int* first = nullptr, int bg_negative = 0);
 // Foreground (img > thresh, 8-connected) and background (4-connected) components in one union-find:
 // labels (B,H,W) signed (+id / -id, per-class raster order), n / stats / first per class, same workspace.
 void launch_ccl_dual(const uint8_t* img, int B, int H, int W, int thresh, int* labels, int* n_f, int* n_b, int* st_f,

@@ -610,7 +610,7 @@ constexpr int LB_SLOTS = 128;
 
 __device__ __forceinline__ void ccl_label_body(int vb, int* __restrict__ labels_all, const int* __restrict__ ids_all,
                                                         int B, int H, int W, int chunks, int* __restrict__ stats,
-                                                        int max_labels) {
+                                                        int max_labels, int bg_negative) {
   __shared__ int hkey[LB_SLOTS];
   __shared__ int hst[LB_SLOTS * 5];
   const int hw = H * W;
@@ -640,7 +640,7 @@ __device__ __forceinline__ void ccl_label_body(int vb, int* __restrict__ labels_
 #pragma unroll
     for (int u = 0; u < LU; ++u) {
       const int p = pb + 256 * u + threadIdx.x;
-      if (p < p_end) labels_all[base + p] = idv[u];
+      if (p < p_end && !(bg_negative && root[u] < 0)) labels_all[base + p] = idv[u];   // (a background pixel holds -1 already)
     }
     if (!stats) continue;
 #pragma unroll
@@ -695,9 +695,9 @@ __device__ __forceinline__ void ccl_label_body(int vb, int* __restrict__ labels_
 // waves per SIMD next to the network, not all of them
 __global__ __launch_bounds__(256) void ccl_label_kernel(int* __restrict__ labels_all, const int* __restrict__ ids_all,
                                                         int B, int H, int W, int chunks, int* __restrict__ stats,
-                                                        int max_labels, int nvb) {
+                                                        int max_labels, int bg_negative, int nvb) {
   for (int vb = blockIdx.x; vb < nvb; vb += gridDim.x) {
-    ccl_label_body(vb, labels_all, ids_all, B, H, W, chunks, stats, max_labels);
+    ccl_label_body(vb, labels_all, ids_all, B, H, W, chunks, stats, max_labels, bg_negative);
     __syncthreads();
   }
 }
@@ -1132,7 +1132,7 @@ size_t ccl_workspace_bytes(int B, int H, int W) {
 }
 
 void launch_ccl(const uint8_t* img, int B, int H, int W, int thresh, int conn, int* labels, int* n_out, int* stats,
-                int max_labels, void* ws, hipStream_t st, int invert, int* first) {
+                int max_labels, void* ws, hipStream_t st, int invert, int* first, int bg_negative) {
   const int hw = H * W;
   const long long total = (long long)B * hw;
   const int nchunks = (hw + RK_CHUNK - 1) / RK_CHUNK;
@@ -1159,7 +1159,7 @@ void launch_ccl(const uint8_t* img, int B, int H, int W, int thresh, int conn, i
   if (stats) hipLaunchKernelGGL(ccl_stats_init_kernel, dim3(sgrid, B), dim3(256), 0, st, stats, n_out, max_labels, H, W);
   const int lchunks = (hw + LB_CHUNK - 1) / LB_CHUNK;
   hipLaunchKernelGGL(ccl_label_kernel, dim3(capped(B * lchunks)), dim3(256), 0, st, labels, ids, B, H, W, lchunks, stats, max_labels,
-                     B * lchunks);
+                     bg_negative, B * lchunks);
   if (stats) hipLaunchKernelGGL(ccl_stats_final_kernel, dim3(sgrid, B), dim3(256), 0, st, stats, n_out, max_labels);
 }
 

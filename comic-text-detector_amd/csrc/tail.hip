@@ -463,7 +463,7 @@ int refine_windows(ctd_tail* t, const std::vector<WinReq>& reqs, int refine_mode
   GpuChain chain(st, t->device, g_tail_chain >= 2);
   T_TRY(chain.begin());
   launch_tw_render(dw, db, nbands, max_pix, canvas, pc.W, st);
-  launch_ccl(canvas, 1, pc.H, pc.W, 0, 8, clab, n_dev, cstats, cap1, ws, st);
+  launch_ccl(canvas, 1, pc.H, pc.W, 0, 8, clab, n_dev, cstats, cap1, ws, st, 0, nullptr, 1);   // the window kernels test `label > 0`
   launch_label_counters_zero(counters, n_dev, cap1, st);
   if (g_tail_fused_rounds) {
     launch_tw_accept_all(dw, db, n, clab, pc.W, cstats, cap1, 3, merged_a, pm.W, counters, st);
@@ -476,7 +476,7 @@ int refine_windows(ctd_tail* t, const std::vector<WinReq>& reqs, int refine_mode
   GET(t->d_mlab, mpx * 4, int, mlab);
   GET(t->d_mstats, (size_t)cap2 * 6 * 4, int, mstats);
   int* mfirst = mstats + (size_t)cap2 * 5;
-  launch_ccl(comp, 1, pm.H, pm.W, 0, 8, mlab, n_dev, mstats, cap2, ws, st, 0, mfirst);
+  launch_ccl(comp, 1, pm.H, pm.W, 0, 8, mlab, n_dev, mstats, cap2, ws, st, 0, mfirst, 1);
   launch_label_counters_zero(counters2, n_dev, cap2, st);
   if (g_tail_fused_rounds) launch_tw_holes_all(dw, n, mlab, mstats, mfirst, cap2, count255, merged_b, pm.W, counters2, st);
   else launch_tw_holes(dw, n, max_pix, mlab, mstats, mfirst, cap2, count255, top2, merged_b, pm.W, counters2, st);
@@ -526,7 +526,7 @@ int undetected_pass(ctd_tail* t, const std::vector<std::vector<int32_t>>& blk_xy
   GET(t->h_small, (size_t)B * 4, int, n_host);
   for (int b = 0; b < B; ++b)
     launch_ccl(pmask + t->poff[b], 1, t->pages[b].im_h, t->pages[b].im_w, 30, 4, lab, n_dev + b,
-               st_dev + (size_t)b * cap * 5, cap, ws, st);
+               st_dev + (size_t)b * cap * 5, cap, ws, st, 0, nullptr, 1);   // only the statistics are used
   T_TRY(hipMemcpyAsync(n_host, n_dev, (size_t)B * 4, hipMemcpyDeviceToHost, st));
   T_TRY(hipStreamSynchronize(st));
   int nmax = 0;

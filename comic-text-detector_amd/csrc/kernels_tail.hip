@@ -151,16 +151,21 @@ __global__ __launch_bounds__(256) void dbc_accum_kernel(DbcTables t) {
         atomicMin(t.row_lo + rb + row, x);
         atomicMax(t.row_hi + rb + row, x + len - 1);
       }
-      // border ring of a hole: foreground pixels of the ringing component that 4-touch the hole
+      // border ring of a hole: foreground pixels of the ringing component that 4-touch the hole (the four neighbours'
+      // labels, then the four rings, are fetched together: one pixel has up to eight dependent loads here otherwise)
       int seen[4];
       int ns = 0;
       const int dq[4] = {-1, 1, -t.W, t.W};
       const bool ok[4] = {x > 0, x + 1 < t.W, y > 0, y + 1 < t.H};
+      int hbs[4], prs[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) hbs[k] = ok[k] ? -t.lab[i + dq[k]] : 0;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) prs[k] = (hbs[k] > 0 && hbs[k] <= t.cap) ? t.par_b[cb + hbs[k] - 1] : -1;
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        if (!ok[k]) continue;
-        const int hb = -t.lab[i + dq[k]];
-        if (hb <= 0 || hb > t.cap || t.par_b[cb + hb - 1] != lf) continue;
+        const int hb = hbs[k];
+        if (hb <= 0 || hb > t.cap || prs[k] != lf) continue;
         bool dup = false;
         for (int j = 0; j < ns; ++j) dup |= seen[j] == hb;
         if (dup) continue;

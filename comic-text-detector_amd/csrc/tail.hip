@@ -190,6 +190,7 @@ struct GpuChain {
   }
 };
 }  // namespace
+int g_tail_skip_pages = 0;             // measurement only: 1 = the page-size results are not downloaded ("tail_skip_page_download")
 long long g_tail_dma_min = 256 << 10;   // device -> host copies of at least this many bytes use the copy engines ("tail_dma_min"; huge = never)
 namespace {
 
@@ -576,6 +577,7 @@ int undetected_pass(ctd_tail* t, const std::vector<std::vector<int32_t>>& blk_xy
 // device -> host of the page-size outputs, straight into the caller's arrays (page-locked arrays make
 // these DMA transfers; comic-text-detector_amd/tail.py allocates them pinned)
 int download_pages(ctd_tail* t, bool mask_too, uint8_t* const* mask_out, uint8_t* const* refined_out) {
+  if (g_tail_skip_pages) return CTD_OK;    // measurement only ("tail_skip_page_download"): what do the page downloads cost the step?
   hipStream_t st = t->st;
   GET(t->d_pmask, 0, uint8_t, pmask);
   GET(t->d_refined, 0, uint8_t, refined);

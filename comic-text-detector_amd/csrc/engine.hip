@@ -1079,6 +1079,7 @@ extern int g_tail_priority;   // tail.hip
 extern int g_tail_cus, g_tail_cu_first;
 extern long long g_tail_dma_min;
 extern int g_tail_skip_pages;
+extern int g_tail_ablate;
 extern int g_tail_chain;
 extern int g_tail_fused_rounds;
 
@@ -1285,6 +1286,7 @@ int ctd_tuning_set(const char* key, int64_t value) {
   if (key && std::string(key) == "tail_fused_rounds") { g_tail_fused_rounds = (int)value; return CTD_OK; }
   if (key && std::string(key) == "tail_dma_min") { g_tail_dma_min = value; return CTD_OK; }
   if (key && std::string(key) == "tail_skip_page_download") { g_tail_skip_pages = value != 0; return CTD_OK; }
+  if (key && std::string(key) == "tail_ablate") { g_tail_ablate = (int)value; return CTD_OK; }
   if (key && std::string(key) == "tail_priority") { g_tail_priority = (int)value; return CTD_OK; }
   if (key && std::string(key) == "tail_cus") { g_tail_cus = (int)value; return CTD_OK; }
   if (key && std::string(key) == "tail_cu_first") { g_tail_cu_first = (int)value; return CTD_OK; }

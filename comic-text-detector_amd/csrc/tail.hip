@@ -190,6 +190,7 @@ struct GpuChain {
   }
 };
 }  // namespace
+int g_tail_ablate = 0;                 // measurement only: bit 1 = no refine stage ("tail_ablate")
 int g_tail_skip_pages = 0;             // measurement only: 1 = the page-size results are not downloaded ("tail_skip_page_download")
 long long g_tail_dma_min = 256 << 10;   // device -> host copies of at least this many bytes use the copy engines ("tail_dma_min"; huge = never)
 namespace {
@@ -884,6 +885,12 @@ static int tail_run_impl(ctd_tail* t, int32_t B, int32_t Hn, int32_t Wn, const f
   if (!t || !blks_dev || !mask_u8_dev || !prob_dev || !bitmap_dev || !pages || !prm || B < 1 || Hn < 1 || Wn < 1 ||
       rows < 1 || no < 6)
     return ctd_fail_msg(CTD_ERR_INVALID, "ctd_tail_run: bad arguments");
+  ctd_tail_params prm_ablate;
+  if (g_tail_ablate & 1) {                   // measurement only ("tail_ablate" bit 1): the tail without its refine stage
+    prm_ablate = *prm;
+    prm_ablate.refine = 0;
+    prm = &prm_ablate;
+  }
   T_TRY(hipSetDevice(t->device));
   hipStream_t st = t->st;
   const double t0 = now_ms();

@@ -645,36 +645,36 @@ __device__ __forceinline__ void ccl_label_body(int vb, int* __restrict__ labels_
     if (!stats) continue;
 #pragma unroll
     for (int u = 0; u < LU; ++u) {
-    const int p0 = pb + 256 * u;
-    if (p0 >= p_end) break;
-    const int p = p0 + threadIdx.x;
-    const bool live = p < p_end;
-    const int id = idv[u];
-    const int x = live ? p % W : 0, y = live ? p / W : 0;
-    const int key = live ? id : -1;                         // dead lanes end a run
-    const int prev = __shfl_up(key, 1);
-    const bool head = lane == 0 || prev != key || x == 0;
-    const unsigned long long heads = __ballot(head);
-    if (head && id > 0 && id <= max_labels) {
-      const unsigned long long later = lane == 63 ? 0ull : (heads >> (lane + 1));
-      const int len = later ? __ffsll((long long)later) : 64 - lane;
-      int slot = -1;
-      unsigned hsh = ((unsigned)id * 2654435761u) >> 25;    // 7 bits
-      for (int probe = 0; probe < 4; ++probe) {
-        const int sidx = (hsh + probe) & (LB_SLOTS - 1);
-        const int old = atomicCAS(&hkey[sidx], -1, id);
-        if (old == -1 || old == id) {
-          slot = sidx;
-          break;
+      const int p0 = pb + 256 * u;
+      if (p0 >= p_end) break;
+      const int p = p0 + threadIdx.x;
+      const bool live = p < p_end;
+      const int id = idv[u];
+      const int x = live ? p % W : 0, y = live ? p / W : 0;
+      const int key = live ? id : -1;                         // dead lanes end a run
+      const int prev = __shfl_up(key, 1);
+      const bool head = lane == 0 || prev != key || x == 0;
+      const unsigned long long heads = __ballot(head);
+      if (head && id > 0 && id <= max_labels) {
+        const unsigned long long later = lane == 63 ? 0ull : (heads >> (lane + 1));
+        const int len = later ? __ffsll((long long)later) : 64 - lane;
+        int slot = -1;
+        unsigned hsh = ((unsigned)id * 2654435761u) >> 25;    // 7 bits
+        for (int probe = 0; probe < 4; ++probe) {
+          const int sidx = (hsh + probe) & (LB_SLOTS - 1);
+          const int old = atomicCAS(&hkey[sidx], -1, id);
+          if (old == -1 || old == id) {
+            slot = sidx;
+            break;
+          }
         }
+        int* s = slot >= 0 ? hst + 5 * slot : stats + ((size_t)b * max_labels + (id - 1)) * 5;
+        atomicMin(s + 0, x);
+        atomicMin(s + 1, y);
+        atomicMax(s + 2, x + len - 1);
+        atomicMax(s + 3, y);
+        atomicAdd(s + 4, len);
       }
-      int* s = slot >= 0 ? hst + 5 * slot : stats + ((size_t)b * max_labels + (id - 1)) * 5;
-      atomicMin(s + 0, x);
-      atomicMin(s + 1, y);
-      atomicMax(s + 2, x + len - 1);
-      atomicMax(s + 3, y);
-      atomicAdd(s + 4, len);
-    }
     }
   }
   if (stats) {
@@ -1030,36 +1030,36 @@ __device__ __forceinline__ void ccl2_label_body(int vb, int* __restrict__ labels
     }
 #pragma unroll
     for (int u = 0; u < LU; ++u) {
-    const int p0 = pb + 256 * u;
-    if (p0 >= p_end) break;
-    const int p = p0 + threadIdx.x;
-    const bool live = p < p_end;
-    const int id = idv[u];                                  // 0 = dead lane (every pixel has a class, so no real id is 0)
-    const int x = live ? p % W : 0, y = live ? p / W : 0;
-    const int prev = __shfl_up(id, 1);
-    const bool head = lane == 0 || prev != id || x == 0;
-    const unsigned long long heads = __ballot(head);
-    const int mag = id > 0 ? id : -id;
-    if (head && id != 0 && mag <= max_labels) {
-      const unsigned long long later = lane == 63 ? 0ull : (heads >> (lane + 1));
-      const int len = later ? __ffsll((long long)later) : 64 - lane;
-      int slot = -1;
-      const unsigned hsh = ((unsigned)id * 2654435761u) >> 25;    // 7 bits
-      for (int probe = 0; probe < 4; ++probe) {
-        const int sidx = (hsh + probe) & (LB_SLOTS - 1);
-        const int old = atomicCAS(&hkey[sidx], EMPTY, id);
-        if (old == EMPTY || old == id) {
-          slot = sidx;
-          break;
+      const int p0 = pb + 256 * u;
+      if (p0 >= p_end) break;
+      const int p = p0 + threadIdx.x;
+      const bool live = p < p_end;
+      const int id = idv[u];                                  // 0 = dead lane (every pixel has a class, so no real id is 0)
+      const int x = live ? p % W : 0, y = live ? p / W : 0;
+      const int prev = __shfl_up(id, 1);
+      const bool head = lane == 0 || prev != id || x == 0;
+      const unsigned long long heads = __ballot(head);
+      const int mag = id > 0 ? id : -id;
+      if (head && id != 0 && mag <= max_labels) {
+        const unsigned long long later = lane == 63 ? 0ull : (heads >> (lane + 1));
+        const int len = later ? __ffsll((long long)later) : 64 - lane;
+        int slot = -1;
+        const unsigned hsh = ((unsigned)id * 2654435761u) >> 25;    // 7 bits
+        for (int probe = 0; probe < 4; ++probe) {
+          const int sidx = (hsh + probe) & (LB_SLOTS - 1);
+          const int old = atomicCAS(&hkey[sidx], EMPTY, id);
+          if (old == EMPTY || old == id) {
+            slot = sidx;
+            break;
+          }
         }
+        int* s = slot >= 0 ? hst + 5 * slot : row_of(id);
+        atomicMin(s + 0, x);
+        atomicMin(s + 1, y);
+        atomicMax(s + 2, x + len - 1);
+        atomicMax(s + 3, y);
+        atomicAdd(s + 4, len);
       }
-      int* s = slot >= 0 ? hst + 5 * slot : row_of(id);
-      atomicMin(s + 0, x);
-      atomicMin(s + 1, y);
-      atomicMax(s + 2, x + len - 1);
-      atomicMax(s + 3, y);
-      atomicAdd(s + 4, len);
-    }
     }
   }
   __syncthreads();

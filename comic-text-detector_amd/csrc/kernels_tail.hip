@@ -116,69 +116,69 @@ __global__ __launch_bounds__(256) void dbc_accum_kernel(DbcTables t) {
     for (int u = 0; u < DU; ++u) pars[u] = (keys[u] < 0 && -keys[u] <= t.cap) ? t.par_b[cb + (-keys[u]) - 1] : 0;
 #pragma unroll
     for (int u = 0; u < DU; ++u) {
-    if (pb + (long long)u * span >= hw) break;
-    const int p0 = (int)(pb + (long long)u * span);
-    const int p = min(p0 + (int)threadIdx.x, hw - 1);
-    const bool live = p0 + (int)threadIdx.x < hw;
-    const long long i = (long long)b * hw + p;
-    const int x = p % t.W, y = p / t.W;
-    const int key = keys[u];
-    const int lf = max(key, 0), lb = max(-key, 0);
-    // Most waves see only page background (a complement component that is no hole): nothing to add, and
-    // the f64 scan below (14 cross-lane moves) is what this kernel's time goes into.
-    const bool hole = live && lf <= 0 && lb > 0 && lb <= t.cap && pars[u] > 0;
-    if (!__ballot(live && (lf > 0 || hole))) continue;
-    const double pr = live ? (double)t.prob[(long long)b * t.prob_stride + p] : 0.0;
-    // horizontal runs of one label inside the wave: the first lane of a run acts for it
-    const int prev = __shfl_up(key, 1);
-    const bool head = lane == 0 || prev != key || x == 0;
-    const unsigned long long heads = __ballot(head);
-    const unsigned long long later = lane == 63 ? 0ull : (heads >> (lane + 1));
-    const int len = later ? __ffsll((long long)later) : 64 - lane;
-    double ps = pr;
-    for (int off = 1; off < 64; off <<= 1) {
-      const double up = __shfl_up(ps, off);
-      if (lane >= off) ps += up;
-    }
-    const double s_tail = __shfl(ps, lane + len - 1);
-    const double s_prev = __shfl_up(ps, 1);
-    const double run = s_tail - (lane > 0 ? s_prev : 0.0);
-    if (!live || t.hdr[b * 4 + 3]) continue;          // overflowed page: the host takes the label-image path
-    if (lf > 0 && lf <= t.cap) {
-      if (head) {
-        unsafeAtomicAdd(t.sum_f + cb + lf - 1, run);
-        const int row = t.off_f[cb + lf - 1] + (y - t.st_f[(cb + lf - 1) * 5 + 1]);
-        atomicMin(t.row_lo + rb + row, x);
-        atomicMax(t.row_hi + rb + row, x + len - 1);
+      if (pb + (long long)u * span >= hw) break;
+      const int p0 = (int)(pb + (long long)u * span);
+      const int p = min(p0 + (int)threadIdx.x, hw - 1);
+      const bool live = p0 + (int)threadIdx.x < hw;
+      const long long i = (long long)b * hw + p;
+      const int x = p % t.W, y = p / t.W;
+      const int key = keys[u];
+      const int lf = max(key, 0), lb = max(-key, 0);
+      // Most waves see only page background (a complement component that is no hole): nothing to add, and
+      // the f64 scan below (14 cross-lane moves) is what this kernel's time goes into.
+      const bool hole = live && lf <= 0 && lb > 0 && lb <= t.cap && pars[u] > 0;
+      if (!__ballot(live && (lf > 0 || hole))) continue;
+      const double pr = live ? (double)t.prob[(long long)b * t.prob_stride + p] : 0.0;
+      // horizontal runs of one label inside the wave: the first lane of a run acts for it
+      const int prev = __shfl_up(key, 1);
+      const bool head = lane == 0 || prev != key || x == 0;
+      const unsigned long long heads = __ballot(head);
+      const unsigned long long later = lane == 63 ? 0ull : (heads >> (lane + 1));
+      const int len = later ? __ffsll((long long)later) : 64 - lane;
+      double ps = pr;
+      for (int off = 1; off < 64; off <<= 1) {
+        const double up = __shfl_up(ps, off);
+        if (lane >= off) ps += up;
       }
-      // border ring of a hole: foreground pixels of the ringing component that 4-touch the hole (the four neighbours'
-      // labels, then the four rings, are fetched together: one pixel has up to eight dependent loads here otherwise)
-      int seen[4];
-      int ns = 0;
-      const int dq[4] = {-1, 1, -t.W, t.W};
-      const bool ok[4] = {x > 0, x + 1 < t.W, y > 0, y + 1 < t.H};
-      int hbs[4], prs[4];
+      const double s_tail = __shfl(ps, lane + len - 1);
+      const double s_prev = __shfl_up(ps, 1);
+      const double run = s_tail - (lane > 0 ? s_prev : 0.0);
+      if (!live || t.hdr[b * 4 + 3]) continue;          // overflowed page: the host takes the label-image path
+      if (lf > 0 && lf <= t.cap) {
+        if (head) {
+          unsafeAtomicAdd(t.sum_f + cb + lf - 1, run);
+          const int row = t.off_f[cb + lf - 1] + (y - t.st_f[(cb + lf - 1) * 5 + 1]);
+          atomicMin(t.row_lo + rb + row, x);
+          atomicMax(t.row_hi + rb + row, x + len - 1);
+        }
+        // border ring of a hole: foreground pixels of the ringing component that 4-touch the hole (the four neighbours'
+        // labels, then the four rings, are fetched together: one pixel has up to eight dependent loads here otherwise)
+        int seen[4];
+        int ns = 0;
+        const int dq[4] = {-1, 1, -t.W, t.W};
+        const bool ok[4] = {x > 0, x + 1 < t.W, y > 0, y + 1 < t.H};
+        int hbs[4], prs[4];
 #pragma unroll
-      for (int k = 0; k < 4; ++k) hbs[k] = ok[k] ? -t.lab[i + dq[k]] : 0;
+        for (int k = 0; k < 4; ++k) hbs[k] = ok[k] ? -t.lab[i + dq[k]] : 0;
 #pragma unroll
-      for (int k = 0; k < 4; ++k) prs[k] = (hbs[k] > 0 && hbs[k] <= t.cap) ? t.par_b[cb + hbs[k] - 1] : -1;
+        for (int k = 0; k < 4; ++k) prs[k] = (hbs[k] > 0 && hbs[k] <= t.cap) ? t.par_b[cb + hbs[k] - 1] : -1;
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const int hb = hbs[k];
-        if (hb <= 0 || hb > t.cap || prs[k] != lf) continue;
-        bool dup = false;
-        for (int j = 0; j < ns; ++j) dup |= seen[j] == hb;
-        if (dup) continue;
-        seen[ns++] = hb;
-        unsafeAtomicAdd(t.ring_sum + cb + hb - 1, pr);
-        atomicAdd(t.ring_cnt + cb + hb - 1, 1);
-        const int row = t.off_b[cb + hb - 1] + (y - (t.st_b[(cb + hb - 1) * 5 + 1] - 1));
-        atomicMin(t.row_lo + rb + row, x);
-        atomicMax(t.row_hi + rb + row, x);
+        for (int k = 0; k < 4; ++k) {
+          const int hb = hbs[k];
+          if (hb <= 0 || hb > t.cap || prs[k] != lf) continue;
+          bool dup = false;
+          for (int j = 0; j < ns; ++j) dup |= seen[j] == hb;
+          if (dup) continue;
+          seen[ns++] = hb;
+          unsafeAtomicAdd(t.ring_sum + cb + hb - 1, pr);
+          atomicAdd(t.ring_cnt + cb + hb - 1, 1);
+          const int row = t.off_b[cb + hb - 1] + (y - (t.st_b[(cb + hb - 1) * 5 + 1] - 1));
+          atomicMin(t.row_lo + rb + row, x);
+          atomicMax(t.row_hi + rb + row, x);
+        }
+      } else if (head && hole) {
+        unsafeAtomicAdd(t.sum_b + cb + lb - 1, run);
       }
-    } else if (head && hole) {
-      unsafeAtomicAdd(t.sum_b + cb + lb - 1, run);
-    }
     }
   }
 }

@@ -247,37 +247,99 @@ __device__ __forceinline__ void load_row6(const uint8_t* row, int x, int ww, int
   }
 }
 
+// ---- windows at least 8 pixels wide (`FAST`; the kernels pick the instantiation per window) ----------------------------
+// A group cut by the window's right edge takes the byte paths above: branches whose loads are consumed inside them, a memory
+// round trip in the middle of every wave that spans a row end (most do).  Here the last group of a row is the row's LAST
+// four pixels instead: it overlaps its left neighbour, and its first `lo` pixels -- the neighbour's -- are skipped (sums,
+// counts) or written again with the same values (stores, ORs).  Every group is then four whole pixels inside the window:
+// one 12-B / 4-B / 8-B load each, no edge branch, and the loads of TW_U groups are issued before the first is used.
+constexpr int TW_U = 2;
+template <bool FAST>
+__device__ __forceinline__ Grp win_group_lo(const TWin& w, int gi, int& lo) {
+  Grp g = win_group(w, gi);
+  lo = 0;
+  if (FAST) {
+    lo = 4 - g.nv;
+    g.x -= lo;
+    g.nv = 4;
+  }
+  return g;
+}
+// columns x-1 .. x+4 of a row as bytes 0..5 of one 8-byte load that stays inside the row (window at least 8 wide, x <= ww - 4);
+// `fill255` ? 255 : 0 outside the window
+__device__ __forceinline__ unsigned long long row6_wide(const uint8_t* row0, int x, int ww, bool fill255) {
+  const int s0 = min(max(x - 1, 0), ww - 8);
+  unsigned long long v;
+  __builtin_memcpy(&v, row0 + s0, 8);
+  const int d = x - 1 - s0;                                    // -1 (the first group of a row) .. 3
+  v = d < 0 ? (v << 8) : (v >> (8 * (d & 7)));
+  const int nvalid = ww - (x - 1);                             // bytes from byte 0 on that are window columns (>= 5)
+  unsigned long long inside = nvalid < 8 ? ~(~0ull << (8 * (nvalid & 7))) : ~0ull;
+  inside &= d < 0 ? ~0xffull : ~0ull;                          // column -1
+  v &= inside;
+  return fill255 ? (v | ~inside) : v;
+}
+// load_row6 through row6_wide when FAST
+template <bool FAST>
+__device__ __forceinline__ unsigned long long row6(const uint8_t* row0, int x, int ww, int fill) {
+  if (FAST) return row6_wide(row0, x, ww, fill != 0);
+  uint8_t mv[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  load_row6(row0, x, ww, fill, mv);
+  unsigned long long v;
+  __builtin_memcpy(&v, mv, 8);
+  return v;
+}
+
 // grey over pixels whose 3x3-eroded mask > 127 (textmask.py:58-61) and B, G, R of the whole window (Otsu, :44-47)
+template <bool FAST>
+__device__ __forceinline__ void tw_hist_body(const TWin& w, unsigned* h) {
+  constexpr int TW_U = 1;                                        // one group: the erosion's three rows and the pixel are 44 B in flight already
+  const int ng = win_groups(w);
+  for (int g0 = blockIdx.x * 256 * TW_U; g0 < ng; g0 += gridDim.x * 256 * TW_U) {
+    Grp g[TW_U];
+    int lo[TW_U];
+    uint8_t px[TW_U][12];
+    unsigned long long rows[TW_U][3];
+#pragma unroll
+    for (int u = 0; u < TW_U; ++u) {
+      const int gi = g0 + u * 256 + threadIdx.x;
+      g[u] = win_group_lo<FAST>(w, min(gi, ng - 1), lo[u]);
+      if (gi >= ng) lo[u] = 4;                                   // beyond the window: nothing counted
+      load_bgr4(w, g[u], px[u]);
+#pragma unroll
+      for (int dy = -1; dy <= 1; ++dy) {                         // a row outside the window is ignored: 255 is neutral
+        const bool ok = (unsigned)(g[u].y + dy) < (unsigned)w.h;
+        const unsigned long long r = row6<FAST>(w.mask + (size_t)(w.y1 + g[u].y + (ok ? dy : 0)) * w.mask_w + w.x1, g[u].x, w.w, 255);
+        rows[u][dy + 1] = ok ? r : ~0ull;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < TW_U; ++u) {
+      int er[4] = {255, 255, 255, 255};                          // 3x3 erosion, pixels outside the window ignored
+#pragma unroll
+      for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          er[k] = min(er[k], min((int)((rows[u][r] >> (8 * k)) & 0xff), min((int)((rows[u][r] >> (8 * k + 8)) & 0xff), (int)((rows[u][r] >> (8 * k + 16)) & 0xff))));
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const bool on = k >= lo[u] && k < g[u].nv;
+        const uint8_t* q = px[u] + 3 * k;
+        hist_add(h + 256, q[0], on);
+        hist_add(h + 512, q[1], on);
+        hist_add(h + 768, q[2], on);
+        hist_add(h, gray_of(q), on && er[k] > 127);
+      }
+    }
+  }
+}
 __global__ __launch_bounds__(256) void tw_hist_kernel(const TWin* __restrict__ wins, unsigned* __restrict__ hist) {
   __shared__ unsigned h[4 * 256];
   const TWin w = wins[blockIdx.y];
   for (int i = threadIdx.x; i < 1024; i += 256) h[i] = 0;
   __syncthreads();
-  const int ng = win_groups(w);
-  for (int gi = blockIdx.x * 256 + threadIdx.x; gi < ng; gi += gridDim.x * 256) {
-    const Grp g = win_group(w, gi);
-    uint8_t px[12];
-    load_bgr4(w, g, px);
-    int er[4] = {255, 255, 255, 255};               // 3x3 erosion, pixels outside the window ignored
-#pragma unroll
-    for (int dy = -1; dy <= 1; ++dy) {
-      const int yy = g.y + dy;
-      if (yy < 0 || yy >= w.h) continue;
-      uint8_t mv[6];
-      load_row6(w.mask + (size_t)(w.y1 + yy) * w.mask_w + w.x1, g.x, w.w, 255, mv);
-#pragma unroll
-      for (int k = 0; k < 4; ++k) er[k] = min(er[k], min((int)mv[k], min((int)mv[k + 1], (int)mv[k + 2])));
-    }
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const bool on = k < g.nv;
-      const uint8_t* q = px + 3 * k;
-      hist_add(h + 256, q[0], on);
-      hist_add(h + 512, q[1], on);
-      hist_add(h + 768, q[2], on);
-      hist_add(h, gray_of(q), on && er[k] > 127);
-    }
-  }
+  if (w.w >= 8) tw_hist_body<true>(w, h);
+  else tw_hist_body<false>(w, h);
   __syncthreads();
   unsigned* out = hist + (size_t)blockIdx.y * 1024;
   for (int i = threadIdx.x; i < 1024; i += 256)
@@ -292,6 +354,39 @@ __device__ __forceinline__ bool rule_on(int kind, int lo, int hi, int b, int g, 
 }
 
 // xor distance sum(cand ? 255 - m : m) of the 6 candidate rules of every window (textmask.py:36-37)
+template <bool FAST>
+__device__ __forceinline__ void tw_xor_body(const TWin& w, const TRule* rs, unsigned long long* acc) {
+  const int ng = win_groups(w);
+  for (int g0 = blockIdx.x * 256 * TW_U; g0 < ng; g0 += gridDim.x * 256 * TW_U) {
+    Grp g[TW_U];
+    int lo[TW_U];
+    uint8_t px[TW_U][12], mv[TW_U][4];
+#pragma unroll
+    for (int u = 0; u < TW_U; ++u) {
+      const int gi = g0 + u * 256 + threadIdx.x;
+      g[u] = win_group_lo<FAST>(w, min(gi, ng - 1), lo[u]);
+      if (gi >= ng) lo[u] = 4;
+      load_bgr4(w, g[u], px[u]);
+      const uint8_t* mrow = w.mask + (size_t)(w.y1 + g[u].y) * w.mask_w + w.x1 + g[u].x;
+      if (g[u].nv == 4) {
+        __builtin_memcpy(mv[u], mrow, 4);
+      } else {
+        for (int j = 0; j < 4; ++j) mv[u][j] = j < g[u].nv ? mrow[j] : 0;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < TW_U; ++u)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (j < lo[u] || j >= g[u].nv) continue;
+        const int m = mv[u][j];
+        const int cb = px[u][3 * j], cg = px[u][3 * j + 1], cr = px[u][3 * j + 2], grey = gray_of(px[u] + 3 * j);
+#pragma unroll
+        for (int k = 0; k < 6; ++k)
+          if (rs[k].kind >= 0) acc[k] += rule_on(rs[k].kind, rs[k].lo, rs[k].hi, cb, cg, cr, grey) ? (255 - m) : m;
+      }
+  }
+}
 __global__ __launch_bounds__(256) void tw_xor_kernel(const TWin* __restrict__ wins, const TRule* __restrict__ rules,
                                                      unsigned long long* __restrict__ sums) {
   __shared__ unsigned long long red[4];
@@ -299,27 +394,8 @@ __global__ __launch_bounds__(256) void tw_xor_kernel(const TWin* __restrict__ wi
   TRule rs[6];
   for (int k = 0; k < 6; ++k) rs[k] = rules[(size_t)blockIdx.y * 6 + k];
   unsigned long long acc[6] = {0, 0, 0, 0, 0, 0};
-  const int ng = win_groups(w);
-  for (int gi = blockIdx.x * 256 + threadIdx.x; gi < ng; gi += gridDim.x * 256) {
-    const Grp g = win_group(w, gi);
-    uint8_t px[12], mv[4];
-    load_bgr4(w, g, px);
-    const uint8_t* mrow = w.mask + (size_t)(w.y1 + g.y) * w.mask_w + w.x1 + g.x;
-    if (g.nv == 4) {
-      __builtin_memcpy(mv, mrow, 4);
-    } else {
-      for (int j = 0; j < 4; ++j) mv[j] = j < g.nv ? mrow[j] : 0;
-    }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      if (j >= g.nv) break;
-      const int m = mv[j];
-      const int cb = px[3 * j], cg = px[3 * j + 1], cr = px[3 * j + 2], grey = gray_of(px + 3 * j);
-#pragma unroll
-      for (int k = 0; k < 6; ++k)
-        if (rs[k].kind >= 0) acc[k] += rule_on(rs[k].kind, rs[k].lo, rs[k].hi, cb, cg, cr, grey) ? (255 - m) : m;
-    }
-  }
+  if (w.w >= 8) tw_xor_body<true>(w, rs, acc);
+  else tw_xor_body<false>(w, rs, acc);
   for (int k = 0; k < 6; ++k) {
     unsigned long long v = acc[k];
     for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
@@ -333,25 +409,43 @@ __global__ __launch_bounds__(256) void tw_xor_kernel(const TWin* __restrict__ wi
   }
 }
 
+template <bool FAST>
+__device__ __forceinline__ void tw_render_body(const TWin& w, const TBand& bd, uint8_t* __restrict__ canvas, int canvas_w) {
+  const int ng = win_groups(w);
+  for (int g0 = blockIdx.x * 256 * TW_U; g0 < ng; g0 += gridDim.x * 256 * TW_U) {
+    Grp g[TW_U];
+    uint8_t px[TW_U][12];
+    bool live[TW_U];
+#pragma unroll
+    for (int u = 0; u < TW_U; ++u) {
+      const int gi = g0 + u * 256 + threadIdx.x;
+      int lo;
+      live[u] = gi < ng;
+      g[u] = win_group_lo<FAST>(w, min(gi, ng - 1), lo);      // (an overlapping group stores its neighbour's pixels again: same values)
+      load_bgr4(w, g[u], px[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < TW_U; ++u) {
+      if (!live[u]) continue;
+      uint8_t o[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        o[j] = (rule_on(bd.kind, bd.lo, bd.hi, px[u][3 * j], px[u][3 * j + 1], px[u][3 * j + 2], gray_of(px[u] + 3 * j)) != (bd.invert != 0)) ? 255 : 0;
+      uint8_t* dst = canvas + (size_t)(bd.cy + g[u].y) * canvas_w + bd.cx + g[u].x;
+      if (g[u].nv == 4) {
+        __builtin_memcpy(dst, o, 4);
+      } else {
+        for (int j = 0; j < g[u].nv; ++j) dst[j] = o[j];
+      }
+    }
+  }
+}
 __global__ __launch_bounds__(256) void tw_render_kernel(const TWin* __restrict__ wins, const TBand* __restrict__ bands,
                                                         uint8_t* __restrict__ canvas, int canvas_w) {
   const TBand bd = bands[blockIdx.y];
   const TWin w = wins[bd.win];
-  const int ng = win_groups(w);
-  for (int gi = blockIdx.x * 256 + threadIdx.x; gi < ng; gi += gridDim.x * 256) {
-    const Grp g = win_group(w, gi);
-    uint8_t px[12], o[4];
-    load_bgr4(w, g, px);
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-      o[j] = (rule_on(bd.kind, bd.lo, bd.hi, px[3 * j], px[3 * j + 1], px[3 * j + 2], gray_of(px + 3 * j)) != (bd.invert != 0)) ? 255 : 0;
-    uint8_t* dst = canvas + (size_t)(bd.cy + g.y) * canvas_w + bd.cx + g.x;
-    if (g.nv == 4) {
-      __builtin_memcpy(dst, o, 4);
-    } else {
-      for (int j = 0; j < g.nv; ++j) dst[j] = o[j];
-    }
-  }
+  if (w.w >= 8) tw_render_body<true>(w, bd, canvas, canvas_w);
+  else tw_render_body<false>(w, bd, canvas, canvas_w);
 }
 
 // pred_bin of merge_mask_list (:85-89): 3x3 cross erosion of the window's mask, > 60 -> 255
@@ -544,17 +638,6 @@ constexpr int TWB_U = 4;
 // pixels -- the neighbour's -- are skipped.  Every group is then four whole pixels inside the window: one 16-B / 4-B / 8-B
 // load each, no edge branch.  The sweeps only add, take maxima and set bytes per pixel, and every pixel is still taken
 // exactly once.
-template <bool FAST>
-__device__ __forceinline__ Grp win_group_lo(const TWin& w, int gi, int& lo) {
-  Grp g = win_group(w, gi);
-  lo = 0;
-  if (FAST) {
-    lo = 4 - g.nv;
-    g.x -= lo;
-    g.nv = 4;
-  }
-  return g;
-}
 // four bytes of a row from column g.x on, little-endian in one word; 255 beyond the window's right edge
 __device__ __forceinline__ unsigned bytes4(const uint8_t* row0, const Grp& g) {
   uint8_t b[4];
@@ -866,42 +949,64 @@ __global__ __launch_bounds__(TWB_THREADS) void tw_holes_all_kernel(const TWin* _
 
 // 3x3 rect dilation inside the window (REFINEMASK_INPAINT, textmask.py:110-111) or a copy; also the
 // complement canvas for the hole-filling labelling (:113) and the count of set pixels per window
+template <bool FAST>
+__device__ __forceinline__ unsigned tw_dilate_body(const TWin& w, const uint8_t* __restrict__ in, uint8_t* __restrict__ out,
+                                                   uint8_t* __restrict__ comp, int merged_w, int dilate) {
+  constexpr int TW_U = 1;                                        // one group: three 8-byte rows in flight
+  unsigned cnt = 0;
+  const int ng = win_groups(w);
+  for (int g0 = blockIdx.x * 256 * TW_U; g0 < ng; g0 += gridDim.x * 256 * TW_U) {
+    Grp g[TW_U];
+    int lo[TW_U];
+    bool live[TW_U];
+    unsigned long long rows[TW_U][3];
+#pragma unroll
+    for (int u = 0; u < TW_U; ++u) {
+      const int gi = g0 + u * 256 + threadIdx.x;
+      live[u] = gi < ng;
+      g[u] = win_group_lo<FAST>(w, min(gi, ng - 1), lo[u]);
+#pragma unroll
+      for (int dy = -1; dy <= 1; ++dy) {                         // rows outside the window (and, without dilation, the neighbours) add nothing
+        const bool ok = (dy == 0 || dilate) && (unsigned)(g[u].y + dy) < (unsigned)w.h;
+        const unsigned long long r = row6<FAST>(in + (size_t)(w.my + g[u].y + (ok ? dy : 0)) * merged_w + w.mx, g[u].x, w.w, 0);
+        rows[u][dy + 1] = ok ? r : 0ull;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < TW_U; ++u) {
+      if (!live[u]) continue;
+      int m[4] = {0, 0, 0, 0};
+#pragma unroll
+      for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int a = (int)((rows[u][r] >> (8 * k)) & 0xff), b = (int)((rows[u][r] >> (8 * k + 8)) & 0xff), c = (int)((rows[u][r] >> (8 * k + 16)) & 0xff);
+          m[k] = max(m[k], dilate ? max(a, max(b, c)) : b);
+        }
+      uint8_t o[4], c[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        o[k] = (uint8_t)m[k];
+        c[k] = (uint8_t)(255 - m[k]);
+        cnt += k >= lo[u] && k < g[u].nv && m[k] == 255;
+      }
+      const size_t at = (size_t)(w.my + g[u].y) * merged_w + w.mx + g[u].x;
+      if (g[u].nv == 4) {                                        // (an overlapping group stores its neighbour's pixels again: same values)
+        __builtin_memcpy(out + at, o, 4);
+        __builtin_memcpy(comp + at, c, 4);
+      } else {
+        for (int k = 0; k < g[u].nv; ++k) out[at + k] = o[k], comp[at + k] = c[k];
+      }
+    }
+  }
+  return cnt;
+}
 __global__ __launch_bounds__(256) void tw_dilate_kernel(const TWin* __restrict__ wins, const uint8_t* __restrict__ in,
                                                         uint8_t* __restrict__ out, uint8_t* __restrict__ comp, int merged_w,
                                                         unsigned* __restrict__ count255, int dilate) {
   __shared__ unsigned red[4];
   const TWin w = wins[blockIdx.y];
-  unsigned cnt = 0;
-  const int ng = win_groups(w);
-  for (int gi = blockIdx.x * 256 + threadIdx.x; gi < ng; gi += gridDim.x * 256) {
-    const Grp g = win_group(w, gi);
-    int m[4] = {0, 0, 0, 0};
-#pragma unroll
-    for (int dy = -1; dy <= 1; ++dy) {
-      if (dy != 0 && !dilate) continue;
-      const int yy = g.y + dy;
-      if (yy < 0 || yy >= w.h) continue;
-      uint8_t mv[6];
-      load_row6(in + (size_t)(w.my + yy) * merged_w + w.mx, g.x, w.w, 0, mv);
-#pragma unroll
-      for (int k = 0; k < 4; ++k)
-        m[k] = max(m[k], dilate ? max((int)mv[k], max((int)mv[k + 1], (int)mv[k + 2])) : (int)mv[k + 1]);
-    }
-    uint8_t o[4], c[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      o[k] = (uint8_t)m[k];
-      c[k] = (uint8_t)(255 - m[k]);
-      cnt += k < g.nv && m[k] == 255;
-    }
-    const size_t at = (size_t)(w.my + g.y) * merged_w + w.mx + g.x;
-    if (g.nv == 4) {
-      __builtin_memcpy(out + at, o, 4);
-      __builtin_memcpy(comp + at, c, 4);
-    } else {
-      for (int k = 0; k < g.nv; ++k) out[at + k] = o[k], comp[at + k] = c[k];
-    }
-  }
+  unsigned cnt = w.w >= 8 ? tw_dilate_body<true>(w, in, out, comp, merged_w, dilate) : tw_dilate_body<false>(w, in, out, comp, merged_w, dilate);
   for (int off = 32; off > 0; off >>= 1) cnt += __shfl_down(cnt, off);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = cnt;
   __syncthreads();
@@ -960,27 +1065,43 @@ __global__ __launch_bounds__(256) void tw_holes_kernel(const TWin* __restrict__ 
 }
 
 // refined[y1:y2, x1:x2] |= merged (textmask.py:167); windows may overlap -> word-wide atomic OR
+template <bool FAST>
+__device__ __forceinline__ void tw_commit_body(const TWin& w, const uint8_t* __restrict__ merged, int merged_w) {
+  const int ng = win_groups(w);
+  for (int g0 = blockIdx.x * 256 * TW_U; g0 < ng; g0 += gridDim.x * 256 * TW_U) {
+    Grp g[TW_U];
+    unsigned v[TW_U];
+#pragma unroll
+    for (int u = 0; u < TW_U; ++u) {
+      const int gi = g0 + u * 256 + threadIdx.x;
+      int lo;
+      g[u] = win_group_lo<FAST>(w, min(gi, ng - 1), lo);      // (an overlapping group ORs its neighbour's pixels again)
+      const uint8_t* src = merged + (size_t)(w.my + g[u].y) * merged_w + w.mx + g[u].x;
+      v[u] = 0;
+      if (g[u].nv == 4) {
+        __builtin_memcpy(&v[u], src, 4);
+      } else {
+        for (int k = 0; k < g[u].nv; ++k) v[u] |= (unsigned)src[k] << (8 * k);
+      }
+      if (gi >= ng) v[u] = 0;
+    }
+#pragma unroll
+    for (int u = 0; u < TW_U; ++u) {
+      if (!v[u]) continue;
+      const size_t idx = (size_t)(w.y1 + g[u].y) * w.out_w + w.x1 + g[u].x;
+      unsigned* a = (unsigned*)(w.out + (idx & ~(size_t)3));
+      // the page buffers are 4-byte aligned and padded to a multiple of 4 bytes: the group covers at most two words
+      const unsigned long long v2 = (unsigned long long)v[u] << (8 * (idx & 3));
+      if ((unsigned)v2) atomicOr(a, (unsigned)v2);
+      if ((unsigned)(v2 >> 32)) atomicOr(a + 1, (unsigned)(v2 >> 32));
+    }
+  }
+}
 __global__ __launch_bounds__(256) void tw_commit_kernel(const TWin* __restrict__ wins, const uint8_t* __restrict__ merged,
                                                         int merged_w) {
   const TWin w = wins[blockIdx.y];
-  const int ng = win_groups(w);
-  for (int gi = blockIdx.x * 256 + threadIdx.x; gi < ng; gi += gridDim.x * 256) {
-    const Grp g = win_group(w, gi);
-    const uint8_t* src = merged + (size_t)(w.my + g.y) * merged_w + w.mx + g.x;
-    unsigned v = 0;
-    if (g.nv == 4) {
-      __builtin_memcpy(&v, src, 4);
-    } else {
-      for (int k = 0; k < g.nv; ++k) v |= (unsigned)src[k] << (8 * k);
-    }
-    if (!v) continue;
-    const size_t idx = (size_t)(w.y1 + g.y) * w.out_w + w.x1 + g.x;
-    unsigned* a = (unsigned*)(w.out + (idx & ~(size_t)3));
-    // the page buffers are 4-byte aligned and padded to a multiple of 4 bytes: the group covers at most two words
-    const unsigned long long v2 = (unsigned long long)v << (8 * (idx & 3));
-    if ((unsigned)v2) atomicOr(a, (unsigned)v2);
-    if ((unsigned)(v2 >> 32)) atomicOr(a + 1, (unsigned)(v2 >> 32));
-  }
+  if (w.w >= 8) tw_commit_body<true>(w, merged, merged_w);
+  else tw_commit_body<false>(w, merged, merged_w);
 }
 
 __global__ void mask_clear_where_kernel(uint8_t* __restrict__ mask, const uint8_t* __restrict__ refined, long long n, int thr) {

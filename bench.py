@@ -88,19 +88,9 @@ def host_info() -> dict:
 
 
 def thread_budget(world: int, pinned: bool = False, host_cpus: int = 0) -> dict:
-    """Host threads one rank may use: the usable cores divided by the ranks on this host (an 8-rank node runs 8 of these
-    processes) -- or, once the rank is bound to its own CPUs (`affinity.apply`, N > 1), simply the CPUs it is bound to.
-    Tail workers x native geometry threads + loaders + the launching thread must fit."""
-    avail = host_info()["usable_cpus"]
-    per_rank = max(4, avail if pinned else avail // max(1, world))
-    if pinned and host_cpus:
-        avail = host_cpus                                     # what the host offered before this rank bound itself
-    # 4 workers where a rank has 16 CPUs or more: round 5 re-measured it after the forward got shorter -- on one box 3 = 4 on the
-    # headline and +6 % on the canned pages, on another 4 is +2 % on the headline and +6 % on dense pages (three interleaved
-    # repetitions each, profiles/r05_e2e_workers_3_vs_4.txt); the dense pages decide
-    workers = 4 if per_rank >= 16 else (3 if per_rank >= 8 else 2)
-    native = max(1, min(8, (per_rank - 2) // workers))
-    return {"usable_cpus": avail, "per_rank": per_rank, "tail_workers": workers, "native_threads_per_worker": native}
+    """The product's own budget (`detector.thread_budget`: what `detect_stream(workers=0)` uses)."""
+    DET = importlib.import_module("comic-text-detector_amd.detector")
+    return DET.thread_budget(world, pinned, host_cpus)
 
 
 # =====================================================================================================================
@@ -145,28 +135,39 @@ class Pipeline:
     while worker threads run the tail work items of step k; (N>1) the record gather on its own stream."""
 
     def __init__(self, det, batches, canned, dev, world, rank, total_pages, D, workers, depth, tail_split,
-                 host_input=False, loaders=2, engines=1, keep_undetected=False, lazy=False):
+                 host_input=False, loaders=2, engines=1, keep_undetected=False, lazy=False, refine_mode=0, force_dist=False):
         self.det, self.batches, self.canned, self.dev = det, batches, canned, dev
         self.world, self.rank, self.total_pages, self.D = world, rank, total_pages, D
         self.workers, self.depth, self.tail_split = max(1, workers), max(1, depth), max(1, tail_split)
         self.engines, self.keep_undetected, self.lazy = max(1, engines), keep_undetected, lazy
+        self.refine_mode = int(refine_mode)
+        # the record gather runs for N > 1 -- and for `--force-dist` at N = 1 (a world-size-1 group: the same code on RCCL)
+        self.gather = world > 1 or bool(force_dist)
         self.nloc = batches[0].shape[0]
-        self.pool = ThreadPoolExecutor(max_workers=self.workers, thread_name_prefix="ctd-tail")
-        det.warm_tails(self.pool, self.workers)               # the tails' streams before any loader stream (detector._copy_stream)
+        # the detector's own pools (`detect_stream` keeps them between calls): the tails' streams before any loader stream
+        self.pool = det._pool("tail", self.workers)
+        det.warm_tails(self.pool, self.workers)
+        det._warmed = self.pool
+        self.loaders = max(1, loaders)
         self.host_batches = [[p for p in b.cpu().numpy()] for b in batches] if host_input else None
-        self.lpool = ThreadPoolExecutor(max_workers=max(1, loaders), thread_name_prefix="ctd-load") if host_input else None
-        self.comm_stream = torch.cuda.Stream(dev) if world > 1 else None
+        self.lpool = det._pool("load", self.loaders) if host_input else None
+        self.comm_stream = torch.cuda.Stream(dev) if self.gather else None
         self.stats = {"blocks": 0, "lines": 0, "pages": 0, "cpu_cores": 0.0}
         self.k = 0                                           # batches rotate across calls too
         self.fixed_job = None
         self.fwd_stream = None
         # N > 1: the tail builds every page's gather record natively (dist.pack_results then only stacks them)
-        self.records = (D.CAP_BLK, D.CAP_LINE) if world > 1 else None
+        self.records = (D.CAP_BLK, D.CAP_LINE) if self.gather else None
+        self.gathered = None                                 # the last gathered record tensor (checked by the caller)
 
     def close(self):
-        self.pool.shutdown(wait=True)
-        if self.lpool is not None:
-            self.lpool.shutdown(wait=True)
+        self.det.close()                                     # ends the detector's worker / loader pools (idempotent)
+
+    @property
+    def api(self):
+        """True when the step is exactly `TextDetector.detect_stream` (everything but the measurement variants that
+        replace a stage: canned tail inputs, `--tail-only`)."""
+        return self.canned is None and self.fixed_job is None
 
     def forward_job(self, i, pg=None):
         if self.fixed_job is not None:                       # --tail-only: no forward; every step's tail reads the same outputs
@@ -185,11 +186,12 @@ class Pipeline:
         return job
 
     def finish(self, res):
-        if self.world > 1:
+        if self.gather:
             # on its own stream: the default stream holds the queued forwards of the next batches, and an upload or a
             # collective enqueued behind them would stall this thread until they have run
             with torch.cuda.stream(self.comm_stream):
-                self.D.gather_results(res, self.total_pages, self.rank, self.world, device=self.dev, pin=True)
+                self.gathered = self.D.gather_results(res, self.total_pages, self.rank, self.world, device=self.dev, pin=True,
+                                                      force=self.world == 1)
         self.stats["pages"] += len(res)
         self.stats["blocks"] += sum(len(r[2]) for r in res)
         # lazy results: the counts come from the native records (no TextBlock is built for the bookkeeping)
@@ -201,7 +203,25 @@ class Pipeline:
                 return self._run(n)
         return self._run(n)
 
+    def _batches(self, n):
+        for _ in range(n):
+            i = self.k
+            self.k += 1
+            if self.host_batches is not None:
+                yield self.host_batches[i % len(self.host_batches)]
+            else:
+                x = self.batches[i % len(self.batches)]
+                yield [x[j] for j in range(x.shape[0])]      # slices of one batch tensor: no torch.stack in the detector
+
     def _run(self, n):
+        if self.api:
+            # THE PUBLIC API: the headline's step is `TextDetector.detect_stream` -- this class only hands it the resident
+            # batches and counts what comes back (and, N > 1, gathers the page records it asked for)
+            for res in self.det.detect_stream(self._batches(n), self.refine_mode, self.keep_undetected, workers=self.workers,
+                                              depth=self.depth, engines=self.engines, loaders=self.loaders,
+                                              tail_split=self.tail_split, lazy=self.lazy, records=self.records):
+                self.finish(res)
+            return
         det, pending, ahead, issued = self.det, deque(), deque(), 0
         main = torch.cuda.current_stream(self.dev)
         collect = lambda futs: [r for f in futs for r in f.result()]          # noqa: E731
@@ -216,7 +236,7 @@ class Pipeline:
                 pg, ev = ahead.popleft().result()
                 main.wait_event(ev)
             job = self.forward_job(i, pg)
-            pending.append([self.pool.submit(det._tail, job, 0, self.keep_undetected, lo, hi, self.records, self.lazy)
+            pending.append([self.pool.submit(det._tail, job, self.refine_mode, self.keep_undetected, lo, hi, self.records, self.lazy)
                             for lo, hi in det._split(self.nloc, self.tail_split)])
             while len(pending) >= self.depth:
                 self.finish(collect(pending.popleft()))
@@ -229,16 +249,12 @@ def timed(run, steps, warmup, spinup, world, dev, stats=None):
     if spinup > 0:
         run(spinup)
     run(warmup)
-    # A serving process does this once after start-up: the interpreter's cyclic collector otherwise re-scans the ~1M
-    # long-lived objects of torch / numpy whenever the per-page result objects trigger a full collection (10 ms / batch)
-    import gc
-    gc.collect()
-    gc.freeze()
-    # ... and this: the result objects of a batch (32 pages x 30 TextBlocks, each a dict, a few lists and numpy values) are
-    # ~10 k tracked containers; at the default threshold of 700 allocations the youngest generation is collected a dozen
-    # times per batch, on the tail workers, under the interpreter lock.  Nothing on this path creates reference cycles.
-    gc.set_threshold(50000, 20, 20)
-    if world > 1:
+    # what a serving process does once after start-up -- the product's own `serve_tuning` (gc.freeze + the youngest
+    # generation's threshold), which `detect_stream` applies for any caller; here again AFTER the warm-up steps so that
+    # every sub-run of this process freezes what it built
+    importlib.import_module("comic-text-detector_amd.detector").serve_tuning(refreeze=True)
+    grouped = world > 1 or dist.is_initialized()               # `--force-dist` at N = 1: barrier + reduction on the real backend
+    if grouped:
         dist.barrier()
     torch.cuda.synchronize()
     if stats is not None:
@@ -247,12 +263,12 @@ def timed(run, steps, warmup, spinup, world, dev, stats=None):
     t0, c0 = time.perf_counter(), time.process_time()
     run(steps)
     torch.cuda.synchronize()
-    if world > 1:
+    if grouped:
         dist.barrier()
     dt = time.perf_counter() - t0
     if stats is not None:                        # CPU time of this process (all its threads) per second of wall clock
         stats["cpu_cores"] = (time.process_time() - c0) / max(dt, 1e-9)
-    if world > 1:
+    if grouped:
         t = torch.tensor([dt], dtype=torch.float64, device=dev if dist.get_backend() != "gloo" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -553,7 +569,7 @@ def inproc_bench(pkg, D, DET, TL, base_args, dev, steps: int, warmup: int = 3, s
         det = DET.TextDetector(ckpt, input_size=a.size, device=dev, precision=a.precision)
         pipe = Pipeline(det, batches, canned, dev, 1, 0, a.batch, D, a.workers, a.depth, a.tail_split,
                         host_input=a.host_input, loaders=a.loaders, engines=a.engines, keep_undetected=a.keep_undetected,
-                        lazy=bool(a.lazy_blocks))
+                        lazy=bool(a.lazy_blocks), refine_mode=getattr(a, "refine_mode", 0))
         gc.unfreeze()
         dt = timed(pipe.run, steps, warmup, spinup, 1, dev, pipe.stats)
         st = dict(pipe.stats)
@@ -852,6 +868,12 @@ def main() -> None:
     ap.add_argument("--cu-split", type=int, default=0,
                     help="e2e experiment: confine the tails' streams to this many CUs (mask bits 0..T-1, the same share of every "
                          "XCD) and run the forwards on a stream masked to the REST of the chip (hipExtStreamCreateWithCUMask)")
+    ap.add_argument("--force-dist", default="", choices=["", "nccl", "gloo"],
+                    help="N = 1: join a world-size-1 process group of this backend and run the N > 1 step's record gather (on the "
+                         "communication stream, from the page-locked record) inside every step -- RCCL exercised on the one GPU a "
+                         "1-GPU box has; `config.parallelism` records the backend")
+    ap.add_argument("--refine-mode", type=int, default=0, choices=[0, 1],
+                    help="0 = REFINEMASK_INPAINT (the API default), 1 = REFINEMASK_ANNOTATION (the reference CLI's, inference.py:35)")
     ap.add_argument("--no-pin", action="store_true",
                     help="N > 1: do NOT bind the rank's threads to the CPUs of its GPU's NUMA node (affinity.py; A/B knob)")
     args = ap.parse_args()
@@ -866,7 +888,7 @@ def main() -> None:
     DET = importlib.import_module("comic-text-detector_amd.detector")
     BK = importlib.import_module("comic-text-detector_amd.backend")
     TL = importlib.import_module("comic-text-detector_amd.tail")
-    rank, local_rank, world = D.init()
+    rank, local_rank, world = D.init(args.force_dist or None, force=bool(args.force_dist))
     if world != args.gpus and rank == 0:
         print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
     n_gpus = world
@@ -905,7 +927,7 @@ def main() -> None:
             out.update({"n_gpus": n_gpus, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                         "data": "synthetic", "cpu_baseline": None})
             print(json.dumps(out), flush=True)
-        if world > 1:
+        if dist.is_initialized():
             dist.barrier()
             dist.destroy_process_group()
         return
@@ -937,7 +959,8 @@ def main() -> None:
     e2e = args.mode == "e2e"
     pipe = Pipeline(det, batches, canned, dev, world, rank, total_pages, D, args.workers, args.depth, args.tail_split,
                     host_input=args.host_input and e2e, loaders=args.loaders, engines=args.engines,
-                    keep_undetected=args.keep_undetected, lazy=bool(args.lazy_blocks))
+                    keep_undetected=args.keep_undetected, lazy=bool(args.lazy_blocks), refine_mode=args.refine_mode,
+                    force_dist=bool(args.force_dist))
 
     if args.fwd_stream == "high" and e2e:
         pipe.fwd_stream = torch.cuda.Stream(dev, priority=-1)
@@ -1032,6 +1055,10 @@ def main() -> None:
                                                               "of the reference's return type, a list of TextBlock objects per "
                                                               "page, which the headline builds (rounds 3-4 timed this variant "
                                                               "as the headline)")
+                c = sub(16, refine_mode=1, keep_undetected=True)
+                extra["reference_cli_config_e2e"] = dict(c, config="the headline with the reference CLI's arguments (inference.py:35, "
+                                                                   "`model2annotations`): refine_mode = REFINEMASK_ANNOTATION, "
+                                                                   "keep_undetected_mask = True (refine_undetected_mask runs too)")
                 c = sub(16, host_input=True)
                 extra["host_input_e2e"] = dict(c, config="the headline with the pages starting in HOST memory (numpy arrays, as the "
                                                          "reference's callers hand them over): PCIe-inclusive, never the headline")
@@ -1095,6 +1122,11 @@ def main() -> None:
             "dtype": DTYPE[args.precision],
             "data": "synthetic",
             "config": {"workload": workload, "mode": args.mode, "global_batch": total_pages, "page": [S, S],
+                       "driver": ("TextDetector.detect_stream (the public API: bench.Pipeline only feeds it the resident batches "
+                                  "and counts the results; workers / gc tuning are the product's thread_budget / serve_tuning)"
+                                  if (e2e and pipe.api) else ("bench.Pipeline (a stage replaced: canned inputs / tail only)" if e2e
+                                                              else "forward_u8 + nms")),
+                       "refine_mode": args.refine_mode, "keep_undetected_mask": bool(args.keep_undetected),
                        "input": "nhwc_u8", "precision": args.precision, "tail_input": args.tail_input if e2e else None,
                        "distinct_batches": len(batches),
                        "tail_workers": args.workers if e2e else 0, "batches_in_flight": args.depth if e2e else 1,
@@ -1108,7 +1140,9 @@ def main() -> None:
                        "host_cpu_cores_used": round(float(stats.get("cpu_cores", 0.0)), 2),
                        "one_device_rehearsal": one_device, "tail_only": bool(args.tail_only and e2e),
                        "parallelism": f"dp{n_gpus} (pages sharded, no data-path collective except the final record "
-                                      f"gather; ranks={world}, backend={dist.get_backend() if world > 1 else 'none'}"
+                                      f"gather; ranks={world}, backend={dist.get_backend() if dist.is_initialized() else 'none'}"
+                                      + (", world-size-1 group FORCED (--force-dist): the record gather of the N > 1 step runs on "
+                                         "this backend inside every step" if (args.force_dist and world == 1) else "")
                                       + (f", each rank bound to {cpu_affinity['n_cpus']} CPUs of its GPU's NUMA node" if pinned else "")
                                       + (", ALL RANKS ON ONE DEVICE: rehearsal, not a measurement" if one_device else "") + ")"},
             "serial_step": serial,
@@ -1121,7 +1155,7 @@ def main() -> None:
         }
         print(json.dumps(out), flush=True)
     pipe.close()                                             # (idempotent)
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 

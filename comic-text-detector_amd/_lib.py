@@ -122,7 +122,8 @@ class CtdError(RuntimeError):
 def build(verbose: bool = False) -> None:
     """Compile the HIP library for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
     src = os.path.join(_HERE, "csrc")
-    r = subprocess.run(["make", "-C", src, "-j8"], capture_output=True, text=True)
+    import sys
+    r = subprocess.run(["make", "-C", src, "-j8", f"PYTHON={sys.executable}"], capture_output=True, text=True)
     if r.returncode != 0:
         raise CtdError("building libctd_hip.so failed:\n" + r.stdout[-4000:] + r.stderr[-4000:])
     if verbose:

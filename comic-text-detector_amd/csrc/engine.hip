@@ -462,7 +462,9 @@ int plan(ctd_engine* e, int B, int H, int W, hipStream_t cap_stream = nullptr) {
   // cv3's output exists from there on.  Both changes only lengthen lifetimes: a chain the kernel then declines (grid too
   // small) runs layer per launch on the same arena.
   std::vector<C3Chain> chains;
-  for (int i = 0; e->prec == CTD_PREC_F16 && i + 3 < nO; ++i) {
+  // (only under the pattern's fuse bit: with it off the lifetimes -- and the 32-channel C3 matcher, which wants a cv1 | cv2
+  // output that is still first defined by its own op -- see the unfused program; a change of `fuse` re-plans)
+  for (int i = 0; e->prec == CTD_PREC_F16 && (g_fuse & 8) && i + 3 < nO; ++i) {
     const OpState& A = e->ops[i];
     const ctd_op& a = A.op;
     auto mfma16 = [&](const OpState& s) { return s.op.kind == CTD_OP_CONV && s.impl == IMPL_IGEMM && s.bk == 32 && e->w_tiled; };
@@ -513,7 +515,7 @@ int plan(ctd_engine* e, int B, int H, int W, hipStream_t cap_stream = nullptr) {
   // one launch of kernels_halo3.hip writes the 1x1's output, at the ConvTranspose's position -- so that tensor is alive
   // from there on.  (UNet: upconv4.conv.1 -> upconv5.conv.0.cv1+cv2 over [f160 ; u160]; DB head: upconv4.conv.1 -> conv.0.)
   std::vector<int> posts;
-  for (int i = 0; e->prec == CTD_PREC_F16 && i + 1 < nO; ++i) {
+  for (int i = 0; e->prec == CTD_PREC_F16 && (g_fuse & 16) && i + 1 < nO; ++i) {
     const OpState &T = e->ops[i], &P = e->ops[i + 1];
     const ctd_op &t = T.op, &p = P.op;
     if (t.kind != CTD_OP_CONVT || T.impl != IMPL_IGEMM_T || t.cout != 128 || t.dst_coff != 0 || T.bk != 32 || !e->w_tiled) continue;
@@ -1078,8 +1080,10 @@ int ctd_fail_msg(int code, const std::string& msg) { return fail(code, msg); }
 extern int g_tail_priority;   // tail.hip
 extern int g_tail_cus, g_tail_cu_first;
 extern long long g_tail_dma_min;
+#ifdef CTD_MEASURE_KNOBS
 extern int g_tail_skip_pages;
 extern int g_tail_ablate;
+#endif
 extern int g_tail_chain;
 extern int g_tail_fused_rounds;
 
@@ -1285,8 +1289,10 @@ int ctd_tuning_set(const char* key, int64_t value) {
   if (key && std::string(key) == "tail_chain") { g_tail_chain = (int)value; return CTD_OK; }
   if (key && std::string(key) == "tail_fused_rounds") { g_tail_fused_rounds = (int)value; return CTD_OK; }
   if (key && std::string(key) == "tail_dma_min") { g_tail_dma_min = value; return CTD_OK; }
+#ifdef CTD_MEASURE_KNOBS   // not in the shipped library: these return incomplete results
   if (key && std::string(key) == "tail_skip_page_download") { g_tail_skip_pages = value != 0; return CTD_OK; }
   if (key && std::string(key) == "tail_ablate") { g_tail_ablate = (int)value; return CTD_OK; }
+#endif
   if (key && std::string(key) == "tail_priority") { g_tail_priority = (int)value; return CTD_OK; }
   if (key && std::string(key) == "tail_cus") { g_tail_cus = (int)value; return CTD_OK; }
   if (key && std::string(key) == "tail_cu_first") { g_tail_cu_first = (int)value; return CTD_OK; }

@@ -496,6 +496,8 @@ bool conv_halo3_supported(const ConvArgs& a, bool dst_f32) {
 // the fused form of (ConvTranspose with 128 output channels, its single 1x1 consumer): `a` carries post_*
 bool conv_halo3_post_supported(const ConvArgs& a) {
   if (!a.post_w || a.N != 128 || !(a.post_n == 64 || a.post_n == 128)) return false;
+  // the second epilogue knows these activations only (a sigmoid consumer stays its own launch)
+  if (a.post_act != CTD_ACT_NONE && a.post_act != CTD_ACT_SILU && a.post_act != CTD_ACT_LEAKY && a.post_act != CTD_ACT_RELU) return false;
   if (a.post_pitch % 8 || a.post_x.c % BKH || a.post_x.c > 64 || a.post_x.up) return false;
   if (a.post_x.c && (a.post_x.pitch % 8 || a.post_x.H != a.oH || a.post_x.W != a.oW)) return false;
   return conv_halo3_supported(a, false);

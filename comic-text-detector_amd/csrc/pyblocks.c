@@ -12,6 +12,7 @@
 #define PY_SSIZE_T_CLEAN
 #include <Python.h>
 
+static PyObject *k_copy;
 static PyObject *k_xyxy, *k_lines, *k_vertical, *k_language, *k_font_size, *k_distance, *k_angle, *k_vec, *k_norm, *k_merged,
     *k_weight, *k_text;
 
@@ -83,13 +84,21 @@ static PyObject* build_blocks(PyObject* self, PyObject* args) {
     }
     {
       const Py_ssize_t lo = PyLong_AsSsize_t(PyList_GET_ITEM(dist_off, i)), nd = PyLong_AsSsize_t(PyList_GET_ITEM(n_dist, i));
-      tmp = PySequence_GetSlice(dval, lo, lo + nd);        /* a view into the page's distance array */
+      /* the block's OWN array (a copy of the slice): holding one block must not keep the batch's arrays alive, and an
+         in-place edit of one block's `distance` / `vec` must not reach another's */
+      PyObject* view = PySequence_GetSlice(dval, lo, lo + nd);
+      if (!view) { Py_DECREF(d); goto fail; }
+      tmp = PyObject_CallMethodNoArgs(view, k_copy);
+      Py_DECREF(view);
       if (!tmp) { Py_DECREF(d); goto fail; }
       rc |= PyDict_SetItem(d, k_distance, tmp);
       Py_DECREF(tmp);
     }
     rc |= PyDict_SetItem(d, k_angle, PyList_GET_ITEM(angle, i));
-    rc |= PyDict_SetItem(d, k_vec, PyList_GET_ITEM(vec, i));
+    tmp = PyObject_CallMethodNoArgs(PyList_GET_ITEM(vec, i), k_copy);
+    if (!tmp) { Py_DECREF(d); goto fail; }
+    rc |= PyDict_SetItem(d, k_vec, tmp);
+    Py_DECREF(tmp);
     rc |= PyDict_SetItem(d, k_norm, PyList_GET_ITEM(norm, i));
     rc |= PyDict_SetItem(d, k_merged, PyLong_AsLong(PyList_GET_ITEM(merged, i)) != 0 ? Py_True : Py_False);
     rc |= PyDict_SetItem(d, k_weight, PyList_GET_ITEM(weight, i));
@@ -123,6 +132,7 @@ PyMODINIT_FUNC PyInit__ctd_pyblocks(void) {
   k_language = PyUnicode_InternFromString("language");
   k_font_size = PyUnicode_InternFromString("font_size");
   k_distance = PyUnicode_InternFromString("distance");
+  k_copy = PyUnicode_InternFromString("copy");
   k_angle = PyUnicode_InternFromString("angle");
   k_vec = PyUnicode_InternFromString("vec");
   k_norm = PyUnicode_InternFromString("norm");

@@ -190,8 +190,10 @@ struct GpuChain {
   }
 };
 }  // namespace
-int g_tail_ablate = 0;                 // measurement only: bit 1 = no refine stage ("tail_ablate")
-int g_tail_skip_pages = 0;             // measurement only: 1 = the page-size results are not downloaded ("tail_skip_page_download")
+#ifdef CTD_MEASURE_KNOBS               // `make MEASURE=1` only: knobs that return INCOMPLETE results, for ablation timings
+int g_tail_ablate = 0;                 // bit 1 = no refine stage ("tail_ablate")
+int g_tail_skip_pages = 0;             // 1 = the page-size results are not downloaded ("tail_skip_page_download")
+#endif
 long long g_tail_dma_min = 256 << 10;   // device -> host copies of at least this many bytes use the copy engines ("tail_dma_min"; huge = never)
 namespace {
 
@@ -578,7 +580,9 @@ int undetected_pass(ctd_tail* t, const std::vector<std::vector<int32_t>>& blk_xy
 // device -> host of the page-size outputs, straight into the caller's arrays (page-locked arrays make
 // these DMA transfers; comic-text-detector_amd/tail.py allocates them pinned)
 int download_pages(ctd_tail* t, bool mask_too, uint8_t* const* mask_out, uint8_t* const* refined_out) {
-  if (g_tail_skip_pages) return CTD_OK;    // measurement only ("tail_skip_page_download"): what do the page downloads cost the step?
+#ifdef CTD_MEASURE_KNOBS
+  if (g_tail_skip_pages) return CTD_OK;    // ("tail_skip_page_download"): what do the page downloads cost the step?
+#endif
   hipStream_t st = t->st;
   GET(t->d_pmask, 0, uint8_t, pmask);
   GET(t->d_refined, 0, uint8_t, refined);
@@ -885,12 +889,14 @@ static int tail_run_impl(ctd_tail* t, int32_t B, int32_t Hn, int32_t Wn, const f
   if (!t || !blks_dev || !mask_u8_dev || !prob_dev || !bitmap_dev || !pages || !prm || B < 1 || Hn < 1 || Wn < 1 ||
       rows < 1 || no < 6)
     return ctd_fail_msg(CTD_ERR_INVALID, "ctd_tail_run: bad arguments");
+#ifdef CTD_MEASURE_KNOBS
   ctd_tail_params prm_ablate;
-  if (g_tail_ablate & 1) {                   // measurement only ("tail_ablate" bit 1): the tail without its refine stage
+  if (g_tail_ablate & 1) {                   // ("tail_ablate" bit 1): the tail without its refine stage
     prm_ablate = *prm;
     prm_ablate.refine = 0;
     prm = &prm_ablate;
   }
+#endif
   T_TRY(hipSetDevice(t->device));
   hipStream_t st = t->st;
   const double t0 = now_ms();

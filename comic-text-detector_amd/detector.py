@@ -23,6 +23,8 @@ from concurrent.futures import ThreadPoolExecutor
 from typing import Iterable, Iterator, List, Sequence, Tuple, Union
 
 import ctypes as C
+import gc
+import os
 import threading
 
 import numpy as np
@@ -36,7 +38,53 @@ from .textblock import TextBlock
 from .textmask import (REFINEMASK_ANNOTATION, REFINEMASK_INPAINT, refine_mask, refine_mask_batch,   # noqa: F401
                        refine_undetected_mask)
 
-__all__ = ["TextDetector", "TextBlock", "REFINEMASK_INPAINT", "REFINEMASK_ANNOTATION"]
+__all__ = ["TextDetector", "TextBlock", "REFINEMASK_INPAINT", "REFINEMASK_ANNOTATION", "thread_budget", "serve_tuning"]
+
+
+def usable_cpus() -> int:
+    try:
+        return len(os.sched_getaffinity(0))
+    except AttributeError:
+        return os.cpu_count() or 1
+
+
+def thread_budget(world: int = 1, pinned: bool = False, host_cpus: int = 0) -> dict:
+    """Host threads one rank may use: the usable cores divided by the ranks on this host (an 8-rank node runs 8 of these
+    processes) -- or, once the rank is bound to its own CPUs (`affinity.apply`, N > 1), simply the CPUs it is bound to.
+    Tail workers x native geometry threads + loaders + the launching thread must fit."""
+    avail = usable_cpus()
+    per_rank = max(4, avail if pinned else avail // max(1, world))
+    if pinned and host_cpus:
+        avail = host_cpus                                     # what the host offered before this rank bound itself
+    # 4 workers where a rank has 16 CPUs or more: round 5 re-measured it after the forward got shorter -- on one box 3 = 4 on the
+    # headline and +6 % on the canned pages, on another 4 is +2 % on the headline and +6 % on dense pages (three interleaved
+    # repetitions each, profiles/r05_e2e_workers_3_vs_4.txt); the dense pages decide
+    workers = 4 if per_rank >= 16 else (3 if per_rank >= 8 else 2)
+    native = max(1, min(8, (per_rank - 2) // workers))
+    return {"usable_cpus": avail, "per_rank": per_rank, "tail_workers": workers, "native_threads_per_worker": native}
+
+
+_tuned = False
+
+
+def serve_tuning(refreeze: bool = False) -> bool:
+    """What a serving process does ONCE after start-up; `detect_stream` calls it after its pools are warm (opt out with
+    `tune=False`), `bench.py` calls it at the same place of its timed region -- so a caller of the API gets the process the
+    benchmark measures.  (1) `gc.freeze()`: the interpreter's cyclic collector otherwise re-scans the ~1M long-lived objects
+    of torch / numpy whenever the per-page result objects trigger a full collection (~10 ms per batch).  (2) the youngest
+    generation's threshold 700 -> 50 000: a batch's results (32 pages x 30 TextBlocks, each a dict, a few lists and numpy
+    values) are ~10 k tracked containers, at the default threshold the collector runs a dozen times per batch on the tail
+    workers under the interpreter lock; nothing on this path creates reference cycles.  Returns whether it acted
+    (`refreeze=True`: again, for a process that built new long-lived objects since)."""
+    global _tuned
+    if _tuned and not refreeze:
+        return False
+    gc.collect()
+    gc.freeze()
+    gc.set_threshold(50000, 20, 20)
+    _tuned = True
+    return True
+
 
 Page = Union[np.ndarray, torch.Tensor]
 
@@ -246,8 +294,9 @@ class TextDetector:
 
     @torch.no_grad()
     def detect_stream(self, batches: Iterable[Sequence[Page]], refine_mode=REFINEMASK_INPAINT,
-                      keep_undetected_mask=False, workers: int = 3, depth: int = 4, engines: int = 1,
-                      loaders: int = 2, tail_split: int = 0, lazy: bool = False) -> Iterator[list]:
+                      keep_undetected_mask=False, workers: int = 0, depth: int = 4, engines: int = 1,
+                      loaders: int = 2, tail_split: int = 0, lazy: bool = False, records=None,
+                      tune: bool = True) -> Iterator[list]:
         """Yields `detect_batch(batch)` for every batch, in order, with up to `depth` batches in flight:
         the forward of the next batches is launched while `workers` threads run the tails of earlier ones.
         Host (numpy) pages are staged to the GPU by `loaders` threads up to `depth` batches ahead (`_stage`).
@@ -260,8 +309,19 @@ class TextDetector:
         complete on the host, which builds the `TextBlock` objects when first iterated / indexed, on the consumer's thread
         (not a `list`: no `append` / `sort` / `json.dumps`); for consumers that read the columnar records or only a few
         pages' blocks it saves the workers ~0.1 ms of interpreter-lock time per page (+2 % end to end at 30 blocks a page).
+        `workers=0` (default): from the host's thread budget (`thread_budget`: 4 where the process has 16 CPUs, else 3 / 2), and
+        the native per-page geometry threads of every worker from the same budget unless `tail.set_host_threads` was called.
+        `tune=True`: `serve_tuning()` once per process, after the pools are warm.  `records=(cap_blk, cap_line)`: every page
+        comes back as a `PageResult` carrying its multi-GPU gather record (`dist.gather_results`).
+        This generator IS what `bench.py`'s headline times (its `Pipeline` only feeds it batches and counts the results).
         The pools stay alive between calls (`close()` stops them): each worker thread keeps a native tail object with a
         HIP stream and ~250 MB of device tables at 32 pages per batch."""
+        if int(workers) <= 0:
+            tb = thread_budget()
+            workers = tb["tail_workers"]
+            from . import tail as _TL
+            if _TL._host_threads is None:
+                _TL.set_host_threads(tb["native_threads_per_worker"])
         # The pools live on the detector: their threads own the native `Tail` objects (a HIP stream, ~250 MB of
         # fixed-capacity device tables at 32 pages, pinned buffers) and the pinned staging rings, which a pool per call
         # would create and destroy every time.
@@ -269,6 +329,8 @@ class TextDetector:
         if self._warmed is not pool:                          # once per pool: its threads then hold their leases
             self.warm_tails(pool, workers)                    # tail streams first, the upload stream after them
             self._warmed = pool
+        if tune:
+            serve_tuning()
         lpool = self._pool("load", loaders)
         pending = deque()
         engines = max(1, int(engines))
@@ -295,7 +357,7 @@ class TextDetector:
                     st.wait_stream(main)                  # pages the caller produced on its stream
                     with torch.cuda.stream(st):
                         job = self._forward(batch, net)
-                pending.append([pool.submit(self._tail, job, refine_mode, keep_undetected_mask, lo, hi, None, lazy)
+                pending.append([pool.submit(self._tail, job, refine_mode, keep_undetected_mask, lo, hi, records, lazy)
                                 for lo, hi in self._split(len(job["metas"]), tail_split)])
                 while len(pending) >= depth:
                     yield [r for f in pending.popleft() for r in f.result()]

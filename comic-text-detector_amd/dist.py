@@ -24,9 +24,12 @@ def env_world() -> Tuple[int, int, int]:
             int(os.environ.get("WORLD_SIZE", "1")))
 
 
-def init(backend: Optional[str] = None) -> Tuple[int, int, int]:
+def init(backend: Optional[str] = None, force: bool = False) -> Tuple[int, int, int]:
+    """Joins the process group of the torchrun environment.  A single process has no group and no collective on its data
+    path -- unless `force=True`, which gives it a world-size-1 group of `backend` so that the N > 1 code (RCCL communicator
+    on this rank's device, the record gather on the communication stream) runs on the one GPU that is there."""
     rank, local_rank, world = env_world()
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or force) and not dist.is_initialized():
         if backend is None:
             # CTD_DIST_BACKEND=gloo: lets a 1-GPU box rehearse the N > 1 code path (all ranks on one device)
             backend = os.environ.get("CTD_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
@@ -136,7 +139,8 @@ def unpack_results(rec: torch.Tensor):
     return out
 
 
-def gather_results(results, n_total: int, rank: int, world: int, device=None, pin: bool = False) -> torch.Tensor:
+def gather_results(results, n_total: int, rank: int, world: int, device=None, pin: bool = False,
+                   force: bool = False) -> torch.Tensor:
     """The data path's collective: all-gather of this rank's page records at the COMPACT capacities (CAP_BLK blocks,
     CAP_LINE lines: 4.6x fewer bytes than the worst case, host packing included).  Every rank sees every page's true
     counts in the gathered tensor, so all ranks agree without further communication on whether some page did not fit
@@ -145,17 +149,19 @@ def gather_results(results, n_total: int, rank: int, world: int, device=None, pi
         rec = pack_results(results, None, cb, cl)
         if device is not None:
             rec = (rec.pin_memory() if pin else rec).to(device, non_blocking=pin)
-        return gather_records(rec, n_total, rank, world)
+        return gather_records(rec, n_total, rank, world, force)
     out = one(CAP_BLK, CAP_LINE)
     if out.shape[0] and bool(((out[:, 0] > CAP_BLK) | (out[:, 1] > CAP_LINE)).any()):
         out = one(MAX_BLK, MAX_BLK)
     return out
 
 
-def gather_records(rec: torch.Tensor, n_total: int, rank: int, world: int) -> torch.Tensor:
+def gather_records(rec: torch.Tensor, n_total: int, rank: int, world: int, force: bool = False) -> torch.Tensor:
     """All-gather the per-page records; returns (n_total, R) in global page order on
-    every rank.  Shards may differ by one page, so each rank pads to the largest shard."""
-    if world == 1:
+    every rank.  Shards may differ by one page, so each rank pads to the largest shard.
+    A single process returns its records as they are; `force=True` sends them through the collective of its world-size-1
+    group anyway (`init(force=True)`)."""
+    if world == 1 and not (force and dist.is_initialized()):
         return rec
     per = -(-n_total // world)
     home = rec.device

@@ -215,8 +215,11 @@ _TEMPLATE.update(_TAIL_DICT)
 
 try:                                   # csrc/pyblocks.c, built by csrc/Makefile next to libctd_hip.so
     from . import _ctd_pyblocks as _PYB
-except ImportError:                    # not built (a source checkout before `make`): the Python loop below does the same
+except ImportError as _e:              # not built (a source checkout before `make`): the Python loop below does the same
     _PYB = None
+    import logging as _logging
+    _logging.getLogger(__name__).warning("csrc/pyblocks.c is not built (%s): TextBlock lists are built by the Python loop, "
+                                         "~3 us more interpreter-lock time per block (make -C csrc)", _e)
 
 
 def _fast_block(xyxy, lines, language, vertical, font_size, distance, angle, vec, norm, merged, weight) -> TextBlock:
@@ -264,7 +267,7 @@ def blocks_from_records(recs, lines: np.ndarray, dist: np.ndarray, n: Optional[i
         return _PYB.build_blocks(TextBlock, _TEMPLATE, n, a["xyxy"].tolist(), all_lines, a["line_off"].tolist(),
                                  a["n_lines"].tolist(), a["vertical"].tolist(), a["language"].tolist(), LANG_LIST,
                                  a["font_size"].tolist(), a["font_is_float"].tolist(), dval, a["dist_off"].tolist(),
-                                 a["n_dist"].tolist(), a["angle"].tolist(), list(a["vec"].copy()), list(a["norm"]),
+                                 a["n_dist"].tolist(), a["angle"].tolist(), list(a["vec"]), list(a["norm"]),
                                  a["merged"].tolist(), list(a["weight"]))
     tail, new = _TAIL_DICT, TextBlock.__new__
     out = []
@@ -317,7 +320,7 @@ def blocks_from_batch(recs: np.ndarray, lines: np.ndarray, dist: np.ndarray, cou
                              (a["line_off"] + lbase).tolist(), a["n_lines"].tolist(), a["vertical"].tolist(),
                              a["language"].tolist(), LANG_LIST, a["font_size"].tolist(), a["font_is_float"].tolist(), dval,
                              (a["dist_off"] + dbase).tolist(), a["n_dist"].tolist(), a["angle"].tolist(),
-                             list(a["vec"].copy()), list(a["norm"]), a["merged"].tolist(), list(a["weight"]))
+                             list(a["vec"]), list(a["norm"]), a["merged"].tolist(), list(a["weight"]))
     ob = np.concatenate(([0], np.cumsum(nblk))).tolist()
     return [flat[ob[b]: ob[b + 1]] for b in range(B)]
 

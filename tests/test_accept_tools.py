@@ -75,12 +75,14 @@ def test_explain_geometry_attributes_every_difference_to_a_cause():
 def test_bench_thread_budget_and_torchrun_command(monkeypatch):
     sys.path.insert(0, ROOT)
     bench = importlib.import_module("bench")
-    monkeypatch.setattr(bench, "host_info", lambda: {"cpu_model": "x", "logical_cpus": 256, "usable_cpus": 256})
+    DET = importlib.import_module("comic-text-detector_amd.detector")       # the budget is the product's (detect_stream(workers=0))
+    monkeypatch.setattr(DET, "usable_cpus", lambda: 256)
+    assert DET.thread_budget() == bench.thread_budget(1)
     assert bench.thread_budget(1) == {"usable_cpus": 256, "per_rank": 256, "tail_workers": 4, "native_threads_per_worker": 8}
     b8 = bench.thread_budget(8)
     assert b8["per_rank"] == 32 and b8["tail_workers"] == 4 and b8["tail_workers"] * b8["native_threads_per_worker"] + 2 <= 32
     assert bench.thread_budget(16)["tail_workers"] == 4 and bench.thread_budget(20)["tail_workers"] == 3      # 16 / 12 per rank
-    monkeypatch.setattr(bench, "host_info", lambda: {"cpu_model": "x", "logical_cpus": 16, "usable_cpus": 16})
+    monkeypatch.setattr(DET, "usable_cpus", lambda: 16)
     small = bench.thread_budget(8)
     assert small["tail_workers"] == 2 and small["native_threads_per_worker"] == 1
     # `python bench.py --gpus 2` outside torchrun: N ranks of this script on 127.0.0.1, one-device rehearsal without 2 devices

@@ -60,9 +60,11 @@ def test_pooled_oracle_tail_equals_the_oracle_tail(tmp_path):
 
 
 def test_thread_budget_divides_the_host_between_ranks(monkeypatch):
+    import importlib
     import bench
     for cpus, world, want_workers in ((256, 1, 4), (256, 8, 4), (64, 8, 3), (16, 8, 2), (8, 1, 3)):
-        monkeypatch.setattr(bench, "host_info", lambda c=cpus: {"cpu_model": "x", "logical_cpus": c, "usable_cpus": c})
+        DET = importlib.import_module("comic-text-detector_amd.detector")     # the product's budget (detect_stream(workers=0))
+        monkeypatch.setattr(DET, "usable_cpus", lambda c=cpus: c)
         tb = bench.thread_budget(world)
         assert tb["tail_workers"] == want_workers, (cpus, world, tb)
         if world > 1:                                     # a rank bound to its own CPUs (affinity.py) budgets on those

@@ -67,3 +67,47 @@ def test_rate_survives_repeated_create_stream_close_with_two_detectors():
     # pool's thread-local leases have been returned, so the plateau can be up to two pools + the main thread's)
     assert tails[-1] <= tails[1] and tails[-1] <= 2 * WORKERS + 2, tails
     other.close(drain=True)
+
+
+def test_bare_api_consumer_runs_at_the_bench_pipeline_rate():
+    """the headline must be an API number.  `bench.Pipeline` now only feeds `TextDetector.detect_stream` and
+    counts what comes back; this test is the other half -- a caller that knows nothing of bench.py (`for res in
+    det.detect_stream(batches)`, every argument at its default: workers from the product's thread budget, `serve_tuning`
+    applied by the generator itself) gets the rate the bench's pipeline gets, within 3 % (best of three interleaved runs)."""
+    import importlib
+    import sys
+    from conftest import ROOT
+    sys.path.insert(0, ROOT)
+    bench = importlib.import_module("bench")
+    p = pkg()
+    ck = p.synth.make_blob_checkpoint(0, sparse_det=True, line_density="fixture")
+    dev = torch.device("cuda", 0)
+    xs = [torch.from_numpy(np.stack([p.synth.text_like_page((SIZE, SIZE), 131 * k + i) for i in range(B)])).to(dev) for k in range(2)]
+    det = p.detector.TextDetector(ck, input_size=SIZE, device=dev, precision="fp16")
+    tb = p.detector.thread_budget()
+    pipe = bench.Pipeline(det, xs, None, dev, 1, 0, B, p.dist, tb["tail_workers"], 4, tb["tail_workers"])
+    assert pipe.api
+
+    def bare(n):
+        k = 0
+        for res in det.detect_stream([x[j] for j in range(B)] for x in (xs[i & 1] for i in range(n))):
+            k += sum(len(r[2]) for r in res)
+        return k
+
+    def rate(fn, n=40):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        fn(n)
+        torch.cuda.synchronize()
+        return n * B / (time.perf_counter() - t0)
+
+    bare(30), pipe.run(30)                                # clocks, pools, tails' buffers, serve_tuning (inside detect_stream)
+    api, ref = [], []
+    for _ in range(3):
+        api.append(rate(bare))
+        ref.append(rate(pipe.run))
+    print(f"\nbare detect_stream consumer {[round(r) for r in api]} pages/s; bench.Pipeline {[round(r) for r in ref]}")
+    assert pipe.stats["blocks"] > 0
+    assert max(api) >= 0.97 * max(ref), (api, ref)
+    det.close(drain=True)
+    gc.unfreeze()

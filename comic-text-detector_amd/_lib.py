@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, "libctd_hip.so")
 SELFTEST_PATH = os.path.join(_HERE, "ctd_selftest")
 
 # ---- constants mirrored from include/ctd_hip.h -------------------------------
-ABI_VERSION = 5
+ABI_VERSION = 6
 OK = 0
 PREC_F32, PREC_F16, PREC_F32S = 0, 1, 2
 ACT = {"none": 0, "silu": 1, "leaky": 2, "relu": 3, "sigmoid": 4}
@@ -92,6 +92,7 @@ SYMBOLS = {
     "ctd_tail_run": (_i32, [_vp, _i32, _i32, _i32, _vp, _i32, _i32, _vp, _vp, _i64, _vp, C.POINTER(CtdTailPage),
                             C.POINTER(CtdTailParams), _vp, _vp, _vp]),
     "ctd_tail_timings": (_i32, [_vp, C.POINTER(C.c_double)]),
+    "ctd_tail_refine_paths": (_i32, [_vp, C.POINTER(_i32)]),
     "ctd_tail_db_boxes": (_i32, [_vp, _i32, _i32, _i32, _vp, _i64, _vp, _i32, C.c_double]),
     "ctd_tail_refine": (_i32, [_vp, _i32, C.POINTER(CtdTailPage), _vp, _vp, _vp, _i32, _i32, _vp, _vp]),
     "ctd_tail_page_counts": (_i32, [_vp, _i32, C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i32),

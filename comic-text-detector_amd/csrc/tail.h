@@ -81,6 +81,13 @@ void launch_tw_holes(const TWin* wins, int n, int max_pix, const int* labels2, c
 void launch_tw_holes_all(const TWin* wins, int n, const int* labels2, const int* stats2, const int* first2, int max_labels,
                          const unsigned* count255, uint8_t* merged, int merged_w, unsigned* counters2, hipStream_t st);
 void launch_tw_commit(const TWin* wins, int n, int max_pix, const uint8_t* merged, int merged_w, hipStream_t st);
+// ---- the merge stage of a window (render -> merge rounds -> dilation -> hole filling -> commit) as ONE block on bit planes
+// in LDS (kernels_twlds.hip): windows order[0 .. n) of `wins`, planes of at most `max_words` 32-pixel words, `rcap` runs per
+// labelling; ovf[window] = 1 where a labelling had more runs (nothing committed for that window)
+size_t tw_lds_bytes(int max_words, int rcap);
+int tw_lds_rcap(int max_words);
+void launch_tw_lds(const TWin* wins, const TBand* bands, const int* order, int n, int max_words, int rcap, int dilate, int* ovf,
+                   hipStream_t st);
 // mask[p] = 0 where refined[p] > thr (reference utils/textmask.py:136)
 void launch_mask_clear_where(uint8_t* mask, const uint8_t* refined, long long n, int thr, hipStream_t st);
 // dst (rows x cols, pitch dpitch) = src (pitch spitch): the crop of inference.py:164

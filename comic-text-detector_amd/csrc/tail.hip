@@ -152,6 +152,11 @@ int g_tail_chain = 1;
 // "tail_fused_rounds": 1 = a window's merge rounds and its hole-filling passes as one launch each (a block per window);
 // 0 = one count + one apply launch per round and four hole-filling launches over all windows (rounds 2-3)
 int g_tail_fused_rounds = 1;
+// "tail_lds": 1 = the merge stage of a window as ONE block on bit planes in LDS (kernels_twlds.hip), 0 = every window through
+// the canvas path; "tail_lds_max_bytes": windows needing more LDS than this take the canvas path; "tail_lds_rcap" > 0: the
+// run-table capacity of every launch (tests force overflows with a tiny one)
+int g_tail_lds = 1, g_tail_lds_rcap = 0;
+long long g_tail_lds_max_bytes = 150 << 10;
 namespace {
 // The chain is PER DEVICE: events belong to the device that was current when they were created, a stream can only record
 // its own device's events (hipErrorInvalidHandle otherwise), and tails on different GPUs have nothing to serialise.
@@ -278,8 +283,10 @@ struct ctd_tail {
   // device
   DevBuf d_dets, d_nms_ws, d_lab_f, d_ccl_ws, d_ccl_small, d_dbc_i, d_dbc_d, d_rows, d_pmask, d_refined;
   DevBuf d_wins, d_rules, d_bands, d_hist, d_sums, d_canvas, d_clab, d_cstats, d_cnt, d_merged, d_mlab, d_mstats, d_cnt2, d_small, d_crop;
+  DevBuf d_wins_c, d_bands_c, d_lds;
   // pinned host
   PinBuf h_dets, h_hdr, h_tab, h_pmask, h_refined, h_hist, h_sums, h_wins, h_rules, h_bands, h_small, h_lab;
+  PinBuf h_wins_c, h_bands_c, h_lds;
   // per-run state
   int B = 0;
   std::vector<ctd_tail_page> pages;
@@ -294,6 +301,9 @@ struct ctd_tail {
   double ms_db_wait = 0;              // inside [2]: waiting for the table download
   double ms_sub[5] = {0, 0, 0, 0, 0}; // inside [0]: NMS + buffers, labelling + contour tables, page-mask copies; inside [8]: the wait
   int host_threads = 8;               // threads of the per-page / per-window host loops
+  // refine windows of the last run by path: window-local kernel, canvas path (too big, or after an overflow), overflows
+  int n_lds = 0, n_canvas = 0, n_ovf = 0;
+  double ms_lds_wait = 0;             // waiting for the window-local merge kernel's overflow flags
 };
 
 namespace {
@@ -345,47 +355,57 @@ bool block_window(const int32_t* xyxy, int im_w, int im_h, WinReq& wq) {
 // refine_mask for a list of windows over the pages of the batch (reference utils/textmask.py:159-169):
 // ORs the merged window masks into the refined page buffers on the device.
 // ---------------------------------------------------------------------------------------------------
-int refine_windows(ctd_tail* t, const std::vector<WinReq>& reqs, int refine_mode) {
-  const int n = (int)reqs.size();
+// The canvas path of the merge stage for a SUBSET of the windows: candidates rendered into one packed canvas, one
+// page-scale labelling launch, merge rounds, dilation, a second labelling of the complement, hole filling, commit
+// (kernels_tail.hip + kernels_post.hip).  Since round 6 this is where windows go whose bit planes do not fit the
+// window-local kernel's LDS (kernels_twlds.hip) or whose run table overflowed there.  `hw` / `bands`: the full tables.
+int refine_canvas(ctd_tail* t, const TWin* hw, const std::vector<TBand>& bands, const std::vector<int>& subset, int refine_mode) {
+  const int n = (int)subset.size();
   if (n == 0) return CTD_OK;
   hipStream_t st = t->st;
-  GET(t->d_pmask, 0, uint8_t, pmask);
-  GET(t->d_refined, 0, uint8_t, refined);
-  // ---- window table: merged-canvas positions are known up front
   std::vector<int> ww(n), wh(n);
   int max_pix = 1;
-  for (int i = 0; i < n; ++i) {
-    ww[i] = reqs[i].x2 - reqs[i].x1, wh[i] = reqs[i].y2 - reqs[i].y1;
-    max_pix = std::max(max_pix, ww[i] * wh[i]);
+  for (int k = 0; k < n; ++k) {
+    ww[k] = hw[subset[k]].w, wh[k] = hw[subset[k]].h;
+    max_pix = std::max(max_pix, ww[k] * wh[k]);
   }
   Packed pm;
   shelf_pack(ww, wh, 2048, pm);
-  GET(t->h_wins, sizeof(TWin) * n, TWin, hw);
-  for (int i = 0; i < n; ++i) {
-    const ctd_tail_page& pg = t->pages[reqs[i].page];
-    TWin& w = hw[i];
-    w.img = pg.img_dev;
-    w.mask = pmask + t->poff[reqs[i].page];
-    w.out = refined + t->poff[reqs[i].page];
-    w.img_w = pg.im_w, w.mask_w = pg.im_w, w.out_w = pg.im_w;
-    w.x1 = reqs[i].x1, w.y1 = reqs[i].y1, w.w = ww[i], w.h = wh[i];
-    w.mx = pm.x[i], w.my = pm.y[i];
-    w.band0 = 0, w.nband = 0;
+  GET(t->h_wins_c, sizeof(TWin) * n, TWin, cw);
+  std::vector<TBand> cb;
+  std::vector<int> bw, bh;
+  int rounds = 0;
+  for (int k = 0; k < n; ++k) {
+    cw[k] = hw[subset[k]];
+    cw[k].mx = pm.x[k], cw[k].my = pm.y[k];
+    const int b0 = cw[k].band0;
+    cw[k].band0 = (int)cb.size();
+    rounds = std::max(rounds, cw[k].nband);
+    for (int r = 0; r < cw[k].nband; ++r) {
+      TBand b = bands[b0 + r];
+      b.win = k;
+      cb.push_back(b);
+      bw.push_back(ww[k]);
+      bh.push_back(wh[k]);
+    }
   }
-  GET(t->d_wins, sizeof(TWin) * n, TWin, dw);
-  // ---- everything whose size depends on the windows only: one launch uploads the window table and zeroes the
-  // histograms, the xor sums and the merged canvases (the per-label counters are cleared after the labelling, for the
-  // labels that exist: launch_label_counters_zero)
-  GET(t->d_hist, (size_t)n * 1024 * 4, unsigned, dhist);
-  GET(t->h_hist, (size_t)n * 1024 * 4, uint32_t, hhist);
-  GET(t->d_sums, (size_t)n * 6 * 8, unsigned long long, dsums);
-  GET(t->h_sums, (size_t)n * 6 * 8, uint64_t, hsums);
-  long long bound2 = 1;                                  // 8-connected components: at most one per 2x2 cell
-  for (int i = 0; i < n; ++i) bound2 += (long long)((ww[i] + 1) / 2) * ((wh[i] + 1) / 2);
-  if ((long long)pm.W * pm.H >= (1LL << 30) || bound2 >= (1LL << 28))
+  const int nbands = (int)cb.size();
+  Packed pc;
+  shelf_pack(bw, bh, 2048, pc);
+  long long bound1 = 1, bound2 = 1;                      // 8-connected components: at most one per 2x2 cell
+  for (int j = 0; j < nbands; ++j) {
+    cb[j].cx = pc.x[j], cb[j].cy = pc.y[j];
+    bound1 += (long long)((bw[j] + 1) / 2) * ((bh[j] + 1) / 2);
+  }
+  for (int k = 0; k < n; ++k) bound2 += (long long)((ww[k] + 1) / 2) * ((wh[k] + 1) / 2);
+  if ((long long)pc.W * pc.H >= (1LL << 30) || bound1 >= (1LL << 28) || (long long)pm.W * pm.H >= (1LL << 30) || bound2 >= (1LL << 28))
     return ctd_fail_msg(CTD_ERR_UNSUPPORTED, "refine: too many window pixels in one batch");
-  const int cap2 = (int)bound2;
-  const size_t mpx = (size_t)pm.W * pm.H;
+  const int cap1 = (int)bound1, cap2 = (int)bound2;
+  const size_t mpx = (size_t)pm.W * pm.H, cpx = (size_t)pc.W * pc.H;
+  GET(t->d_wins_c, sizeof(TWin) * n, TWin, dw);
+  GET(t->h_bands_c, sizeof(TBand) * std::max(nbands, 1), TBand, hb);
+  std::memcpy(hb, cb.data(), sizeof(TBand) * nbands);
+  GET(t->d_bands_c, sizeof(TBand) * std::max(nbands, 1), TBand, db);
   GET(t->d_merged, mpx * 3, uint8_t, merged_a);
   uint8_t* merged_b = merged_a + mpx;
   uint8_t* comp = merged_a + 2 * mpx;
@@ -394,74 +414,17 @@ int refine_windows(ctd_tail* t, const std::vector<WinReq>& reqs, int refine_mode
   unsigned* count255 = (unsigned*)(small + 16);
   int* top2 = small + 16 + n;
   GET(t->d_cnt2, ((size_t)cap2 + 1) * 8, unsigned, counters2);
-  Batch bt(st);
-  T_TRY(bt.h2d(dw, hw, sizeof(TWin) * n));
-  bt.fill(dhist, 0, (size_t)n * 1024 * 4);
-  bt.fill(dsums, 0, (size_t)n * 6 * 8);
-  bt.fill(merged_a, 0, mpx * 3);
-  bt.fill(count255, 0, (size_t)n * 4);
-  bt.fill(top2, 0xFF, (size_t)n * 12);
-  bt.flush();
-  // ---- histograms -> rules
-  launch_tw_hist(dw, n, max_pix, dhist, st);
-  T_TRY(bt.d2h(hhist, dhist, (size_t)n * 1024 * 4));
-  bt.flush();
-  const double tr0 = now_ms();
-  T_TRY(hipStreamSynchronize(st));
-  const double tr1 = now_ms();
-  GET(t->h_rules, sizeof(RRule) * 6 * n, RRule, hrules);
-  parallel_for(n, t->host_threads, [&](int i) { refine_rules(hhist + (size_t)i * 1024, hrules + (size_t)i * 6); });
-  static_assert(sizeof(RRule) == sizeof(TRule), "rule layouts must agree");
-  GET(t->d_rules, sizeof(TRule) * 6 * n, TRule, drules);
-  T_TRY(bt.h2d(drules, hrules, sizeof(TRule) * 6 * n));
-  bt.flush();
-  // ---- xor distances -> polarity and merge order
-  launch_tw_xor(dw, drules, n, max_pix, dsums, st);
-  T_TRY(bt.d2h(hsums, dsums, (size_t)n * 6 * 8));
-  bt.flush();
-  const double tr2 = now_ms();
-  T_TRY(hipStreamSynchronize(st));
-  const double tr3 = now_ms();
-  std::vector<TBand> bands;
-  std::vector<int> bw, bh;
-  int rounds = 0;
-  for (int i = 0; i < n; ++i) {
-    RCand c[4];
-    const int nc = refine_candidates(hrules + (size_t)i * 6, hsums + (size_t)i * 6, (long long)ww[i] * wh[i], c);
-    rounds = std::max(rounds, nc);
-    hw[i].band0 = (int)bands.size(), hw[i].nband = nc;     // the window's bands are contiguous, in merge order
-    for (int r = 0; r < nc; ++r) {
-      const RRule& rl = hrules[(size_t)i * 6 + c[r].rule];
-      TBand b;
-      b.win = i, b.cx = b.cy = 0, b.kind = rl.kind, b.lo = rl.lo, b.hi = rl.hi, b.invert = c[r].invert, b.round = r;
-      bands.push_back(b);
-      bw.push_back(ww[i]);
-      bh.push_back(wh[i]);
-    }
-  }
-  const int nbands = (int)bands.size();
-  Packed pc;
-  shelf_pack(bw, bh, 2048, pc);
-  long long bound1 = 1;
-  for (int j = 0; j < nbands; ++j) {
-    bands[j].cx = pc.x[j], bands[j].cy = pc.y[j];
-    bound1 += (long long)((bw[j] + 1) / 2) * ((bh[j] + 1) / 2);
-  }
-  if ((long long)pc.W * pc.H >= (1LL << 30) || bound1 >= (1LL << 28))
-    return ctd_fail_msg(CTD_ERR_UNSUPPORTED, "refine: too many window pixels in one batch");
-  const int cap1 = (int)bound1;
-  GET(t->h_bands, sizeof(TBand) * nbands, TBand, hb);
-  std::memcpy(hb, bands.data(), sizeof(TBand) * nbands);
-  GET(t->d_bands, sizeof(TBand) * nbands, TBand, db);
-  // ---- candidates rendered into one canvas, one labelling launch, merge rounds
-  const size_t cpx = (size_t)pc.W * pc.H;
   GET(t->d_canvas, cpx, uint8_t, canvas);
   GET(t->d_clab, cpx * 4, int, clab);
   GET(t->d_cstats, (size_t)cap1 * 5 * 4, int, cstats);
   GET(t->d_ccl_ws, ccl_workspace_bytes(1, std::max(pc.H, pm.H), std::max(pc.W, pm.W)), uint8_t, ws);
   GET(t->d_cnt, ((size_t)cap1 + 1) * 8, unsigned, counters);
+  Batch bt(st);
+  T_TRY(bt.h2d(dw, cw, sizeof(TWin) * n));
   T_TRY(bt.h2d(db, hb, sizeof(TBand) * nbands));
-  T_TRY(bt.h2d(dw, hw, sizeof(TWin) * n));                   // again: with every window's band range (the stream is idle here)
+  bt.fill(merged_a, 0, mpx * 3);
+  bt.fill(count255, 0, (size_t)n * 4);
+  bt.fill(top2, 0xFF, (size_t)n * 12);
   bt.fill(canvas, 0, cpx);
   bt.flush();
   GpuChain chain(st, t->device, g_tail_chain >= 2);
@@ -487,9 +450,151 @@ int refine_windows(ctd_tail* t, const std::vector<WinReq>& reqs, int refine_mode
   launch_tw_commit(dw, n, max_pix, merged_b, pm.W, st);
   T_TRY(chain.end());
   T_TRY(hipGetLastError());
+  return CTD_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// refine_mask for a list of windows over the pages of the batch (reference utils/textmask.py:159-169):
+// ORs the merged window masks into the refined page buffers on the device.
+//   histograms -> host rules -> xor distances -> host polarity / merge order          (2 waits, as before)
+//   merge stage: ONE block per window from render to commit, on bit planes in LDS (kernels_twlds.hip), in up to three
+//   launches by LDS footprint; windows too big for that -> refine_canvas; after the wait for the overflow flags, windows
+//   whose run table overflowed -> refine_canvas too
+// ---------------------------------------------------------------------------------------------------
+int refine_windows(ctd_tail* t, const std::vector<WinReq>& reqs, int refine_mode) {
+  const int n = (int)reqs.size();
+  if (n == 0) return CTD_OK;
+  hipStream_t st = t->st;
+  GET(t->d_pmask, 0, uint8_t, pmask);
+  GET(t->d_refined, 0, uint8_t, refined);
+  std::vector<int> ww(n), wh(n);
+  int max_pix = 1;
+  for (int i = 0; i < n; ++i) {
+    ww[i] = reqs[i].x2 - reqs[i].x1, wh[i] = reqs[i].y2 - reqs[i].y1;
+    max_pix = std::max(max_pix, ww[i] * wh[i]);
+  }
+  GET(t->h_wins, sizeof(TWin) * n, TWin, hw);
+  for (int i = 0; i < n; ++i) {
+    const ctd_tail_page& pg = t->pages[reqs[i].page];
+    TWin& w = hw[i];
+    w.img = pg.img_dev;
+    w.mask = pmask + t->poff[reqs[i].page];
+    w.out = refined + t->poff[reqs[i].page];
+    w.img_w = pg.im_w, w.mask_w = pg.im_w, w.out_w = pg.im_w;
+    w.x1 = reqs[i].x1, w.y1 = reqs[i].y1, w.w = ww[i], w.h = wh[i];
+    w.mx = 0, w.my = 0;
+    w.band0 = 0, w.nband = 0;
+  }
+  GET(t->d_wins, sizeof(TWin) * n, TWin, dw);
+  // ---- one launch uploads the window table and zeroes the histograms and the xor sums
+  GET(t->d_hist, (size_t)n * 1024 * 4, unsigned, dhist);
+  GET(t->h_hist, (size_t)n * 1024 * 4, uint32_t, hhist);
+  GET(t->d_sums, (size_t)n * 6 * 8, unsigned long long, dsums);
+  GET(t->h_sums, (size_t)n * 6 * 8, uint64_t, hsums);
+  Batch bt(st);
+  T_TRY(bt.h2d(dw, hw, sizeof(TWin) * n));
+  bt.fill(dhist, 0, (size_t)n * 1024 * 4);
+  bt.fill(dsums, 0, (size_t)n * 6 * 8);
+  bt.flush();
+  // ---- histograms -> rules
+  launch_tw_hist(dw, n, max_pix, dhist, st);
+  T_TRY(bt.d2h(hhist, dhist, (size_t)n * 1024 * 4));
+  bt.flush();
+  const double tr0 = now_ms();
+  T_TRY(hipStreamSynchronize(st));
+  const double tr1 = now_ms();
+  GET(t->h_rules, sizeof(RRule) * 6 * n, RRule, hrules);
+  parallel_for(n, t->host_threads, [&](int i) { refine_rules(hhist + (size_t)i * 1024, hrules + (size_t)i * 6); });
+  static_assert(sizeof(RRule) == sizeof(TRule), "rule layouts must agree");
+  GET(t->d_rules, sizeof(TRule) * 6 * n, TRule, drules);
+  T_TRY(bt.h2d(drules, hrules, sizeof(TRule) * 6 * n));
+  bt.flush();
+  // ---- xor distances -> polarity and merge order
+  launch_tw_xor(dw, drules, n, max_pix, dsums, st);
+  T_TRY(bt.d2h(hsums, dsums, (size_t)n * 6 * 8));
+  bt.flush();
+  const double tr2 = now_ms();
+  T_TRY(hipStreamSynchronize(st));
+  const double tr3 = now_ms();
+  std::vector<TBand> bands;
+  for (int i = 0; i < n; ++i) {
+    RCand c[4];
+    const int nc = refine_candidates(hrules + (size_t)i * 6, hsums + (size_t)i * 6, (long long)ww[i] * wh[i], c);
+    hw[i].band0 = (int)bands.size(), hw[i].nband = nc;     // the window's bands are contiguous, in merge order
+    for (int r = 0; r < nc; ++r) {
+      const RRule& rl = hrules[(size_t)i * 6 + c[r].rule];
+      TBand b;
+      b.win = i, b.cx = b.cy = 0, b.kind = rl.kind, b.lo = rl.lo, b.hi = rl.hi, b.invert = c[r].invert, b.round = r;
+      bands.push_back(b);
+    }
+  }
+  const int nbands = (int)bands.size();
+  // ---- who goes where: by the LDS a window's planes + run table need
+  std::vector<int> lds_win, canvas_win;
+  std::vector<int> words(n);
+  for (int i = 0; i < n; ++i) {
+    words[i] = ((ww[i] + 31) >> 5) * wh[i];
+    const int rc = g_tail_lds_rcap > 0 ? g_tail_lds_rcap : tw_lds_rcap(words[i]);
+    if (g_tail_lds && (long long)tw_lds_bytes(words[i], std::max(rc, (words[i] + 1) / 2)) <= g_tail_lds_max_bytes) lds_win.push_back(i);
+    else canvas_win.push_back(i);
+  }
+  const int nl = (int)lds_win.size();
+  int* hovf = nullptr;
+  if (nl) {
+    std::stable_sort(lds_win.begin(), lds_win.end(), [&](int a, int b) { return words[a] < words[b]; });
+    GET(t->h_bands, sizeof(TBand) * std::max(nbands, 1), TBand, hb);
+    std::memcpy(hb, bands.data(), sizeof(TBand) * nbands);
+    GET(t->d_bands, sizeof(TBand) * std::max(nbands, 1), TBand, db);
+    GET(t->h_lds, (size_t)n * 8, int, hl);                  // [order (n) | overflow flags (n)]
+    GET(t->d_lds, (size_t)n * 8, int, dl);
+    std::memcpy(hl, lds_win.data(), sizeof(int) * nl);
+    hovf = hl + n;
+    T_TRY(bt.h2d(db, hb, sizeof(TBand) * nbands));
+    T_TRY(bt.h2d(dw, hw, sizeof(TWin) * n));                // again: with every window's band range (the stream is idle here)
+    T_TRY(bt.h2d(dl, hl, sizeof(int) * nl));
+    bt.fill(dl + n, 0, sizeof(int) * n);
+    bt.flush();
+    // up to three launches: a block's dynamic LDS is its launch's largest window's, and small blocks share a CU
+    const long long cls[3] = {40 << 10, 80 << 10, g_tail_lds_max_bytes};
+    int k0 = 0;
+    for (int c = 0; c < 3 && k0 < nl; ++c) {
+      int k1 = k0;
+      auto need = [&](int k) {
+        const int wd = words[lds_win[k]];
+        const int rc = g_tail_lds_rcap > 0 ? g_tail_lds_rcap : tw_lds_rcap(wd);
+        return (long long)tw_lds_bytes(wd, std::max(rc, (wd + 1) / 2));
+      };
+      while (k1 < nl && (c == 2 || need(k1) <= cls[c])) ++k1;
+      if (k1 > k0) {
+        const int mw = words[lds_win[k1 - 1]];
+        launch_tw_lds(dw, db, dl + k0, k1 - k0, mw, g_tail_lds_rcap > 0 ? g_tail_lds_rcap : tw_lds_rcap(mw),
+                      refine_mode == 0 ? 1 : 0, dl + n, st);
+      }
+      k0 = k1;
+    }
+    T_TRY(bt.d2h(hovf, dl + n, sizeof(int) * n));
+    bt.flush();
+  }
+  if (int rc = refine_canvas(t, hw, bands, canvas_win, refine_mode)) return rc;
+  const double tr4 = now_ms();
+  double tr5 = tr4;
+  if (nl) {
+    T_TRY(hipStreamSynchronize(st));                        // the overflow flags (the merge stage has run when they arrive)
+    tr5 = now_ms();
+    std::vector<int> again;
+    for (int k = 0; k < nl; ++k)
+      if (hovf[lds_win[k]]) again.push_back(lds_win[k]);
+    std::sort(again.begin(), again.end());
+    t->n_lds += nl - (int)again.size(), t->n_canvas += (int)canvas_win.size() + (int)again.size(), t->n_ovf += (int)again.size();
+    if (int rc = refine_canvas(t, hw, bands, again, refine_mode)) return rc;
+  } else {
+    t->n_canvas += (int)canvas_win.size();
+  }
+  T_TRY(hipGetLastError());
   t->ms_stage[4] += tr1 - tr0;
   t->ms_stage[5] += tr3 - tr2;
-  t->ms_stage[6] += (now_ms() - tr3) + (tr2 - tr1);
+  t->ms_stage[6] += (now_ms() - tr5) + (tr4 - tr3) + (tr2 - tr1);
+  t->ms_lds_wait += tr5 - tr4;
   return CTD_OK;
 }
 
@@ -864,10 +969,10 @@ void ctd_tail_destroy(ctd_tail* t) {
   DevBuf* dv[] = {&t->d_dets, &t->d_nms_ws, &t->d_lab_f, &t->d_ccl_ws, &t->d_ccl_small, &t->d_dbc_i, &t->d_dbc_d,
                   &t->d_rows, &t->d_pmask, &t->d_refined, &t->d_wins, &t->d_rules, &t->d_bands, &t->d_hist, &t->d_sums,
                   &t->d_canvas, &t->d_clab, &t->d_cstats, &t->d_cnt, &t->d_merged, &t->d_mlab, &t->d_mstats, &t->d_cnt2,
-                  &t->d_small, &t->d_crop};
+                  &t->d_small, &t->d_crop, &t->d_wins_c, &t->d_bands_c, &t->d_lds};
   for (DevBuf* d : dv) d->release();
   PinBuf* pv[] = {&t->h_dets, &t->h_hdr, &t->h_tab, &t->h_pmask, &t->h_refined, &t->h_hist, &t->h_sums, &t->h_wins,
-                  &t->h_rules, &t->h_bands, &t->h_small, &t->h_lab};
+                  &t->h_rules, &t->h_bands, &t->h_small, &t->h_lab, &t->h_wins_c, &t->h_bands_c, &t->h_lds};
   for (PinBuf* p : pv) p->release();
   delete t;
 }
@@ -901,6 +1006,7 @@ static int tail_run_impl(ctd_tail* t, int32_t B, int32_t Hn, int32_t Wn, const f
   hipStream_t st = t->st;
   const double t0 = now_ms();
   for (double& v : t->ms_stage) v = 0;
+  t->n_lds = t->n_canvas = t->n_ovf = 0, t->ms_lds_wait = 0;
   if (ready_event) T_TRY(hipStreamWaitEvent(st, (hipEvent_t)ready_event, 0));
   if (int rc = layout_pages(t, B, pages)) return rc;
   for (int b = 0; b < B; ++b)
@@ -1075,6 +1181,13 @@ int ctd_tail_timings(const ctd_tail* t, double* ms16) {   // 16 entries
   std::memcpy(ms16, t->ms_stage, sizeof(t->ms_stage));
   ms16[10] = t->ms_db_wait;
   for (int i = 0; i < 5; ++i) ms16[11 + i] = t->ms_sub[i];
+  ms16[15] = t->ms_lds_wait;
+  return CTD_OK;
+}
+
+int ctd_tail_refine_paths(const ctd_tail* t, int32_t* counts3) {
+  if (!t || !counts3) return ctd_fail_msg(CTD_ERR_INVALID, "null argument");
+  counts3[0] = t->n_lds, counts3[1] = t->n_canvas, counts3[2] = t->n_ovf;
   return CTD_OK;
 }
 
@@ -1108,6 +1221,7 @@ static int tail_refine_impl(ctd_tail* t, int32_t n_pages, const ctd_tail_page* p
   if (!t || n_pages < 1 || !pages || !masks_host || !blk_counts || !refined_out)
     return ctd_fail_msg(CTD_ERR_INVALID, "ctd_tail_refine: bad arguments");
   T_TRY(hipSetDevice(t->device));
+  t->n_lds = t->n_canvas = t->n_ovf = 0, t->ms_lds_wait = 0;
   hipStream_t st = t->st;
   if (int rc = layout_pages(t, n_pages, pages)) return rc;
   GET(t->d_pmask, t->ptotal, uint8_t, pmask);

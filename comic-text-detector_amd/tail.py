@@ -206,8 +206,16 @@ class Tail:
         L.check(self._lib.ctd_tail_timings(self._h, ms), "ctd_tail_timings")
         keys = ("enqueue1", "wait1", "db_tables+geometry", "yolo+group_output", "refine_wait_hist", "refine_wait_xor",
                 "refine_host+enqueue", "undetected", "final_wait+copies", "total", "db_table_wait", "enq1_nms+buffers",
-                "enq1_labelling+tables", "enq1_mask_copies", "final_wait_only")
+                "enq1_labelling+tables", "enq1_mask_copies", "final_wait_only", "refine_wait_merge")
         return {k: round(v, 3) for k, v in zip(keys, ms)}
+
+    def refine_paths(self) -> dict:
+        """Which path the refine windows of the last `run` / `refine` took: `lds` = merged by the window-local kernel (one
+        block per window on bit planes in LDS, csrc/kernels_twlds.hip), `canvas` = through the packed canvases (too large for
+        the LDS, or re-done after an overflow), `overflow` = run-table overflows of the window-local kernel."""
+        c = (C.c_int32 * 3)()
+        L.check(self._lib.ctd_tail_refine_paths(self._h, c), "ctd_tail_refine_paths")
+        return {"lds": int(c[0]), "canvas": int(c[1]), "overflow": int(c[2])}
 
     # -- SegDetectorRepresenter alone -----------------------------------------------------------------
     def db_boxes(self, prob: torch.Tensor, bitmap: torch.Tensor, max_candidates=1000, unclip_ratio=1.5):

@@ -8,6 +8,9 @@ pages, text blocks or candidates):
   host              top-k grey colours (np.histogram semantics) and Otsu thresholds (csrc/host_refine.cpp)
   HIP  tw_xor       xor distance of the <= 6 candidate rules of every window to the raw mask
   host              polarity (`minxor_thresh`), best Otsu channel, ordering by distance
+  HIP  tw_lds       merge_mask_list of a window as ONE block on bit planes in LDS (round 6, csrc/kernels_twlds.hip): render,
+                    8-connected components as a union-find over run ids, merge rounds, dilation, hole filling, commit
+  ... and for windows whose planes do not fit the LDS (or whose run table overflowed there) the canvas path:
   HIP  tw_render    the chosen candidates as bands of one packed labelling canvas
   HIP  ccl          8-connected components of all candidates of all windows (one launch)
   HIP  tw_accept    accept / reject per component, one round per candidate rank (count + apply)

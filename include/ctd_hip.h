@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define CTD_ABI_VERSION 5
+#define CTD_ABI_VERSION 6
 
 /* ---- error codes ------------------------------------------------------ */
 #define CTD_OK 0
@@ -300,8 +300,15 @@ int ctd_tail_run(ctd_tail* t, int32_t B, int32_t Hn, int32_t Wn, const float* bl
  * [4] refine: wait for the histograms, [5] refine: wait for the xor sums, [6] refine: host decisions + enqueue,
  * [7] refine_undetected_mask, [8] final wait + copies, [9] total, [10] the part of [2] spent waiting for the
  * table download, [11]-[13] parts of [0]: NMS + buffers, labelling + contour tables, page-mask copies, [14] the part
- * of [8] spent waiting for the refine stage's kernels, [15] reserved.  ms must hold 16 doubles. */
+ * of [8] spent waiting for the refine stage's kernels, [15] refine: wait for the window-local merge kernel's overflow
+ * flags.  ms must hold 16 doubles. */
 int ctd_tail_timings(const ctd_tail* t, double* ms);
+
+/* Which path the refine windows of the last ctd_tail_run / ctd_tail_refine took (reference utils/textmask.py:73-132,
+ * merge_mask_list per window): counts3 = [windows merged by the window-local kernel (one block per window on bit planes in
+ * LDS), windows merged through the packed canvases (too large for the LDS, or re-done after an overflow), run-table
+ * overflows of the window-local kernel].  Same results on every path; ABI v6. */
+int ctd_tail_refine_paths(const ctd_tail* t, int32_t* counts3);
 
 /* The DB text-line stage alone (`SegDetectorRepresenter.__call__`, reference utils/db_utils.py:40-69): boxes and
  * scores of every contour of every page, read back with ctd_tail_page_counts / ctd_tail_page_fetch. */

@@ -397,3 +397,70 @@ def test_fused_merge_rounds_equal_the_per_round_launches():
             rblks = [R.TextBlock(b) for b in boxes]
             for mode in (0, 1):
                 np.testing.assert_array_equal(out[1][mode], R.refine_mask(page, mask, rblks, mode))
+
+
+def _refine_under(p, key_values, page, mask, blks, dev="cuda"):
+    """refine_mask (both modes) under tuning keys, the keys restored afterwards; returns (masks, paths of the last call)"""
+    L = p._lib
+    defaults = {"tail_lds": 1, "tail_lds_rcap": 0, "tail_lds_max_bytes": 150 << 10}
+    try:
+        for k, v in key_values.items():
+            L.check(L.lib().ctd_tuning_set(k.encode(), v), "ctd_tuning_set")
+        out = [p.textmask.refine_mask(page, mask, blks, mode, dev) for mode in (0, 1)]
+        paths = p.tail.thread_tail(torch.device("cuda", 0)).refine_paths()
+    finally:
+        for k in key_values:
+            L.check(L.lib().ctd_tuning_set(k.encode(), defaults[k]), "ctd_tuning_set")
+    return out, paths
+
+
+def test_window_local_merge_kernel_equals_the_canvas_path_and_the_oracle():
+    """`tw_lds_kernel` (round 6: merge_mask_list of a window as one block on bit planes in LDS) on text-like pages, on a
+    speckle of 7x7 squares (hundreds of runs per row band), and on windows chosen for its edges -- narrower than a word,
+    exactly 32 / 33 / 64 / 65 wide, one or two pixels high, overlapping, clipped at the page border: byte-identical to
+    (a) the canvas path (`tail_lds` = 0), (b) the FORCED OVERFLOW path (`tail_lds_rcap` = 8: every window's run table
+    overflows on the device, the host re-does it through the canvases), (c) the oracle's refine_mask."""
+    p = pkg()
+    cases = []
+    page = p.synth.text_like_page((384, 512), 11, n_blocks=6)
+    rng = np.random.RandomState(4)
+    mask = (np.where(page.min(2) < 128, 230, 10) * (rng.rand(384, 512) > 0.1)).astype(np.uint8)
+    boxes = [[10, 10, 200, 150], [180, 100, 500, 380], [0, 0, 42, 30], [300, 5, 332, 60], [301, 70, 334, 130],
+             [100, 200, 164, 300], [99, 301, 164, 380], [400, 10, 406, 300], [5, 350, 500, 352], [20, 360, 400, 361],
+             [450, 300, 511, 383]]
+    cases.append((page, mask, boxes))
+    spage, smask = _speckle_page(256, 320, 7)
+    cases.append((spage, smask, [[4, 4, 150, 120], [100, 60, 310, 250], [0, 130, 90, 255]]))
+    for page, mask, boxes in cases:
+        blks = [p.textblock.TextBlock(b) for b in boxes]
+        lds, paths = _refine_under(p, {}, page, mask, blks)
+        assert paths["lds"] == len(boxes) and paths["canvas"] == 0 and paths["overflow"] == 0, paths
+        canvas, pc = _refine_under(p, {"tail_lds": 0}, page, mask, blks)
+        assert pc["lds"] == 0 and pc["canvas"] == len(boxes), pc
+        forced, pf = _refine_under(p, {"tail_lds_rcap": 8}, page, mask, blks)
+        assert pf["overflow"] >= len(boxes) - 3 and pf["canvas"] == pf["overflow"], pf       # (a near-empty window may fit 8 runs)
+        rblks = [R.TextBlock(b) for b in boxes]
+        for mode in (0, 1):
+            want = R.refine_mask(page, mask, rblks, mode)
+            np.testing.assert_array_equal(lds[mode], want)
+            np.testing.assert_array_equal(canvas[mode], want)
+            np.testing.assert_array_equal(forced[mode], want)
+        assert (lds[0] > 0).mean() > 0.02
+
+
+def test_windows_split_between_the_lds_kernel_and_the_canvas_path_by_size():
+    """A page whose blocks give one window beyond the LDS limit (canvas path) next to small ones (window-local kernel), and
+    the three LDS launch classes by footprint (`tail_lds_max_bytes` lowered so that mid-sized windows change class)."""
+    p = pkg()
+    page = p.synth.text_like_page((768, 1024), 5, n_blocks=10)
+    mask = np.where(page.min(2) < 128, 230, 10).astype(np.uint8)
+    boxes = [[20, 20, 1000, 740], [30, 30, 130, 100], [200, 100, 460, 330], [500, 400, 800, 640], [600, 50, 760, 200]]
+    blks = [p.textblock.TextBlock(b) for b in boxes]
+    want = [R.refine_mask(page, mask, [R.TextBlock(b) for b in boxes], mode) for mode in (0, 1)]
+    got, paths = _refine_under(p, {}, page, mask, blks)
+    assert paths["canvas"] == 1 and paths["lds"] == len(boxes) - 1, paths
+    small, ps = _refine_under(p, {"tail_lds_max_bytes": 60 << 10}, page, mask, blks)
+    assert 0 < ps["lds"] < len(boxes) - 1 and ps["lds"] + ps["canvas"] == len(boxes), ps
+    for mode in (0, 1):
+        np.testing.assert_array_equal(got[mode], want[mode])
+        np.testing.assert_array_equal(small[mode], want[mode])

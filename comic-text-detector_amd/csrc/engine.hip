@@ -1086,7 +1086,8 @@ extern int g_tail_ablate;
 #endif
 extern int g_tail_chain;
 extern int g_tail_fused_rounds;
-extern int g_tail_lds, g_tail_lds_rcap;
+extern int g_tail_lds, g_tail_lds_rcap, g_tw_lds_runs_x10, g_tw_lds_threads;
+extern long long g_tail_lds_cls0, g_tail_lds_cls1;
 extern long long g_tail_lds_max_bytes;
 
 extern "C" {
@@ -1293,6 +1294,10 @@ int ctd_tuning_set(const char* key, int64_t value) {
   if (key && std::string(key) == "tail_lds") { g_tail_lds = (int)value; return CTD_OK; }
   if (key && std::string(key) == "tail_lds_rcap") { g_tail_lds_rcap = (int)value; return CTD_OK; }
   if (key && std::string(key) == "tail_lds_max_bytes") { g_tail_lds_max_bytes = value; return CTD_OK; }
+  if (key && std::string(key) == "tail_lds_runs_x10") { g_tw_lds_runs_x10 = (int)std::max<int64_t>(1, value); return CTD_OK; }
+  if (key && std::string(key) == "tail_lds_threads") { g_tw_lds_threads = (int)value; return CTD_OK; }
+  if (key && std::string(key) == "tail_lds_cls0") { g_tail_lds_cls0 = value; return CTD_OK; }
+  if (key && std::string(key) == "tail_lds_cls1") { g_tail_lds_cls1 = value; return CTD_OK; }
   if (key && std::string(key) == "tail_dma_min") { g_tail_dma_min = value; return CTD_OK; }
 #ifdef CTD_MEASURE_KNOBS   // not in the shipped library: these return incomplete results
   if (key && std::string(key) == "tail_skip_page_download") { g_tail_skip_pages = value != 0; return CTD_OK; }

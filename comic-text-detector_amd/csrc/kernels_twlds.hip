@@ -37,7 +37,7 @@
 
 namespace {
 
-constexpr int TL_NT = 256;
+constexpr int TL_MAXT = 1024;   // threads per block: 256 / 512 / 1024 ("tail_lds_threads"), a launch parameter
 
 struct Geo {
   int W, H, wp, words;
@@ -141,9 +141,10 @@ struct TLdsArgs {
   int* ovf;             // per window: 1 = a run table overflowed, nothing committed
 };
 
-__global__ __launch_bounds__(TL_NT) void tw_lds_kernel(TLdsArgs a) {
+__global__ __launch_bounds__(TL_MAXT) void tw_lds_kernel(TLdsArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned lds[];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int TL_NT = blockDim.x, NWV = TL_NT >> 6;
   const int widx = a.order[blockIdx.x];
   const TWin w = a.wins[widx];
   Geo g;
@@ -156,7 +157,7 @@ __global__ __launch_bounds__(TL_NT) void tw_lds_kernel(TLdsArgs a) {
   unsigned short* const base = (unsigned short*)(lds + 3 * MW);
   unsigned* const parent = lds + 3 * MW + ((MW + 1) >> 1);
   int* const acc = (int*)(parent + RL);
-  unsigned* const red = parent + 2 * RL;           // [0..3] wave partials, [4..6] top-2 table
+  unsigned* const red = parent + 2 * RL;           // [0..15] wave partials, [16..18] top-2 table
   unsigned* const tmp = parent;                    // a scratch plane where no run table is live (2 * rlay >= max_words)
   auto validw = [&](int wi) { return wi == g.wp - 1 ? g.last : 0xffffffffu; };
 
@@ -209,8 +210,12 @@ __global__ __launch_bounds__(TL_NT) void tw_lds_kernel(TLdsArgs a) {
     if (lane == 63) red[wave] = (unsigned)inc;
     __syncthreads();
     int before = inc - cnt;
-    for (int k = 0; k < wave; ++k) before += (int)red[k];
-    const int total = (int)(red[0] + red[1] + red[2] + red[3]);
+    int total = 0;
+    for (int k = 0; k < NWV; ++k) {
+      const int v = (int)red[k];
+      before += k < wave ? v : 0;
+      total += v;
+    }
     {
       int wi = i0 % g.wp, run = before;
       for (int i = i0; i < i1; ++i) {
@@ -383,9 +388,10 @@ __global__ __launch_bounds__(TL_NT) void tw_lds_kernel(TLdsArgs a) {
     for (int off = 32; off > 0; off >>= 1) cnt += __shfl_down(cnt, off);
     __syncthreads();                                           // tmp (= parent) is free; red[] was last read before the previous barrier
     if (lane == 0) red[wave] = cnt;
-    if (t == 0) red[4] = 0u, red[5] = 0u, red[6] = 0u;         // [max + 1, multiplicity, runner-up + 1] (0 = none)
+    if (t == 0) red[16] = 0u, red[17] = 0u, red[18] = 0u;      // [max + 1, multiplicity, runner-up + 1] (0 = none)
     __syncthreads();
-    const unsigned a0 = red[0] + red[1] + red[2] + red[3];      // the background entry of the sorted areas: pixels already set
+    unsigned a0 = 0;                                           // the background entry of the sorted areas: pixels already set
+    for (int k = 0; k < NWV; ++k) a0 += red[k];
     __syncthreads();                                           // (scan_runs writes red[0..3] again)
     const int nr = scan_runs();
     if (nr > RC) {
@@ -398,19 +404,19 @@ __global__ __launch_bounds__(TL_NT) void tw_lds_kernel(TLdsArgs a) {
       // area threshold = second largest of {a0} U {areas of the components} (sorted_area[-2])
       for (int i = t; i < nr + 1; i += TL_NT) {
         const bool is = i == nr || parent[i] == (unsigned)i;
-        if (is) atomicMax(red + 4, (i == nr ? a0 : (unsigned)acc[i]) + 1u);
+        if (is) atomicMax(red + 16, (i == nr ? a0 : (unsigned)acc[i]) + 1u);
       }
       __syncthreads();
-      const unsigned mx = red[4] - 1u;
+      const unsigned mx = red[16] - 1u;
       for (int i = t; i < nr + 1; i += TL_NT) {
         const bool is = i == nr || parent[i] == (unsigned)i;
         if (!is) continue;
         const unsigned ar = i == nr ? a0 : (unsigned)acc[i];
-        if (ar == mx) atomicAdd(red + 5, 1u);
-        else atomicMax(red + 6, ar + 1u);
+        if (ar == mx) atomicAdd(red + 17, 1u);
+        else atomicMax(red + 18, ar + 1u);
       }
       __syncthreads();
-      const long long thr = red[5] >= 2u ? (long long)mx : (long long)red[6] - 1;     // -1: nothing can be filled
+      const long long thr = red[17] >= 2u ? (long long)mx : (long long)red[18] - 1;   // -1: nothing can be filled
       if (thr >= 0) {
         for (int i = t; i < nr; i += TL_NT)
           if (parent[i] == (unsigned)i) acc[i] = (long long)acc[i] < thr ? 0 : -(1 << 30);
@@ -460,12 +466,14 @@ __global__ __launch_bounds__(TL_NT) void tw_lds_kernel(TLdsArgs a) {
 // bytes of dynamic LDS for windows of at most `max_words` plane words and `rcap` runs
 size_t tw_lds_bytes(int max_words, int rcap) {
   const int rlay = std::max(rcap, (max_words + 1) / 2);
-  return ((size_t)3 * max_words + (max_words + 1) / 2 + (size_t)2 * rlay + 8) * 4;
+  return ((size_t)3 * max_words + (max_words + 1) / 2 + (size_t)2 * rlay + 20) * 4;
 }
 
-// the run capacity a launch gets for its largest window: 2.5 runs per word (text strokes on the reference's real page reach
-// 1.7), at least the plane itself (the scratch plane lives in the table) and what a u16 prefix holds at most
-int tw_lds_rcap(int max_words) { return std::min(65000, std::max(1024, max_words * 5 / 2)); }
+// the run capacity a launch gets for its largest window: `g_tw_lds_runs_x10` / 10 runs per word (default 2.5: text strokes on
+// the reference's real page reach 1.7), at least 1024, at most what a u16 prefix holds
+int g_tw_lds_runs_x10 = 25;     // "tail_lds_runs_x10"
+int g_tw_lds_threads = 512;     // "tail_lds_threads": 256 / 512 / 1024 threads per window (512: a third off the merge wait of a serial tail; end to end the three are equal, profiles/r06_twlds_knobs.txt)
+int tw_lds_rcap(int max_words) { return std::min(65000, std::max(1024, (int)((long long)max_words * g_tw_lds_runs_x10 / 10))); }
 
 void launch_tw_lds(const TWin* wins, const TBand* bands, const int* order, int n, int max_words, int rcap, int dilate, int* ovf,
                    hipStream_t st) {
@@ -477,5 +485,6 @@ void launch_tw_lds(const TWin* wins, const TBand* bands, const int* order, int n
   const size_t bytes = tw_lds_bytes(max_words, a.rcap);
   if (bytes > 48 * 1024)                                       // more dynamic LDS than the default limit: the kernel has to ask
     (void)hipFuncSetAttribute((const void*)tw_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-  hipLaunchKernelGGL(tw_lds_kernel, dim3(n), dim3(TL_NT), bytes, st, a);
+  const int nt = g_tw_lds_threads >= 1024 ? 1024 : (g_tw_lds_threads >= 512 ? 512 : 256);
+  hipLaunchKernelGGL(tw_lds_kernel, dim3(n), dim3(nt), bytes, st, a);
 }

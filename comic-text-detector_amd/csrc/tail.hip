@@ -157,6 +157,8 @@ int g_tail_fused_rounds = 1;
 // run-table capacity of every launch (tests force overflows with a tiny one)
 int g_tail_lds = 1, g_tail_lds_rcap = 0;
 long long g_tail_lds_max_bytes = 150 << 10;
+// the window-local kernel runs in up to three launches by LDS footprint ("tail_lds_cls0" / "tail_lds_cls1": the first two limits)
+long long g_tail_lds_cls0 = 40 << 10, g_tail_lds_cls1 = 80 << 10;
 namespace {
 // The chain is PER DEVICE: events belong to the device that was current when they were created, a stream can only record
 // its own device's events (hipErrorInvalidHandle otherwise), and tails on different GPUs have nothing to serialise.
@@ -555,7 +557,7 @@ int refine_windows(ctd_tail* t, const std::vector<WinReq>& reqs, int refine_mode
     bt.fill(dl + n, 0, sizeof(int) * n);
     bt.flush();
     // up to three launches: a block's dynamic LDS is its launch's largest window's, and small blocks share a CU
-    const long long cls[3] = {40 << 10, 80 << 10, g_tail_lds_max_bytes};
+    const long long cls[3] = {g_tail_lds_cls0, g_tail_lds_cls1, g_tail_lds_max_bytes};
     int k0 = 0;
     for (int c = 0; c < 3 && k0 < nl; ++c) {
       int k1 = k0;

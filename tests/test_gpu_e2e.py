@@ -422,12 +422,12 @@ def test_window_local_merge_kernel_equals_the_canvas_path_and_the_oracle():
     overflows on the device, the host re-does it through the canvases), (c) the oracle's refine_mask."""
     p = pkg()
     cases = []
-    page = p.synth.text_like_page((384, 512), 11, n_blocks=6)
+    page, _, mask, _, _ = p.synth.text_like_outputs(11, 512, n_blocks=8)       # ink + a mask a trained detector would give
     rng = np.random.RandomState(4)
-    mask = (np.where(page.min(2) < 128, 230, 10) * (rng.rand(384, 512) > 0.1)).astype(np.uint8)
+    mask = (mask * (rng.rand(512, 512) > 0.1)).astype(np.uint8)                  # ... with a tenth of its pixels knocked out
     boxes = [[10, 10, 200, 150], [180, 100, 500, 380], [0, 0, 42, 30], [300, 5, 332, 60], [301, 70, 334, 130],
              [100, 200, 164, 300], [99, 301, 164, 380], [400, 10, 406, 300], [5, 350, 500, 352], [20, 360, 400, 361],
-             [450, 300, 511, 383]]
+             [450, 300, 511, 383], [40, 390, 480, 505]]
     cases.append((page, mask, boxes))
     spage, smask = _speckle_page(256, 320, 7)
     cases.append((spage, smask, [[4, 4, 150, 120], [100, 60, 310, 250], [0, 130, 90, 255]]))
@@ -445,7 +445,7 @@ def test_window_local_merge_kernel_equals_the_canvas_path_and_the_oracle():
             np.testing.assert_array_equal(lds[mode], want)
             np.testing.assert_array_equal(canvas[mode], want)
             np.testing.assert_array_equal(forced[mode], want)
-        assert (lds[0] > 0).mean() > 0.02
+        assert (lds[0] > 0).mean() > 0.005
 
 
 def test_windows_split_between_the_lds_kernel_and_the_canvas_path_by_size():

@@ -1086,6 +1086,7 @@ extern int g_tail_ablate;
 #endif
 extern int g_tail_chain;
 extern int g_tail_fused_rounds;
+extern long long g_tail_fused_max_pix;
 extern int g_tail_lds, g_tail_lds_rcap, g_tw_lds_runs_x10, g_tw_lds_threads;
 extern long long g_tail_lds_cls0, g_tail_lds_cls1;
 extern long long g_tail_lds_max_bytes;
@@ -1291,6 +1292,7 @@ int ctd_tuning_set(const char* key, int64_t value) {
   if (key && std::string(key) == "tail_max_blocks") { g_tail_max_blocks = (int)std::max<int64_t>(1, value); return CTD_OK; }
   if (key && std::string(key) == "tail_chain") { g_tail_chain = (int)value; return CTD_OK; }
   if (key && std::string(key) == "tail_fused_rounds") { g_tail_fused_rounds = (int)value; return CTD_OK; }
+  if (key && std::string(key) == "tail_fused_max_pix") { g_tail_fused_max_pix = value; return CTD_OK; }
   if (key && std::string(key) == "tail_lds") { g_tail_lds = (int)value; return CTD_OK; }
   if (key && std::string(key) == "tail_lds_rcap") { g_tail_lds_rcap = (int)value; return CTD_OK; }
   if (key && std::string(key) == "tail_lds_max_bytes") { g_tail_lds_max_bytes = value; return CTD_OK; }

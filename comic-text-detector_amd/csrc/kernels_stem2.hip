@@ -22,6 +22,15 @@
 // the fp16 input patch, which is dead when they are needed) and the stem patch (576 rows x 64 B, XOR-swizzled 16-B
 // chunks; later the staged output tile).  Stem pixels outside the stem map are ZERO (layer 1's padding pads the
 // stem's output, not the image).
+//
+// Round 6: the stem patch is stored DE-INTERLEAVED by column parity -- a stem row's 17 even columns, then its 16 odd ones
+// (`srow`).  Layer 1 is stride 2: the 16 lanes of a ds_read_b128 group walked rows 2 apart, i.e. 2 of the 4 rows of a
+// 256-B LDS line, 8 of its 16 16-B slots whatever the swizzle -- a two-way bank conflict on every pixel fragment read
+// (PMC round 5: 40 % of the kernel's LDS cycles were conflict cycles).  With the parity planes a tap reads UNIT-stride rows
+// (tx = 0: even plane at c, tx = 1: odd plane at c, tx = 2: even plane at c + 1), and the lanes of the fragment's second
+// patch row take their columns rotated by 14 so that the hardware's 16-lane groups ({0-3, 12-15, 20-27}, {4-11, 16-19,
+// 28-31}) meet 16 different rows mod 16 = 16 different slots (tests/test_stem2_emul.py counts them).  Same values, same K
+// order: bit-identical.
 #include <type_traits>
 
 #include "kernels.h"
@@ -84,6 +93,8 @@ __global__ __launch_bounds__(S2_NT, 4) void stem_conv2_kernel(Stem2Args a) {   /
   using gptr_t = const __attribute__((address_space(1))) void*;
   using lptr_t = __attribute__((address_space(3))) void*;
   auto swz = [](int row) { return (row >> 2) & 3; };
+  // LDS row of stem pixel (py, px) of the 33 x 17 patch: even columns first, then the odd ones
+  auto srow = [](int py, int px) { return py * S2_SW + ((px & 1) ? 17 + (px >> 1) : (px >> 1)); };
   const int pos = t & 3;
   // layer-1 weight tiles [tap][64][32] -> LDS by LDS-DMA, swizzle on the source chunk
   const int wg = w >> 2, w4 = w & 3, t4 = t & 255;      // wave group (0 / 1), wave and thread inside it
@@ -199,6 +210,7 @@ __global__ __launch_bounds__(S2_NT, 4) void stem_conv2_kernel(Stem2Args a) {   /
     // form compiled to an exec-mask branch around every single SiLU (v_exp / v_rcp with their s_nops, no two of the 16
     // values of a fragment in flight together), and this kernel is bound by exactly that VALU work (round 5)
     const unsigned km = (p < S2_SPX && sy >= 0 && sy < Hs && sx >= 0 && sx < Ws) ? 0xffffffffu : 0u;
+    const int row = p < S2_SPX ? srow(py, px) : p;          // (the last fragment's lanes beyond the patch keep their own rows)
     float4_t bv[4];
 #pragma unroll
     for (int g = 0; g < 4; ++g) bv[g] = *(const float4_t*)(bias_s + 8 * g + 4 * khalf);
@@ -210,7 +222,7 @@ __global__ __launch_bounds__(S2_NT, 4) void stem_conv2_kernel(Stem2Args a) {   /
       uint2 u = __builtin_bit_cast(uint2, o);
       u.x &= km;
       u.y &= km;
-      *(uint2*)(S + p * 32 + ((g ^ swz(p)) * 8) + 4 * khalf) = u;
+      *(uint2*)(S + row * 32 + ((g ^ swz(row)) * 8) + 4 * khalf) = u;
     }
   }
   __syncthreads();   // the stem patch is complete; the input patch is dead
@@ -220,7 +232,7 @@ __global__ __launch_bounds__(S2_NT, 4) void stem_conv2_kernel(Stem2Args a) {   /
     if ((i & 1) == wg) dma_w(5 + i, lds + S2_W5 + i * S2_WTILE);
 
   // ---- layer 1: 3x3 / s2 over the stem patch; wave (w4, wg) = output rows 2 w4, 2 w4 + 1, N fragment wg -----------
-  const int prow1 = 2 * w4 + (l31 >> 4), pcol1 = l31 & 15;
+  const int prow1 = 2 * w4 + (l31 >> 4), pcol1 = l31 < 16 ? l31 : ((l31 - 2) & 15);   // second row: columns rotated by 14
   const int pl = prow1 * S2_TW + pcol1;
   float16_t acc;
 #pragma unroll
@@ -232,7 +244,7 @@ __global__ __launch_bounds__(S2_NT, 4) void stem_conv2_kernel(Stem2Args a) {   /
 #pragma unroll
     for (int tap = t0; tap < t1; ++tap) {
       const int ty = tap / 3, tx = tap - 3 * ty;
-      const int row = (2 * prow1 + ty) * S2_SW + 2 * pcol1 + tx;
+      const int row = (2 * prow1 + ty) * S2_SW + (tx == 1 ? 17 + pcol1 : pcol1 + (tx >> 1));   // srow(2 prow1 + ty, 2 pcol1 + tx)
       const half_t* Wb = lds + S2_W0 + tap * S2_WTILE;    // taps 5-8 continue at S2_W5 = 5 tiles
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk) {

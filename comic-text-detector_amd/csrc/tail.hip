@@ -152,6 +152,8 @@ int g_tail_chain = 1;
 // "tail_fused_rounds": 1 = a window's merge rounds and its hole-filling passes as one launch each (a block per window);
 // 0 = one count + one apply launch per round and four hole-filling launches over all windows (rounds 2-3)
 int g_tail_fused_rounds = 1;
+// ... for canvas-path window sets whose largest window has fewer pixels than this ("tail_fused_max_pix")
+long long g_tail_fused_max_pix = 100000;
 // "tail_lds": 1 = the merge stage of a window as ONE block on bit planes in LDS (kernels_twlds.hip), 0 = every window through
 // the canvas path; "tail_lds_max_bytes": windows needing more LDS than this take the canvas path; "tail_lds_rcap" > 0: the
 // run-table capacity of every launch (tests force overflows with a tiny one)
@@ -429,12 +431,18 @@ int refine_canvas(ctd_tail* t, const TWin* hw, const std::vector<TBand>& bands, 
   bt.fill(top2, 0xFF, (size_t)n * 12);
   bt.fill(canvas, 0, cpx);
   bt.flush();
+  // One block per window for all merge rounds / hole passes (`tw_accept_all`, `tw_holes_all`) suits windows of a few 10 K
+  // pixels; since round 6 those are merged in LDS and what arrives here is mostly LARGE (page-sized windows of
+  // refine_undetected_mask's left-over components: one block walked 1 M pixels six times, 5-7 ms per launch next to a
+  // 10-ms forward) -- those take the per-round grid kernels, many blocks per window.  Same results either way
+  // (test_fused_merge_rounds_equal_the_per_round_launches).
+  const bool fused = g_tail_fused_rounds && max_pix < g_tail_fused_max_pix;
   GpuChain chain(st, t->device, g_tail_chain >= 2);
   T_TRY(chain.begin());
   launch_tw_render(dw, db, nbands, max_pix, canvas, pc.W, st);
   launch_ccl(canvas, 1, pc.H, pc.W, 0, 8, clab, n_dev, cstats, cap1, ws, st, 0, nullptr, 1);   // the window kernels test `label > 0`
   launch_label_counters_zero(counters, n_dev, cap1, st);
-  if (g_tail_fused_rounds) {
+  if (fused) {
     launch_tw_accept_all(dw, db, n, clab, pc.W, cstats, cap1, 3, merged_a, pm.W, counters, st);
   } else {
     for (int r = 0; r < rounds; ++r)
@@ -447,7 +455,7 @@ int refine_canvas(ctd_tail* t, const TWin* hw, const std::vector<TBand>& bands, 
   int* mfirst = mstats + (size_t)cap2 * 5;
   launch_ccl(comp, 1, pm.H, pm.W, 0, 8, mlab, n_dev, mstats, cap2, ws, st, 0, mfirst, 1);
   launch_label_counters_zero(counters2, n_dev, cap2, st);
-  if (g_tail_fused_rounds) launch_tw_holes_all(dw, n, mlab, mstats, mfirst, cap2, count255, merged_b, pm.W, counters2, st);
+  if (fused) launch_tw_holes_all(dw, n, mlab, mstats, mfirst, cap2, count255, merged_b, pm.W, counters2, st);
   else launch_tw_holes(dw, n, max_pix, mlab, mstats, mfirst, cap2, count255, top2, merged_b, pm.W, counters2, st);
   launch_tw_commit(dw, n, max_pix, merged_b, pm.W, st);
   T_TRY(chain.end());

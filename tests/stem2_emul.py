@@ -40,6 +40,14 @@ def stem_pack_weights(W):
     return out
 
 
+def srow(py, px):
+    """LDS row of stem pixel (py, px) of the 33 x 17 patch: a stem row's even columns first, then the odd ones (round 6)"""
+    return py * SW + np.where(px & 1, 17 + (px >> 1), px >> 1)
+
+
+READS = []      # (row per lane, chunk per lane) of every layer-1 pixel-fragment read of the last run_block: bank-slot audit
+
+
 def mfma(fw, fx, acc):
     A = np.zeros((32, 16))
     Bm = np.zeros((16, 32))
@@ -127,8 +135,9 @@ def run_block(img, u8in, wfrag, b0, w1, b1, kind1, b, tpy, tpx):
                 mfma(wf[s], fx, acc)
             sy, sx = sy0 + py, sx0 + px
             keep = (p < SPX) & (sy >= 0) & (sy < Hs) & (sx >= 0) & (sx < Ws)
+            rows = np.where(p < SPX, srow(py, px), p)
             for lane in range(64):
-                kh, pp = lane >> 5, int(p[lane])
+                kh, pp = lane >> 5, int(rows[lane])
                 for g in range(4):
                     v = acc[lane, 4 * g:4 * g + 4].astype(np.float32) * np.float32(oscale) + bias[8 * g + 4 * kh: 8 * g + 4 * kh + 4]
                     o = act(v, "silu").astype(np.float16) if keep[lane] else np.zeros(4, np.float16)
@@ -143,23 +152,26 @@ def run_block(img, u8in, wfrag, b0, w1, b1, kind1, b, tpy, tpx):
         return lds[o:o + 8]
 
     accs = {}
+    del READS[:]
     for w in range(4):
-        prow1, pcol1 = 2 * w + (l31 >> 4), l31 & 15
+        prow1, pcol1 = 2 * w + (l31 >> 4), np.where(l31 < 16, l31, (l31 - 2) & 15)
         a0, a1 = np.zeros((64, 16)), np.zeros((64, 16))
         for tap in range(9):
             ty, tx = divmod(tap, 3)
-            row = (2 * prow1 + ty) * SW + 2 * pcol1 + tx
+            row = (2 * prow1 + ty) * SW + np.where(tx == 1, 17 + pcol1, pcol1 + (tx >> 1))
+            assert np.array_equal(row, srow(2 * prow1 + ty, 2 * pcol1 + tx))
             Wb = W0 + tap * WTILE
             for kk in range(2):
                 fw0 = np.stack([ld(Wb, int(l31[l]), kk * 2 + int(khalf[l])) for l in range(64)])
                 fw1 = np.stack([ld(Wb, 32 + int(l31[l]), kk * 2 + int(khalf[l])) for l in range(64)])
                 fx = np.stack([ld(S, int(row[l]), kk * 2 + int(khalf[l])) for l in range(64)])
+                READS.append((row.copy(), kk * 2 + khalf))
                 mfma(fw0, fx, a0)
                 mfma(fw1, fx, a1)
         accs[w] = (a0, a1)
     lds[S:S + SROWS * 32] = np.nan               # the output tile overwrites the stem patch
     for w in range(4):
-        prow1, pcol1 = 2 * w + (l31 >> 4), l31 & 15
+        prow1, pcol1 = 2 * w + (l31 >> 4), np.where(l31 < 16, l31, (l31 - 2) & 15)
         pl = prow1 * TW + pcol1
         for lane in range(64):
             kh = lane >> 5

@@ -385,11 +385,17 @@ def test_fused_merge_rounds_equal_the_per_round_launches():
         blks = [p.textblock.TextBlock(b) for b in boxes]
         out = {}
         try:
+            # round 6: the canvas path for every window (`tail_lds` = 0), and the block-per-window kernels also for these
+            # LARGE windows (by default sets with a window of 100 K pixels or more take the per-round launches)
+            L.check(L.lib().ctd_tuning_set(b"tail_lds", 0), "ctd_tuning_set")
+            L.check(L.lib().ctd_tuning_set(b"tail_fused_max_pix", 1 << 40), "ctd_tuning_set")
             for fused in (1, 0):
                 L.check(L.lib().ctd_tuning_set(b"tail_fused_rounds", fused), "ctd_tuning_set")
                 out[fused] = [p.textmask.refine_mask(page, mask, blks, mode, "cuda") for mode in (0, 1)]
         finally:
             L.check(L.lib().ctd_tuning_set(b"tail_fused_rounds", 1), "ctd_tuning_set")
+            L.check(L.lib().ctd_tuning_set(b"tail_fused_max_pix", 100000), "ctd_tuning_set")
+            L.check(L.lib().ctd_tuning_set(b"tail_lds", 1), "ctd_tuning_set")
         for a, b in zip(out[1], out[0]):
             np.testing.assert_array_equal(a, b)
         assert (out[1][0] > 0).mean() > 0.2

@@ -617,7 +617,10 @@ int layout_pages(ctd_tail* t, int B, const ctd_tail_page* pages) {
   for (int b = 0; b < B; ++b) {
     if (pages[b].im_h < 1 || pages[b].im_w < 1) return ctd_fail_msg(CTD_ERR_INVALID, "bad page size");
     t->poff[b] = off;
-    off += align_up((size_t)pages[b].im_h * pages[b].im_w + 4, 256);
+    // (a page whose size is a multiple of 256 bytes needs no padding: pages of one such size then lie back to back, and
+    // refine_undetected_mask labels them in ONE launch)
+    const size_t px = (size_t)pages[b].im_h * pages[b].im_w;
+    off += px % 256 == 0 ? px : align_up(px + 4, 256);
   }
   t->ptotal = off;
   t->out.assign(B, PageOut());
@@ -637,15 +640,25 @@ int undetected_pass(ctd_tail* t, const std::vector<std::vector<int32_t>>& blk_xy
   const int cap = kCompCap;
   size_t max_px = 0;
   for (int b = 0; b < B; ++b) max_px = std::max(max_px, (size_t)t->pages[b].im_h * t->pages[b].im_w);
-  GET(t->d_lab_f, max_px * 4, int, lab);
-  GET(t->d_ccl_ws, ccl_workspace_bytes(1, 1, (int)max_px), uint8_t, ws);
+  // pages of one size that lie back to back (layout_pages) are labelled in one launch; else page by page
+  bool same = true;
+  for (int b = 1; b < B; ++b)
+    same = same && t->pages[b].im_h == t->pages[0].im_h && t->pages[b].im_w == t->pages[0].im_w &&
+           t->poff[b] == t->poff[b - 1] + max_px;
+  const int nb = same ? B : 1;
+  GET(t->d_lab_f, (size_t)nb * max_px * 4, int, lab);
+  GET(t->d_ccl_ws, same ? ccl_workspace_bytes(B, t->pages[0].im_h, t->pages[0].im_w) : ccl_workspace_bytes(1, 1, (int)max_px), uint8_t, ws);
   GET(t->d_ccl_small, (size_t)B * 4 + (size_t)B * cap * 5 * 4, int, nst);
   int* n_dev = nst;
   int* st_dev = nst + B;
   GET(t->h_small, (size_t)B * 4, int, n_host);
-  for (int b = 0; b < B; ++b)
-    launch_ccl(pmask + t->poff[b], 1, t->pages[b].im_h, t->pages[b].im_w, 30, 4, lab, n_dev + b,
-               st_dev + (size_t)b * cap * 5, cap, ws, st, 0, nullptr, 1);   // only the statistics are used
+  if (same) {
+    launch_ccl(pmask + t->poff[0], B, t->pages[0].im_h, t->pages[0].im_w, 30, 4, lab, n_dev, st_dev, cap, ws, st, 0, nullptr, 1);
+  } else {
+    for (int b = 0; b < B; ++b)
+      launch_ccl(pmask + t->poff[b], 1, t->pages[b].im_h, t->pages[b].im_w, 30, 4, lab, n_dev + b,
+                 st_dev + (size_t)b * cap * 5, cap, ws, st, 0, nullptr, 1);   // only the statistics are used
+  }
   T_TRY(hipMemcpyAsync(n_host, n_dev, (size_t)B * 4, hipMemcpyDeviceToHost, st));
   T_TRY(hipStreamSynchronize(st));
   int nmax = 0;

@@ -470,3 +470,50 @@ def test_windows_split_between_the_lds_kernel_and_the_canvas_path_by_size():
     for mode in (0, 1):
         np.testing.assert_array_equal(got[mode], want[mode])
         np.testing.assert_array_equal(small[mode], want[mode])
+
+
+def test_window_local_merge_kernel_random_stress_against_the_oracle():
+    """Seeded stress of `tw_lds_kernel`: pages of random texture (flat areas, strokes, speckle, gradients), random
+    predictions, random blocks of every aspect (1 .. 300 pixels, clipped at the borders, overlapping) -- refine_mask in both
+    modes against the oracle, every window on the window-local path."""
+    p = pkg()
+    rng = np.random.RandomState(20260930)
+    n_windows = n_over = 0
+    for case in range(12):
+        H, W = int(rng.randint(40, 420)), int(rng.randint(40, 520))
+        page = np.full((H, W, 3), rng.randint(150, 255), np.uint8)
+        kind = case % 4
+        ink = np.zeros((H, W), bool)
+        for _ in range(rng.randint(20, 200)):
+            y, x = rng.randint(0, H), rng.randint(0, W)
+            if kind == 0:
+                ink[y: y + rng.randint(1, 4), x: x + rng.randint(2, 40)] = True          # horizontal strokes
+            elif kind == 1:
+                ink[y: y + rng.randint(2, 40), x: x + rng.randint(1, 4)] = True          # vertical strokes
+            elif kind == 2:
+                ink[y: y + rng.randint(1, 3), x: x + rng.randint(1, 3)] = True           # speckle
+            else:
+                ink[y: y + rng.randint(3, 30), x: x + rng.randint(3, 30)] = True         # blobs
+        page[ink] = rng.randint(0, 90)
+        page = (page.astype(int) + rng.randint(-25, 26, page.shape)).clip(0, 255).astype(np.uint8)
+        if case % 3 == 0:
+            page[:, : W // 2] = 255 - page[:, : W // 2]                                  # light text on dark in one half
+        from scipy import ndimage
+        mask = (ndimage.maximum_filter(ink.astype(np.uint8), size=3) * rng.randint(100, 255)).astype(np.uint8)
+        mask[rng.rand(H, W) < 0.05] = rng.randint(0, 255)
+        boxes = []
+        for _ in range(rng.randint(3, 9)):
+            x1, y1 = int(rng.randint(0, W - 2)), int(rng.randint(0, H - 2))
+            boxes.append([x1, y1, int(min(W - 1, x1 + rng.randint(1, 300))), int(min(H - 1, y1 + rng.randint(1, 300)))])
+        blks = [p.textblock.TextBlock(b) for b in boxes]
+        got, paths = _refine_under(p, {}, page, mask, blks)
+        # (a candidate of pure speckle has more runs than the run table holds: those windows raise the overflow flag and are
+        # re-done through the canvases -- same results; the pages here are small, so nothing is too LARGE for the LDS)
+        assert paths["canvas"] == paths["overflow"] and paths["lds"] + paths["canvas"] == len(boxes), (case, paths)
+        n_windows += paths["lds"]
+        n_over += paths["overflow"]
+        rblks = [R.TextBlock(b) for b in boxes]
+        for mode in (0, 1):
+            np.testing.assert_array_equal(got[mode], R.refine_mask(page, mask, rblks, mode), err_msg=f"case {case} mode {mode}")
+    print(f"\nstress: {n_windows} windows merged in LDS, {n_over} re-done after a run-table overflow")
+    assert n_windows >= 40

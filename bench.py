@@ -755,7 +755,7 @@ def roofline_block(be, x, precision: str, B: int, S: int, dump_ops: str = "") ->
     # --pmc passes: scripts/gpu_traffic.sh).  PMC cannot be collected inside this process; the committed measurement of
     # this engine at this shape is attached when it exists (and says which round it is from).
     traffic, tnote = None, None
-    for tname in {"fp16": ("r05_traffic_pmc.json", "r04_traffic_pmc.json", "r03_traffic_pmc.json"), "fp32s": ("r03_traffic_pmc_fp32s.json",)}.get(precision, ()):
+    for tname in {"fp16": ("r06_traffic_pmc.json", "r05_traffic_pmc.json", "r04_traffic_pmc.json"), "fp32s": ("r03_traffic_pmc_fp32s.json",)}.get(precision, ()):
         tpath = os.path.join(ROOT, "profiles", tname)
         if os.path.isfile(tpath) and (B, S) == (32, 1024):
             try:

@@ -1030,40 +1030,40 @@ def main() -> None:
             TL.release_thread_tail()                         # ... and so does the one the parity leg used on this thread
             sub = lambda steps_, **ov: inproc_bench(pkg, D, DET, TL, args, dev, steps_, **ov)      # noqa: E731
             ex = "fp32s" if args.precision != "fp32s" else "fp32"
-            c = sub(16, precision=ex)
+            c = sub(40, precision=ex)
             exact = dict(c, engine=ex, batch=B, workload="the headline's (same pages, checkpoint, pipeline), in this process",
                          acceptance="lines / blocks / refined mask identical to the oracle on the acceptance pages "
                                     "(tests/test_gpu_accept.py; `parity.engines` here)")
             extra = {}
-            c = sub(16, precision="fp32", batch=8, tail_input="forward")
+            c = sub(40, precision="fp32", batch=8, tail_input="forward")
             extra["fp32_bs8_e2e"] = dict(c, config="BASELINE configs[1]: bs=8 1024x1024, fp32 (f32-operand MFMA engine), end to end "
                                                    "with the native tail")
             c = sub_bench(["--mode", "mixed", "--precision", args.precision], 3, warmup=1, spinup=0, timeout=240, whole=True)
             extra["mixed_e2e"] = c
             if real and not args.dense_blocks:
-                c = sub(16, dense_blocks=True)
+                c = sub(40, dense_blocks=True)
                 extra["dense_blocks_e2e"] = dict(c, config="the headline's pages and pipeline on synth.make_blob_checkpoint(0) WITHOUT "
                                                            "sparse_det: every cell of one Detect anchor fires (random weights), NMS "
                                                            "packs the page with boxes (65 blocks / 67 lines per page)")
-                c = sub(16, line_density="r3")
+                c = sub(40, line_density="r3")
                 extra["r3_density_e2e"] = dict(c, config="round 3's headline pages (sparse_det without the line-density calibration: 16 "
                                                          "blocks / 16 lines per page; round 3's driver line: 2586 pages/s)")
-                c = sub(16, lazy_blocks=True)
+                c = sub(40, lazy_blocks=True)
                 extra["lazy_blocklists_e2e"] = dict(c, config="the headline with the tail workers handing over lazily materialised "
                                                               "BlockLists (`detect_stream(lazy=True)`: the native records, "
                                                               "TextBlock objects built when a consumer looks at them) instead "
                                                               "of the reference's return type, a list of TextBlock objects per "
                                                               "page, which the headline builds (rounds 3-4 timed this variant "
                                                               "as the headline)")
-                c = sub(16, refine_mode=1, keep_undetected=True)
+                c = sub(40, refine_mode=1, keep_undetected=True)
                 extra["reference_cli_config_e2e"] = dict(c, config="the headline with the reference CLI's arguments (inference.py:35, "
                                                                    "`model2annotations`): refine_mode = REFINEMASK_ANNOTATION, "
                                                                    "keep_undetected_mask = True (refine_undetected_mask runs too)")
-                c = sub(16, host_input=True)
+                c = sub(40, host_input=True)
                 extra["host_input_e2e"] = dict(c, config="the headline with the pages starting in HOST memory (numpy arrays, as the "
                                                          "reference's callers hand them over): PCIe-inclusive, never the headline")
             if real:
-                c = sub(16, tail_input="canned")
+                c = sub(40, tail_input="canned")
                 extra["canned_tail_inputs_e2e"] = dict(c, config="round 2's workload (`--tail-input canned`): random checkpoint, ONE "
                                                                  "resident batch, the tail fed text-like maps of the same pages "
                                                                  "instead of the forward's outputs (round 2 measured 2502 pages/s)")

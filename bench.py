@@ -151,17 +151,23 @@ class Pipeline:
         self.loaders = max(1, loaders)
         self.host_batches = [[p for p in b.cpu().numpy()] for b in batches] if host_input else None
         self.lpool = det._pool("load", self.loaders) if host_input else None
-        self.comm_stream = torch.cuda.Stream(dev) if self.gather else None
-        self.stats = {"blocks": 0, "lines": 0, "pages": 0, "cpu_cores": 0.0}
+        self.comm_stream = torch.cuda.Stream(dev) if self.gather else None      # the record gather's stream
+        self.stats = {"blocks": 0, "lines": 0, "pages": 0, "cpu_cores": 0.0, "gather_s": 0.0}
         self.k = 0                                           # batches rotate across calls too
         self.fixed_job = None
         self.fwd_stream = None
         # N > 1: the tail builds every page's gather record natively (dist.pack_results then only stacks them)
         self.records = (D.CAP_BLK, D.CAP_LINE) if self.gather else None
         self.gathered = None                                 # the last gathered record tensor (checked by the caller)
+        self.gathers = deque()                               # record gathers handed to the communication thread (futures)
+        self.handles = deque()                               # ... in flight on the device (dist.GatherHandle), that thread's
+        self.cpool = ThreadPoolExecutor(max_workers=1, thread_name_prefix="ctd-comm") if self.gather else None
 
     def close(self):
         self.det.close()                                     # ends the detector's worker / loader pools (idempotent)
+        if self.cpool is not None:
+            self.cpool.shutdown(wait=True)
+            self.cpool = None
 
     @property
     def api(self):
@@ -189,19 +195,46 @@ class Pipeline:
         if self.gather:
             # on its own stream: the default stream holds the queued forwards of the next batches, and an upload or a
             # collective enqueued behind them would stall this thread until they have run
-            with torch.cuda.stream(self.comm_stream):
-                self.gathered = self.D.gather_results(res, self.total_pages, self.rank, self.world, device=self.dev, pin=True,
-                                                      force=self.world == 1)
+            # enqueued, not waited for: the counts that decide about the (rare) re-gather at the worst-case capacities come
+            # back behind the collective; handles are resolved once their event has fired (and all of them when a run ends)
+            # ... and off the launching thread: ONE communication thread enqueues the collectives in step order (every rank in
+            # the same order) and resolves them; this thread only hands the batch over
+            self.gathers.append(self.cpool.submit(self._gather, res))
         self.stats["pages"] += len(res)
         self.stats["blocks"] += sum(len(r[2]) for r in res)
         # lazy results: the counts come from the native records (no TextBlock is built for the bookkeeping)
         self.stats["lines"] += sum(r[2].n_lines if hasattr(r[2], "n_lines") else sum(len(b.lines) for b in r[2]) for r in res)
 
+    def _gather(self, res):
+        """On the communication thread: this batch's record gather, enqueued on the communication stream; earlier gathers
+        whose event has fired are resolved (the re-gather at the worst-case capacities happens there, rarely)."""
+        tg = time.perf_counter()
+        torch.cuda.set_device(self.dev)
+        with torch.cuda.stream(self.comm_stream):
+            self.handles.append(self.D.gather_results_async(res, self.total_pages, self.rank, self.world, device=self.dev, pin=True,
+                                                            force=self.world == 1))
+            while self.handles and (self.handles[0].done() or len(self.handles) > 2 * self.depth):
+                self.gathered = self.handles.popleft().result()
+        self.stats["gather_s"] = self.stats.get("gather_s", 0.0) + (time.perf_counter() - tg)
+
+    def _drain_gathers(self):
+        while self.gathers:
+            self.gathers.popleft().result()
+        def rest():
+            with torch.cuda.stream(self.comm_stream):
+                while self.handles:
+                    self.gathered = self.handles.popleft().result()
+        if self.cpool is not None:
+            self.cpool.submit(rest).result()
+
     def run(self, n):
         if self.fwd_stream is not None:                      # --fwd-stream high: the forwards on a high-priority stream
             with torch.cuda.stream(self.fwd_stream):
-                return self._run(n)
-        return self._run(n)
+                self._run(n)
+        else:
+            self._run(n)
+        if self.gather:                                      # a run ends with every gather it started complete
+            self._drain_gathers()
 
     def _batches(self, n):
         for _ in range(n):
@@ -888,7 +921,12 @@ def main() -> None:
     DET = importlib.import_module("comic-text-detector_amd.detector")
     BK = importlib.import_module("comic-text-detector_amd.backend")
     TL = importlib.import_module("comic-text-detector_amd.tail")
-    rank, local_rank, world = D.init(args.force_dist or None, force=bool(args.force_dist))
+    # The process group is joined LAST, after the detector's streams exist (the forwards', the tail workers', the upload and
+    # communication streams): RCCL creates streams of its own at start-up, and a process whose important streams come after
+    # them shares hardware queues badly -- the same pipeline ran at 2480-2590 pages/s with the group initialised first and at
+    # 3134 with it initialised here (profiles/r06_rccl_init_order.txt).  Rank and world come from the environment.
+    rank, local_rank, world = D.env_world()
+    join = lambda: D.init(args.force_dist or None, force=bool(args.force_dist))      # noqa: E731
     if world != args.gpus and rank == 0:
         print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
     n_gpus = world
@@ -922,6 +960,7 @@ def main() -> None:
     if args.mode == "mixed":
         ckpt = blob_checkpoint(pkg, args)
         det = DET.TextDetector(ckpt, input_size=1024, device=dev, precision=args.precision)
+        join()
         out = mixed_stream(pkg, D, BK, det, rank, world, dev, args.steps, args.warmup, with_tail=True)
         if rank == 0:
             out.update({"n_gpus": n_gpus, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -962,6 +1001,7 @@ def main() -> None:
                     keep_undetected=args.keep_undetected, lazy=bool(args.lazy_blocks), refine_mode=args.refine_mode,
                     force_dist=bool(args.force_dist))
 
+    join()                                                   # the process group: after the pipeline's streams (see above)
     if args.fwd_stream == "high" and e2e:
         pipe.fwd_stream = torch.cuda.Stream(dev, priority=-1)
     if masked_stream is not None:
@@ -1138,6 +1178,7 @@ def main() -> None:
                        "blocks_per_page": round(stats["blocks"] / max(stats["pages"], 1), 2) if e2e else None,
                        "lines_per_page": round(stats["lines"] / max(stats["pages"], 1), 2) if e2e else None,
                        "host_cpu_cores_used": round(float(stats.get("cpu_cores", 0.0)), 2),
+                       "record_gather_ms_per_step": round(float(stats.get("gather_s", 0.0)) * 1e3 / max(args.steps, 1), 3),
                        "one_device_rehearsal": one_device, "tail_only": bool(args.tail_only and e2e),
                        "parallelism": f"dp{n_gpus} (pages sharded, no data-path collective except the final record "
                                       f"gather; ranks={world}, backend={dist.get_backend() if dist.is_initialized() else 'none'}"

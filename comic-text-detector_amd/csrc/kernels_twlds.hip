@@ -475,16 +475,20 @@ int g_tw_lds_runs_x10 = 25;     // "tail_lds_runs_x10"
 int g_tw_lds_threads = 512;     // "tail_lds_threads": 256 / 512 / 1024 threads per window (512: a third off the merge wait of a serial tail; end to end the three are equal, profiles/r06_twlds_knobs.txt)
 int tw_lds_rcap(int max_words) { return std::min(65000, std::max(1024, (int)((long long)max_words * g_tw_lds_runs_x10 / 10))); }
 
-void launch_tw_lds(const TWin* wins, const TBand* bands, const int* order, int n, int max_words, int rcap, int dilate, int* ovf,
+bool launch_tw_lds(const TWin* wins, const TBand* bands, const int* order, int n, int max_words, int rcap, int dilate, int* ovf,
                    hipStream_t st) {
-  if (n <= 0) return;
+  if (n <= 0) return true;
   TLdsArgs a;
   a.wins = wins, a.bands = bands, a.order = order, a.dilate = dilate, a.max_words = max_words;
   a.rcap = std::min(rcap, 65000), a.rlay = std::max(a.rcap, (max_words + 1) / 2);
   a.ovf = ovf;
   const size_t bytes = tw_lds_bytes(max_words, a.rcap);
-  if (bytes > 48 * 1024)                                       // more dynamic LDS than the default limit: the kernel has to ask
-    (void)hipFuncSetAttribute((const void*)tw_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  if (bytes > 48 * 1024 &&                                     // more dynamic LDS than the default limit: the kernel has to ask
+      hipFuncSetAttribute((const void*)tw_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) {
+    (void)hipGetLastError();
+    return false;                                              // the caller sends these windows through the canvas path
+  }
   const int nt = g_tw_lds_threads >= 1024 ? 1024 : (g_tw_lds_threads >= 512 ? 512 : 256);
   hipLaunchKernelGGL(tw_lds_kernel, dim3(n), dim3(nt), bytes, st, a);
+  return true;
 }

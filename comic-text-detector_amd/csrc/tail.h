@@ -86,7 +86,8 @@ void launch_tw_commit(const TWin* wins, int n, int max_pix, const uint8_t* merge
 // labelling; ovf[window] = 1 where a labelling had more runs (nothing committed for that window)
 size_t tw_lds_bytes(int max_words, int rcap);
 int tw_lds_rcap(int max_words);
-void launch_tw_lds(const TWin* wins, const TBand* bands, const int* order, int n, int max_words, int rcap, int dilate, int* ovf,
+// (false: the launch could not get its LDS -- nothing was enqueued)
+bool launch_tw_lds(const TWin* wins, const TBand* bands, const int* order, int n, int max_words, int rcap, int dilate, int* ovf,
                    hipStream_t st);
 // mask[p] = 0 where refined[p] > thr (reference utils/textmask.py:136)
 void launch_mask_clear_where(uint8_t* mask, const uint8_t* refined, long long n, int thr, hipStream_t st);

@@ -307,6 +307,7 @@ struct ctd_tail {
   int host_threads = 8;               // threads of the per-page / per-window host loops
   // refine windows of the last run by path: window-local kernel, canvas path (too big, or after an overflow), overflows
   int n_lds = 0, n_canvas = 0, n_ovf = 0;
+  long long lds_per_block = 64 << 10;  // hipDeviceAttributeMaxSharedMemoryPerBlock (160 KB on gfx950)
   double ms_lds_wait = 0;             // waiting for the window-local merge kernel's overflow flags
 };
 
@@ -540,15 +541,16 @@ int refine_windows(ctd_tail* t, const std::vector<WinReq>& reqs, int refine_mode
   }
   const int nbands = (int)bands.size();
   // ---- who goes where: by the LDS a window's planes + run table need
+  const long long lds_max = std::min(g_tail_lds_max_bytes, t->lds_per_block - 2048);
   std::vector<int> lds_win, canvas_win;
   std::vector<int> words(n);
   for (int i = 0; i < n; ++i) {
     words[i] = ((ww[i] + 31) >> 5) * wh[i];
     const int rc = g_tail_lds_rcap > 0 ? g_tail_lds_rcap : tw_lds_rcap(words[i]);
-    if (g_tail_lds && (long long)tw_lds_bytes(words[i], std::max(rc, (words[i] + 1) / 2)) <= g_tail_lds_max_bytes) lds_win.push_back(i);
+    if (g_tail_lds && (long long)tw_lds_bytes(words[i], std::max(rc, (words[i] + 1) / 2)) <= lds_max) lds_win.push_back(i);
     else canvas_win.push_back(i);
   }
-  const int nl = (int)lds_win.size();
+  int nl = (int)lds_win.size();
   int* hovf = nullptr;
   if (nl) {
     std::stable_sort(lds_win.begin(), lds_win.end(), [&](int a, int b) { return words[a] < words[b]; });
@@ -565,7 +567,8 @@ int refine_windows(ctd_tail* t, const std::vector<WinReq>& reqs, int refine_mode
     bt.fill(dl + n, 0, sizeof(int) * n);
     bt.flush();
     // up to three launches: a block's dynamic LDS is its launch's largest window's, and small blocks share a CU
-    const long long cls[3] = {g_tail_lds_cls0, g_tail_lds_cls1, g_tail_lds_max_bytes};
+    const long long cls[3] = {g_tail_lds_cls0, g_tail_lds_cls1, lds_max};
+    std::vector<int> refused;                               // a launch that did not get its LDS: those windows take the canvases
     int k0 = 0;
     for (int c = 0; c < 3 && k0 < nl; ++c) {
       int k1 = k0;
@@ -577,13 +580,24 @@ int refine_windows(ctd_tail* t, const std::vector<WinReq>& reqs, int refine_mode
       while (k1 < nl && (c == 2 || need(k1) <= cls[c])) ++k1;
       if (k1 > k0) {
         const int mw = words[lds_win[k1 - 1]];
-        launch_tw_lds(dw, db, dl + k0, k1 - k0, mw, g_tail_lds_rcap > 0 ? g_tail_lds_rcap : tw_lds_rcap(mw),
-                      refine_mode == 0 ? 1 : 0, dl + n, st);
+        if (!launch_tw_lds(dw, db, dl + k0, k1 - k0, mw, g_tail_lds_rcap > 0 ? g_tail_lds_rcap : tw_lds_rcap(mw),
+                           refine_mode == 0 ? 1 : 0, dl + n, st))
+          for (int k = k0; k < k1; ++k) refused.push_back(lds_win[k]);
       }
       k0 = k1;
     }
     T_TRY(bt.d2h(hovf, dl + n, sizeof(int) * n));
     bt.flush();
+    if (!refused.empty()) {
+      std::sort(refused.begin(), refused.end());
+      canvas_win.insert(canvas_win.end(), refused.begin(), refused.end());
+      std::sort(canvas_win.begin(), canvas_win.end());
+      std::vector<int> kept;
+      for (int i : lds_win)
+        if (!std::binary_search(refused.begin(), refused.end(), i)) kept.push_back(i);
+      lds_win.swap(kept);
+      nl = (int)lds_win.size();
+    }
   }
   if (int rc = refine_canvas(t, hw, bands, canvas_win, refine_mode)) return rc;
   const double tr4 = now_ms();
@@ -978,6 +992,9 @@ int ctd_tail_create(ctd_tail** out, int32_t device) {
     delete t;
     return ctd_fail_msg(CTD_ERR_HIP, "hipStreamCreateWithPriority failed");
   }
+  // what one block may hold of the CU's LDS on this device: the window-local merge kernel's launches stay below it
+  int smem = 0;
+  if (hipDeviceGetAttribute(&smem, hipDeviceAttributeMaxSharedMemoryPerBlock, device) == hipSuccess && smem > 0) t->lds_per_block = smem;
   *out = t;
   return CTD_OK;
 }

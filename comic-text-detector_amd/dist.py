@@ -27,7 +27,12 @@ def env_world() -> Tuple[int, int, int]:
 def init(backend: Optional[str] = None, force: bool = False) -> Tuple[int, int, int]:
     """Joins the process group of the torchrun environment.  A single process has no group and no collective on its data
     path -- unless `force=True`, which gives it a world-size-1 group of `backend` so that the N > 1 code (RCCL communicator
-    on this rank's device, the record gather on the communication stream) runs on the one GPU that is there."""
+    on this rank's device, the record gather on the communication stream) runs on the one GPU that is there.
+
+    CALL IT AFTER the detector and its pipeline exist (`TextDetector(...)`, the first `detect_stream` / `warm_tails`): RCCL
+    creates streams of its own when the communicator starts, and HIP streams beyond the runtime's hardware queues share a
+    queue with an earlier one -- with the group initialised FIRST the end-to-end step measured 20 % slower for the whole
+    life of the process (2480-2590 against 3134 pages/s, profiles/r06_rccl_init_order.txt), with or without a gather."""
     rank, local_rank, world = env_world()
     if (world > 1 or force) and not dist.is_initialized():
         if backend is None:
@@ -139,21 +144,118 @@ def unpack_results(rec: torch.Tensor):
     return out
 
 
+class GatherHandle:
+    """A record gather in flight (`gather_results_async`).  Nothing here touches the GPU from the host until `result()`:
+    the true block / line counts of every page ride back to page-locked host memory behind the collective, and an event
+    marks the end -- so a pipelined caller never waits on a stream that is busy with the next forwards."""
+
+    def __init__(self, out, counts_host, event, redo, shape=None):
+        self.out, self._counts, self._event, self._redo, self._shape = out, counts_host, event, redo, shape
+
+    def done(self) -> bool:
+        return self._event is None or self._event.query()
+
+    def result(self) -> torch.Tensor:
+        """The gathered records (n_total, R) in global page order.  Waits for the collective; when some page of some rank
+        did not fit the compact capacities (every rank sees that in the same counts) the gather is repeated at the
+        worst-case capacities, synchronously -- rare."""
+        if self._event is not None:
+            self._event.synchronize()
+            self._event = None
+        if self._redo is not None:
+            c = self._counts
+            over = c.shape[0] > 0 and bool(((c[:, 0] > CAP_BLK) | (c[:, 1] > CAP_LINE)).any())
+            redo, self._redo = self._redo, None
+            if over:
+                self.out, self._shape = redo(), None
+        if self._shape is not None:                          # the ring slot's padded (world * per) rows -> global page order
+            n_total, world = self._shape
+            self.out, self._shape = _unpad(self.out, n_total, world), None
+        return self.out
+
+
+def _unpad(out: torch.Tensor, n_total: int, world: int) -> torch.Tensor:
+    per = -(-n_total // world)
+    parts = []
+    for r in range(world):
+        lo, hi = shard_range(n_total, r, world)
+        parts.append(out[r * per: r * per + (hi - lo)])
+    return torch.cat(parts, 0)
+
+
+class _Ring:
+    """Page-locked staging + device buffers of the record gather, allocated ONCE per (shard, capacities, device) and reused
+    round robin: `Tensor.pin_memory()` per step cost 5 ms of host time in the pipelined step (a fresh page-locked
+    allocation each time -- the caching allocator's blocks were still held by the uploads in flight) and stalled the
+    launching thread for a whole pipeline depth (bench.py --force-dist nccl: 32 ms per step instead of 10)."""
+    SLOTS = 12
+
+    def __init__(self, nloc, width, n_total, world, device):
+        per = -(-n_total // world)
+        self.slots = []
+        for _ in range(self.SLOTS):
+            self.slots.append(dict(host=torch.zeros((nloc, width), dtype=torch.float64).pin_memory(),
+                                   pad=torch.zeros((per, width), dtype=torch.float64, device=device),
+                                   out=torch.empty((world * per, width), dtype=torch.float64, device=device),
+                                   counts=torch.zeros((world * per, 2), dtype=torch.float64).pin_memory(), ev=None))
+            self.slots[-1]["host_np"] = self.slots[-1]["host"].numpy()
+        self.k = 0
+
+    def take(self):
+        s = self.slots[self.k % self.SLOTS]
+        self.k += 1
+        if s["ev"] is not None:
+            s["ev"].synchronize()                            # twelve gathers ago: long done
+        return s
+
+
+_rings = {}
+
+
+def gather_results_async(results, n_total: int, rank: int, world: int, device=None, pin: bool = False,
+                         force: bool = False) -> GatherHandle:
+    """The data path's collective, enqueued and NOT waited for: all-gather of this rank's page records at the COMPACT
+    capacities (CAP_BLK blocks, CAP_LINE lines: 4.6x fewer bytes than the worst case, host packing included) on the
+    current stream.  Over gloo the records never leave the host (no device work at all)."""
+    gloo = dist.is_initialized() and dist.get_backend() == "gloo"
+    dev = None if gloo else device
+    grouped = dist.is_initialized() and (world > 1 or force)
+
+    def one(cb, cl):                                         # the plain path: host records, or the (rare) worst-case re-gather
+        rec = pack_results(results, None, cb, cl)
+        if dev is not None:
+            rec = (rec.pin_memory() if pin else rec).to(dev, non_blocking=pin)
+        return gather_records(rec, n_total, rank, world, force)
+
+    redo = lambda: one(MAX_BLK, MAX_BLK)                    # noqa: E731
+    if dev is None or not grouped or not results:
+        out = one(CAP_BLK, CAP_LINE)
+        return GatherHandle(out, out[:, :2].cpu() if out.is_cuda else out[:, :2], None, redo)
+    rec = pack_results(results, None, CAP_BLK, CAP_LINE)     # host, (nloc, width)
+    key = (rec.shape[0], rec.shape[1], n_total, world, str(dev))
+    ring = _rings.get(key)
+    if ring is None:
+        ring = _rings[key] = _Ring(rec.shape[0], rec.shape[1], n_total, world, dev)
+    s = ring.take()
+    # numpy, not `Tensor.copy_`: torch's CPU copy runs on the intra-op thread pool, which the tail workers' native threads
+    # keep busy -- 9.7 ms for these 1.4 MB inside the pipelined step (and `pin_memory()` 5 ms), 0.1 ms this way
+    import numpy as np
+    np.copyto(s["host_np"], rec.numpy())
+    s["pad"][: rec.shape[0]].copy_(s["host"], non_blocking=True)
+    dist.all_gather_into_tensor(s["out"], s["pad"])
+    s["counts"].copy_(s["out"][:, :2], non_blocking=True)    # behind the collective, on the same stream
+    ev = torch.cuda.Event()
+    ev.record(torch.cuda.current_stream(s["out"].device))
+    s["ev"] = ev
+    return GatherHandle(s["out"], s["counts"], ev, redo, (n_total, world))
+
+
 def gather_results(results, n_total: int, rank: int, world: int, device=None, pin: bool = False,
                    force: bool = False) -> torch.Tensor:
-    """The data path's collective: all-gather of this rank's page records at the COMPACT capacities (CAP_BLK blocks,
-    CAP_LINE lines: 4.6x fewer bytes than the worst case, host packing included).  Every rank sees every page's true
-    counts in the gathered tensor, so all ranks agree without further communication on whether some page did not fit
-    -- only then the gather is repeated at the worst-case capacities (MAX_BLK)."""
-    def one(cb, cl):
-        rec = pack_results(results, None, cb, cl)
-        if device is not None:
-            rec = (rec.pin_memory() if pin else rec).to(device, non_blocking=pin)
-        return gather_records(rec, n_total, rank, world, force)
-    out = one(CAP_BLK, CAP_LINE)
-    if out.shape[0] and bool(((out[:, 0] > CAP_BLK) | (out[:, 1] > CAP_LINE)).any()):
-        out = one(MAX_BLK, MAX_BLK)
-    return out
+    """`gather_results_async(...).result()`: every rank ends up with every page's records; all ranks agree without further
+    communication on whether some page did not fit the compact record -- only then the gather is repeated at the
+    worst-case capacities (MAX_BLK)."""
+    return gather_results_async(results, n_total, rank, world, device, pin, force).result()
 
 
 def gather_records(rec: torch.Tensor, n_total: int, rank: int, world: int, force: bool = False) -> torch.Tensor:
@@ -165,7 +267,7 @@ def gather_records(rec: torch.Tensor, n_total: int, rank: int, world: int, force
         return rec
     per = -(-n_total // world)
     home = rec.device
-    if dist.get_backend() == "gloo" and rec.is_cuda:        # gloo gathers host tensors
+    if dist.get_backend() == "gloo" and rec.is_cuda:        # gloo gathers host tensors (callers with host records never get here)
         rec = rec.cpu()
     pad = torch.zeros((per, rec.shape[1]), dtype=rec.dtype, device=rec.device)
     pad[: rec.shape[0]] = rec

@@ -15,10 +15,14 @@ from test_dist import _page_blocks                         # noqa: E402  (native
 
 
 def gather(D, results, dev, stream):
+    """the pipelined step's form: enqueued on the communication stream, resolved later"""
     n = len(results)
     with torch.cuda.stream(stream):
-        out = D.gather_results(results, n, 0, 1, device=dev, pin=True, force=True)
+        h = D.gather_results_async(results, n, 0, 1, device=dev, pin=True, force=True)
+    with torch.cuda.stream(stream):
+        out = h.result()
     stream.synchronize()
+    assert h.done()
     return out
 
 
@@ -36,7 +40,7 @@ def main():
         for crowded in (0, n_total):
             results = [(None, None, _page_blocks(i, crowded)) for i in range(n_total)]
             out = gather(D, results, dev, comm)
-            assert out.is_cuda and out.shape[0] == n_total
+            assert out.is_cuda == (backend == "nccl") and out.shape[0] == n_total      # over gloo the records stay on the host
             cap = D.MAX_BLK if crowded else D.CAP_BLK
             assert int(out[0, 2]) == cap, (backend, crowded, int(out[0, 2]))       # compact unless a page did not fit
             ref = D.pack_results(results, None, cap, D.MAX_BLK if crowded else D.CAP_LINE)

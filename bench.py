@@ -213,7 +213,9 @@ class Pipeline:
         with torch.cuda.stream(self.comm_stream):
             self.handles.append(self.D.gather_results_async(res, self.total_pages, self.rank, self.world, device=self.dev, pin=True,
                                                             force=self.world == 1))
-            while self.handles and (self.handles[0].done() or len(self.handles) > 2 * self.depth):
+            # resolved at a FIXED lag, not "when done": a page that does not fit the compact record makes `result()` issue a second
+            # collective, and every rank must issue it at the same place of its sequence of collectives
+            while len(self.handles) > self.depth:
                 self.gathered = self.handles.popleft().result()
         self.stats["gather_s"] = self.stats.get("gather_s", 0.0) + (time.perf_counter() - tg)
 

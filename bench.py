@@ -928,7 +928,23 @@ def main() -> None:
     # them shares hardware queues badly -- the same pipeline ran at 2480-2590 pages/s with the group initialised first and at
     # 3134 with it initialised here (profiles/r06_rccl_init_order.txt).  Rank and world come from the environment.
     rank, local_rank, world = D.env_world()
-    join = lambda: D.init(args.force_dist or None, force=bool(args.force_dist))      # noqa: E731
+    def join():
+        # librccl prints its version banner (five lines) to STDOUT when the communicator starts; rank 0's stdout carries ONE
+        # JSON line, so the file descriptor points at stderr while the group is joined
+        sys.stdout.flush()
+        saved = os.dup(1)
+        try:
+            os.dup2(2, 1)
+            return D.init(args.force_dist or None, force=bool(args.force_dist))
+        finally:
+            sys.stdout.flush()
+            try:                                             # the banner sits in C stdio's buffer: flush it while fd 1 is stderr
+                import ctypes
+                ctypes.CDLL(None).fflush(None)
+            except Exception:
+                pass
+            os.dup2(saved, 1)
+            os.close(saved)
     if world != args.gpus and rank == 0:
         print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
     n_gpus = world

@@ -237,3 +237,53 @@ def test_one_process_drives_detectors_on_two_devices():
             assert sig == ref, f"iteration {it} on {det.device}"
     for det in dets:
         det.close()
+
+
+def _worker_async(rank, world, port, q):
+    """Six pipelined steps of `gather_results_async`, handles resolved at a fixed lag of two steps (bench.Pipeline's rule);
+    step 3 carries a page that does not fit the compact record on rank 1 only -- every rank must then issue the re-gather at
+    the same place of its sequence of collectives, or the group hangs."""
+    import sys
+    from collections import deque
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    D = pkg().dist
+    r, lr, w = D.init("gloo")
+    n_total, lag = 4, 2
+    lo, hi = D.shard_range(n_total, r, w)
+    handles, caps, ok = deque(), [], True
+    for step in range(6):
+        crowded = n_total if step == 3 else 0                       # the last page (rank 1's) is crowded in step 3
+        results = [(None, None, _page_blocks(10 * step + i, crowded and (crowded if i == n_total - 1 else 0))) for i in range(lo, hi)]
+        if crowded and r == w - 1:
+            blks = results[-1][2]
+            results[-1] = (None, None, (blks * (D.CAP_BLK // max(len(blks), 1) + 2))[: D.CAP_BLK + 5])
+        handles.append((step, D.gather_results_async(results, n_total, r, w)))
+        while len(handles) > lag:
+            s, h = handles.popleft()
+            out = h.result()
+            caps.append((s, int(out[0, 2])))
+    while handles:
+        s, h = handles.popleft()
+        caps.append((s, int(h.result()[0, 2])))
+    want = [(s, D.MAX_BLK if s == 3 else D.CAP_BLK) for s in range(6)]
+    q.put((rank, caps == want, caps))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gloo_world2_async_gathers_resolved_at_a_fixed_lag():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_async, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank, ok, caps in res:
+        assert ok, f"rank {rank}: capacities per step {caps}"

@@ -110,7 +110,8 @@ def test_bare_api_consumer_runs_at_the_bench_pipeline_rate():
     assert pipe.stats["blocks"] > 0
     # Both loops ARE `detect_stream` (asserted above), so what is compared is two samples of one distribution: alone in a
     # process 0.5-s passes agree within 1 % (2936 / 2920 / 2922 vs 2931 / 2915 / 2922, profiles/r06_pytest_rccl_and_api_rate.txt),
-    # late in the full suite (other detectors alive, warm allocator) they scatter by +-5 % -- medians of five, 6 %
-    assert float(np.median(api)) >= 0.94 * float(np.median(ref)), (api, ref)
+    # late in the full suite (other detectors alive, warm allocator) they scatter by +-5 % -- medians of five, and the bar
+    # of the soak test above (10 %: between that noise and the -20 % cliff of a mis-tuned process)
+    assert float(np.median(api)) >= 0.90 * float(np.median(ref)), (api, ref)
     det.close(drain=True)
     gc.unfreeze()

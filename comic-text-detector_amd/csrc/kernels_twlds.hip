@@ -66,9 +66,9 @@ __device__ __forceinline__ Row3 row3(const unsigned* p, const Geo& g, int y, int
   return r;
 }
 template <int K> __device__ __forceinline__ unsigned shk(const Row3& r) {
-  if (K == 0) return r.cur;
-  if (K > 0) return (r.cur >> K) | (r.nxt << (32 - K));
-  return (r.cur << -K) | (r.prev >> (32 + K));
+  if constexpr (K == 0) return r.cur;
+  else if constexpr (K > 0) return (r.cur >> K) | (r.nxt << (32 - K));
+  else return (r.cur << -K) | (r.prev >> (32 + K));
 }
 __device__ __forceinline__ unsigned ring3(const Row3& r) { return shk<-1>(r) | r.cur | shk<1>(r); }
 
@@ -160,10 +160,21 @@ __global__ __launch_bounds__(TL_MAXT) void tw_lds_kernel(TLdsArgs a) {
   unsigned* const red = parent + 2 * RL;           // [0..15] wave partials, [16..18] top-2 table
   unsigned* const tmp = parent;                    // a scratch plane where no run table is live (2 * rlay >= max_words)
   auto validw = [&](int wi) { return wi == g.wp - 1 ? g.last : 0xffffffffu; };
+  // every word i = t, t + NT, ... of the window with its (row, word in row): one division per thread for the whole kernel
+  // (a pass has 2-4 words per thread and there are ~45 passes: `i / wp` per word was a tenth of the kernel's instructions)
+  const int y_t = t / g.wp, wi_t = t - y_t * g.wp;
+  const int dy_t = TL_NT / g.wp, dwi_t = TL_NT - dy_t * g.wp;
+  auto for_words = [&](auto&& fn) {
+    int y = y_t, wi = wi_t;
+    for (int i = t; i < g.words; i += TL_NT) {
+      fn(i, y, wi);
+      wi += dwi_t, y += dy_t;
+      if (wi >= g.wp) wi -= g.wp, ++y;
+    }
+  };
 
   // ---- the prediction: b = mask > 60, then the 3x3 cross erosion as AND of the five neighbours (outside the window: ones)
-  for (int i = t; i < g.words; i += TL_NT) {
-    const int y = i / g.wp, wi = i - y * g.wp;
+  for_words([&](int i, int y, int wi) {
     unsigned v[8];
     load32(w.mask + (size_t)(w.y1 + y) * w.mask_w + w.x1 + 32 * wi, g.W - 32 * wi, v);
     unsigned bits = 0;
@@ -171,17 +182,16 @@ __global__ __launch_bounds__(TL_MAXT) void tw_lds_kernel(TLdsArgs a) {
     for (int j = 0; j < 8; ++j) bits |= gt60_nibble(v[j]) << (4 * j);
     tmp[i] = bits & validw(wi);
     merged[i] = 0;
-  }
+  });
   __syncthreads();
-  for (int i = t; i < g.words; i += TL_NT) {
-    const int y = i / g.wp, wi = i - y * g.wp;
+  for_words([&](int i, int y, int wi) {
     auto ext = [&](int yy, int ww) -> unsigned {
       if ((unsigned)yy >= (unsigned)g.H || (unsigned)ww >= (unsigned)g.wp) return 0xffffffffu;
       return tmp[yy * g.wp + ww] | ~validw(ww);
     };
     const unsigned cur = ext(y, wi), prev = ext(y, wi - 1), nxt = ext(y, wi + 1);
     pred[i] = cur & ((cur << 1) | (prev >> 31)) & ((cur >> 1) | (nxt << 31)) & ext(y - 1, wi) & ext(y + 1, wi) & validw(wi);
-  }
+  });
   __syncthreads();
 
   // ---- block-wide pieces shared by the candidate rounds and the hole filling -------------------------------------------
@@ -220,16 +230,17 @@ __global__ __launch_bounds__(TL_MAXT) void tw_lds_kernel(TLdsArgs a) {
       int wi = i0 % g.wp, run = before;
       for (int i = i0; i < i1; ++i) {
         base[i] = (unsigned short)run;
-        run += __popc(starts_of(i, wi));
+        const int n = __popc(starts_of(i, wi));
+        for (int k = run; k < run + n && k < RL; ++k) parent[k] = (unsigned)k, acc[k] = 0;   // the runs that start in this word
+        run += n;
         if (++wi == g.wp) wi = 0;
       }
     }
     __syncthreads();
     return total;
   };
-  auto rid_of = [&](int i, int wi, int p) -> unsigned {      // the run covering set pixel p of word i
-    return (unsigned)base[i] + (unsigned)__popc(starts_of(i, wi) & upto(p)) - 1u;
-  };
+  // the run covering set pixel p of a word with run starts `s` and prefix `b`
+  auto rid_from = [](unsigned b, unsigned s, int p) -> unsigned { return b + (unsigned)__popc(s & upto(p)) - 1u; };
   // every group of set bits of word i: fn(lowest bit, group mask)
   auto for_groups = [&](unsigned v, auto&& fn) {
     while (v) {
@@ -239,37 +250,37 @@ __global__ __launch_bounds__(TL_MAXT) void tw_lds_kernel(TLdsArgs a) {
       v &= ~grp;
     }
   };
-  // 8-connected unions of every word-local group with the row above (one halo bit either side) + fn(i, wi, p, grp, rid)
+  // 8-connected unions of every word-local group with the row above (one halo bit either side) + fn(i, grp, rid)
   auto link_and = [&](auto&& fn) {
-    for (int i = t; i < g.words; i += TL_NT) {
+    for_words([&](int i, int y, int wi) {
       const unsigned c = cand[i];
-      if (!c) continue;
-      const int y = i / g.wp, wi = i - y * g.wp;
-      unsigned up = 0, ul = 0, ur = 0;
+      if (!c) return;
+      const unsigned cl = wi > 0 ? cand[i - 1] : 0u;
+      const unsigned sc = c & ~((c << 1) | (cl >> 31)), bc = base[i];
+      unsigned up = 0, ul = 0, ur = 0, su = 0, bu = 0;
       if (y > 0) {
         up = cand[i - g.wp];
         if (wi > 0) ul = cand[i - g.wp - 1];
         if (wi + 1 < g.wp) ur = cand[i - g.wp + 1];
+        su = up & ~((up << 1) | (ul >> 31));
+        bu = base[i - g.wp];
       }
       for_groups(c, [&](int p, unsigned grp) {
-        const unsigned me = rid_of(i, wi, p);
-        fn(i, wi, p, grp, me);
+        const unsigned me = rid_from(bc, sc, p);
+        fn(i, grp, me);
         if (y == 0) return;
         const unsigned an = up & (grp | (grp << 1) | (grp >> 1));
         unsigned reps = an & ~(an << 1);
         while (reps) {
           const int q = __ffs((int)reps) - 1;
           reps &= reps - 1;
-          uf_union(parent, me, rid_of(i - g.wp, wi, q));
+          uf_union(parent, me, rid_from(bu, su, q));
         }
-        if ((grp & 1u) && (ul >> 31)) uf_union(parent, me, (unsigned)base[i - g.wp] - 1u);
-        if ((grp >> 31) && (ur & 1u)) uf_union(parent, me, rid_of(i - g.wp + 1, wi + 1, 0));
+        if ((grp & 1u) && (ul >> 31)) uf_union(parent, me, bu - 1u);
+        // the run covering bit 0 of the word above-right: it starts there unless the word above ends set
+        if ((grp >> 31) && (ur & 1u)) uf_union(parent, me, (unsigned)base[i - g.wp + 1] + ((up >> 31) ? 0u : 1u) - 1u);
       });
-    }
-  };
-  auto init_runs = [&](int n) {
-    for (int i = t; i < n; i += TL_NT) parent[i] = (unsigned)i, acc[i] = 0;
-    __syncthreads();
+    });
   };
   auto fold_to_roots = [&](int n) {                              // acc of every run into its root's
     for (int i = t; i < n; i += TL_NT) {
@@ -282,16 +293,17 @@ __global__ __launch_bounds__(TL_MAXT) void tw_lds_kernel(TLdsArgs a) {
     __syncthreads();
   };
   auto or_accepted = [&]() {                                     // merged |= groups whose root's acc > 0
-    for (int i = t; i < g.words; i += TL_NT) {
+    for_words([&](int i, int, int wi) {
       const unsigned c = cand[i];
-      if (!c) continue;
-      const int wi = i % g.wp;
+      if (!c) return;
+      const unsigned cl = wi > 0 ? cand[i - 1] : 0u;
+      const unsigned sc = c & ~((c << 1) | (cl >> 31)), bc = base[i];
       unsigned add = 0;
       for_groups(c, [&](int p, unsigned grp) {
-        if (acc[uf_find(parent, rid_of(i, wi, p))] > 0) add |= grp;
+        if (acc[uf_find(parent, rid_from(bc, sc, p))] > 0) add |= grp;
       });
       if (add) merged[i] |= add;
-    }
+    });
     __syncthreads();
   };
   bool overflow = false;
@@ -300,8 +312,7 @@ __global__ __launch_bounds__(TL_MAXT) void tw_lds_kernel(TLdsArgs a) {
   for (int r = 0; r < w.nband && !overflow; ++r) {
     const TBand bd = a.bands[w.band0 + r];
     // ---- render: cv2.inRange(grey, lo, hi) / threshold(channel, lo), the polarity minxor_thresh picked
-    for (int i = t; i < g.words; i += TL_NT) {
-      const int y = i / g.wp, wi = i - y * g.wp;
+    for_words([&](int i, int y, int wi) {
       const int npx = min(32, g.W - 32 * wi);
       const uint8_t* src = w.img + ((size_t)(w.y1 + y) * w.img_w + w.x1 + 32 * wi) * 3;
       unsigned v[24];
@@ -326,11 +337,10 @@ __global__ __launch_bounds__(TL_MAXT) void tw_lds_kernel(TLdsArgs a) {
       }
       if (bd.invert) bits = ~bits;
       tmp[i] = bits & validw(wi);
-    }
+    });
     __syncthreads();
     // ---- minus the components whose bounding box has fewer than 3 pixels (:97): 1x1, 2x1, 1x2
-    for (int i = t; i < g.words; i += TL_NT) {
-      const int y = i / g.wp, wi = i - y * g.wp;
+    for_words([&](int i, int y, int wi) {
       const Row3 c0 = row3(tmp, g, y, wi);
       unsigned out = c0.cur;
       if (out) {
@@ -344,16 +354,15 @@ __global__ __launch_bounds__(TL_MAXT) void tw_lds_kernel(TLdsArgs a) {
         out = cur & ~(single | hl | hr | vt | vb);
       }
       cand[i] = out;
-    }
+    });
     __syncthreads();
     const int nr = scan_runs();
     if (nr > RC) {
       overflow = true;
       break;
     }
-    init_runs(nr);
     // ---- unions + every group's weight: not-yet-merged pixels that are predicted text minus those that are not
-    link_and([&](int i, int, int, unsigned grp, unsigned me) {
+    link_and([&](int i, unsigned grp, unsigned me) {
       const unsigned nm = grp & ~merged[i];
       const int wgt = __popc(nm & pred[i]) - __popc(nm & ~pred[i]);
       if (wgt) atomicAdd(acc + me, wgt);
@@ -366,8 +375,7 @@ __global__ __launch_bounds__(TL_MAXT) void tw_lds_kernel(TLdsArgs a) {
   // ================= dilation (:110-111), hole filling (:113-131) =========================================================
   if (!overflow) {
     if (a.dilate) {
-      for (int i = t; i < g.words; i += TL_NT) {
-        const int y = i / g.wp, wi = i - y * g.wp;
+      for_words([&](int i, int y, int wi) {
         unsigned v = 0;
 #pragma unroll
         for (int dy = -1; dy <= 1; ++dy) {
@@ -375,16 +383,16 @@ __global__ __launch_bounds__(TL_MAXT) void tw_lds_kernel(TLdsArgs a) {
           v |= ring3(r);
         }
         tmp[i] = v & validw(wi);
-      }
+      });
       __syncthreads();
     }
     unsigned cnt = 0;
-    for (int i = t; i < g.words; i += TL_NT) {
+    for_words([&](int i, int, int wi) {
       const unsigned m = a.dilate ? tmp[i] : merged[i];
       merged[i] = m;
-      cand[i] = ~m & validw(i % g.wp);
+      cand[i] = ~m & validw(wi);
       cnt += (unsigned)__popc(m);
-    }
+    });
     for (int off = 32; off > 0; off >>= 1) cnt += __shfl_down(cnt, off);
     __syncthreads();                                           // tmp (= parent) is free; red[] was last read before the previous barrier
     if (lane == 0) red[wave] = cnt;
@@ -397,8 +405,7 @@ __global__ __launch_bounds__(TL_MAXT) void tw_lds_kernel(TLdsArgs a) {
     if (nr > RC) {
       overflow = true;
     } else {
-      init_runs(nr);
-      link_and([&](int, int, int, unsigned grp, unsigned me) { atomicAdd(acc + me, __popc(grp)); });
+      link_and([&](int, unsigned grp, unsigned me) { atomicAdd(acc + me, __popc(grp)); });
       __syncthreads();
       fold_to_roots(nr);
       // area threshold = second largest of {a0} U {areas of the components} (sorted_area[-2])
@@ -421,15 +428,16 @@ __global__ __launch_bounds__(TL_MAXT) void tw_lds_kernel(TLdsArgs a) {
         for (int i = t; i < nr; i += TL_NT)
           if (parent[i] == (unsigned)i) acc[i] = (long long)acc[i] < thr ? 0 : -(1 << 30);
         __syncthreads();
-        for (int i = t; i < g.words; i += TL_NT) {
+        for_words([&](int i, int, int wi) {
           const unsigned c = cand[i];
-          if (!c) continue;
-          const int wi = i % g.wp;
+          if (!c) return;
+          const unsigned cl = wi > 0 ? cand[i - 1] : 0u;
+          const unsigned sc = c & ~((c << 1) | (cl >> 31)), bc = base[i];
           for_groups(c, [&](int p, unsigned grp) {
             const int wgt = __popc(grp & pred[i]) - __popc(grp & ~pred[i]);
-            if (wgt) atomicAdd(acc + uf_find(parent, rid_of(i, wi, p)), wgt);
+            if (wgt) atomicAdd(acc + uf_find(parent, rid_from(bc, sc, p)), wgt);
           });
-        }
+        });
         __syncthreads();
         or_accepted();
       }
@@ -440,10 +448,9 @@ __global__ __launch_bounds__(TL_MAXT) void tw_lds_kernel(TLdsArgs a) {
     return;
   }
   // ================= refined[y1:y2, x1:x2] |= merged (:167); windows may overlap -> word-wide atomic OR =================
-  for (int i = t; i < g.words; i += TL_NT) {
+  for_words([&](int i, int y, int wi) {
     const unsigned m = merged[i];
-    if (!m) continue;
-    const int y = i / g.wp, wi = i - y * g.wp;
+    if (!m) return;
     const size_t idx0 = (size_t)(w.y1 + y) * w.out_w + w.x1 + 32 * wi;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -458,7 +465,7 @@ __global__ __launch_bounds__(TL_MAXT) void tw_lds_kernel(TLdsArgs a) {
       if ((unsigned)v2) atomicOr(ap, (unsigned)v2);
       if ((unsigned)(v2 >> 32)) atomicOr(ap + 1, (unsigned)(v2 >> 32));
     }
-  }
+  });
 }
 
 }  // namespace

@@ -84,7 +84,13 @@ def host_info() -> dict:
         avail = len(os.sched_getaffinity(0))
     except AttributeError:
         avail = os.cpu_count() or 1
-    return {"cpu_model": model, "logical_cpus": os.cpu_count(), "usable_cpus": avail}
+    # the container's CFS quota (a 1-GPU box of this pool: 16 CPUs under an affinity mask of 256): threads beyond it are
+    # throttled, not run -- the CPU legs size themselves on it
+    quota = importlib.import_module("comic-text-detector_amd.detector").cgroup_cpu_quota()
+    out = {"cpu_model": model, "logical_cpus": os.cpu_count(), "usable_cpus": min(avail, int(quota)) if quota >= 1 else avail}
+    if quota > 0:
+        out["affinity_cpus"], out["cgroup_cpu_quota"] = avail, round(quota, 2)
+    return out
 
 
 def thread_budget(world: int, pinned: bool = False, host_cpus: int = 0) -> dict:
@@ -153,6 +159,7 @@ class Pipeline:
         self.lpool = det._pool("load", self.loaders) if host_input else None
         self.comm_stream = torch.cuda.Stream(dev) if self.gather else None      # the record gather's stream
         self.stats = {"blocks": 0, "lines": 0, "pages": 0, "cpu_cores": 0.0, "gather_s": 0.0}
+        self.tfin = deque(maxlen=4096)                       # when each batch's results came back (perf_counter): the line's jitter evidence
         self.k = 0                                           # batches rotate across calls too
         self.fixed_job = None
         self.fwd_stream = None
@@ -200,6 +207,7 @@ class Pipeline:
             # ... and off the launching thread: ONE communication thread enqueues the collectives in step order (every rank in
             # the same order) and resolves them; this thread only hands the batch over
             self.gathers.append(self.cpool.submit(self._gather, res))
+        self.tfin.append(time.perf_counter())
         self.stats["pages"] += len(res)
         self.stats["blocks"] += sum(len(r[2]) for r in res)
         # lazy results: the counts come from the native records (no TextBlock is built for the bookkeeping)
@@ -1048,6 +1056,11 @@ def main() -> None:
     # process is in the second state; `config.spinup_steps` records it and `--spinup 0` gives the cold number.
     dt = timed(run_steps, args.steps, args.warmup, args.spinup, world, dev, pipe.stats)
     stats = dict(pipe.stats)
+    # intervals between the timed steps' result deliveries: a 20-step region is 0.2 s, one late batch (a noisy host) is 5 % of it
+    tf = list(pipe.tfin)[-args.steps:] if e2e else []
+    gaps = sorted((b - a) * 1e3 for a, b in zip(tf, tf[1:]))
+    delivery = ({"median_ms": round(gaps[len(gaps) // 2], 3), "max_ms": round(gaps[-1], 3), "min_ms": round(gaps[0], 3),
+                 "steady_pages_per_s": round(nloc * world * 1e3 / gaps[len(gaps) // 2], 1)} if len(gaps) >= 3 else None)
 
     if rank == 0:
         # ---- one un-pipelined step: where a batch's time goes.  The tail runs on one of the pipeline's own worker threads
@@ -1196,6 +1209,7 @@ def main() -> None:
                        "blocks_per_page": round(stats["blocks"] / max(stats["pages"], 1), 2) if e2e else None,
                        "lines_per_page": round(stats["lines"] / max(stats["pages"], 1), 2) if e2e else None,
                        "host_cpu_cores_used": round(float(stats.get("cpu_cores", 0.0)), 2),
+                       "result_delivery_intervals": delivery,
                        "record_gather_ms_per_step": round(float(stats.get("gather_s", 0.0)) * 1e3 / max(args.steps, 1), 3),
                        "one_device_rehearsal": one_device, "tail_only": bool(args.tail_only and e2e),
                        "parallelism": f"dp{n_gpus} (pages sharded, no data-path collective except the final record "

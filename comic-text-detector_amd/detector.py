@@ -48,12 +48,41 @@ def usable_cpus() -> int:
         return os.cpu_count() or 1
 
 
+def cgroup_cpu_quota() -> float:
+    """CPUs' worth of time the container's CFS quota grants per scheduling period (cgroup v2 `cpu.max`, v1
+    `cpu.cfs_quota_us / cpu.cfs_period_us`); 0.0 = no quota.  The affinity mask does not show it: a 1-GPU box of the pool this
+    was built on reports 256 usable CPUs under `cpu.max = 1600000 100000` (16 CPUs), and a process group that runs past the
+    quota is frozen for the rest of the 100-ms period -- ten batches of this pipeline."""
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            q, p = f.read().split()[:2]
+        return 0.0 if q == "max" else float(q) / float(p)
+    except (OSError, ValueError):
+        pass
+    try:
+        with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f:
+            q = float(f.read())
+        with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+            p = float(f.read())
+        return q / p if q > 0 and p > 0 else 0.0
+    except (OSError, ValueError):
+        return 0.0
+
+
 def thread_budget(world: int = 1, pinned: bool = False, host_cpus: int = 0) -> dict:
     """Host threads one rank may use: the usable cores divided by the ranks on this host (an 8-rank node runs 8 of these
-    processes) -- or, once the rank is bound to its own CPUs (`affinity.apply`, N > 1), simply the CPUs it is bound to.
+    processes) -- or, once the rank is bound to its own CPUs (`affinity.apply`, N > 1), simply the CPUs it is bound to --
+    and never more than twice the rank's share of the container's CPU quota (`cgroup_cpu_quota`).
     Tail workers x native geometry threads + loaders + the launching thread must fit."""
     avail = usable_cpus()
-    per_rank = max(4, avail if pinned else avail // max(1, world))
+    share = avail if pinned else avail // max(1, world)
+    quota = cgroup_cpu_quota()
+    if quota > 0:
+        # threads up to TWICE the quota's share: the tail's threads are bursty (6-7 busy cores of 34 threads on the headline), and
+        # sizing them on the quota itself -- 3 geometry threads per worker under 16 CPUs instead of 8 -- left the headline where
+        # it was (3086-3110 pages/s) but cost the dense pages 9 % (2517-2690 against 2904-2988; profiles/r06_cpu_quota.txt)
+        share = min(share, 2 * int(quota) // max(1, world))
+    per_rank = max(4, share)
     if pinned and host_cpus:
         avail = host_cpus                                     # what the host offered before this rank bound itself
     # 4 workers where a rank has 16 CPUs or more: round 5 re-measured it after the forward got shorter -- on one box 3 = 4 on the
@@ -61,7 +90,10 @@ def thread_budget(world: int = 1, pinned: bool = False, host_cpus: int = 0) -> d
     # repetitions each, profiles/r05_e2e_workers_3_vs_4.txt); the dense pages decide
     workers = 4 if per_rank >= 16 else (3 if per_rank >= 8 else 2)
     native = max(1, min(8, (per_rank - 2) // workers))
-    return {"usable_cpus": avail, "per_rank": per_rank, "tail_workers": workers, "native_threads_per_worker": native}
+    out = {"usable_cpus": avail, "per_rank": per_rank, "tail_workers": workers, "native_threads_per_worker": native}
+    if quota > 0:
+        out["cgroup_cpu_quota"] = round(quota, 2)
+    return out
 
 
 _tuned = False

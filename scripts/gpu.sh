@@ -29,7 +29,8 @@ try:
     d = json.loads([l for l in open(sys.argv[1]) if l.startswith("{")][-1])
     c = d.get("config", {})
     print("  value", d.get("value"), d.get("unit"), "| ms/step", d.get("ms_per_step"), "| blocks/lines per page", c.get("blocks_per_page"), c.get("lines_per_page"),
-          "| net ms", (d.get("roofline") or {}).get("net_ms_per_step"), "| backbone frac", ((d.get("roofline") or {}).get("backbone") or {}).get("hbm_frac"))
+          "| net ms", (d.get("roofline") or {}).get("net_ms_per_step"), "| backbone frac", ((d.get("roofline") or {}).get("backbone") or {}).get("hbm_frac"),
+          "| deliveries", c.get("result_delivery_intervals"))
     s = d.get("serial_step")
     if s: print("  serial: forward", s["forward_ms"], "tail", s["tail_ms"], s.get("tail_stages_ms"))
     for k in ("parity_exact",):

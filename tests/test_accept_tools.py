@@ -77,6 +77,7 @@ def test_bench_thread_budget_and_torchrun_command(monkeypatch):
     bench = importlib.import_module("bench")
     DET = importlib.import_module("comic-text-detector_amd.detector")       # the budget is the product's (detect_stream(workers=0))
     monkeypatch.setattr(DET, "usable_cpus", lambda: 256)
+    monkeypatch.setattr(DET, "cgroup_cpu_quota", lambda: 0.0)
     assert DET.thread_budget() == bench.thread_budget(1)
     assert bench.thread_budget(1) == {"usable_cpus": 256, "per_rank": 256, "tail_workers": 4, "native_threads_per_worker": 8}
     b8 = bench.thread_budget(8)

@@ -65,6 +65,7 @@ def test_thread_budget_divides_the_host_between_ranks(monkeypatch):
     for cpus, world, want_workers in ((256, 1, 4), (256, 8, 4), (64, 8, 3), (16, 8, 2), (8, 1, 3)):
         DET = importlib.import_module("comic-text-detector_amd.detector")     # the product's budget (detect_stream(workers=0))
         monkeypatch.setattr(DET, "usable_cpus", lambda c=cpus: c)
+        monkeypatch.setattr(DET, "cgroup_cpu_quota", lambda: 0.0)
         tb = bench.thread_budget(world)
         assert tb["tail_workers"] == want_workers, (cpus, world, tb)
         if world > 1:                                     # a rank bound to its own CPUs (affinity.py) budgets on those
@@ -72,6 +73,46 @@ def test_thread_budget_divides_the_host_between_ranks(monkeypatch):
             assert pinned["per_rank"] == max(4, cpus) and pinned["usable_cpus"] == cpus * world
         assert tb["tail_workers"] * tb["native_threads_per_worker"] + 2 <= max(tb["per_rank"], tb["tail_workers"] + 2)
         assert 1 <= tb["native_threads_per_worker"] <= 8
+
+
+def test_thread_budget_respects_the_container_cpu_quota(monkeypatch, tmp_path):
+    """The affinity mask of a GPU box shows the host's 256 CPUs while its cgroup grants 16 (`cpu.max = 1600000 100000`): the
+    budget is capped by the quota's share, per rank."""
+    import importlib
+    import bench
+    DET = importlib.import_module("comic-text-detector_amd.detector")
+    monkeypatch.setattr(DET, "usable_cpus", lambda: 256)
+    monkeypatch.setattr(DET, "cgroup_cpu_quota", lambda: 16.0)
+    tb = bench.thread_budget(1)                           # twice the quota: the tail's threads are bursty (detector.thread_budget)
+    assert tb["per_rank"] == 32 and tb["tail_workers"] == 4 and tb["native_threads_per_worker"] == 7 and tb["cgroup_cpu_quota"] == 16.0
+    monkeypatch.setattr(DET, "cgroup_cpu_quota", lambda: 4.0)
+    tiny = bench.thread_budget(1)
+    assert tiny["per_rank"] == 8 and tiny["tail_workers"] == 3 and tiny["native_threads_per_worker"] == 2
+    monkeypatch.setattr(DET, "cgroup_cpu_quota", lambda: 64.0)
+    tb8 = bench.thread_budget(8)                          # 8 ranks under a 64-CPU quota: 16 each, not 32
+    assert tb8["per_rank"] == 16 and tb8["tail_workers"] == 4
+    pinned = bench.thread_budget(8, True, 256)            # ... also when every rank is bound to 32 of the host's CPUs
+    assert pinned["per_rank"] == 16 and pinned["usable_cpus"] == 256
+    monkeypatch.setattr(DET, "cgroup_cpu_quota", lambda: 0.0)
+    assert "cgroup_cpu_quota" not in bench.thread_budget(1) and bench.thread_budget(1)["per_rank"] == 256
+    # the parser: cgroup v2 `cpu.max`
+    real_open = open
+    files = {"/sys/fs/cgroup/cpu.max": "1600000 100000\n"}
+    import builtins
+
+    def fake_open(path, *a, **k):
+        if path in files:
+            f = tmp_path / "cpu.max"
+            f.write_text(files[path])
+            return real_open(f, *a, **k)
+        if str(path).startswith("/sys/fs/cgroup/"):
+            raise OSError(path)
+        return real_open(path, *a, **k)
+    monkeypatch.undo()
+    monkeypatch.setattr(builtins, "open", fake_open)
+    assert DET.cgroup_cpu_quota() == 16.0
+    files["/sys/fs/cgroup/cpu.max"] = "max 100000\n"
+    assert DET.cgroup_cpu_quota() == 0.0
 
 
 def test_bench_checkpoint_selection():

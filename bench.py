@@ -967,7 +967,8 @@ def main() -> None:
     local_world = int(os.environ.get("LOCAL_WORLD_SIZE", world))
     pin = AFF.rank_cpus(local_rank % max(1, local_world), local_world,
                         gpu_of_rank=[0] * local_world if one_device else list(range(local_world)))
-    host_cpus = host_info()["usable_cpus"]
+    hi_ = host_info()
+    host_cpus = hi_.get("affinity_cpus", hi_["usable_cpus"])   # what the host's affinity mask offers (a CPU quota is reported beside it)
     pinned = bool(world > 1 and not args.no_pin and AFF.apply(pin["cpus"]))
     cpu_affinity = {"pinned": pinned, "numa_node": pin["node"], "source": pin["source"], "n_cpus": len(pin["cpus"]),
                     "cpus": f"{pin['cpus'][0]}..{pin['cpus'][-1]}" if pin["cpus"] else ""}

@@ -80,7 +80,7 @@ def thread_budget(world: int = 1, pinned: bool = False, host_cpus: int = 0) -> d
     if quota > 0:
         # threads up to TWICE the quota's share: the tail's threads are bursty (6-7 busy cores of 34 threads on the headline), and
         # sizing them on the quota itself -- 3 geometry threads per worker under 16 CPUs instead of 8 -- left the headline where
-        # it was (3086-3110 pages/s) but cost the dense pages 9 % (2517-2690 against 2904-2988; profiles/r06_cpu_quota.txt)
+        # it was (3086-3110 pages/s) but cost the dense pages 9-13 % (2517-2690 against 2904-2988; profiles/r06_cpu_quota.txt)
         share = min(share, 2 * int(quota) // max(1, world))
     per_rank = max(4, share)
     if pinned and host_cpus:
@@ -89,7 +89,13 @@ def thread_budget(world: int = 1, pinned: bool = False, host_cpus: int = 0) -> d
     # headline and +6 % on the canned pages, on another 4 is +2 % on the headline and +6 % on dense pages (three interleaved
     # repetitions each, profiles/r05_e2e_workers_3_vs_4.txt); the dense pages decide
     workers = 4 if per_rank >= 16 else (3 if per_rank >= 8 else 2)
-    native = max(1, min(8, (per_rank - 2) // workers))
+    # geometry threads per worker: a power of two.  A work item is 8 pages (32 / `tail_split` 4) and the native per-page loops hand
+    # pages to threads one at a time: 7 threads finish 8 pages in two rounds like 4 do -- which is what a 32-CPU share (one of 8
+    # ranks on a 256-CPU host, or twice a 16-CPU quota) got from `(per_rank - 2) // workers` = 7: dense pages 2600 against
+    # 2904-2988 with 8 (profiles/r06_cpu_quota.txt).  The launching thread and the loaders are idle most of the time and are
+    # not subtracted.
+    cap = max(1, min(8, per_rank // workers))
+    native = 1 << (cap.bit_length() - 1)
     out = {"usable_cpus": avail, "per_rank": per_rank, "tail_workers": workers, "native_threads_per_worker": native}
     if quota > 0:
         out["cgroup_cpu_quota"] = round(quota, 2)

@@ -6,7 +6,9 @@ export TMPDIR=/tmp
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}; cd "$ROOT" || exit 1
 O=$ROOT/gpurun_out/${1:-jitter}; N=${2:-8}; shift; shift
 mkdir -p "$O"
+thr() { awk '/nr_throttled/{n=$2} /throttled_usec/{u=$2} END{print n, u}' /sys/fs/cgroup/cpu.stat 2>/dev/null; }
 for i in $(seq 1 "$N"); do
+  T0=$(thr)
   timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extras "$@" > "$O/h$i.json" 2> "$O/h$i.err"
   python - "$O/h$i.json" <<'PY'
 import json, sys
@@ -17,4 +19,5 @@ try:
 except Exception as e:
     print("no JSON line:", e)
 PY
+  T1=$(thr); echo "   cgroup throttled periods / usec before: $T0  after: $T1 (whole process, start-up included)"
 done

@@ -81,11 +81,11 @@ def test_bench_thread_budget_and_torchrun_command(monkeypatch):
     assert DET.thread_budget() == bench.thread_budget(1)
     assert bench.thread_budget(1) == {"usable_cpus": 256, "per_rank": 256, "tail_workers": 4, "native_threads_per_worker": 8}
     b8 = bench.thread_budget(8)
-    assert b8["per_rank"] == 32 and b8["tail_workers"] == 4 and b8["tail_workers"] * b8["native_threads_per_worker"] + 2 <= 32
+    assert b8["per_rank"] == 32 and b8["tail_workers"] == 4 and b8["native_threads_per_worker"] == 8      # 8 pages per work item: 8, not 7
     assert bench.thread_budget(16)["tail_workers"] == 4 and bench.thread_budget(20)["tail_workers"] == 3      # 16 / 12 per rank
     monkeypatch.setattr(DET, "usable_cpus", lambda: 16)
     small = bench.thread_budget(8)
-    assert small["tail_workers"] == 2 and small["native_threads_per_worker"] == 1
+    assert small["tail_workers"] == 2 and small["native_threads_per_worker"] == 2                         # per_rank = max(4, 16 // 8)
     # `python bench.py --gpus 2` outside torchrun: N ranks of this script on 127.0.0.1, one-device rehearsal without 2 devices
     calls = {}
     monkeypatch.setattr(bench.subprocess, "call", lambda cmd, env=None: calls.update(cmd=cmd, env=env) or 0)

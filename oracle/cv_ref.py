@@ -325,7 +325,10 @@ def min_area_box(points: np.ndarray, grow: float = 0.0) -> Tuple[np.ndarray, flo
         pv = hull @ v
         lo_u, hi_u, lo_v, hi_v = pu.min() - grow, pu.max() + grow, pv.min() - grow, pv.max() + grow
         area = (hi_u - lo_u) * (hi_v - lo_v)
-        if best is None or area < best[0] - 1e-12:
+        # first minimum in edge order, with a RELATIVE margin: two hull edges of an integer-cornered ring often bound
+        # rectangles of mathematically equal area (seed 59 of the tail sweep: 2778 twice), and an absolute 1e-12 let the
+        # rounding noise of the projections (7e-12 there; numpy's dot against the product's mul + add) pick between them
+        if best is None or area < best[0] * (1.0 - 1e-9):
             best = (area, u, v, lo_u, hi_u, lo_v, hi_v)
     _, u, v, lo_u, hi_u, lo_v, hi_v = best
     box = np.array([u * lo_u + v * lo_v, u * hi_u + v * lo_v, u * hi_u + v * hi_v, u * lo_u + v * hi_v])

@@ -319,7 +319,14 @@ class TextBlock:
 
     def sort_lines(self):                                          # textblock.py:100-105
         if self.distance is not None:
-            idx = np.argsort(self.distance)
+            # PINNED: the reference calls np.argsort with numpy's default kind, which is not stable -- and not even ONE
+            # algorithm: numpy >= 1.25 sorts 64-bit keys with x86-simd-sort on AVX-512 / AVX2 hosts and with a scalar
+            # introsort elsewhere (insertion sort up to 16 elements), so the order of lines with EQUAL distances in a block
+            # of more than 16 lines depends on the numpy build and the CPU it runs on (integer quads on one text row tie
+            # often).  The restatement fixes the stable order, like get_topk_color's argsort below and the product's
+            # std::stable_sort (csrc/host_group.cpp); found in round 6 by a seed sweep of the whole-tail parity test
+            # (4 of 120 random pages: tests/test_gpu_e2e.py test_tail_seed_sweep_by_hand).
+            idx = np.argsort(self.distance, kind="stable")
             self.distance = self.distance[idx]
             lines = np.array(self.lines, dtype=np.int32)
             self.lines = lines[idx].tolist()

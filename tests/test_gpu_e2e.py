@@ -75,6 +75,62 @@ def test_tail_on_text_like_outputs_matches_oracle(seed, keep):
     assert len(got[2]) > 3 and (got[1] > 0).mean() > 0.005
 
 
+def _equal_up_to_tied_lines(got, ref):
+    """Same blocks, and every block's lines equal as a set and in order except among lines whose distances agree to 1e-6:
+    `TextBlock.sort_lines` orders lines of one text row -- a mathematical tie -- by the last bit of `|sin(acos(c))| * len`,
+    which numpy's SIMD libm and glibc compute differently now and then ("ties")."""
+    if len(got) != len(ref):
+        return False
+    for a, b in zip(got, ref):
+        if [int(v) for v in a.xyxy] != [int(v) for v in b.xyxy] or len(a.lines) != len(b.lines):
+            return False
+        key = lambda blk: sorted((round(float(d), 6), tuple(np.asarray(l).reshape(-1).tolist()))               # noqa: E731
+                                 for d, l in zip(np.asarray(blk.distance).reshape(-1), blk.lines))
+        if key(a) != key(b):
+            return False
+    return True
+
+
+def test_tail_seed_sweep_by_hand():
+    """CTD_TAIL_SWEEP="first:last[:size]" -- the whole-tail parity of the test above over a range of seeds, alternating the two
+    configurations (by hand; the suite skips it).  A page whose ONLY difference is the order of lines with tied distances is
+    counted apart (see `_equal_up_to_tied_lines`); anything else fails.  Round 6: the first sweep (120 pages) found four
+    mismatching pages -- numpy's unstable default argsort on blocks of more than 16 lines (the oracle now pins the stable order,
+    like the product), and two hull edges bounding rectangles of equal area told apart by rounding noise (both
+    `min_area_box` now use a relative margin) -- and this libm class."""
+    spec = os.environ.get("CTD_TAIL_SWEEP", "")
+    if not spec:
+        pytest.skip("set CTD_TAIL_SWEEP=first:last[:size]")
+    parts = [int(v) for v in spec.split(":")]
+    first, last, size = parts[0], parts[1], (parts[2] if len(parts) > 2 else 1024)
+    det = detector(size)
+    bad, tied = [], []
+    for seed in range(first, last + 1):
+        keep = bool(seed & 1)
+        page, mask_u8, prob, blks = fake_outputs(seed, size)
+        bt = blks_tensor(blks)
+        bitmap = (prob > 0.3).astype(np.uint8)
+        got = det.tail_batch([page], torch.from_numpy(bt).cuda(), torch.from_numpy(mask_u8)[None].cuda(),
+                             torch.from_numpy(prob)[None].cuda(), torch.from_numpy(bitmap)[None].cuda(),
+                             refine_mode=1 if keep else 0, keep_undetected_mask=keep)[0]
+        mask_f = (mask_u8.astype(np.float32) + 0.5) / 255
+        lines_map = np.stack([prob, np.zeros_like(prob)])[None]
+        ref = R.detector_tail(page, bt, mask_f[None, None], lines_map, input_size=(size, size),
+                              refine_mode=1 if keep else 0, keep_undetected_mask=keep)
+        try:
+            np.testing.assert_array_equal(got[0], ref[0])
+            blocks_equal(got[2], ref[2])
+            np.testing.assert_array_equal(got[1], ref[1])
+        except AssertionError as e:
+            if np.array_equal(got[0], ref[0]) and np.array_equal(got[1], ref[1]) and _equal_up_to_tied_lines(got[2], ref[2]):
+                tied.append(seed)
+            else:
+                bad.append((seed, keep, str(e)[:200]))
+    print(f"\ntail sweep: seeds {first}..{last} at {size}: {len(bad)} mismatching pages {bad[:5]}; "
+          f"{len(tied)} pages equal up to the order of tied lines {tied}")
+    assert not bad, bad
+
+
 def test_full_detector_on_network_outputs_matches_oracle():
     """The real forward (random weights -> noisy maps: many tiny contours, the worst case for
     the contour/box code) feeding the tail; the oracle tail runs on the same network outputs."""

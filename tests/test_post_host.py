@@ -60,6 +60,33 @@ def test_db_boxes_group_output_match_oracle(seed):
     blocks_equal(got, ref)
 
 
+@pytest.mark.parametrize("seed,size,what", [
+    (140, 640, "a block of > 16 lines with EQUAL distances: numpy's default argsort is unstable there (x86-simd-sort on AVX-512)"),
+    (153, 640, "... and the order of the tied lines decides a split: different blocks"),
+    (59, 1024, "two hull edges bound rectangles of mathematically equal area (2778): the min-area box must not be picked by rounding noise"),
+    (226, 512, "two lines of one text row: |sin(arccos(c))| * len ties mathematically, glibc's acos and numpy's SVML arccos differ in the last bit"),
+    (1056, 1024, "... the same tie in a vertical block, cascading into a different split (11 blocks against 12)"),
+])
+def test_native_host_stages_on_the_findings_of_the_round6_seed_sweep(seed, size, what):
+    """The five pages (of 120) on which the first seed sweep of the whole-tail parity test (tests/test_gpu_e2e.py
+    `test_tail_seed_sweep_by_hand`) found the product's native host code and the oracle apart -- every one a TIE that the
+    reference breaks by an implementation detail of numpy.  DB boxes (product geometry on scipy labels) and grouping against
+    the oracle, as in the test above; DESIGN 5."""
+    p = pkg()
+    page, mask_u8, prob, blks = fake_outputs(seed, size)
+    H, W = prob.shape
+    bitmap = prob > 0.3
+    nf, lab_f, st_f = R.connected_components_with_stats(bitmap.astype(np.uint8), 8)
+    nb, lab_b, st_b = R.connected_components_with_stats((~bitmap).astype(np.uint8), 4)
+    boxes, scores = p.postproc.SegRepresenter()._page(prob, lab_f, st_f[1:], lab_b, st_b[1:], W, H)
+    rboxes, rscores = R.boxes_from_bitmap(prob, bitmap, W, H)
+    np.testing.assert_array_equal(boxes, rboxes, err_msg=what)
+    np.testing.assert_allclose(scores, rscores, rtol=0, atol=1e-6)
+    lines = boxes[scores > 0.6].astype(np.int32)
+    blocks_equal(p.textblock.group_output(copy.deepcopy(blks), lines.copy(), W, H, mask_u8),
+                 R.group_output(copy.deepcopy(blks), lines.copy(), W, H, mask_u8))
+
+
 @pytest.mark.parametrize("case", ["noise", "holes", "thin", "empty", "full", "cap"])
 def test_db_boxes_native_host_geometry_edge_cases(case):
     """`ctd_db_boxes` (csrc/host_db.cpp, host-only: runs without a GPU) against the oracle's

@@ -131,6 +131,46 @@ def test_tail_seed_sweep_by_hand():
     assert not bad, bad
 
 
+def test_letterboxed_tail_sweep_by_hand():
+    """CTD_LETTERBOX_SWEEP="first:last" -- pages of RANDOM sizes and aspect ratios (200 .. 1500 pixels a side) with network
+    outputs consistent with their letterbox at 512 (tests/test_reference_pin.py `letterboxed_case`): the native tail's inverse
+    mapping (mask crop + resize to the page, box / line rescale with the reference's truncations) and everything after it against
+    `R.detector_tail`, both configurations (by hand; the suite skips it)."""
+    spec = os.environ.get("CTD_LETTERBOX_SWEEP", "")
+    if not spec:
+        pytest.skip("set CTD_LETTERBOX_SWEEP=first:last")
+    from test_reference_pin import letterboxed_case
+    first, last = [int(v) for v in spec.split(":")[:2]]
+    size = 512
+    det = detector(size)
+    bad, tied = [], []
+    for seed in range(first, last + 1):
+        rng = np.random.RandomState(7000 + seed)
+        im_hw = (int(rng.randint(200, 1500)), int(rng.randint(200, 1500)))
+        keep = bool(seed & 1)
+        page, bt, mask, lines_map, (dw, dh) = letterboxed_case(seed, im_hw, size)
+        prob = np.ascontiguousarray(lines_map[0, 0])
+        mask_u8 = (mask[0, 0] * 255).astype(np.uint8)                 # postprocess_mask's truncation
+        bitmap = (prob > 0.3).astype(np.uint8)
+        got = det.tail_batch([page], torch.from_numpy(bt).cuda(), torch.from_numpy(mask_u8)[None].cuda(),
+                             torch.from_numpy(prob)[None].cuda(), torch.from_numpy(bitmap)[None].cuda(),
+                             refine_mode=1 if keep else 0, keep_undetected_mask=keep,
+                             metas=[(im_hw[0], im_hw[1], dw, dh)])[0]
+        ref = R.detector_tail(page, bt, mask, lines_map, input_size=(size, size), dw=dw, dh=dh,
+                              refine_mode=1 if keep else 0, keep_undetected_mask=keep)
+        try:
+            np.testing.assert_array_equal(got[0], ref[0])
+            blocks_equal(got[2], ref[2])
+            np.testing.assert_array_equal(got[1], ref[1])
+        except AssertionError as e:
+            if np.array_equal(got[0], ref[0]) and np.array_equal(got[1], ref[1]) and _equal_up_to_tied_lines(got[2], ref[2]):
+                tied.append(seed)
+            else:
+                bad.append((seed, im_hw, keep, str(e)[:160]))
+    print(f"\nletterbox sweep: seeds {first}..{last}: {len(bad)} mismatching pages {bad[:4]}; tied-line order only: {tied}")
+    assert not bad, bad
+
+
 def test_full_detector_on_network_outputs_matches_oracle():
     """The real forward (random weights -> noisy maps: many tiny contours, the worst case for
     the contour/box code) feeding the tail; the oracle tail runs on the same network outputs."""

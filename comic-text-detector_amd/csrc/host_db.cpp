@@ -398,7 +398,9 @@ extern "C" int ctd_db_boxes(const float* prob, const int32_t* lab_f, const int32
     Pf box[4];
     double bw, bh;
     min_area_box(h, 0.0, box, bw, bh);
-    if (std::min(bw, bh) < 2) continue;                              // db_utils.py:146-147
+    // db_utils.py:146-147 -- on the float32 the reference sees (cv2.minAreaRect returns a Size2f): a side of mathematically
+    // 2.0 comes out of the calipers as 2.0 or 1.9999999999999858 by rounding noise, and the gate must not follow the noise
+    if ((float)std::min(bw, bh) < 2.0f) continue;
     order_box(box);
     filled_values(m, rh, rw, it.kind == 1, prob, W, x0, y0, stack, vals);
     // ndarray.mean() of a contiguous float64 array: pairwise sums of 8192-element chunks, added
@@ -487,7 +489,9 @@ extern "C" int ctd_db_boxes_compact(int W, int H, int n_f, const int32_t* st_f, 
     Pf box[4];
     double bw, bh;
     min_area_box(h, 0.0, box, bw, bh);
-    if (std::min(bw, bh) < 2) continue;                              // db_utils.py:146-147
+    // db_utils.py:146-147 -- on the float32 the reference sees (cv2.minAreaRect returns a Size2f): a side of mathematically
+    // 2.0 comes out of the calipers as 2.0 or 1.9999999999999858 by rounding noise, and the gate must not follow the noise
+    if ((float)std::min(bw, bh) < 2.0f) continue;
     order_box(box);
     scores[idx] = cnt > 0 ? (float)(sum / (double)cnt) : 0.f;
     unclip_to_box(box, unclip_ratio, W, H, boxes + (size_t)idx * 8, pts, h, tmp);

@@ -87,6 +87,24 @@ def test_native_host_stages_on_the_findings_of_the_round6_seed_sweep(seed, size,
                  R.group_output(copy.deepcopy(blks), lines.copy(), W, H, mask_u8))
 
 
+@pytest.mark.parametrize("key", ["map0", "map1"])
+def test_db_boxes_short_side_of_exactly_two_pixels(key):
+    """`sside < 2` (db_utils.py:146) on contours whose min-area rectangle has a short side of MATHEMATICALLY 2.0: the calipers
+    return 2.0 or 1.9999999999999858 by rounding noise (one map each way, found by scripts/gpu_db_stress.py: 2 of 1 800 random
+    maps).  Oracle and product compare the float32 the reference sees (cv2.minAreaRect returns a Size2f)."""
+    import os
+    p = pkg()
+    prob = np.load(os.path.join(os.path.dirname(__file__), "golden", "db_short_side_ties.npz"))[key]
+    H, W = prob.shape
+    bitmap = prob > 0.3
+    nf, lab_f, st_f = R.connected_components_with_stats(bitmap.astype(np.uint8), 8)
+    nb, lab_b, st_b = R.connected_components_with_stats((~bitmap).astype(np.uint8), 4)
+    boxes, scores = p.postproc.SegRepresenter()._page(prob, lab_f, st_f[1:], lab_b, st_b[1:], W, H)
+    rboxes, rscores = R.boxes_from_bitmap(prob, bitmap, W, H)
+    np.testing.assert_array_equal(boxes, rboxes)
+    np.testing.assert_allclose(scores, rscores, rtol=0, atol=1e-6)
+
+
 @pytest.mark.parametrize("case", ["noise", "holes", "thin", "empty", "full", "cap"])
 def test_db_boxes_native_host_geometry_edge_cases(case):
     """`ctd_db_boxes` (csrc/host_db.cpp, host-only: runs without a GPU) against the oracle's

@@ -94,6 +94,60 @@ def test_native_group_output_equals_oracle(seed):
     same_blocks(got, ref)
 
 
+def grid_page(seed):
+    """Clusters of axis-aligned integer quads on a grid (rows x columns of equal boxes, some missing), shuffled: lines of one row
+    or column tie MATHEMATICALLY in `TextBlock.distance`, blocks reach 60 lines -- what the random quads above never produce
+    (round 6: the seed sweep of the whole-tail test found the ties)."""
+    rng = np.random.RandomState(seed)
+    im_w, im_h = int(rng.choice([640, 1024, 1400])), int(rng.choice([640, 1024, 1654]))
+    lines, blines, cls = [], [], []
+    for _ in range(rng.randint(1, 6)):
+        vertical = rng.rand() < 0.5
+        fs, gap = int(rng.randint(10, 36)), int(rng.randint(2, 14))
+        nrow, ncol = int(rng.randint(1, 9)), int(rng.randint(1, 9))
+        x0, y0, length = int(rng.randint(0, im_w - 200)), int(rng.randint(0, im_h - 200)), int(rng.randint(20, 90))
+        quads = []
+        for r in range(nrow):
+            for c in range(ncol):
+                if rng.rand() < 0.2:
+                    continue
+                x, y, w, h = (x0 + c * (fs + gap), y0 + r * (length + gap), fs, length) if vertical else \
+                             (x0 + c * (length + gap), y0 + r * (fs + gap), length, fs)
+                if x + w < im_w and y + h < im_h:
+                    quads.append(np.array([[x, y], [x + w, y], [x + w, y + h], [x, y + h]], np.int32))
+        if not quads:
+            continue
+        lines += quads
+        if rng.rand() < 0.7:
+            pts = np.concatenate(quads)
+            lo, hi = pts.min(0) - rng.randint(0, 10, 2), pts.max(0) + rng.randint(0, 10, 2)
+            blines.append([lo[0], lo[1], hi[0], hi[1]])
+            cls.append(int(rng.randint(0, 3)))
+    if not lines:
+        return grid_page(seed + 100000)
+    order = rng.permutation(len(lines))
+    lines = np.array([lines[i] for i in order], np.int32).reshape(-1, 4, 2)
+    mask = np.zeros((im_h, im_w), np.uint8)
+    for q in lines:
+        if rng.rand() < 0.8:
+            mask[q[0, 1]: q[2, 1], q[0, 0]: q[2, 0]] = rng.randint(20, 256)
+    blks = (np.array(blines, np.int32).reshape(-1, 4), np.array(cls, np.int32), np.ones(len(cls)))
+    return blks, lines, im_w, im_h, mask
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_native_group_output_equals_oracle_on_tied_lines(seed):
+    """Grids of equal boxes: every distance ties with others.  The product (std::stable_sort on numpy's own arccos values) and the
+    oracle (np.argsort kind="stable") must agree bit for bit; the reference's own code orders EQUAL distances in a block of more
+    than 16 lines by numpy's default argsort -- x86-simd-sort on this host -- and differs from both on about half of such pages
+    (300 cases: native == oracle 300, oracle == reference's own 151): implementation-defined, pinned to the stable order."""
+    p = pkg()
+    blks, lines, im_w, im_h, mask = grid_page(seed)
+    got = p.textblock.group_output(copy.deepcopy(blks), lines.copy(), im_w, im_h, mask)
+    ref = R.group_output(copy.deepcopy(blks), lines.copy(), im_w, im_h, mask)
+    same_blocks(got, ref)
+
+
 def test_native_group_output_empty_inputs():
     p = pkg()
     none = (np.zeros((0, 4), np.int32), np.zeros((0,), np.int32), np.zeros((0,)))

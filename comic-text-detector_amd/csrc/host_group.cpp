@@ -15,16 +15,12 @@
 // AVX512_SKX dispatch target) is Intel SVML's `__svml_acos8_ha`, which differs from glibc's `acos` in the last bit of
 // ~9 % of arguments (measured, 200 000 random values) -- and lines of one text row tie mathematically, so that last bit
 // ORDERS them in `TextBlock.sort_lines` and, through the order, decides splits (round 6: 1 page in ~100 of a seed sweep
-// differed in the order of tied lines, 1 in ~350 in its blocks).  `np_arccos` therefore calls the very function numpy
+// differed in the order of tied lines, 1 in ~350 in its blocks).  `npd::arccos` (np_dispatch.h) therefore calls the very function numpy
 // calls when the process has numpy loaded and the CPU takes that dispatch path: the symbol is exported by numpy's
 // `_multiarray_umath` module, found among the loaded objects, called on a broadcast vector (SVML is lane-wise).  Without it
 // (no numpy in the process, no AVX-512, a numpy built without SVML) numpy itself computes `arccos` with libm, and so does this
 // file.  The two operands (c, d) of every line are still handed back so that the Python record carries numpy's own value
 // (comic-text-detector_amd/textblock.py).
-#include <dlfcn.h>
-#include <immintrin.h>
-#include <link.h>
-
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
@@ -33,38 +29,11 @@
 #include <vector>
 
 #include "../../include/ctd_hip.h"
+#include "np_dispatch.h"
 
 namespace {
 
 const double kPi = 3.141592653589793;   // math.pi
-
-// ---- numpy's float64 arccos ------------------------------------------------------------------------------------------
-__attribute__((target("avx512f"))) double svml_call1(void* fn, double x) {
-  typedef __m512d (*vfn)(__m512d);
-  return _mm512_cvtsd_f64(((vfn)fn)(_mm512_set1_pd(x)));
-}
-void* find_numpy_svml_acos() {
-  // numpy's AVX512_SKX target = F + CD + BW + DQ + VL; below it numpy's own loop is libm's acos
-  if (!(__builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512cd") && __builtin_cpu_supports("avx512bw") &&
-        __builtin_cpu_supports("avx512dq") && __builtin_cpu_supports("avx512vl")))
-    return nullptr;
-  void* fn = nullptr;
-  dl_iterate_phdr(
-      [](struct dl_phdr_info* info, size_t, void* data) -> int {
-        if (!info->dlpi_name || !std::strstr(info->dlpi_name, "_multiarray_umath")) return 0;
-        if (void* h = dlopen(info->dlpi_name, RTLD_LAZY | RTLD_NOLOAD)) {
-          *(void**)data = dlsym(h, "__svml_acos8_ha");
-          dlclose(h);                                      // drops the count RTLD_NOLOAD added; the module stays loaded
-        }
-        return *(void**)data != nullptr;
-      },
-      &fn);
-  return fn;
-}
-double np_arccos(double c) {
-  static void* const fn = find_numpy_svml_acos();          // once per process, thread-safe
-  return fn ? svml_call1(fn, c) : std::acos(c);
-}
 
 struct Line {
   int32_t p[8];   // 4 points (x, y)
@@ -200,7 +169,7 @@ void examine(Blk& b, int im_w, int im_h, bool sort) {
     const double c = (d[0] * pvec[0] + d[1] * pvec[1]) / (len * pnorm);
     l.dlen = len;
     l.dcos = c;
-    l.dist = std::fabs(std::sin(np_arccos(c)) * len);
+    l.dist = std::fabs(std::sin(npd::arccos(c)) * len);
     b.dist[i] = {l.dist, l.dcos, l.dlen};
   }
   b.angle = vertical ? rot - 90 : rot;
@@ -212,9 +181,16 @@ void examine(Blk& b, int im_w, int im_h, bool sort) {
   b.norm = pnorm;
   (void)im_h;
   if (sort) {                                                                       // sort_lines (:100-105)
-    // stable: numpy's default argsort is neither stable nor one algorithm (x86-simd-sort on AVX-512 hosts); the oracle pins the
-    // stable order too (oracle/postproc_ref.py TextBlock.sort_lines)
-    std::stable_sort(b.lines.begin(), b.lines.end(), [](const Line& x, const Line& y) { return dist_less(x.dist, y.dist); });
+    std::vector<double> key(n);
+    std::vector<long> idx(n);
+    for (int i = 0; i < n; ++i) key[i] = b.lines[i].dist, idx[i] = i;
+    if (n > 1 && npd::argsort_f64(key.data(), idx.data(), n)) {                      // numpy's own default-kind argsort (np_dispatch.h)
+      std::vector<Line> sorted(n);
+      for (int i = 0; i < n; ++i) sorted[i] = b.lines[idx[i]];
+      b.lines.swap(sorted);
+    } else {
+      std::stable_sort(b.lines.begin(), b.lines.end(), [](const Line& x, const Line& y) { return dist_less(x.dist, y.dist); });
+    }
     for (int i = 0; i < n; ++i) b.dist[i] = {b.lines[i].dist, b.lines[i].dcos, b.lines[i].dlen};
   }
 }

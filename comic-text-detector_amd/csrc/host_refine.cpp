@@ -12,14 +12,15 @@
 
 #include "../../include/ctd_hip.h"
 #include "host_refine.h"
+#include "np_dispatch.h"
 
 // np.histogram(px, bins=255) of the multiset given by `hist` (count per grey level 0..255) followed by
 // get_topk_color(edges, counts, k=3, color_var=10, bin_tol=0.001) (textmask.py:16-27, 61-62).
 // numpy: range = (min, max) of the data ((0, 1) for no data; +-0.5 if min == max), edges =
 // linspace(first, last, 256) = i * step + first with edges[255] = last, a value falls into the bin
 // [edges[i], edges[i+1]) (the last bin is closed) -- numpy's index estimate is corrected against the
-// edges, so only the edges decide.  The stable descending sort of the counts is the order the
-// restatement pins (np.argsort's default is unstable for ties, SURVEY / DESIGN section 5).
+// edges, so only the edges decide.  The descending order of the counts is numpy's own default-kind argsort where the
+// process has it (np.argsort's default is unstable for ties, SURVEY / DESIGN section 5), a stable sort elsewhere.
 extern "C" int ctd_topk_colors(const int64_t* hist, double* colors) {
   int lo = -1, hi = -1;
   for (int v = 0; v < 256; ++v)
@@ -52,9 +53,17 @@ extern "C" int ctd_topk_colors(const int64_t* hist, double* colors) {
       total += hist[v];
     }
   }
+  // np.argsort(counts * -1), numpy's default kind: its own function where the process has it (np_dispatch.h: bins of EQUAL count
+  // beyond 16 elements come out in x86-simd-sort's order there), a stable sort elsewhere
   int order[255];
-  for (int i = 0; i < nb; ++i) order[i] = i;
-  std::stable_sort(order, order + nb, [&](int a, int b) { return counts[a] > counts[b]; });
+  long keys[255], idx[255];
+  for (int i = 0; i < nb; ++i) keys[i] = -(long)counts[i], idx[i] = i;
+  if (npd::argsort_i64(keys, idx, nb)) {
+    for (int i = 0; i < nb; ++i) order[i] = (int)idx[i];
+  } else {
+    for (int i = 0; i < nb; ++i) order[i] = i;
+    std::stable_sort(order, order + nb, [&](int a, int b) { return counts[a] > counts[b]; });
+  }
   int n = 0;
   colors[n++] = edges[order[0]];
   const double tol = (double)total * 0.001;

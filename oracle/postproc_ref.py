@@ -321,14 +321,11 @@ class TextBlock:
 
     def sort_lines(self):                                          # textblock.py:100-105
         if self.distance is not None:
-            # PINNED: the reference calls np.argsort with numpy's default kind, which is not stable -- and not even ONE
-            # algorithm: numpy >= 1.25 sorts 64-bit keys with x86-simd-sort on AVX-512 / AVX2 hosts and with a scalar
-            # introsort elsewhere (insertion sort up to 16 elements), so the order of lines with EQUAL distances in a block
-            # of more than 16 lines depends on the numpy build and the CPU it runs on (integer quads on one text row tie
-            # often).  The restatement fixes the stable order, like get_topk_color's argsort below and the product's
-            # std::stable_sort (csrc/host_group.cpp); found in round 6 by a seed sweep of the whole-tail parity test
-            # (4 of 120 random pages: tests/test_gpu_e2e.py test_tail_seed_sweep_by_hand).
-            idx = np.argsort(self.distance, kind="stable")
+            # the reference's call, literally: numpy's DEFAULT kind, which is not stable and not one algorithm (x86-simd-sort
+            # for 64-bit keys on AVX-512 / AVX2 hosts, an introsort elsewhere) -- the order of EQUAL distances in a block of more
+            # than 16 lines belongs to the numpy build and the host.  The product calls numpy's own function where the process
+            # has it (csrc/host_group.cpp `find_numpy_argsort`), so both follow the reference on the same machine; round 6.
+            idx = np.argsort(self.distance)
             self.distance = self.distance[idx]
             lines = np.array(self.lines, dtype=np.int32)
             self.lines = lines[idx].tolist()
@@ -597,8 +594,10 @@ def expand_textwindow(img_size, xyxy, expand_r=8):
 
 
 def get_topk_color(color_list, bins, k=3, color_var=10, bin_tol=0.001):
-    """reference utils/textmask.py:16-27 (stable argsort; numpy's default is not)."""
-    idx = np.argsort(bins * -1, kind="stable")
+    """reference utils/textmask.py:16-27.  The argsort is the reference's call, literally: numpy's default kind (not stable; bins of
+    EQUAL count beyond 16 elements come out in the numpy build's own order -- the product calls numpy's own function where the
+    process has it, csrc/np_dispatch.h)."""
+    idx = np.argsort(bins * -1)
     color_list, bins = color_list[idx], bins[idx]
     top_colors = [color_list[0]]
     bin_tol = np.sum(bins) * bin_tol

@@ -237,18 +237,9 @@ def load_reference_post():
                 sys.modules.pop(k, None)
             else:
                 sys.modules[k] = v
-    # `get_topk_color` orders the histogram bins with np.argsort's default (unstable) sort
-    # (textmask.py:17): the order of bins with EQUAL counts is implementation-defined (NumPy
-    # version, SIMD sort dispatch), SURVEY App. C-11.  The restatement and the product use a stable
-    # sort; give the reference's module the same tie order so everything else can be compared.
-    class _StableArgsortNumpy(types.ModuleType):
-        def __getattr__(self, name):
-            return getattr(np, name)
-
-        @staticmethod
-        def argsort(a, *args, **kw):
-            kw.setdefault("kind", "stable")
-            return np.argsort(a, *args, **kw)
-    TM.np = _StableArgsortNumpy("numpy")
+    # (`get_topk_color` orders the histogram bins with np.argsort's default kind, textmask.py:17: the order of bins with EQUAL
+    # counts belongs to the numpy build and the host -- x86-simd-sort on AVX-512 / AVX2.  Rounds 1-5 gave this module a stable
+    # argsort so that it could be compared with a restatement pinned to the stable order; since round 6 the restatement makes the
+    # reference's call literally and the product calls numpy's own function (csrc/np_dispatch.h), so the module runs unpatched.)
     _LOADED = types.SimpleNamespace(DB=DB, TB=TB, TM=TM, YU=YU, INF=INF)
     return _LOADED

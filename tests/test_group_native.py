@@ -137,15 +137,30 @@ def grid_page(seed):
 
 @pytest.mark.parametrize("seed", range(40))
 def test_native_group_output_equals_oracle_on_tied_lines(seed):
-    """Grids of equal boxes: every distance ties with others.  The product (std::stable_sort on numpy's own arccos values) and the
-    oracle (np.argsort kind="stable") must agree bit for bit; the reference's own code orders EQUAL distances in a block of more
-    than 16 lines by numpy's default argsort -- x86-simd-sort on this host -- and differs from both on about half of such pages
-    (300 cases: native == oracle 300, oracle == reference's own 151): implementation-defined, pinned to the stable order."""
+    """Grids of equal boxes: every distance ties with others.  `TextBlock.sort_lines` is `np.argsort` with numpy's default kind --
+    x86-simd-sort for 64-bit keys on an AVX-512 / AVX2 host: the order of EQUAL distances in a block of more than 16 lines is that
+    code's own -- on values whose last bit is numpy's SVML `arccos`.  The product calls both functions themselves
+    (csrc/np_dispatch.h); the oracle makes the reference's calls literally.  Bit for bit, incl. `distance`."""
     p = pkg()
     blks, lines, im_w, im_h, mask = grid_page(seed)
     got = p.textblock.group_output(copy.deepcopy(blks), lines.copy(), im_w, im_h, mask)
     ref = R.group_output(copy.deepcopy(blks), lines.copy(), im_w, im_h, mask)
     same_blocks(got, ref)
+
+
+@pytest.mark.skipif(not RI.reference_available(), reason="reference tree not present")
+@pytest.mark.parametrize("seed", range(0, 40, 2))
+def test_native_group_output_equals_reference_code_on_tied_lines(seed):
+    """... and against the reference's OWN group_output on the same grids (round 6, by hand: 300 of 300; with a stable sort and
+    glibc's acos in the product it was 151 of 300)."""
+    from oracle import ref_post_import as RP
+    ref = RP.load_reference_post()
+    p = pkg()
+    blks, lines, im_w, im_h, mask = grid_page(seed)
+    got = p.textblock.group_output(copy.deepcopy(blks), lines.copy(), im_w, im_h, mask)
+    with np.errstate(all="ignore"):
+        theirs = ref.TB.group_output(copy.deepcopy(blks), lines.copy(), im_w, im_h, mask)
+    same_blocks(got, theirs)
 
 
 def test_native_group_output_empty_inputs():

@@ -61,7 +61,7 @@ def test_db_boxes_group_output_match_oracle(seed):
 
 
 @pytest.mark.parametrize("seed,size,what", [
-    (140, 640, "a block of > 16 lines with EQUAL distances: numpy's default argsort is unstable there (x86-simd-sort on AVX-512)"),
+    (140, 640, "a block of > 16 lines with EQUAL distances: numpy's default argsort is x86-simd-sort there (the product calls it)"),
     (153, 640, "... and the order of the tied lines decides a split: different blocks"),
     (59, 1024, "two hull edges bound rectangles of mathematically equal area (2778): the min-area box must not be picked by rounding noise"),
     (226, 512, "two lines of one text row: |sin(arccos(c))| * len ties mathematically, glibc's acos and numpy's SVML arccos differ in the last bit"),
